@@ -1,0 +1,230 @@
+/*
+ * selenite_rx.h -- C-ABI of the MI355X-native Selenite Lite RX DSP block path.
+ *
+ * Drop-in boundary.  Every entry point mirrors the CMSIS-DSP
+ * "instance / init / process(S, pSrc, pDst, blockSize)" convention that the
+ * reference vendors (Drivers/CMSIS/DSP/Include/arm_math.h:1175-1195 arm_fir_f32,
+ * :1326-1344 arm_biquad_cascade_df1_f32, :3288-3312 arm_fir_decimate_f32) and sits
+ * in the per-block callback slot of the firmware
+ * (Core/Src/dsp_if.c:50-54,63-67 HAL_I2SEx_TxRx{Half,}CpltCallback, between the
+ * int16 I/Q that DSP_In_Buff_Write (dsp_if.c:250-301) receives and the int16
+ * audio DSP_Out_Buff_Read (dsp_if.c:204-219) hands back).
+ *
+ * Plain C: pointers and sizes only, no C++/torch types.  The library behind it
+ * (libselenite_rx.so) is hand-written HIP for gfx950; there is NO CPU fallback:
+ * selenite_rx_init() fails with SELENITE_RX_DEVICE_ERROR when no HIP device is
+ * usable.
+ *
+ * Data layout (device and host views are the same):
+ *   pSrcIQ    float  [channels][blockSize][2]   I,Q adjacent  (dsp_if.c:286-289 interleave)
+ *   pDstAudio float  [channels][blockSize/decim]
+ *   q15 variants: int16_t with the same shapes (arm_q15_to_float / arm_float_to_q15
+ *   semantics, SupportFunctions/arm_q15_to_float.c:65-113, arm_float_to_q15.c:64-122).
+ *
+ * The chain that runs per channel and per DSP block is specified in DESIGN.md
+ * ("Chain specification"); every step is one CMSIS-DSP primitive:
+ *   NCO (arm_sin_f32/arm_cos_f32 + arm_cmplx_mult_cmplx_f32)
+ *   -> arm_fir_decimate_f32 on the I and the Q rail
+ *   -> arm_fir_f32 (delay taps) on I, arm_fir_f32 (Hilbert taps) on Q
+ *   -> arm_sub_f32 / arm_add_f32 (USB / LSB)   [AM: arm_cmplx_mag_f32]
+ *   -> arm_biquad_cascade_df1_f32 (CW narrow filter)
+ *   -> arm_abs_f32 + arm_max_f32 -> gain law -> arm_scale_f32 (AGC)
+ */
+#ifndef SELENITE_RX_H
+#define SELENITE_RX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SELENITE_RX_ABI_VERSION 1
+
+/* Status codes: numerically identical to arm_status (arm_math.h:399-408). */
+#define SELENITE_RX_SUCCESS          0   /* ARM_MATH_SUCCESS          */
+#define SELENITE_RX_ARGUMENT_ERROR (-1)  /* ARM_MATH_ARGUMENT_ERROR   */
+#define SELENITE_RX_LENGTH_ERROR   (-2)  /* ARM_MATH_LENGTH_ERROR     */
+#define SELENITE_RX_DEVICE_ERROR   (-7)  /* outside arm_status: HIP device/runtime failure */
+
+/* Demodulator modes: the values of the firmware's Mode enum (Core/Inc/rxtx_if.h:33-43),
+ * i.e. the byte DSP_Set_Mode() (Core/Src/dsp_if.c:367-370) receives from the CAT parser. */
+#define SELENITE_MODE_LSB 0x00
+#define SELENITE_MODE_USB 0x01
+#define SELENITE_MODE_CW  0x02
+#define SELENITE_MODE_CWR 0x03
+#define SELENITE_MODE_AM  0x04
+#define SELENITE_MODE_FM  0x08   /* not demodulated: init/set_mode return ARGUMENT_ERROR */
+#define SELENITE_MODE_DIG 0x0A   /* = USB */
+#define SELENITE_MODE_PKT 0x0C   /* = LSB */
+
+/* Arithmetic contract of the MAC loops (DESIGN.md "Arithmetic modes"). */
+#define SELENITE_ARITH_CMSIS 0   /* product rounded, then sum rounded: bit-exact vs CMSIS-DSP 1.5.3 C code */
+#define SELENITE_ARITH_FMA   1   /* same operation order, each multiply-add fused (fmaf): bit-exact vs the
+                                    oracle's fmaf restatement, <=1e-5 relative vs CMSIS */
+
+typedef struct selenite_rx_config {
+    uint32_t struct_size;     /* = sizeof(selenite_rx_config) */
+    uint32_t channels;        /* C: independent I/Q channels handled by this instance */
+    uint32_t block;           /* DSP block: complex input samples per CMSIS call / AGC update */
+    uint32_t decim;           /* M (arm_fir_decimate_instance_f32.M); 1 = no decimator */
+    uint32_t nd_taps;         /* decimator taps (numTaps); 0 = decimator bypassed (requires decim==1) */
+    uint32_t nh_taps;         /* taps of the Hilbert / delay FIR pair; 0 = no FIR pair */
+    uint32_t n_biquad;        /* DF1 biquad stages applied in CW/CWR; 0 = none */
+    uint32_t arith;           /* SELENITE_ARITH_* */
+    uint8_t  mode;            /* SELENITE_MODE_* */
+    uint8_t  nco_enable;      /* 1 = quadrature NCO mix in front of the chain */
+    uint8_t  agc_enable;      /* 1 = AGC at the end of the chain */
+    uint8_t  agc_global;      /* 1 = one gain from the envelope maximum over ALL channels (and ranks) */
+    uint32_t nco_step_all;    /* phase step per input sample (2^32 = one turn) when nco_step == NULL */
+    const float    *dec_coeffs;    /* [nd_taps]  CMSIS order {b[N-1] .. b[0]} (arm_fir_decimate_f32.c:64-69) */
+    const float    *hilb_coeffs;   /* [nh_taps]  arm_fir_f32 taps applied to the Q rail */
+    const float    *delay_coeffs;  /* [nh_taps]  arm_fir_f32 taps applied to the I rail */
+    const float    *biquad_coeffs; /* [5*n_biquad] {b0,b1,b2,a1,a2} per stage, feedback ADDED
+                                      (arm_biquad_cascade_df1_f32.c:52-63) */
+    const uint32_t *nco_step;      /* [channels] per-channel phase step, or NULL */
+    float agc_target;         /* wanted peak level of the audio block */
+    float agc_attack;         /* one-pole rate when the gain has to fall */
+    float agc_decay;          /* one-pole rate when the gain may rise */
+    float agc_gain_min;
+    float agc_gain_max;
+    float agc_env_floor;      /* envelope is clamped from below to this before target/env */
+    float agc_gain_init;      /* gain before the first block */
+} selenite_rx_config;
+
+/* Host-side view of the per-channel streaming state (what CMSIS keeps in pState).
+ * Any pointer may be NULL (skipped).  Layouts:
+ *   dec_state  [channels][2][nd_taps-1]   rail 0 = I, rail 1 = Q; oldest sample first
+ *                                         (arm_fir_decimate_f32.c:396-426 copy-back order)
+ *   fir_state  [channels][2][nh_taps-1]   rail 0 = delay FIR (I), rail 1 = Hilbert FIR (Q)
+ *                                         (arm_fir_f32.c:947-978)
+ *   biq_state  [channels][n_biquad][4]    {x[n-1], x[n-2], y[n-1], y[n-2]}
+ *                                         (arm_biquad_cascade_df1_f32.c:319-322)
+ *   agc_gain   [channels]
+ *   nco_phase  [channels]                 uint32 phase accumulator
+ */
+typedef struct selenite_rx_state_view {
+    float    *dec_state;
+    float    *fir_state;
+    float    *biq_state;
+    float    *agc_gain;
+    uint32_t *nco_phase;
+} selenite_rx_state_view;
+
+typedef struct selenite_rx_instance selenite_rx_instance;  /* opaque; state lives in HBM */
+
+/* ---- instance life cycle ------------------------------------------------------------- */
+
+/* Mirrors arm_fir_decimate_init_f32 (FilteringFunctions/arm_fir_decimate_init_f32.c:63-101):
+ * validates (block % decim != 0 -> SELENITE_RX_LENGTH_ERROR), clears all state.  Coefficient
+ * arrays are copied to the device; the caller may free them afterwards.  Uses the calling
+ * thread's current HIP device.  On failure *S is set to NULL. */
+int  selenite_rx_init(selenite_rx_instance **S, const selenite_rx_config *cfg);
+void selenite_rx_free(selenite_rx_instance *S);
+
+/* Mirrors DSP_Set_Mode(uint8_t) (Core/Src/dsp_if.c:367-370).  Filter state is kept. */
+int  selenite_rx_set_mode(selenite_rx_instance *S, uint8_t mode);
+
+/* Sticky status of the instance: first error raised by a process call (they return void, as
+ * their CMSIS counterparts do), or SELENITE_RX_SUCCESS. */
+int  selenite_rx_status(const selenite_rx_instance *S);
+/* Human-readable text for the last error of this thread / instance (never NULL). */
+const char *selenite_rx_error_string(const selenite_rx_instance *S);
+
+/* ---- the per-block process call ------------------------------------------------------- */
+
+/* Host buffers, synchronous (copies in, runs the HIP path, copies out).  blockSize = complex
+ * input samples per channel in this call; it must be a non-zero multiple of cfg.block (several
+ * DSP blocks are processed back to back exactly as successive CMSIS calls would). */
+void selenite_rx_process_f32(selenite_rx_instance *S, const float *pSrcIQ,
+                             float *pDstAudio, uint32_t blockSize);
+
+/* Device buffers (HBM-resident), asynchronous on the instance's stream. */
+void selenite_rx_process_f32_device(selenite_rx_instance *S, const float *dSrcIQ,
+                                    float *dDstAudio, uint32_t blockSize);
+
+/* int16 wire format of the slot (dsp_if.c:286-289): q15 in, q15 out; conversion is fused into
+ * the kernels' load and store (arm_q15_to_float: /32768.0f; arm_float_to_q15: *32768.0f,
+ * truncate, saturate). */
+void selenite_rx_process_q15(selenite_rx_instance *S, const int16_t *pSrcIQ,
+                             int16_t *pDstAudio, uint32_t blockSize);
+void selenite_rx_process_q15_device(selenite_rx_instance *S, const int16_t *dSrcIQ,
+                                    int16_t *dDstAudio, uint32_t blockSize);
+
+/* Global-gain AGC (cfg.agc_global) split at the only cross-GPU exchange point:
+ *   phase 1 runs the chain up to the un-scaled audio and leaves, per DSP block of this call,
+ *           max|audio| over this instance's channels in dEnv[blockSize/cfg.block] (device);
+ *   the caller all-reduces dEnv with MAX across ranks (RCCL) -- or not, single GPU;
+ *   phase 2 runs the gain law on dEnv and scales dDstAudio in place.
+ * selenite_rx_process_f32_device() on an agc_global instance = phase 1 + phase 2. */
+void selenite_rx_global_phase1_device(selenite_rx_instance *S, const float *dSrcIQ,
+                                      float *dDstAudio, float *dEnv, uint32_t blockSize);
+void selenite_rx_global_phase2_device(selenite_rx_instance *S, float *dDstAudio,
+                                      const float *dEnv, uint32_t blockSize);
+
+/* ---- streams, state, memory ----------------------------------------------------------- */
+
+/* hipStream_t passed as void*; NULL = the library-owned stream created at init. */
+int  selenite_rx_set_stream(selenite_rx_instance *S, void *hip_stream);
+int  selenite_rx_sync(selenite_rx_instance *S);
+
+int  selenite_rx_get_state(selenite_rx_instance *S, const selenite_rx_state_view *dst);
+int  selenite_rx_set_state(selenite_rx_instance *S, const selenite_rx_state_view *src);
+int  selenite_rx_reset(selenite_rx_instance *S);      /* state back to the post-init values */
+
+void *selenite_rx_device_alloc(size_t bytes);          /* hipMalloc; NULL on failure */
+void  selenite_rx_device_free(void *dptr);
+int   selenite_rx_memcpy_h2d(void *dptr, const void *hptr, size_t bytes);
+int   selenite_rx_memcpy_d2h(void *hptr, const void *dptr, size_t bytes);
+int   selenite_rx_device_count(void);                  /* number of HIP devices, 0 if none */
+int   selenite_rx_set_device(int ordinal);             /* hipSetDevice for the calling thread */
+
+/* ---- measurement support (bench.py) -------------------------------------- */
+
+/* Synthetic I/Q of SURVEY.md 8d: per channel 3 complex tones + uniform noise, integer phase
+ * accumulators and table-lerp sin/cos only, so host and device produce identical bits.
+ * Fills iq[nch][nsamp][2] for channels first_channel .. first_channel+nch-1 and samples
+ * first_sample .. first_sample+nsamp-1. */
+void selenite_rx_synth_iq_host(float *iq, uint32_t first_channel, uint32_t nch,
+                               uint64_t first_sample, uint32_t nsamp, uint64_t seed);
+int  selenite_rx_synth_iq_device(selenite_rx_instance *S, float *dIQ, uint32_t first_channel,
+                                 uint32_t nch, uint64_t first_sample, uint32_t nsamp,
+                                 uint64_t seed);
+
+/* Runs `iters` back-to-back process_f32_device calls bracketed by HIP events recorded on the
+ * instance's stream; returns the mean milliseconds per call in *ms_per_call (state advances
+ * as in normal streaming).  This is the live per-launch duration bench.py reports. */
+int  selenite_rx_time_process_device(selenite_rx_instance *S, const float *dSrcIQ,
+                                     float *dDstAudio, uint32_t blockSize, uint32_t iters,
+                                     float *ms_per_call);
+
+/* Name of the kernel variant process_f32_device dispatches to for this instance
+ * (e.g. "rx_ssb_fused<256,4,63>" or "generic"); for logs and profiles. */
+const char *selenite_rx_kernel_name(const selenite_rx_instance *S);
+
+/* Algorithmic HBM bytes of one process call (SURVEY.md 8d formula):
+ *   channels * (8*blockSize + 4*blockSize/decim + S_in + S_out).
+ * read_bytes (optional) receives the read-only part 8*blockSize + S_in per channel. */
+uint64_t selenite_rx_algorithmic_bytes(const selenite_rx_config *cfg, uint32_t blockSize,
+                                       uint64_t *read_bytes);
+
+/* ---- coefficient design helpers (host only, double precision -> float) ------------------ */
+/* All write CMSIS coefficient order.  They are conveniences for callers and tests; the chain
+ * itself only ever sees the arrays in selenite_rx_config. */
+
+/* Hamming-windowed sinc low-pass, unity DC gain; cutoff as a fraction of the INPUT sample rate. */
+int selenite_rx_design_lowpass(float *coeffs, uint32_t num_taps, double cutoff);
+/* Hamming-windowed type-III Hilbert transformer (odd num_taps) and its matched delay
+ * (unit impulse at (num_taps-1)/2). */
+int selenite_rx_design_hilbert(float *hilb, float *delay, uint32_t num_taps);
+/* n_stages identical RBJ constant-peak band-pass sections centred on f0 (fraction of the
+ * sample rate) with quality factor q; coefficients in CMSIS sign convention (+a1, +a2). */
+int selenite_rx_design_bandpass(float *coeffs, uint32_t n_stages, double f0, double q);
+
+int selenite_rx_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SELENITE_RX_H */

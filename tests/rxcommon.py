@@ -1,0 +1,325 @@
+"""Shared test plumbing: ctypes views of include/selenite_rx.h, the oracle (oracle/librx_oracle.so)
+and -- in the build container only -- the real CMSIS-DSP composition (oracle/_ref/libcmsis_ref.so).
+
+TEST INFRASTRUCTURE.  Nothing here is imported by the product.
+"""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
+PKG_DIR = os.path.join(ROOT, "selenite-lite_amd")
+if PKG_DIR not in sys.path:
+    sys.path.insert(0, PKG_DIR)
+
+MODE_LSB, MODE_USB, MODE_CW, MODE_CWR, MODE_AM, MODE_FM, MODE_DIG, MODE_PKT = 0, 1, 2, 3, 4, 8, 0x0A, 0x0C
+ARITH_CMSIS, ARITH_FMA = 0, 1
+SUCCESS, ARGUMENT_ERROR, LENGTH_ERROR, DEVICE_ERROR = 0, -1, -2, -7
+SEED = 0x5E1E917E
+
+f32p = C.POINTER(C.c_float)
+u32p = C.POINTER(C.c_uint32)
+i16p = C.POINTER(C.c_int16)
+
+
+class Config(C.Structure):
+    """struct selenite_rx_config (include/selenite_rx.h)."""
+    _fields_ = [
+        ("struct_size", C.c_uint32), ("channels", C.c_uint32), ("block", C.c_uint32),
+        ("decim", C.c_uint32), ("nd_taps", C.c_uint32), ("nh_taps", C.c_uint32),
+        ("n_biquad", C.c_uint32), ("arith", C.c_uint32),
+        ("mode", C.c_uint8), ("nco_enable", C.c_uint8), ("agc_enable", C.c_uint8), ("agc_global", C.c_uint8),
+        ("nco_step_all", C.c_uint32),
+        ("dec_coeffs", f32p), ("hilb_coeffs", f32p), ("delay_coeffs", f32p), ("biquad_coeffs", f32p),
+        ("nco_step", u32p),
+        ("agc_target", C.c_float), ("agc_attack", C.c_float), ("agc_decay", C.c_float),
+        ("agc_gain_min", C.c_float), ("agc_gain_max", C.c_float), ("agc_env_floor", C.c_float),
+        ("agc_gain_init", C.c_float),
+    ]
+
+
+class StateView(C.Structure):
+    _fields_ = [("dec_state", f32p), ("fir_state", f32p), ("biq_state", f32p),
+                ("agc_gain", f32p), ("nco_phase", u32p)]
+
+
+def fptr(a):
+    return a.ctypes.data_as(f32p) if a is not None else None
+
+
+def as_f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+# ---------------------------------------------------------------------------------------------
+# coefficient design used by the tests (numpy, float64 -> float32).  The product ships the same
+# designs in C (selenite_rx_design_*); tests/test_design.py checks they agree.  Parity never
+# depends on this: the chain only sees the arrays.
+# ---------------------------------------------------------------------------------------------
+def design_lowpass(num_taps, cutoff):
+    n = np.arange(num_taps, dtype=np.float64)
+    m = n - (num_taps - 1) / 2.0
+    h = 2.0 * cutoff * np.sinc(2.0 * cutoff * m)
+    w = 0.54 - 0.46 * np.cos(2.0 * np.pi * n / (num_taps - 1))
+    h = h * w
+    h = h / h.sum()
+    return as_f32(h[::-1])          # CMSIS order {b[N-1]..b[0]}
+
+
+def design_hilbert(num_taps):
+    assert num_taps % 2 == 1
+    c = (num_taps - 1) // 2
+    n = np.arange(num_taps, dtype=np.float64)
+    m = n - c
+    h = np.zeros(num_taps, dtype=np.float64)
+    odd = (m.astype(np.int64) % 2) != 0
+    h[odd] = 2.0 / (np.pi * m[odd])
+    w = 0.54 - 0.46 * np.cos(2.0 * np.pi * n / (num_taps - 1))
+    h = h * w
+    d = np.zeros(num_taps, dtype=np.float64)
+    d[c] = 1.0
+    return as_f32(h[::-1]), as_f32(d[::-1])
+
+
+def design_bandpass(n_stages, f0, q):
+    w0 = 2.0 * np.pi * f0
+    alpha = np.sin(w0) / (2.0 * q)
+    a0 = 1.0 + alpha
+    b = np.array([alpha, 0.0, -alpha]) / a0
+    a1, a2 = -2.0 * np.cos(w0) / a0, (1.0 - alpha) / a0
+    one = np.array([b[0], b[1], b[2], -a1, -a2], dtype=np.float64)   # CMSIS adds the feedback
+    return as_f32(np.tile(one, n_stages))
+
+
+class ChainSpec:
+    """Python-side description of one instance; keeps the numpy arrays alive for ctypes."""
+
+    def __init__(self, channels, block, decim=1, nd_taps=0, nh_taps=0, n_biquad=0, mode=MODE_USB,
+                 arith=ARITH_CMSIS, nco=False, nco_step_all=0, nco_steps=None, agc=True,
+                 agc_global=False, dec_cutoff=None, bp_f0=500.0 / 48000.0, bp_q=4.0,
+                 agc_params=None):
+        self.channels, self.block, self.decim = channels, block, decim
+        self.nd_taps, self.nh_taps, self.n_biquad = nd_taps, nh_taps, n_biquad
+        self.mode, self.arith = mode, arith
+        self.nco, self.nco_step_all = nco, nco_step_all
+        self.nco_steps = None if nco_steps is None else np.ascontiguousarray(nco_steps, dtype=np.uint32)
+        self.agc, self.agc_global = agc, agc_global
+        if dec_cutoff is None:
+            dec_cutoff = 0.4 / decim
+        self.dec = design_lowpass(nd_taps, dec_cutoff) if nd_taps else None
+        self.hilb, self.delay = design_hilbert(nh_taps) if nh_taps else (None, None)
+        self.biq = design_bandpass(n_biquad, bp_f0, bp_q) if n_biquad else None
+        self.agc_params = dict(target=0.5, attack=0.5, decay=0.05, gain_min=1e-3, gain_max=1e4,
+                               env_floor=1e-6, gain_init=1.0)
+        if agc_params:
+            self.agc_params.update(agc_params)
+
+    def config(self):
+        g = Config()
+        g.struct_size = C.sizeof(Config)
+        g.channels, g.block, g.decim = self.channels, self.block, self.decim
+        g.nd_taps, g.nh_taps, g.n_biquad, g.arith = self.nd_taps, self.nh_taps, self.n_biquad, self.arith
+        g.mode, g.nco_enable = self.mode, int(self.nco)
+        g.agc_enable, g.agc_global = int(self.agc), int(self.agc_global)
+        g.nco_step_all = self.nco_step_all
+        g.dec_coeffs, g.hilb_coeffs = fptr(self.dec), fptr(self.hilb)
+        g.delay_coeffs, g.biquad_coeffs = fptr(self.delay), fptr(self.biq)
+        g.nco_step = self.nco_steps.ctypes.data_as(u32p) if self.nco_steps is not None else None
+        p = self.agc_params
+        g.agc_target, g.agc_attack, g.agc_decay = p["target"], p["attack"], p["decay"]
+        g.agc_gain_min, g.agc_gain_max = p["gain_min"], p["gain_max"]
+        g.agc_env_floor, g.agc_gain_init = p["env_floor"], p["gain_init"]
+        return g
+
+    def state_arrays(self):
+        c = self.channels
+        return dict(
+            dec_state=np.zeros((c, 2, max(self.nd_taps - 1, 0)), np.float32),
+            fir_state=np.zeros((c, 2, max(self.nh_taps - 1, 0)), np.float32),
+            biq_state=np.zeros((c, self.n_biquad, 4), np.float32),
+            agc_gain=np.zeros((c,), np.float32),
+            nco_phase=np.zeros((c,), np.uint32),
+        )
+
+    def out_len(self, block_size):
+        return block_size // self.decim
+
+
+def state_view(arrs):
+    v = StateView()
+    v.dec_state = fptr(arrs["dec_state"]) if arrs["dec_state"].size else None
+    v.fir_state = fptr(arrs["fir_state"]) if arrs["fir_state"].size else None
+    v.biq_state = fptr(arrs["biq_state"]) if arrs["biq_state"].size else None
+    v.agc_gain = fptr(arrs["agc_gain"])
+    v.nco_phase = arrs["nco_phase"].ctypes.data_as(u32p)
+    return v
+
+
+# ---------------------------------------------------------------------------------------------
+# oracle / reference libraries
+# ---------------------------------------------------------------------------------------------
+def build_oracle():
+    """(Re)build oracle/librx_oracle.so (gcc) and, where /root/reference exists, oracle/_ref."""
+    subprocess.run(["make", "-s", "-C", ORACLE_DIR], check=True,
+                   stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+
+
+_oracle = None
+_ref = None
+
+
+def oracle_lib():
+    global _oracle
+    if _oracle is None:
+        path = os.path.join(ORACLE_DIR, "librx_oracle.so")
+        src_m = max(os.path.getmtime(os.path.join(ORACLE_DIR, f)) for f in ("rx_oracle.c", "rx_oracle.h"))
+        if not os.path.exists(path) or os.path.getmtime(path) < src_m:
+            build_oracle()
+        L = C.CDLL(path)
+        L.orc_sin_table.restype = f32p
+        L.orc_sin_f32.restype = C.c_float
+        L.orc_sin_f32.argtypes = [C.c_float, C.c_int]
+        L.orc_cos_f32.restype = C.c_float
+        L.orc_cos_f32.argtypes = [C.c_float, C.c_int]
+        L.orc_agc_update.restype = C.c_float
+        L.orc_agc_update.argtypes = [C.POINTER(Config), C.c_float, C.c_float, C.c_int]
+        L.orc_rx_create.argtypes = [C.POINTER(C.c_void_p), C.POINTER(Config)]
+        L.orc_rx_destroy.argtypes = [C.c_void_p]
+        L.orc_rx_set_mode.argtypes = [C.c_void_p, C.c_uint8]
+        L.orc_rx_process_f32.argtypes = [C.c_void_p, f32p, f32p, C.c_uint32, C.c_int]
+        L.orc_rx_process_q15.argtypes = [C.c_void_p, i16p, i16p, C.c_uint32, C.c_int]
+        L.orc_rx_process_f32_env.argtypes = [C.c_void_p, f32p, f32p, C.c_uint32, f32p, f32p]
+        L.orc_rx_get_state.argtypes = [C.c_void_p, C.POINTER(StateView)]
+        L.orc_rx_set_state.argtypes = [C.c_void_p, C.POINTER(StateView)]
+        L.orc_synth_iq.argtypes = [f32p, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint64]
+        _oracle = L
+    return _oracle
+
+
+def ref_available():
+    return os.path.exists(os.path.join(ORACLE_DIR, "_ref", "libcmsis_ref.so"))
+
+
+def ref_lib():
+    """Real CMSIS-DSP 1.5.3 (+ composition harness).  Build container only."""
+    global _ref
+    if _ref is None:
+        L = C.CDLL(os.path.join(ORACLE_DIR, "_ref", "libcmsis_ref.so"))
+        L.ref_sin_table.restype = f32p
+        L.ref_rx_create.argtypes = [C.POINTER(C.c_void_p), C.POINTER(Config)]
+        L.ref_rx_destroy.argtypes = [C.c_void_p]
+        L.ref_rx_set_mode.argtypes = [C.c_void_p, C.c_uint8]
+        L.ref_rx_process_f32.argtypes = [C.c_void_p, f32p, f32p, C.c_uint32]
+        L.ref_rx_process_q15.argtypes = [C.c_void_p, i16p, i16p, C.c_uint32]
+        L.ref_rx_process_f32_env.argtypes = [C.c_void_p, f32p, f32p, C.c_uint32, f32p, f32p]
+        L.ref_rx_get_state.argtypes = [C.c_void_p, C.POINTER(StateView)]
+        L.ref_fir_decimate.argtypes = [f32p, C.c_uint32, C.c_uint32, f32p, f32p, f32p, C.c_uint32]
+        L.ref_fir.argtypes = [f32p, C.c_uint32, f32p, f32p, f32p, C.c_uint32]
+        L.ref_biquad.argtypes = [f32p, C.c_uint32, f32p, f32p, f32p, C.c_uint32]
+        L.ref_sin_cos.argtypes = [f32p, f32p, f32p, C.c_uint32]
+        L.ref_fir_decimate_init_status.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32]
+        _ref = L
+    return _ref
+
+
+def synth_iq(first_channel, nch, first_sample, nsamp, seed=SEED):
+    iq = np.empty((nch, nsamp, 2), np.float32)
+    oracle_lib().orc_synth_iq(fptr(iq), first_channel, nch, first_sample, nsamp, seed)
+    return iq
+
+
+class CpuChain:
+    """Oracle ('orc') or real-CMSIS composition ('ref') behind one Python face."""
+
+    def __init__(self, spec, which="orc"):
+        self.spec, self.which = spec, which
+        self.L = oracle_lib() if which == "orc" else ref_lib()
+        self.h = C.c_void_p()
+        self.cfg = spec.config()
+        self.rc = getattr(self.L, which + "_rx_create")(C.byref(self.h), C.byref(self.cfg))
+
+    def ok(self):
+        return self.rc == 0
+
+    def set_mode(self, mode):
+        return getattr(self.L, self.which + "_rx_set_mode")(self.h, mode)
+
+    def process(self, iq, nthreads=1):
+        iq = as_f32(iq)
+        c, bs = iq.shape[0], iq.shape[1]
+        out = np.empty((c, self.spec.out_len(bs)), np.float32)
+        if self.which == "orc":
+            self.L.orc_rx_process_f32(self.h, fptr(iq), fptr(out), bs, nthreads)
+        else:
+            self.L.ref_rx_process_f32(self.h, fptr(iq), fptr(out), bs)
+        return out
+
+    def process_env(self, iq, env_override=None):
+        iq = as_f32(iq)
+        c, bs = iq.shape[0], iq.shape[1]
+        out = np.empty((c, self.spec.out_len(bs)), np.float32)
+        env = np.empty((bs // self.spec.block,), np.float32)
+        fn = getattr(self.L, self.which + "_rx_process_f32_env")
+        fn(self.h, fptr(iq), fptr(out), bs, fptr(env_override) if env_override is not None else None, fptr(env))
+        return out, env
+
+    def process_q15(self, iq):
+        iq = np.ascontiguousarray(iq, dtype=np.int16)
+        c, bs = iq.shape[0], iq.shape[1]
+        out = np.empty((c, self.spec.out_len(bs)), np.int16)
+        if self.which == "orc":
+            self.L.orc_rx_process_q15(self.h, iq.ctypes.data_as(i16p), out.ctypes.data_as(i16p), bs, 1)
+        else:
+            self.L.ref_rx_process_q15(self.h, iq.ctypes.data_as(i16p), out.ctypes.data_as(i16p), bs)
+        return out
+
+    def state(self):
+        arrs = self.spec.state_arrays()
+        v = state_view(arrs)
+        getattr(self.L, self.which + "_rx_get_state")(self.h, C.byref(v))
+        return arrs
+
+    def close(self):
+        if self.h:
+            getattr(self.L, self.which + "_rx_destroy")(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def bits_equal(a, b):
+    """Bit-for-bit equality of float32 arrays, +0/-0 and NaN payloads included."""
+    a = np.ascontiguousarray(a, np.float32)
+    b = np.ascontiguousarray(b, np.float32)
+    return a.shape == b.shape and np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+def rel_err(got, ref):
+    """SURVEY.md 8d parity metric: max|got-ref| / max(|ref|_inf, 1e-30)."""
+    got = np.asarray(got, np.float64)
+    ref = np.asarray(ref, np.float64)
+    return float(np.max(np.abs(got - ref)) / max(float(np.max(np.abs(ref))), 1e-30))
+
+
+# named BASELINE.json configurations (scaled by the caller through `channels` / block_size)
+def baseline_spec(name, channels, arith=ARITH_CMSIS, **kw):
+    if name == "cfg1":   # single 256-sample block, USB, 63-tap Hilbert + AGC
+        return ChainSpec(channels, 256, 1, 0, 63, 0, MODE_USB, arith, agc=True, **kw)
+    if name == "cfg2":   # 127-tap Hilbert SSB + AGC @48k
+        return ChainSpec(channels, 256, 1, 0, 127, 0, MODE_USB, arith, agc=True, **kw)
+    if name == "cfg3":   # NCO + 256-tap /4 + 63-tap SSB + AGC  (the headline config)
+        return ChainSpec(channels, 256, 4, 256, 63, 0, MODE_USB, arith, nco=True,
+                         nco_step_all=0x01000000, agc=True, **kw)
+    if name == "cfg4":   # CW narrow: NCO (BFO) + 4-stage biquad @500 Hz + AGC
+        return ChainSpec(channels, 256, 1, 0, 0, 4, MODE_CW, arith, nco=True,
+                         nco_step_all=0x00800000, agc=True, **kw)
+    raise KeyError(name)
