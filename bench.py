@@ -1,0 +1,231 @@
+#!/usr/bin/env python3
+"""bench.py -- Msamples/s of complex I/Q through the full Selenite RX chain on MI355X.
+
+One "step" = one selenite_rx_process_f32_device() call over the whole resident batch
+(channels x block_size complex samples per GPU).  Inputs are generated on the device by the
+library's synthetic generator and are resident in HBM before the timed region starts.
+
+    python bench.py --gpus 1 --steps K --warmup W            # single GPU
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+Multi-GPU: channels shard across ranks with NO data-path collective (independent channels,
+SURVEY.md 8e) -> weak scaling, channels per GPU fixed.  The only exchange the chain can have is the
+optional global-gain AGC (--global-gain): 4 bytes per DSP block all-reduced with MAX over RCCL.
+
+Rank 0 prints ONE JSON line (see the driver contract in the task statement) carrying `roofline`
+and, at N=1, `cpu_baseline` (the oracle -- a bit-exact CPU restatement of the CMSIS-DSP chain --
+timed on this box's host cores on a bounded sample of the same workload).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "selenite-lite_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+F32_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: f32 vector (= f32 MFMA) peak
+SEED = 0x5E1E917E
+
+WORKLOADS = {
+    # name: (baseline config, channels per GPU, block_size per call)
+    "cfg3": ("cfg3", 65536, 4096),     # headline: NCO + 256-tap /4 + 63-tap SSB + AGC
+    "cfg2": ("cfg2", 4096, 48000 - 48000 % 256),
+    "cfg4": ("cfg4", 65536, 4096),
+    "cfg5": ("cfg2", 131072, 1024),    # weak-scaling shape of BASELINE cfg5 (cfg2 chain)
+}
+
+
+def flops_per_sample(spec):
+    """SURVEY.md 8d algorithmic flops per complex input sample."""
+    f = 0.0
+    if spec.nd_taps:
+        f += 2.0 * 2.0 * spec.nd_taps / spec.decim
+    if spec.nh_taps:
+        f += 2.0 * spec.nh_taps / spec.decim
+    if spec.nco:
+        f += 20.0
+    if spec.n_biquad:
+        f += 9.0 * spec.n_biquad / spec.decim
+    return f
+
+
+def cpu_baseline(name, arith, budget_s=12.0):
+    """Oracle (kind 'port') on the host cores, bounded sample of the same workload."""
+    import numpy as np
+    import rxcommon as rc
+    cores = min(os.cpu_count() or 1, 64)
+    cfg_name, _, bs = WORKLOADS[name]
+    bs = min(bs, 4096)
+    channels = 32 * cores
+    spec = rc.baseline_spec(cfg_name, channels, arith)
+    iq = rc.synth_iq(0, channels, 0, bs, SEED)
+    chain = rc.CpuChain(spec, "orc")
+    chain.process(iq, nthreads=cores)          # warm-up (page in, threads)
+    calls, t0 = 0, time.perf_counter()
+    while True:
+        chain.process(iq, nthreads=cores)
+        calls += 1
+        el = time.perf_counter() - t0
+        if el >= budget_s or calls >= 1000:
+            break
+    value = channels * bs * calls / el / 1e6
+    model = ""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {"value": round(value, 3), "unit": "Msamples/s", "cores": cores, "kind": "port",
+            "sample": "%d channels x %d samples x %d calls, %s chain, oracle/rx_oracle.c "
+                      "(bit-exact vs CMSIS-DSP 1.5.3), gcc -O2 -ffp-contract=off, %d pthreads; cpu=%s"
+                      % (channels, bs, calls, cfg_name, cores, model),
+            "seconds": round(el, 2)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
+    ap.add_argument("--channels", type=int, default=0, help="channels per GPU (default: workload's)")
+    ap.add_argument("--block-size", type=int, default=0)
+    ap.add_argument("--arith", default=os.environ.get("SELENITE_BENCH_ARITH", "cmsis"), choices=["cmsis", "fma"])
+    ap.add_argument("--global-gain", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"])
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    n_gpus = args.gpus
+    dist = None
+    torch = None
+    if world > 1:
+        # torch FIRST: its bundled libamdhip64 (same soname) then serves libselenite_rx.so too, so
+        # the process holds exactly one HIP runtime.
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend=args.dist_backend, rank=rank, world_size=world)
+    elif args.global_gain:
+        import torch
+
+    import numpy as np
+    import rxcommon as rc
+    import selenite_rx as sr
+
+    arith = rc.ARITH_FMA if args.arith == "fma" else rc.ARITH_CMSIS
+    cfg_name, channels, bs = WORKLOADS[args.workload]
+    channels = args.channels or channels
+    bs = args.block_size or bs
+    sr.lib().selenite_rx_set_device(local_rank)
+    spec = rc.baseline_spec(cfg_name, channels, arith, agc_global=args.global_gain)
+    rx = sr.Rx(spec.config())
+    nout = bs // spec.decim
+
+    d_in = sr.DeviceBuffer(channels * bs * 8)
+    d_out = sr.DeviceBuffer(channels * nout * 4)
+    rx.synth_device(d_in.ptr, rank * channels, channels, 0, bs, SEED)
+    rx.sync()
+
+    def barrier():
+        rx.sync()
+        if dist is not None:
+            if args.dist_backend == "nccl":
+                torch.cuda.synchronize()
+            dist.barrier()
+
+    env_t = None
+    if args.global_gain:
+        env_t = torch.zeros(bs // spec.block, dtype=torch.float32, device="cuda:%d" % local_rank)
+
+    def step():
+        if args.global_gain:
+            rx.global_phase1(d_in.ptr, d_out.ptr, env_t.data_ptr(), bs)
+            rx.sync()
+            if dist is not None:
+                dist.all_reduce(env_t, op=dist.ReduceOp.MAX)     # RCCL over xGMI: 4 B per DSP block
+                torch.cuda.synchronize()
+            rx.global_phase2(d_out.ptr, env_t.data_ptr(), bs)
+        else:
+            rx.process_device(d_in.ptr, d_out.ptr, bs)
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    if args.global_gain:
+        for _ in range(args.steps):
+            step()
+        ev_ms = None
+    else:
+        # the K timed steps are issued by the library between two HIP events recorded on the
+        # stream the kernels run on; the wall clock brackets the same region
+        ev_ms = rx.time_process(d_in.ptr, d_out.ptr, bs, args.steps)
+    barrier()
+    t1 = time.perf_counter()
+    rx.check()
+    elapsed = t1 - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64,
+                         device=("cuda:%d" % local_rank) if args.dist_backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        ms_per_step = elapsed * 1e3 / args.steps
+        total_samples = float(world) * channels * bs * args.steps
+        value = total_samples / elapsed / 1e6
+        alg_bytes, rd_bytes = rx.algorithmic_bytes(bs)
+        k_ms = ev_ms if ev_ms is not None else ms_per_step
+        achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+        fl = flops_per_sample(spec) * channels * bs
+        out = {
+            "metric": "Msamples/s complex I/Q through full RX chain (whole job)",
+            "value": round(value, 2), "unit": "Msamples/s", "n_gpus": n_gpus, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%s: %d channels/GPU x %d complex samples/call, %s" % (
+                           args.workload, channels, bs,
+                           {"cfg3": "NCO + 256-tap arm_fir_decimate/4 + 63-tap Hilbert SSB (USB) + AGC",
+                            "cfg2": "127-tap Hilbert SSB (USB) + AGC",
+                            "cfg4": "CW: NCO + 4-stage DF1 biquad @500 Hz + AGC",
+                            "cfg5": "127-tap Hilbert SSB (USB) + AGC, cfg5 weak-scaling shape"}[args.workload]),
+                       "arith": "cmsis-exact (mul,add)" if arith == rc.ARITH_CMSIS else "fma (<=1e-5 rel vs CMSIS)",
+                       "kernel": rx.kernel_name(), "agc": "global" if args.global_gain else "per-channel",
+                       "parallelism": "channels sharded x%d, no data-path collective" % world},
+            "per_gpu_msamples_s": round(value / world, 2),
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "algorithmic_bytes_per_launch": alg_bytes, "read_bytes_per_launch": rd_bytes,
+                         "read_frac": round(rd_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                         "launch_ms_hip_events": round(k_ms, 4)},
+            "fma_roof": {"achieved": round(fl / (k_ms * 1e-3) / 1e12, 2), "peak": F32_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": round(fl / (k_ms * 1e-3) / 1e12 / F32_PEAK_TFLOPS, 4),
+                         "flops_per_sample": flops_per_sample(spec)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.workload, arith)
+        print(json.dumps(out), flush=True)
+
+    rx.close()
+    d_in.free()
+    d_out.free()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

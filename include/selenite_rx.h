@@ -61,8 +61,9 @@ extern "C" {
 
 /* Arithmetic contract of the MAC loops (DESIGN.md "Arithmetic modes"). */
 #define SELENITE_ARITH_CMSIS 0   /* product rounded, then sum rounded: bit-exact vs CMSIS-DSP 1.5.3 C code */
-#define SELENITE_ARITH_FMA   1   /* same operation order, each multiply-add fused (fmaf): bit-exact vs the
-                                    oracle's fmaf restatement, <=1e-5 relative vs CMSIS */
+#define SELENITE_ARITH_FMA   1   /* same operation order, the multiply-add of the FIR tap loops fused (fmaf);
+                                    NCO, biquad recurrence and AGC keep the reference rounding.  Bit-exact
+                                    vs the oracle's fmaf restatement, <=1e-5 relative vs CMSIS */
 
 typedef struct selenite_rx_config {
     uint32_t struct_size;     /* = sizeof(selenite_rx_config) */

@@ -1,0 +1,551 @@
+// rx_api.hip -- the C-ABI of include/selenite_rx.h over the HIP kernels.
+//
+// Host side of the drop-in boundary: mirrors the CMSIS-DSP init/process convention
+// (arm_fir_decimate_init_f32.c:63-101 validation and state clearing; process calls return void)
+// and the firmware's DSP_Set_Mode hook (Core/Src/dsp_if.c:367-370).  No CPU compute path exists
+// here: without a usable HIP device init fails with SELENITE_RX_DEVICE_ERROR.
+#include "rx_internal.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+
+using namespace srx;
+
+static thread_local std::string g_last_error = "";
+
+static int fail(selenite_rx_instance *S, int code, const std::string &msg)
+{
+    g_last_error = msg;
+    if (S) {
+        if (S->status == SELENITE_RX_SUCCESS) S->status = code;
+        S->err = msg;
+    }
+    return code;
+}
+#define HIPCHK(S, call)                                                                     \
+    do {                                                                                    \
+        hipError_t e_ = (call);                                                             \
+        if (e_ != hipSuccess)                                                               \
+            return fail((S), SELENITE_RX_DEVICE_ERROR,                                      \
+                        std::string(#call) + ": " + hipGetErrorString(e_));                 \
+    } while (0)
+
+// sinTable_f32[513] (CommonTables/arm_common_tables.c:21895) regenerated from the generator the
+// reference documents (:21881-21891): the source holds every entry as an 8-decimal literal, so
+// entry n = float("%.8f" % sin(2*pi*n/512)), sign of the (tiny negative) last entry included.
+const float *srx::host_sin_table()
+{
+    static float table[513];
+    static std::once_flag once;
+    std::call_once(once, [] {
+        for (int n = 0; n <= 512; ++n) {
+            const double s = std::sin(2.0 * 3.14159265358979323846 * (double)n / 512.0);
+            char buf[32];
+            std::snprintf(buf, sizeof buf, "%.8f", s);
+            table[n] = std::strtof(buf, nullptr);
+        }
+    });
+    return table;
+}
+
+static bool mode_valid(uint8_t m)
+{
+    return m == SELENITE_MODE_LSB || m == SELENITE_MODE_USB || m == SELENITE_MODE_CW ||
+           m == SELENITE_MODE_CWR || m == SELENITE_MODE_AM || m == SELENITE_MODE_DIG ||
+           m == SELENITE_MODE_PKT;
+}
+
+template <typename T>
+static hipError_t dev_upload(T **d, const T *h, size_t n)
+{
+    *d = nullptr;
+    if (n == 0) return hipSuccess;
+    hipError_t e = hipMalloc((void **)d, n * sizeof(T));
+    if (e != hipSuccess) return e;
+    return hipMemcpy(*d, h, n * sizeof(T), hipMemcpyHostToDevice);
+}
+template <typename T>
+static hipError_t dev_zero(T **d, size_t n)
+{
+    *d = nullptr;
+    if (n == 0) return hipSuccess;
+    hipError_t e = hipMalloc((void **)d, n * sizeof(T));
+    if (e != hipSuccess) return e;
+    return hipMemset(*d, 0, n * sizeof(T));
+}
+
+static void classify_coeffs(selenite_rx_instance *S)
+{
+    const uint32_t nh = S->cfg.nh_taps;
+    S->delay_is_impulse = false;
+    S->hilb_odd_only = false;
+    if (!nh) return;
+    // delay FIR that is exactly a unit impulse: arm_fir_f32 then returns x + 0.0f
+    int ones = 0, idx = -1;
+    bool rest_zero = true;
+    for (uint32_t k = 0; k < nh; ++k) {
+        const float v = S->h_delay[k];
+        if (v == 1.0f) { ++ones; idx = (int)k; }
+        else if (!(v == 0.0f && !std::signbit(v))) rest_zero = false;
+    }
+    if (ones == 1 && rest_zero) { S->delay_is_impulse = true; S->delay_index = idx; }
+    // type-III Hilbert: taps at even distance from the centre are exactly +0.0f
+    if (nh % 2 == 1) {
+        const int c = (int)(nh - 1) / 2;
+        bool ok = true;
+        for (uint32_t k = 0; k < nh && ok; ++k)
+            if ((((int)k - c) & 1) == 0) {
+                const float v = S->h_hilb[k];
+                if (!(v == 0.0f && !std::signbit(v))) ok = false;
+            }
+        S->hilb_odd_only = ok;
+    }
+}
+
+static void free_device(selenite_rx_instance *S)
+{
+    void *ptrs[] = { S->d_dec_c, S->d_hilb_c, S->d_delay_c, S->d_biq_c, S->d_sintab, S->d_step, S->d_phase,
+                     S->d_dec_state, S->d_fir_state, S->d_biq_state, S->d_gain, S->d_scratch, S->d_env,
+                     S->d_io_in, S->d_io_out };
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    if (S->own_stream) (void)hipStreamDestroy(S->own_stream);
+}
+
+static int reset_state(selenite_rx_instance *S)
+{
+    const selenite_rx_config &g = S->cfg;
+    const size_t C = g.channels;
+    if (g.nd_taps > 1) HIPCHK(S, hipMemsetAsync(S->d_dec_state, 0, C * 2 * (g.nd_taps - 1) * sizeof(float), S->stream));
+    if (g.nh_taps > 1) HIPCHK(S, hipMemsetAsync(S->d_fir_state, 0, C * 2 * (g.nh_taps - 1) * sizeof(float), S->stream));
+    if (g.n_biquad) HIPCHK(S, hipMemsetAsync(S->d_biq_state, 0, C * 4 * g.n_biquad * sizeof(float), S->stream));
+    HIPCHK(S, hipMemsetAsync(S->d_phase, 0, C * sizeof(uint32_t), S->stream));
+    std::vector<float> gi(C, g.agc_gain_init);
+    HIPCHK(S, hipMemcpyAsync(S->d_gain, gi.data(), C * sizeof(float), hipMemcpyHostToDevice, S->stream));
+    HIPCHK(S, hipStreamSynchronize(S->stream));
+    return SELENITE_RX_SUCCESS;
+}
+
+extern "C" int selenite_rx_abi_version(void) { return SELENITE_RX_ABI_VERSION; }
+
+extern "C" int selenite_rx_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" int selenite_rx_set_device(int ordinal)
+{
+    HIPCHK(nullptr, hipSetDevice(ordinal));
+    return SELENITE_RX_SUCCESS;
+}
+
+extern "C" int selenite_rx_init(selenite_rx_instance **out, const selenite_rx_config *cfg)
+{
+    if (!out) return fail(nullptr, SELENITE_RX_ARGUMENT_ERROR, "selenite_rx_init: S is NULL");
+    *out = nullptr;
+    if (!cfg || cfg->struct_size != sizeof(selenite_rx_config))
+        return fail(nullptr, SELENITE_RX_ARGUMENT_ERROR, "selenite_rx_init: bad config / struct_size");
+    if (cfg->channels == 0 || cfg->block == 0 || cfg->decim == 0)
+        return fail(nullptr, SELENITE_RX_ARGUMENT_ERROR, "selenite_rx_init: channels, block, decim must be non-zero");
+    if (!mode_valid(cfg->mode))
+        return fail(nullptr, SELENITE_RX_ARGUMENT_ERROR, "selenite_rx_init: unsupported mode (FM is not demodulated)");
+    if (cfg->arith != SELENITE_ARITH_CMSIS && cfg->arith != SELENITE_ARITH_FMA)
+        return fail(nullptr, SELENITE_RX_ARGUMENT_ERROR, "selenite_rx_init: bad arith");
+    if (cfg->nd_taps == 0 && cfg->decim != 1)
+        return fail(nullptr, SELENITE_RX_ARGUMENT_ERROR, "selenite_rx_init: decim > 1 needs a decimator (nd_taps)");
+    if (cfg->nd_taps && !cfg->dec_coeffs)
+        return fail(nullptr, SELENITE_RX_ARGUMENT_ERROR, "selenite_rx_init: dec_coeffs is NULL");
+    if (cfg->nh_taps && (!cfg->hilb_coeffs || !cfg->delay_coeffs))
+        return fail(nullptr, SELENITE_RX_ARGUMENT_ERROR, "selenite_rx_init: hilb_coeffs / delay_coeffs is NULL");
+    if (cfg->n_biquad && !cfg->biquad_coeffs)
+        return fail(nullptr, SELENITE_RX_ARGUMENT_ERROR, "selenite_rx_init: biquad_coeffs is NULL");
+    if (cfg->nd_taps > 65535 || cfg->nh_taps > 65535 || cfg->decim > 255)   // CMSIS field widths
+        return fail(nullptr, SELENITE_RX_ARGUMENT_ERROR, "selenite_rx_init: taps > 65535 or decim > 255");
+    // arm_fir_decimate_init_f32.c:74-97
+    if (cfg->block % cfg->decim != 0)
+        return fail(nullptr, SELENITE_RX_LENGTH_ERROR, "selenite_rx_init: block is not a multiple of decim");
+
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(nullptr, SELENITE_RX_DEVICE_ERROR,
+                    "selenite_rx_init: no HIP device (this library has no CPU fallback)");
+
+    selenite_rx_instance *S = new selenite_rx_instance();
+    S->cfg = *cfg;
+    const size_t C = cfg->channels;
+    if (cfg->nd_taps) S->h_dec.assign(cfg->dec_coeffs, cfg->dec_coeffs + cfg->nd_taps);
+    if (cfg->nh_taps) {
+        S->h_hilb.assign(cfg->hilb_coeffs, cfg->hilb_coeffs + cfg->nh_taps);
+        S->h_delay.assign(cfg->delay_coeffs, cfg->delay_coeffs + cfg->nh_taps);
+    }
+    if (cfg->n_biquad) S->h_biq.assign(cfg->biquad_coeffs, cfg->biquad_coeffs + 5 * cfg->n_biquad);
+    S->h_step.resize(C);
+    for (size_t c = 0; c < C; ++c) S->h_step[c] = cfg->nco_step ? cfg->nco_step[c] : cfg->nco_step_all;
+    S->cfg.dec_coeffs = S->h_dec.data(); S->cfg.hilb_coeffs = S->h_hilb.data();
+    S->cfg.delay_coeffs = S->h_delay.data(); S->cfg.biquad_coeffs = S->h_biq.data();
+    S->cfg.nco_step = S->h_step.data();
+    const char *fg = std::getenv("SELENITE_RX_FORCE_GENERIC");
+    S->force_generic = (fg && fg[0] == '1') ? 1 : 0;
+
+#define INITCHK(call)                                                                        \
+    do {                                                                                     \
+        hipError_t e_ = (call);                                                              \
+        if (e_ != hipSuccess) {                                                              \
+            int rc_ = fail(nullptr, SELENITE_RX_DEVICE_ERROR,                                \
+                           std::string("selenite_rx_init: " #call ": ") + hipGetErrorString(e_)); \
+            free_device(S);                                                                  \
+            delete S;                                                                        \
+            return rc_;                                                                      \
+        }                                                                                    \
+    } while (0)
+
+    INITCHK(hipGetDevice(&S->device));
+    INITCHK(hipStreamCreateWithFlags(&S->own_stream, hipStreamNonBlocking));
+    S->stream = S->own_stream;
+    INITCHK(dev_upload(&S->d_dec_c, S->h_dec.data(), S->h_dec.size()));
+    INITCHK(dev_upload(&S->d_hilb_c, S->h_hilb.data(), S->h_hilb.size()));
+    INITCHK(dev_upload(&S->d_delay_c, S->h_delay.data(), S->h_delay.size()));
+    INITCHK(dev_upload(&S->d_biq_c, S->h_biq.data(), S->h_biq.size()));
+    INITCHK(dev_upload(&S->d_sintab, host_sin_table(), (size_t)513));
+    INITCHK(dev_upload(&S->d_step, S->h_step.data(), C));
+    INITCHK(dev_zero(&S->d_phase, C));
+    INITCHK(dev_zero(&S->d_dec_state, cfg->nd_taps > 1 ? C * 2 * (cfg->nd_taps - 1) : 0));
+    INITCHK(dev_zero(&S->d_fir_state, cfg->nh_taps > 1 ? C * 2 * (cfg->nh_taps - 1) : 0));
+    INITCHK(dev_zero(&S->d_biq_state, C * 4 * cfg->n_biquad));
+    INITCHK(dev_zero(&S->d_gain, C));
+#undef INITCHK
+    classify_coeffs(S);
+    S->plan = plan_fused(S->cfg, S->delay_is_impulse, S->delay_index, S->hilb_odd_only);
+    int rc = reset_state(S);
+    if (rc != SELENITE_RX_SUCCESS) { free_device(S); delete S; return rc; }
+    *out = S;
+    return SELENITE_RX_SUCCESS;
+}
+
+extern "C" void selenite_rx_free(selenite_rx_instance *S)
+{
+    if (!S) return;
+    (void)hipSetDevice(S->device);
+    if (S->stream) (void)hipStreamSynchronize(S->stream);
+    free_device(S);
+    delete S;
+}
+
+extern "C" int selenite_rx_set_mode(selenite_rx_instance *S, uint8_t mode)
+{
+    if (!S) return fail(nullptr, SELENITE_RX_ARGUMENT_ERROR, "selenite_rx_set_mode: S is NULL");
+    if (!mode_valid(mode)) {
+        g_last_error = "selenite_rx_set_mode: unsupported mode";
+        return SELENITE_RX_ARGUMENT_ERROR;          // instance stays usable in its old mode
+    }
+    S->cfg.mode = mode;
+    S->plan = plan_fused(S->cfg, S->delay_is_impulse, S->delay_index, S->hilb_odd_only);
+    return SELENITE_RX_SUCCESS;
+}
+
+extern "C" int selenite_rx_status(const selenite_rx_instance *S) { return S ? S->status : SELENITE_RX_ARGUMENT_ERROR; }
+extern "C" const char *selenite_rx_error_string(const selenite_rx_instance *S)
+{
+    return S ? S->err.c_str() : g_last_error.c_str();
+}
+extern "C" const char *selenite_rx_kernel_name(const selenite_rx_instance *S)
+{
+    if (!S) return "";
+    return (S->force_generic || S->plan.kind == 0) ? "generic" : S->plan.name;
+}
+
+extern "C" int selenite_rx_set_stream(selenite_rx_instance *S, void *hip_stream)
+{
+    if (!S) return SELENITE_RX_ARGUMENT_ERROR;
+    S->stream = hip_stream ? (hipStream_t)hip_stream : S->own_stream;
+    return SELENITE_RX_SUCCESS;
+}
+
+extern "C" int selenite_rx_sync(selenite_rx_instance *S)
+{
+    if (!S) return SELENITE_RX_ARGUMENT_ERROR;
+    HIPCHK(S, hipStreamSynchronize(S->stream));
+    return S->status;
+}
+
+extern "C" int selenite_rx_reset(selenite_rx_instance *S)
+{
+    if (!S) return SELENITE_RX_ARGUMENT_ERROR;
+    return reset_state(S);
+}
+
+// ------------------------------------------------------------------------------------------
+static RxParams make_params(selenite_rx_instance *S, uint32_t block_size)
+{
+    const selenite_rx_config &g = S->cfg;
+    RxParams p{};
+    p.channels = g.channels; p.block = g.block; p.decim = g.decim;
+    p.nd = g.nd_taps; p.nh = g.nh_taps; p.nbiq = g.n_biquad; p.mode = g.mode;
+    p.nco = g.nco_enable ? 1 : 0; p.agc = g.agc_enable ? 1 : 0;
+    p.block_size = block_size; p.nout = block_size / g.decim;
+    p.dec_c = S->d_dec_c; p.hilb_c = S->d_hilb_c; p.delay_c = S->d_delay_c; p.biq_c = S->d_biq_c;
+    p.sintab = S->d_sintab; p.step = S->d_step; p.phase = S->d_phase;
+    p.dec_state = S->d_dec_state; p.fir_state = S->d_fir_state; p.biq_state = S->d_biq_state;
+    p.gain = S->d_gain;
+    p.agcp = AgcParams{ g.agc_target, g.agc_attack, g.agc_decay, g.agc_gain_min, g.agc_gain_max, g.agc_env_floor };
+    // generic front kernel: largest pass (<= 256 outputs) whose LDS image fits 64 KiB
+    uint32_t P = 256;
+    for (;;) {
+        p.pass_out = P;
+        if (front_generic_lds_bytes(p) <= 64 * 1024 || P == 1) break;
+        P >>= 1;
+    }
+    return p;
+}
+
+static int ensure(selenite_rx_instance *S, void **buf, size_t *cap, size_t need)
+{
+    if (*cap >= need) return SELENITE_RX_SUCCESS;
+    if (*buf) { HIPCHK(S, hipStreamSynchronize(S->stream)); HIPCHK(S, hipFree(*buf)); *buf = nullptr; *cap = 0; }
+    HIPCHK(S, hipMalloc(buf, need));
+    *cap = need;
+    return SELENITE_RX_SUCCESS;
+}
+
+static bool block_size_ok(selenite_rx_instance *S, uint32_t block_size, const char *who)
+{
+    if (block_size == 0 || block_size % S->cfg.block != 0) {
+        fail(S, SELENITE_RX_LENGTH_ERROR, std::string(who) + ": blockSize is not a non-zero multiple of cfg.block");
+        return false;
+    }
+    return true;
+}
+
+enum Phase { kAll, kPhase1, kPhase2 };
+
+// The one dispatcher behind every process entry point.
+static int run_chain(selenite_rx_instance *S, const void *src, bool src_q15, void *dst, bool dst_q15,
+                     uint32_t block_size, Phase phase, float *ext_env)
+{
+    const selenite_rx_config &g = S->cfg;
+    HIPCHK(S, hipSetDevice(S->device));
+    RxParams p = make_params(S, block_size);
+    if (front_generic_lds_bytes(p) > 64 * 1024 && (S->force_generic || S->plan.kind == 0))
+        return fail(S, SELENITE_RX_LENGTH_ERROR, "filter lengths exceed the LDS budget of the generic kernel");
+    const int arith = (int)g.arith;
+    const bool global = g.agc_enable && g.agc_global;
+    const bool cw = mode_is_cw(g.mode) && g.n_biquad;
+    hipStream_t st = S->stream;
+
+    if (phase != kPhase2 && !global && !S->force_generic && S->plan.kind != 0) {
+        HIPCHK(S, launch_fused(S->plan, p, arith, src, src_q15, dst, dst_q15, S->delay_index, st));
+        return SELENITE_RX_SUCCESS;
+    }
+
+    // generic path: front -> [biquad] -> AGC / convert.  Un-scaled audio lives in dst itself when
+    // dst is f32, else in the scratch buffer.
+    float *audio = (float *)dst;
+    if (dst_q15) {
+        const size_t need = (size_t)g.channels * p.nout * sizeof(float);
+        int rc = ensure(S, (void **)&S->d_scratch, &S->scratch_bytes, need);
+        if (rc) return rc;
+        audio = S->d_scratch;
+    }
+    if (phase != kPhase2) {
+        HIPCHK(S, launch_front_generic(p, arith, src, src_q15, audio, st));
+        if (cw) HIPCHK(S, launch_biquad_generic(p, arith, audio, st));
+    }
+    if (global) {
+        float *env = ext_env;
+        if (!env) {
+            const size_t need = sizeof(float) * (block_size / g.block);
+            int rc = ensure(S, (void **)&S->d_env, &S->env_cap, need);
+            if (rc) return rc;
+            env = S->d_env;
+        }
+        if (phase != kPhase2) HIPCHK(S, launch_env_global(p, audio, env, st));
+        if (phase != kPhase1) HIPCHK(S, launch_agc_apply_global(p, arith, audio, env, dst, dst_q15, st));
+    } else if (g.agc_enable || dst_q15) {
+        HIPCHK(S, launch_agc_generic(p, arith, audio, dst, dst_q15, st));
+    }
+    return SELENITE_RX_SUCCESS;
+}
+
+extern "C" void selenite_rx_process_f32_device(selenite_rx_instance *S, const float *dSrcIQ,
+                                               float *dDstAudio, uint32_t blockSize)
+{
+    if (!S || !block_size_ok(S, blockSize, "selenite_rx_process_f32_device")) return;
+    run_chain(S, dSrcIQ, false, dDstAudio, false, blockSize, kAll, nullptr);
+}
+
+extern "C" void selenite_rx_process_q15_device(selenite_rx_instance *S, const int16_t *dSrcIQ,
+                                               int16_t *dDstAudio, uint32_t blockSize)
+{
+    if (!S || !block_size_ok(S, blockSize, "selenite_rx_process_q15_device")) return;
+    run_chain(S, dSrcIQ, true, dDstAudio, true, blockSize, kAll, nullptr);
+}
+
+extern "C" void selenite_rx_global_phase1_device(selenite_rx_instance *S, const float *dSrcIQ,
+                                                 float *dDstAudio, float *dEnv, uint32_t blockSize)
+{
+    if (!S || !block_size_ok(S, blockSize, "selenite_rx_global_phase1_device")) return;
+    if (!(S->cfg.agc_enable && S->cfg.agc_global)) {
+        fail(S, SELENITE_RX_ARGUMENT_ERROR, "selenite_rx_global_phase1_device: instance is not agc_global");
+        return;
+    }
+    run_chain(S, dSrcIQ, false, dDstAudio, false, blockSize, kPhase1, dEnv);
+}
+
+extern "C" void selenite_rx_global_phase2_device(selenite_rx_instance *S, float *dDstAudio,
+                                                 const float *dEnv, uint32_t blockSize)
+{
+    if (!S || !block_size_ok(S, blockSize, "selenite_rx_global_phase2_device")) return;
+    if (!(S->cfg.agc_enable && S->cfg.agc_global)) {
+        fail(S, SELENITE_RX_ARGUMENT_ERROR, "selenite_rx_global_phase2_device: instance is not agc_global");
+        return;
+    }
+    run_chain(S, nullptr, false, dDstAudio, false, blockSize, kPhase2, const_cast<float *>(dEnv));
+}
+
+static void process_host(selenite_rx_instance *S, const void *src, void *dst, uint32_t block_size, bool q15,
+                         const char *who)
+{
+    if (!S || !block_size_ok(S, block_size, who)) return;
+    const selenite_rx_config &g = S->cfg;
+    const size_t esz = q15 ? sizeof(int16_t) : sizeof(float);
+    const size_t nin = (size_t)g.channels * block_size * 2 * esz;
+    const size_t nout = (size_t)g.channels * (block_size / g.decim) * esz;
+    if (hipSetDevice(S->device) != hipSuccess) { fail(S, SELENITE_RX_DEVICE_ERROR, "hipSetDevice"); return; }
+    if (ensure(S, &S->d_io_in, &S->io_in_bytes, nin)) return;
+    if (ensure(S, &S->d_io_out, &S->io_out_bytes, nout)) return;
+    if (hipMemcpyAsync(S->d_io_in, src, nin, hipMemcpyHostToDevice, S->stream) != hipSuccess) {
+        fail(S, SELENITE_RX_DEVICE_ERROR, "H2D copy failed"); return;
+    }
+    if (run_chain(S, S->d_io_in, q15, S->d_io_out, q15, block_size, kAll, nullptr)) return;
+    if (hipMemcpyAsync(dst, S->d_io_out, nout, hipMemcpyDeviceToHost, S->stream) != hipSuccess) {
+        fail(S, SELENITE_RX_DEVICE_ERROR, "D2H copy failed"); return;
+    }
+    if (hipStreamSynchronize(S->stream) != hipSuccess) fail(S, SELENITE_RX_DEVICE_ERROR, "stream sync failed");
+}
+
+extern "C" void selenite_rx_process_f32(selenite_rx_instance *S, const float *pSrcIQ, float *pDstAudio,
+                                        uint32_t blockSize)
+{
+    process_host(S, pSrcIQ, pDstAudio, blockSize, false, "selenite_rx_process_f32");
+}
+extern "C" void selenite_rx_process_q15(selenite_rx_instance *S, const int16_t *pSrcIQ, int16_t *pDstAudio,
+                                        uint32_t blockSize)
+{
+    process_host(S, pSrcIQ, pDstAudio, blockSize, true, "selenite_rx_process_q15");
+}
+
+// ------------------------------------------------------------------------------------------
+extern "C" int selenite_rx_get_state(selenite_rx_instance *S, const selenite_rx_state_view *v)
+{
+    if (!S || !v) return SELENITE_RX_ARGUMENT_ERROR;
+    const selenite_rx_config &g = S->cfg;
+    const size_t C = g.channels;
+    HIPCHK(S, hipSetDevice(S->device));
+    HIPCHK(S, hipStreamSynchronize(S->stream));
+    if (v->dec_state && g.nd_taps > 1)
+        HIPCHK(S, hipMemcpy(v->dec_state, S->d_dec_state, C * 2 * (g.nd_taps - 1) * sizeof(float), hipMemcpyDeviceToHost));
+    if (v->fir_state && g.nh_taps > 1)
+        HIPCHK(S, hipMemcpy(v->fir_state, S->d_fir_state, C * 2 * (g.nh_taps - 1) * sizeof(float), hipMemcpyDeviceToHost));
+    if (v->biq_state && g.n_biquad)
+        HIPCHK(S, hipMemcpy(v->biq_state, S->d_biq_state, C * 4 * g.n_biquad * sizeof(float), hipMemcpyDeviceToHost));
+    if (v->agc_gain) HIPCHK(S, hipMemcpy(v->agc_gain, S->d_gain, C * sizeof(float), hipMemcpyDeviceToHost));
+    if (v->nco_phase) HIPCHK(S, hipMemcpy(v->nco_phase, S->d_phase, C * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return SELENITE_RX_SUCCESS;
+}
+
+extern "C" int selenite_rx_set_state(selenite_rx_instance *S, const selenite_rx_state_view *v)
+{
+    if (!S || !v) return SELENITE_RX_ARGUMENT_ERROR;
+    const selenite_rx_config &g = S->cfg;
+    const size_t C = g.channels;
+    HIPCHK(S, hipSetDevice(S->device));
+    HIPCHK(S, hipStreamSynchronize(S->stream));
+    if (v->dec_state && g.nd_taps > 1)
+        HIPCHK(S, hipMemcpy(S->d_dec_state, v->dec_state, C * 2 * (g.nd_taps - 1) * sizeof(float), hipMemcpyHostToDevice));
+    if (v->fir_state && g.nh_taps > 1)
+        HIPCHK(S, hipMemcpy(S->d_fir_state, v->fir_state, C * 2 * (g.nh_taps - 1) * sizeof(float), hipMemcpyHostToDevice));
+    if (v->biq_state && g.n_biquad)
+        HIPCHK(S, hipMemcpy(S->d_biq_state, v->biq_state, C * 4 * g.n_biquad * sizeof(float), hipMemcpyHostToDevice));
+    if (v->agc_gain) HIPCHK(S, hipMemcpy(S->d_gain, v->agc_gain, C * sizeof(float), hipMemcpyHostToDevice));
+    if (v->nco_phase) HIPCHK(S, hipMemcpy(S->d_phase, v->nco_phase, C * sizeof(uint32_t), hipMemcpyHostToDevice));
+    return SELENITE_RX_SUCCESS;
+}
+
+extern "C" void *selenite_rx_device_alloc(size_t bytes)
+{
+    void *p = nullptr;
+    if (hipMalloc(&p, bytes ? bytes : 1) != hipSuccess) { g_last_error = "hipMalloc failed"; return nullptr; }
+    return p;
+}
+extern "C" void selenite_rx_device_free(void *dptr) { if (dptr) (void)hipFree(dptr); }
+extern "C" int selenite_rx_memcpy_h2d(void *dptr, const void *hptr, size_t bytes)
+{
+    HIPCHK(nullptr, hipMemcpy(dptr, hptr, bytes, hipMemcpyHostToDevice));
+    return SELENITE_RX_SUCCESS;
+}
+extern "C" int selenite_rx_memcpy_d2h(void *hptr, const void *dptr, size_t bytes)
+{
+    HIPCHK(nullptr, hipMemcpy(hptr, dptr, bytes, hipMemcpyDeviceToHost));
+    return SELENITE_RX_SUCCESS;
+}
+
+// ------------------------------------------------------------------------------------------
+extern "C" void selenite_rx_synth_iq_host(float *iq, uint32_t first_channel, uint32_t nch,
+                                          uint64_t first_sample, uint32_t nsamp, uint64_t seed)
+{
+    synth_host(iq, host_sin_table(), first_channel, nch, first_sample, nsamp, seed);
+}
+
+extern "C" int selenite_rx_synth_iq_device(selenite_rx_instance *S, float *dIQ, uint32_t first_channel,
+                                           uint32_t nch, uint64_t first_sample, uint32_t nsamp, uint64_t seed)
+{
+    if (!S) return SELENITE_RX_ARGUMENT_ERROR;
+    HIPCHK(S, hipSetDevice(S->device));
+    HIPCHK(S, launch_synth(dIQ, S->d_sintab, first_channel, nch, first_sample, nsamp, seed, S->stream));
+    return SELENITE_RX_SUCCESS;
+}
+
+extern "C" int selenite_rx_time_process_device(selenite_rx_instance *S, const float *dSrcIQ, float *dDstAudio,
+                                               uint32_t blockSize, uint32_t iters, float *ms_per_call)
+{
+    if (!S || !ms_per_call || iters == 0) return SELENITE_RX_ARGUMENT_ERROR;
+    if (!block_size_ok(S, blockSize, "selenite_rx_time_process_device")) return S->status;
+    HIPCHK(S, hipSetDevice(S->device));
+    hipEvent_t e0, e1;
+    HIPCHK(S, hipEventCreate(&e0));
+    HIPCHK(S, hipEventCreate(&e1));
+    HIPCHK(S, hipEventRecord(e0, S->stream));
+    for (uint32_t i = 0; i < iters; ++i) {
+        int rc = run_chain(S, dSrcIQ, false, dDstAudio, false, blockSize, kAll, nullptr);
+        if (rc) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return rc; }
+    }
+    HIPCHK(S, hipEventRecord(e1, S->stream));
+    HIPCHK(S, hipEventSynchronize(e1));
+    float ms = 0.0f;
+    HIPCHK(S, hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *ms_per_call = ms / (float)iters;
+    return SELENITE_RX_SUCCESS;
+}
+
+extern "C" uint64_t selenite_rx_algorithmic_bytes(const selenite_rx_config *g, uint32_t blockSize, uint64_t *read_bytes)
+{
+    if (!g || g->decim == 0) return 0;
+    // state = FIR histories (both rails) + 16 B per biquad stage + AGC/NCO scalars,
+    // read once and written once per channel-block.
+    uint64_t state = 0;
+    if (g->nd_taps > 1) state += 4ull * 2 * (g->nd_taps - 1);
+    if (g->nh_taps > 1) state += 4ull * 2 * (g->nh_taps - 1);
+    state += 16ull * g->n_biquad;
+    state += 4ull * ((g->agc_enable ? 1 : 0) + (g->nco_enable ? 1 : 0));
+    const uint64_t rd = 8ull * blockSize + state;
+    const uint64_t wr = 4ull * (blockSize / g->decim) + state;
+    if (read_bytes) *read_bytes = rd * g->channels;
+    return (rd + wr) * g->channels;
+}

@@ -1,0 +1,166 @@
+// rx_device.h -- device-side primitives of the Selenite RX block path (gfx950).
+//
+// Each helper reproduces, operation for operation, one CMSIS-DSP 1.5.3 f32 primitive of the
+// reference (citations relative to /root/reference/Drivers/CMSIS/DSP/Source).  ARITH selects the
+// rounding contract (include/selenite_rx.h):
+//   0  SELENITE_ARITH_CMSIS  product rounded, then sum rounded (what the reference C code does)
+//   1  SELENITE_ARITH_FMA    same order, the multiply-add of the FIR tap loops (mac<>) fused;
+//                            NCO, biquad recurrence, AGC law and magnitude keep the reference
+//                            rounding in both modes (fusing the IIR recurrence moves a high-Q
+//                            cascade by more than the 1e-5 the north star allows)
+// The translation unit is compiled with -ffp-contract=off; fusion happens only through
+// __builtin_fmaf below.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#pragma clang fp contract(off)
+
+namespace srx {
+
+constexpr int kWave = 64;
+constexpr float kNcoK = 0x1.921fb6p-22f;        // 2*pi / 2^24: radians per (phase >> 8) unit
+constexpr float kInv2Pi = 0.159154943092f;      // arm_sin_f32.c:88, arm_cos_f32.c:81
+
+template <int ARITH>
+__host__ __device__ __forceinline__ float mac(float acc, float x, float c)
+{
+    if constexpr (ARITH == 1) {
+        return __builtin_fmaf(x, c, acc);
+    } else {
+        float p = x * c;
+        return acc + p;
+    }
+}
+
+// FastMathFunctions/arm_sin_f32.c:72-119; T = sinTable_f32[513] (LDS or global)
+template <int ARITH>
+__host__ __device__ __forceinline__ float sin_f32(const float *T, float x)
+{
+    if ((x < 0.0f) && (x >= -1.9e-7f)) return x;
+    float in = x * kInv2Pi;
+    int n = (int)in;
+    if (x < 0.0f) n--;
+    in = in - (float)n;
+    float findex = 512.0f * in;
+    unsigned index = ((unsigned)(unsigned short)findex) & 0x1ffu;
+    float fract = findex - (float)index;
+    float a = T[index], b = T[index + 1];
+    float w = 1.0f - fract;
+    float p0 = w * a, p1 = fract * b;
+    return p0 + p1;
+}
+
+// FastMathFunctions/arm_cos_f32.c:70-111
+template <int ARITH>
+__host__ __device__ __forceinline__ float cos_f32(const float *T, float x)
+{
+    float p = x * kInv2Pi;
+    float in = p + 0.25f;
+    int n = (int)in;
+    if (in < 0.0f) n--;
+    in = in - (float)n;
+    float findex = 512.0f * in;
+    unsigned index = ((unsigned)(unsigned short)findex) & 0x1ffu;
+    float fract = findex - (float)index;
+    float a = T[index], b = T[index + 1];
+    float w = 1.0f - fract;
+    float p0 = w * a, p1 = fract * b;
+    return p0 + p1;
+}
+
+// NCO local oscillator sample for an integer phase: LO = cos(x) - j sin(x),
+// x = (float)(phase >> 8) * 2pi/2^24  (build-defined, DESIGN.md "NCO")
+template <int ARITH>
+__host__ __device__ __forceinline__ float2 nco_lo(const float *T, uint32_t phase)
+{
+    float x = (float)(phase >> 8) * kNcoK;
+    float c = cos_f32<ARITH>(T, x);
+    float s = sin_f32<ARITH>(T, x);
+    return make_float2(c, -s);
+}
+
+// ComplexMathFunctions/arm_cmplx_mult_cmplx_f32.c:186-187
+template <int ARITH>
+__device__ __forceinline__ float2 cmul(float2 A, float2 B)
+{
+    float a = A.x, b = A.y, c = B.x, d = B.y;
+    float ac = a * c, bd = b * d, ad = a * d, bc = b * c;
+    return make_float2(ac - bd, ad + bc);
+}
+
+// ComplexMathFunctions/arm_cmplx_mag_f32.c:72-149 (arm_sqrt_f32: arm_math.h:5726-5752)
+template <int ARITH>
+__device__ __forceinline__ float cmag(float re, float im)
+{
+    float rr = re * re, ii = im * im;
+    float s = rr + ii;
+    return (s >= 0.0f) ? __fsqrt_rn(s) : 0.0f;
+}
+
+// FilteringFunctions/arm_biquad_cascade_df1_f32.c:220 -- one DF1 section, left-to-right sum,
+// feedback added
+template <int ARITH>
+__device__ __forceinline__ float biquad_step(float b0, float b1, float b2, float a1, float a2,
+                                             float x, float &x1, float &x2, float &y1, float &y2)
+{
+    float p0 = b0 * x, p1 = b1 * x1, p2 = b2 * x2, p3 = a1 * y1, p4 = a2 * y2;
+    float y = p0 + p1;
+    y = y + p2;
+    y = y + p3;
+    y = y + p4;
+    x2 = x1; x1 = x; y2 = y1; y1 = y;
+    return y;
+}
+
+struct AgcParams {
+    float target, attack, decay, gain_min, gain_max, env_floor;
+};
+
+// AGC gain law (build-defined, DESIGN.md "AGC"); same statement order as oracle/rx_oracle.c
+template <int ARITH>
+__device__ __forceinline__ float agc_update(const AgcParams &p, float gain, float env)
+{
+    float e = (env < p.env_floor) ? p.env_floor : env;
+    float d = __fdiv_rn(p.target, e);
+    if (d > p.gain_max) d = p.gain_max;
+    if (d < p.gain_min) d = p.gain_min;
+    float diff = d - gain;
+    float rate = (diff < 0.0f) ? p.attack : p.decay;
+    float q = rate * diff;
+    return gain + q;
+}
+
+// SupportFunctions/arm_q15_to_float.c:87 and arm_float_to_q15.c:117 (ARM_MATH_ROUNDING off)
+__device__ __forceinline__ float q15_to_float(int16_t v) { return (float)v / 32768.0f; }
+__device__ __forceinline__ int16_t float_to_q15(float f)
+{
+    float v = f * 32768.0f;
+    int q = (int)v;                      // v_cvt_i32_f32: truncates, saturates at int32 range
+    q = q > 32767 ? 32767 : q;
+    q = q < -32768 ? -32768 : q;
+    return (int16_t)q;
+}
+
+// max over the 64 lanes of a wavefront (exact: max is associative/commutative for non-NaN)
+__device__ __forceinline__ float wave_max(float v)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    return v;
+}
+
+// sample loaders: f32 slot or q15 slot (int16 interleaved I/Q, dsp_if.c:286-289)
+__device__ __forceinline__ float2 load_iq(const float *p, size_t i)
+{
+    return reinterpret_cast<const float2 *>(p)[i];
+}
+__device__ __forceinline__ float2 load_iq(const int16_t *p, size_t i)
+{
+    short2 v = reinterpret_cast<const short2 *>(p)[i];
+    return make_float2(q15_to_float(v.x), q15_to_float(v.y));
+}
+__device__ __forceinline__ void store_audio(float *p, size_t i, float v) { p[i] = v; }
+__device__ __forceinline__ void store_audio(int16_t *p, size_t i, float v) { p[i] = float_to_q15(v); }
+
+}  // namespace srx

@@ -1,0 +1,98 @@
+// rx_internal.h -- instance layout and kernel-launch interfaces shared by the translation units
+// of libselenite_rx.so.  Not part of the C-ABI (include/selenite_rx.h is).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "../../include/selenite_rx.h"
+#include "rx_device.h"
+
+namespace srx {
+
+// Everything a kernel needs, passed by value (kernarg segment -> SGPRs).
+struct RxParams {
+    uint32_t channels;
+    uint32_t block;        // DSP block (input samples)
+    uint32_t decim;        // M
+    uint32_t nd;           // decimator taps (0 = bypass)
+    uint32_t nh;           // Hilbert / delay taps (0 = none)
+    uint32_t nbiq;         // biquad stages
+    uint32_t mode;         // SELENITE_MODE_*
+    uint32_t nco;          // NCO enabled
+    uint32_t agc;          // AGC enabled
+    uint32_t block_size;   // input samples per channel in this call
+    uint32_t nout;         // block_size / decim
+    uint32_t pass_out;     // generic front kernel: decimated outputs per pass
+    const float *dec_c, *hilb_c, *delay_c, *biq_c, *sintab;
+    const uint32_t *step;
+    uint32_t *phase;
+    float *dec_state;      // [C][2][nd-1]
+    float *fir_state;      // [C][2][nh-1]
+    float *biq_state;      // [C][nbiq][4]
+    float *gain;           // [C]
+    AgcParams agcp;
+};
+
+__host__ __device__ inline bool mode_is_cw(uint32_t m) { return m == SELENITE_MODE_CW || m == SELENITE_MODE_CWR; }
+__host__ __device__ inline bool mode_is_upper(uint32_t m)
+{
+    return m == SELENITE_MODE_USB || m == SELENITE_MODE_DIG || m == SELENITE_MODE_CW;
+}
+
+// ---- generic path (rx_generic.hip): any configuration, three simple kernels ----
+// front: NCO -> decimator -> demodulator, un-scaled audio (f32) to `audio`
+hipError_t launch_front_generic(const RxParams &p, int arith, const void *src, bool src_q15,
+                                float *audio, hipStream_t st);
+size_t front_generic_lds_bytes(const RxParams &p);
+// CW biquad cascade, in place on f32 audio
+hipError_t launch_biquad_generic(const RxParams &p, int arith, float *audio, hipStream_t st);
+// per-channel AGC (or plain copy/convert when p.agc == 0): audio -> dst
+hipError_t launch_agc_generic(const RxParams &p, int arith, const float *audio, void *dst,
+                              bool dst_q15, hipStream_t st);
+// global-gain AGC pieces: env[b] = max over channels of max|audio| in DSP block b
+hipError_t launch_env_global(const RxParams &p, const float *audio, float *env, hipStream_t st);
+hipError_t launch_agc_apply_global(const RxParams &p, int arith, const float *audio, const float *env,
+                                   void *dst, bool dst_q15, hipStream_t st);
+
+// ---- fused fast paths (rx_fused.hip); return false when the configuration is not covered ----
+struct FusedPlan {
+    int kind = 0;                 // 0 = none
+    const char *name = "generic";
+};
+FusedPlan plan_fused(const selenite_rx_config &cfg, bool delay_is_impulse, int delay_index,
+                     bool hilb_odd_only);
+hipError_t launch_fused(const FusedPlan &plan, const RxParams &p, int arith, const void *src,
+                        bool src_q15, void *dst, bool dst_q15, int delay_index, hipStream_t st);
+
+// ---- synthetic input (rx_synth.hip) ----
+hipError_t launch_synth(float *dIQ, const float *sintab, uint32_t first_channel, uint32_t nch,
+                        uint64_t first_sample, uint32_t nsamp, uint64_t seed, hipStream_t st);
+void synth_host(float *iq, const float *sintab, uint32_t first_channel, uint32_t nch,
+                uint64_t first_sample, uint32_t nsamp, uint64_t seed);
+
+// host copy of sinTable_f32 regenerated from its documented generator (rx_api.hip)
+const float *host_sin_table();
+
+}  // namespace srx
+
+struct selenite_rx_instance {
+    selenite_rx_config cfg;            // pointers inside refer to the host copies below
+    std::vector<float> h_dec, h_hilb, h_delay, h_biq;
+    std::vector<uint32_t> h_step;
+    int device = 0;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    float *d_dec_c = nullptr, *d_hilb_c = nullptr, *d_delay_c = nullptr, *d_biq_c = nullptr, *d_sintab = nullptr;
+    uint32_t *d_step = nullptr, *d_phase = nullptr;
+    float *d_dec_state = nullptr, *d_fir_state = nullptr, *d_biq_state = nullptr, *d_gain = nullptr;
+    float *d_scratch = nullptr;  size_t scratch_bytes = 0;   // intermediate f32 audio
+    float *d_env = nullptr;      size_t env_cap = 0;
+    void *d_io_in = nullptr;     size_t io_in_bytes = 0;     // staging for the host-pointer entry points
+    void *d_io_out = nullptr;    size_t io_out_bytes = 0;
+    bool delay_is_impulse = false; int delay_index = 0; bool hilb_odd_only = false;
+    srx::FusedPlan plan;
+    int force_generic = 0;             // SELENITE_RX_FORCE_GENERIC=1 (tests cross-check both paths)
+    int status = SELENITE_RX_SUCCESS;
+    std::string err;
+};

@@ -1,0 +1,330 @@
+"""ctypes face of libselenite_rx.so (include/selenite_rx.h).
+
+Thin plumbing for tests and bench.py: every call goes straight through the C-ABI into the HIP
+library.  There is no Python or CPU implementation of the chain here -- if the shared library is
+missing or no HIP device is usable, construction fails loudly.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+PKG_ROOT = os.path.dirname(_HERE)
+LIB_PATH = os.path.join(PKG_ROOT, "libselenite_rx.so")
+
+MODE_LSB, MODE_USB, MODE_CW, MODE_CWR, MODE_AM, MODE_FM, MODE_DIG, MODE_PKT = 0, 1, 2, 3, 4, 8, 0x0A, 0x0C
+ARITH_CMSIS, ARITH_FMA = 0, 1
+SUCCESS, ARGUMENT_ERROR, LENGTH_ERROR, DEVICE_ERROR = 0, -1, -2, -7
+
+f32p = C.POINTER(C.c_float)
+u32p = C.POINTER(C.c_uint32)
+i16p = C.POINTER(C.c_int16)
+
+
+class Config(C.Structure):
+    """struct selenite_rx_config."""
+    _fields_ = [
+        ("struct_size", C.c_uint32), ("channels", C.c_uint32), ("block", C.c_uint32),
+        ("decim", C.c_uint32), ("nd_taps", C.c_uint32), ("nh_taps", C.c_uint32),
+        ("n_biquad", C.c_uint32), ("arith", C.c_uint32),
+        ("mode", C.c_uint8), ("nco_enable", C.c_uint8), ("agc_enable", C.c_uint8), ("agc_global", C.c_uint8),
+        ("nco_step_all", C.c_uint32),
+        ("dec_coeffs", f32p), ("hilb_coeffs", f32p), ("delay_coeffs", f32p), ("biquad_coeffs", f32p),
+        ("nco_step", u32p),
+        ("agc_target", C.c_float), ("agc_attack", C.c_float), ("agc_decay", C.c_float),
+        ("agc_gain_min", C.c_float), ("agc_gain_max", C.c_float), ("agc_env_floor", C.c_float),
+        ("agc_gain_init", C.c_float),
+    ]
+
+
+class StateView(C.Structure):
+    """struct selenite_rx_state_view."""
+    _fields_ = [("dec_state", f32p), ("fir_state", f32p), ("biq_state", f32p),
+                ("agc_gain", f32p), ("nco_phase", u32p)]
+
+
+# every symbol include/selenite_rx.h declares (tests check the library exports all of them)
+ABI_SYMBOLS = [
+    "selenite_rx_init", "selenite_rx_free", "selenite_rx_set_mode", "selenite_rx_status",
+    "selenite_rx_error_string", "selenite_rx_process_f32", "selenite_rx_process_f32_device",
+    "selenite_rx_process_q15", "selenite_rx_process_q15_device",
+    "selenite_rx_global_phase1_device", "selenite_rx_global_phase2_device",
+    "selenite_rx_set_stream", "selenite_rx_sync", "selenite_rx_get_state", "selenite_rx_set_state",
+    "selenite_rx_reset", "selenite_rx_device_alloc", "selenite_rx_device_free",
+    "selenite_rx_memcpy_h2d", "selenite_rx_memcpy_d2h", "selenite_rx_device_count",
+    "selenite_rx_set_device", "selenite_rx_synth_iq_host", "selenite_rx_synth_iq_device",
+    "selenite_rx_time_process_device", "selenite_rx_kernel_name", "selenite_rx_algorithmic_bytes",
+    "selenite_rx_design_lowpass", "selenite_rx_design_hilbert", "selenite_rx_design_bandpass",
+    "selenite_rx_abi_version",
+]
+
+_lib = None
+
+
+def build(force=False):
+    """Compile libselenite_rx.so in-tree with hipcc for gfx950 (selenite-lite_amd/Makefile)."""
+    if force:
+        subprocess.run(["make", "-s", "-C", PKG_ROOT, "clean"], check=True)
+    subprocess.run(["make", "-s", "-j4", "-C", PKG_ROOT], check=True)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "libselenite_rx.so is not built (run __graft_entry__.build() or make -C selenite-lite_amd); "
+                "there is no CPU fallback for the RX chain")
+        L = C.CDLL(LIB_PATH)
+        vp = C.c_void_p
+        L.selenite_rx_init.argtypes = [C.POINTER(vp), C.POINTER(Config)]
+        L.selenite_rx_free.argtypes = [vp]
+        L.selenite_rx_set_mode.argtypes = [vp, C.c_uint8]
+        L.selenite_rx_status.argtypes = [vp]
+        L.selenite_rx_error_string.argtypes = [vp]
+        L.selenite_rx_error_string.restype = C.c_char_p
+        L.selenite_rx_process_f32.argtypes = [vp, f32p, f32p, C.c_uint32]
+        L.selenite_rx_process_f32_device.argtypes = [vp, vp, vp, C.c_uint32]
+        L.selenite_rx_process_q15.argtypes = [vp, i16p, i16p, C.c_uint32]
+        L.selenite_rx_process_q15_device.argtypes = [vp, vp, vp, C.c_uint32]
+        L.selenite_rx_global_phase1_device.argtypes = [vp, vp, vp, vp, C.c_uint32]
+        L.selenite_rx_global_phase2_device.argtypes = [vp, vp, vp, C.c_uint32]
+        L.selenite_rx_set_stream.argtypes = [vp, vp]
+        L.selenite_rx_sync.argtypes = [vp]
+        L.selenite_rx_get_state.argtypes = [vp, C.POINTER(StateView)]
+        L.selenite_rx_set_state.argtypes = [vp, C.POINTER(StateView)]
+        L.selenite_rx_reset.argtypes = [vp]
+        L.selenite_rx_device_alloc.argtypes = [C.c_size_t]
+        L.selenite_rx_device_alloc.restype = vp
+        L.selenite_rx_device_free.argtypes = [vp]
+        L.selenite_rx_memcpy_h2d.argtypes = [vp, vp, C.c_size_t]
+        L.selenite_rx_memcpy_d2h.argtypes = [vp, vp, C.c_size_t]
+        L.selenite_rx_set_device.argtypes = [C.c_int]
+        L.selenite_rx_synth_iq_host.argtypes = [f32p, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint64]
+        L.selenite_rx_synth_iq_device.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint64]
+        L.selenite_rx_time_process_device.argtypes = [vp, vp, vp, C.c_uint32, C.c_uint32, f32p]
+        L.selenite_rx_kernel_name.argtypes = [vp]
+        L.selenite_rx_kernel_name.restype = C.c_char_p
+        L.selenite_rx_algorithmic_bytes.argtypes = [C.POINTER(Config), C.c_uint32, C.POINTER(C.c_uint64)]
+        L.selenite_rx_algorithmic_bytes.restype = C.c_uint64
+        L.selenite_rx_design_lowpass.argtypes = [f32p, C.c_uint32, C.c_double]
+        L.selenite_rx_design_hilbert.argtypes = [f32p, f32p, C.c_uint32]
+        L.selenite_rx_design_bandpass.argtypes = [f32p, C.c_uint32, C.c_double, C.c_double]
+        _lib = L
+    return _lib
+
+
+def _fp(a):
+    return a.ctypes.data_as(f32p)
+
+
+def design_lowpass(num_taps, cutoff):
+    h = np.empty(num_taps, np.float32)
+    rc = lib().selenite_rx_design_lowpass(_fp(h), num_taps, cutoff)
+    if rc:
+        raise ValueError("selenite_rx_design_lowpass: %d" % rc)
+    return h
+
+
+def design_hilbert(num_taps):
+    h, d = np.empty(num_taps, np.float32), np.empty(num_taps, np.float32)
+    rc = lib().selenite_rx_design_hilbert(_fp(h), _fp(d), num_taps)
+    if rc:
+        raise ValueError("selenite_rx_design_hilbert: %d" % rc)
+    return h, d
+
+
+def design_bandpass(n_stages, f0, q):
+    c = np.empty(5 * n_stages, np.float32)
+    rc = lib().selenite_rx_design_bandpass(_fp(c), n_stages, f0, q)
+    if rc:
+        raise ValueError("selenite_rx_design_bandpass: %d" % rc)
+    return c
+
+
+def synth_iq_host(first_channel, nch, first_sample, nsamp, seed):
+    iq = np.empty((nch, nsamp, 2), np.float32)
+    lib().selenite_rx_synth_iq_host(_fp(iq), first_channel, nch, first_sample, nsamp, seed)
+    return iq
+
+
+class DeviceBuffer:
+    """hipMalloc'ed bytes owned through the C-ABI helpers."""
+
+    def __init__(self, nbytes):
+        self.nbytes = int(nbytes)
+        self.ptr = lib().selenite_rx_device_alloc(self.nbytes)
+        if not self.ptr:
+            raise MemoryError("selenite_rx_device_alloc(%d) failed" % nbytes)
+
+    def upload(self, arr):
+        arr = np.ascontiguousarray(arr)
+        assert arr.nbytes <= self.nbytes
+        rc = lib().selenite_rx_memcpy_h2d(self.ptr, arr.ctypes.data, arr.nbytes)
+        if rc:
+            raise RuntimeError("h2d failed")
+
+    def download(self, shape, dtype):
+        out = np.empty(shape, dtype)
+        assert out.nbytes <= self.nbytes
+        rc = lib().selenite_rx_memcpy_d2h(out.ctypes.data, self.ptr, out.nbytes)
+        if rc:
+            raise RuntimeError("d2h failed")
+        return out
+
+    def free(self):
+        if self.ptr:
+            lib().selenite_rx_device_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class RxError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("selenite_rx error %d: %s" % (code, msg))
+        self.code = code
+
+
+class Rx:
+    """One selenite_rx_instance.  `cfg` is a filled Config whose coefficient arrays the caller keeps
+    alive until construction returns (the library copies them)."""
+
+    def __init__(self, cfg):
+        self.L = lib()
+        self.cfg = cfg
+        self.h = C.c_void_p()
+        rc = self.L.selenite_rx_init(C.byref(self.h), C.byref(cfg))
+        if rc != SUCCESS:
+            raise RxError(rc, self.L.selenite_rx_error_string(None).decode())
+
+    # -- CMSIS-style calls ------------------------------------------------------------------
+    def out_len(self, block_size):
+        return block_size // self.cfg.decim
+
+    def process(self, iq):
+        iq = np.ascontiguousarray(iq, np.float32)
+        c, bs = iq.shape[0], iq.shape[1]
+        out = np.empty((c, self.out_len(bs)), np.float32)
+        self.L.selenite_rx_process_f32(self.h, _fp(iq), _fp(out), bs)
+        self.check()
+        return out
+
+    def process_q15(self, iq):
+        iq = np.ascontiguousarray(iq, np.int16)
+        c, bs = iq.shape[0], iq.shape[1]
+        out = np.empty((c, self.out_len(bs)), np.int16)
+        self.L.selenite_rx_process_q15(self.h, iq.ctypes.data_as(i16p), out.ctypes.data_as(i16p), bs)
+        self.check()
+        return out
+
+    def process_device(self, d_src, d_dst, block_size):
+        self.L.selenite_rx_process_f32_device(self.h, d_src, d_dst, block_size)
+
+    def process_q15_device(self, d_src, d_dst, block_size):
+        self.L.selenite_rx_process_q15_device(self.h, d_src, d_dst, block_size)
+
+    def global_phase1(self, d_src, d_dst, d_env, block_size):
+        self.L.selenite_rx_global_phase1_device(self.h, d_src, d_dst, d_env, block_size)
+
+    def global_phase2(self, d_dst, d_env, block_size):
+        self.L.selenite_rx_global_phase2_device(self.h, d_dst, d_env, block_size)
+
+    def set_mode(self, mode):
+        return self.L.selenite_rx_set_mode(self.h, mode)
+
+    def set_stream(self, stream_ptr):
+        return self.L.selenite_rx_set_stream(self.h, stream_ptr)
+
+    def sync(self):
+        rc = self.L.selenite_rx_sync(self.h)
+        if rc:
+            raise RxError(rc, self.error())
+
+    def reset(self):
+        return self.L.selenite_rx_reset(self.h)
+
+    def status(self):
+        return self.L.selenite_rx_status(self.h)
+
+    def error(self):
+        return self.L.selenite_rx_error_string(self.h).decode()
+
+    def check(self):
+        rc = self.status()
+        if rc:
+            raise RxError(rc, self.error())
+
+    def kernel_name(self):
+        return self.L.selenite_rx_kernel_name(self.h).decode()
+
+    def time_process(self, d_src, d_dst, block_size, iters):
+        ms = C.c_float()
+        rc = self.L.selenite_rx_time_process_device(self.h, d_src, d_dst, block_size, iters, C.byref(ms))
+        if rc:
+            raise RxError(rc, self.error())
+        return ms.value
+
+    def synth_device(self, d_iq, first_channel, nch, first_sample, nsamp, seed):
+        rc = self.L.selenite_rx_synth_iq_device(self.h, d_iq, first_channel, nch, first_sample, nsamp, seed)
+        if rc:
+            raise RxError(rc, self.error())
+
+    def algorithmic_bytes(self, block_size):
+        rd = C.c_uint64()
+        tot = self.L.selenite_rx_algorithmic_bytes(C.byref(self.cfg), block_size, C.byref(rd))
+        return int(tot), int(rd.value)
+
+    # -- state ------------------------------------------------------------------------------
+    def _state_arrays(self):
+        g = self.cfg
+        c = g.channels
+        return dict(
+            dec_state=np.zeros((c, 2, max(g.nd_taps - 1, 0)), np.float32),
+            fir_state=np.zeros((c, 2, max(g.nh_taps - 1, 0)), np.float32),
+            biq_state=np.zeros((c, g.n_biquad, 4), np.float32),
+            agc_gain=np.zeros((c,), np.float32),
+            nco_phase=np.zeros((c,), np.uint32),
+        )
+
+    @staticmethod
+    def _view(arrs):
+        v = StateView()
+        v.dec_state = _fp(arrs["dec_state"]) if arrs["dec_state"].size else None
+        v.fir_state = _fp(arrs["fir_state"]) if arrs["fir_state"].size else None
+        v.biq_state = _fp(arrs["biq_state"]) if arrs["biq_state"].size else None
+        v.agc_gain = _fp(arrs["agc_gain"])
+        v.nco_phase = arrs["nco_phase"].ctypes.data_as(u32p)
+        return v
+
+    def state(self):
+        arrs = self._state_arrays()
+        v = self._view(arrs)
+        rc = self.L.selenite_rx_get_state(self.h, C.byref(v))
+        if rc:
+            raise RxError(rc, self.error())
+        return arrs
+
+    def set_state(self, arrs):
+        arrs = {k: np.ascontiguousarray(a) for k, a in arrs.items()}
+        v = self._view(arrs)
+        rc = self.L.selenite_rx_set_state(self.h, C.byref(v))
+        if rc:
+            raise RxError(rc, self.error())
+
+    def close(self):
+        if self.h:
+            self.L.selenite_rx_free(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -27,25 +27,7 @@ u32p = C.POINTER(C.c_uint32)
 i16p = C.POINTER(C.c_int16)
 
 
-class Config(C.Structure):
-    """struct selenite_rx_config (include/selenite_rx.h)."""
-    _fields_ = [
-        ("struct_size", C.c_uint32), ("channels", C.c_uint32), ("block", C.c_uint32),
-        ("decim", C.c_uint32), ("nd_taps", C.c_uint32), ("nh_taps", C.c_uint32),
-        ("n_biquad", C.c_uint32), ("arith", C.c_uint32),
-        ("mode", C.c_uint8), ("nco_enable", C.c_uint8), ("agc_enable", C.c_uint8), ("agc_global", C.c_uint8),
-        ("nco_step_all", C.c_uint32),
-        ("dec_coeffs", f32p), ("hilb_coeffs", f32p), ("delay_coeffs", f32p), ("biquad_coeffs", f32p),
-        ("nco_step", u32p),
-        ("agc_target", C.c_float), ("agc_attack", C.c_float), ("agc_decay", C.c_float),
-        ("agc_gain_min", C.c_float), ("agc_gain_max", C.c_float), ("agc_env_floor", C.c_float),
-        ("agc_gain_init", C.c_float),
-    ]
-
-
-class StateView(C.Structure):
-    _fields_ = [("dec_state", f32p), ("fir_state", f32p), ("biq_state", f32p),
-                ("agc_gain", f32p), ("nco_phase", u32p)]
+from selenite_rx import Config, StateView  # noqa: E402  (ctypes structs of include/selenite_rx.h)
 
 
 def fptr(a):
