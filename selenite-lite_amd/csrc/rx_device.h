@@ -95,7 +95,7 @@ __device__ __forceinline__ float cmag(float re, float im)
 {
     float rr = re * re, ii = im * im;
     float s = rr + ii;
-    return (s >= 0.0f) ? __fsqrt_rn(s) : 0.0f;
+    return (s >= 0.0f) ? sqrtf(s) : 0.0f;   // correctly rounded (hipcc default); __fsqrt_rn is not
 }
 
 // FilteringFunctions/arm_biquad_cascade_df1_f32.c:220 -- one DF1 section, left-to-right sum,

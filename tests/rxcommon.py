@@ -47,7 +47,7 @@ def design_lowpass(num_taps, cutoff):
     n = np.arange(num_taps, dtype=np.float64)
     m = n - (num_taps - 1) / 2.0
     h = 2.0 * cutoff * np.sinc(2.0 * cutoff * m)
-    w = 0.54 - 0.46 * np.cos(2.0 * np.pi * n / (num_taps - 1))
+    w = 0.54 - 0.46 * np.cos(2.0 * np.pi * n / max(num_taps - 1, 1)) if num_taps > 1 else np.ones(1)
     h = h * w
     h = h / h.sum()
     return as_f32(h[::-1])          # CMSIS order {b[N-1]..b[0]}
@@ -61,7 +61,7 @@ def design_hilbert(num_taps):
     h = np.zeros(num_taps, dtype=np.float64)
     odd = (m.astype(np.int64) % 2) != 0
     h[odd] = 2.0 / (np.pi * m[odd])
-    w = 0.54 - 0.46 * np.cos(2.0 * np.pi * n / (num_taps - 1))
+    w = 0.54 - 0.46 * np.cos(2.0 * np.pi * n / max(num_taps - 1, 1)) if num_taps > 1 else np.ones(1)
     h = h * w
     d = np.zeros(num_taps, dtype=np.float64)
     d[c] = 1.0
