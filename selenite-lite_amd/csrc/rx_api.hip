@@ -112,6 +112,7 @@ static void free_device(selenite_rx_instance *S)
                      S->d_io_in, S->d_io_out };
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
+    free_fused(S->plan);
     if (S->own_stream) (void)hipStreamDestroy(S->own_stream);
 }
 
@@ -220,7 +221,12 @@ extern "C" int selenite_rx_init(selenite_rx_instance **out, const selenite_rx_co
     INITCHK(dev_zero(&S->d_gain, C));
 #undef INITCHK
     classify_coeffs(S);
-    S->plan = plan_fused(S->cfg, S->delay_is_impulse, S->delay_index, S->hilb_odd_only);
+    if (plan_fused(S->cfg, S->delay_is_impulse, S->delay_index, S->hilb_odd_only, S->plan) != hipSuccess) {
+        int rc_ = fail(nullptr, SELENITE_RX_DEVICE_ERROR, "selenite_rx_init: building fused-kernel tables failed");
+        free_device(S);
+        delete S;
+        return rc_;
+    }
     int rc = reset_state(S);
     if (rc != SELENITE_RX_SUCCESS) { free_device(S); delete S; return rc; }
     *out = S;
@@ -244,7 +250,7 @@ extern "C" int selenite_rx_set_mode(selenite_rx_instance *S, uint8_t mode)
         return SELENITE_RX_ARGUMENT_ERROR;          // instance stays usable in its old mode
     }
     S->cfg.mode = mode;
-    S->plan = plan_fused(S->cfg, S->delay_is_impulse, S->delay_index, S->hilb_odd_only);
+    HIPCHK(S, plan_fused(S->cfg, S->delay_is_impulse, S->delay_index, S->hilb_odd_only, S->plan));
     return SELENITE_RX_SUCCESS;
 }
 
@@ -337,7 +343,8 @@ static int run_chain(selenite_rx_instance *S, const void *src, bool src_q15, voi
     const bool cw = mode_is_cw(g.mode) && g.n_biquad;
     hipStream_t st = S->stream;
 
-    if (phase != kPhase2 && !global && !S->force_generic && S->plan.kind != 0) {
+    if (phase != kPhase2 && !global && !S->force_generic && S->plan.kind != 0 &&
+        fused_block_size_ok(S->plan, g, block_size)) {
         HIPCHK(S, launch_fused(S->plan, p, arith, src, src_q15, dst, dst_q15, S->delay_index, st));
         return SELENITE_RX_SUCCESS;
     }

@@ -1,9 +1,418 @@
-// rx_fused.hip -- fused fast paths (placeholder: no configuration covered yet).
+// rx_fused.hip -- fused single-launch kernels for the SSB receive chain (gfx950).
+//
+//   k_ssb_fused<ARITH, ND, M, NH, TIn, TOut>
+//
+// One wavefront per channel (64-thread workgroups, grid = channels >> 256 CUs).  Per pass the
+// wavefront turns 256*M complex input samples into 256 audio samples entirely on chip:
+//
+//   HBM --dwordx4, 1 KiB/wave-instr--> VGPR --NCO mix (arm_sin/cos table in LDS, cmplx_mult)-->
+//   LDS polyphase image (per rail M arrays S_p[m] = s[m*M+p], history of HQ4 phase-samples in
+//   front) --ds_read_b128, conflict free--> arm_fir_decimate taps (coefficients through SGPRs,
+//   4 adjacent outputs per lane so one b128 read feeds 16 MACs) --> LDS (decimated rails, NH-1
+//   history) --> Hilbert FIR on Q (structurally-zero taps skipped), delay on I (unit impulse =
+//   one LDS read), arm_sub/arm_add --> AGC: |.| and max by 16-lane xor-shuffle, gain law,
+//   arm_scale --> one dwordx4 store per lane.
+//
+// Arithmetic: identical per-output operation order to the reference (single accumulator from
+// 0.0f, taps ascending).  Exact-zero taps are skipped: acc + 0*x == acc for finite x and an
+// accumulator that is never -0 (it starts at +0 and x + y = -0 only for -0 + -0), so results are
+// bit-identical to the dense loop (Inf/NaN inputs excepted; documented in DESIGN.md).
+//
+// Covered: decimator (ND>0, M==4) or none (ND==0, M==1); Hilbert pair with unit-impulse delay
+// and type-III (odd-only) Hilbert taps; USB/LSB/DIG/PKT (and CW/CWR without biquads); per-channel
+// AGC with block/M in {4..256, power of two}.  Everything else runs on rx_generic.hip.
 #include "rx_internal.h"
+
+#pragma clang fp contract(off)
+
 namespace srx {
-FusedPlan plan_fused(const selenite_rx_config &, bool, int, bool) { return FusedPlan{}; }
-hipError_t launch_fused(const FusedPlan &, const RxParams &, int, const void *, bool, void *, bool, int, hipStream_t)
+
+template <int ND, int M, int NH>
+struct Geo {
+    static constexpr int P = 256;                                   // decimated outputs per pass
+    static constexpr int T = P * M;                                 // complex inputs per pass
+    static constexpr int HQ = ND ? (ND - 1 + M - 1) / M : 0;        // decimator history, phase-samples
+    static constexpr int HQ4 = (HQ + 3) & ~3;
+    static constexpr int F = ND ? (HQ4 * M + 1 - ND) : 0;           // leading zero-pad taps
+    static constexpr int PLEN = HQ4 + P;                            // one phase array
+    // phase stride: PLEN rounded up so that 2*PS % 32 == 16 -> the two phases a 32-lane group
+    // writes (p, p+2) fall on disjoint banks
+    static constexpr int PS = ((PLEN + 31) / 32) * 32 + 8;
+    static constexpr int HH = NH ? NH - 1 : 0;                      // Hilbert history
+    static constexpr int HH4 = (HH + 3) & ~3;
+    static constexpr int FH = HH4 - HH;                             // leading pad of the FIR window
+    static constexpr int DLEN = HH4 + P + 4;
+    // LDS image (floats)
+    static constexpr int oTab = 0;
+    static constexpr int oS = 516;                                  // [2 rails][M][PS]   (ND > 0)
+    static constexpr int oD = oS + (ND ? 2 * M * PS : 0);           // [2 rails][DLEN]
+    static constexpr int total = oD + 2 * DLEN;
+};
+
+struct FusedArgs {
+    const float *cq;        // padded decimator taps: cq[k'] = dec[k' - F] (k' >= F), else 0
+    uint32_t delay_idx;     // index of the unit tap in delay_coeffs
+    uint32_t upper;         // 1: audio = I' - Q'   0: audio = I' + Q'
+    uint32_t group;         // lanes per DSP block = (block / M) / 4
+};
+
+__device__ __forceinline__ float f4get(const float4 &v, int e)
 {
+    return e == 0 ? v.x : (e == 1 ? v.y : (e == 2 ? v.z : v.w));
+}
+
+// arm_fir_decimate_f32 for 4 adjacent outputs j = 4*lane + r of one rail.
+// sp: this rail's phase arrays.  Output j needs s[(j - HQ4 + q)*M + p] * cq[q*M + p], q = 0..HQ4.
+template <int ARITH, int ND, int M, int NH>
+__device__ __forceinline__ void decim_quad(const float *sp, int lane, const float *__restrict__ cq,
+                                           float (&acc)[4])
+{
+    using G = Geo<ND, M, NH>;
+#pragma unroll
+    for (int t = 0; t <= G::HQ4 / 4; ++t) {
+        float4 W[M];
+#pragma unroll
+        for (int p = 0; p < M; ++p)
+            W[p] = *reinterpret_cast<const float4 *>(sp + p * G::PS + 4 * lane + 4 * t);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+#pragma unroll
+            for (int p = 0; p < M; ++p) {
+                const float w = f4get(W[p], e);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int q = 4 * t + e - r;
+                    const int kk = q * M + p;
+                    if (q < 0 || q > G::HQ4 || (q == G::HQ4 && p > 0) || kk < G::F) continue;
+                    acc[r] = mac<ARITH>(acc[r], w, cq[kk]);
+                }
+            }
+        }
+    }
+}
+
+// arm_fir_f32 with type-III Hilbert taps for 4 adjacent outputs n = 4*lane + r.
+// dq: decimated Q rail, new samples start at HH4.  y[n] = sum_k h[k] * dq[n + k + FH].
+template <int ARITH, int ND, int M, int NH>
+__device__ __forceinline__ void hilbert_quad(const float *dq, int lane, const float *__restrict__ h,
+                                             float (&acc)[4])
+{
+    using G = Geo<ND, M, NH>;
+    constexpr int C = (NH - 1) / 2;
+#pragma unroll
+    for (int t = 0; t <= (G::HH4 + 3) / 4; ++t) {
+        const float4 W = *reinterpret_cast<const float4 *>(dq + 4 * lane + 4 * t);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float w = f4get(W, e);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int k = 4 * t + e - r - G::FH;
+                if (k < 0 || k >= NH || (((k - C) & 1) == 0)) continue;   // structural zeros
+                acc[r] = mac<ARITH>(acc[r], w, h[k]);
+            }
+        }
+    }
+}
+
+template <int ARITH, int ND, int M, int NH, typename TIn, typename TOut>
+__global__ __launch_bounds__(64) void k_ssb_fused(RxParams p, FusedArgs fa, const TIn *__restrict__ src,
+                                                  TOut *__restrict__ dst)
+{
+    using G = Geo<ND, M, NH>;
+    static_assert(ND == 0 ? M == 1 : true, "decimation needs a decimator");
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x;
+    const uint32_t c = blockIdx.x;
+    float *tab = lds + G::oTab;
+    float *S = lds + G::oS;
+    float *D = lds + G::oD;
+    float *dI = D, *dQ = D + G::DLEN;
+
+    // ---- prologue: tables and streaming state into LDS ----
+    if (p.nco)
+        for (int i = lane; i < 513; i += kWave) tab[i] = p.sintab[i];
+    if constexpr (ND > 0) {
+        // history slot (phase pp, index m) holds sample s = (m*M + pp) - F of the CMSIS state
+        // (oldest first); slots before the state (s < 0) only ever meet zero-padded taps
+        for (int i = lane; i < 2 * M * G::HQ4; i += kWave) {
+            const int rail = i / (M * G::HQ4), rem = i % (M * G::HQ4);
+            const int s = rem - G::F, pp = rem % M, m = rem / M;
+            float v = 0.0f;
+            if (s >= 0) v = p.dec_state[((size_t)c * 2 + rail) * (ND - 1) + s];
+            S[(rail * M + pp) * G::PS + m] = v;
+        }
+    }
+    if constexpr (NH > 0) {
+        for (int i = lane; i < 2 * G::HH4; i += kWave) {
+            const int rail = i / G::HH4, m = i % G::HH4, s = m - G::FH;
+            float v = 0.0f;
+            if (s >= 0) v = p.fir_state[((size_t)c * 2 + rail) * G::HH + s];
+            D[rail * G::DLEN + m] = v;
+        }
+    }
+    const uint32_t ph0 = p.nco ? p.phase[c] : 0u;
+    const uint32_t step = p.nco ? p.step[c] : 0u;
+    float gain = p.agc ? p.gain[c] : 1.0f;
+    const int group = (int)fa.group;
+    __syncthreads();
+
+    const size_t in_base = (size_t)c * p.block_size, out_base = (size_t)c * p.nout;
+    const uint32_t npass = p.nout / G::P;
+    for (uint32_t pass = 0; pass < npass; ++pass) {
+        const uint32_t n0 = pass * G::T;
+        // ---- 1. coalesced load (2 complex samples per lane per instruction), NCO mix, LDS ----
+#pragma unroll
+        for (int i = 0; i < G::T / 128; ++i) {
+            const uint32_t n = 128u * i + 2u * lane;                  // even sample index in the pass
+            float2 a = load_iq(src, in_base + n0 + n);
+            float2 b = load_iq(src, in_base + n0 + n + 1);
+            if (p.nco) {
+                a = cmul<0>(a, nco_lo<0>(tab, ph0 + (n0 + n) * step));
+                b = cmul<0>(b, nco_lo<0>(tab, ph0 + (n0 + n + 1) * step));
+            }
+            if constexpr (ND > 0) {
+                const int m = G::HQ4 + (int)(n / M), pp = (int)(n % M);   // n even: pp in {0,2}, pp+1 valid
+                S[(0 * M + pp) * G::PS + m] = a.x;
+                S[(0 * M + pp + 1) * G::PS + m] = b.x;
+                S[(1 * M + pp) * G::PS + m] = a.y;
+                S[(1 * M + pp + 1) * G::PS + m] = b.y;
+            } else {
+                *reinterpret_cast<float2 *>(dI + G::HH4 + n) = make_float2(a.x, b.x);
+                *reinterpret_cast<float2 *>(dQ + G::HH4 + n) = make_float2(a.y, b.y);
+            }
+        }
+        __syncthreads();
+        // ---- 2. arm_fir_decimate_f32 on both rails, 4 adjacent outputs per lane ----
+        if constexpr (ND > 0) {
+            float aI[4] = { 0.0f, 0.0f, 0.0f, 0.0f }, aQ[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+            decim_quad<ARITH, ND, M, NH>(S, lane, fa.cq, aI);
+            decim_quad<ARITH, ND, M, NH>(S + M * G::PS, lane, fa.cq, aQ);
+            *reinterpret_cast<float4 *>(dI + G::HH4 + 4 * lane) = make_float4(aI[0], aI[1], aI[2], aI[3]);
+            *reinterpret_cast<float4 *>(dQ + G::HH4 + 4 * lane) = make_float4(aQ[0], aQ[1], aQ[2], aQ[3]);
+            __syncthreads();
+        }
+        // ---- 3. Hilbert pair + sideband combine ----
+        float au[4];
+        if constexpr (NH > 0) {
+            float q2[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+            hilbert_quad<ARITH, ND, M, NH>(dQ, lane, p.hilb_c, q2);
+            const float *di = dI + G::FH + fa.delay_idx + 4 * lane;   // unit-impulse delay FIR
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float i2 = di[r] + 0.0f;                        // 0.0f + 1.0f*x of the dense loop
+                au[r] = fa.upper ? (i2 - q2[r]) : (i2 + q2[r]);       // arm_sub_f32 / arm_add_f32
+            }
+        } else {
+            const float4 v = *reinterpret_cast<const float4 *>(dI + 4 * lane);
+            au[0] = v.x; au[1] = v.y; au[2] = v.z; au[3] = v.w;
+        }
+        // ---- 4. AGC: arm_abs + arm_max per DSP block (group lanes), gain law, arm_scale ----
+        if (p.agc) {
+            float m = fmaxf(fmaxf(fabsf(au[0]), fabsf(au[1])), fmaxf(fabsf(au[2]), fabsf(au[3])));
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1)
+                if (off < group) m = fmaxf(m, __shfl_xor(m, off, 64));
+            float g = gain, mine = gain;
+            const int nblk = 64 / group, myblk = lane / group;
+            for (int b = 0; b < nblk; ++b) {
+                const float env = __shfl(m, b * group, 64);
+                g = agc_update<0>(p.agcp, g, env);
+                if (b == myblk) mine = g;
+            }
+            gain = g;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) au[r] = au[r] * mine;
+        }
+        // ---- 5. store: 4 adjacent audio samples per lane ----
+        const size_t o = out_base + (size_t)pass * G::P + 4 * lane;
+        if constexpr (sizeof(TOut) == 4) {
+            *reinterpret_cast<float4 *>(reinterpret_cast<float *>(dst) + o) = make_float4(au[0], au[1], au[2], au[3]);
+        } else {
+            short4 s4;
+            s4.x = float_to_q15(au[0]); s4.y = float_to_q15(au[1]);
+            s4.z = float_to_q15(au[2]); s4.w = float_to_q15(au[3]);
+            *reinterpret_cast<short4 *>(reinterpret_cast<int16_t *>(dst) + o) = s4;
+        }
+        __syncthreads();
+        // ---- 6. history copy-back (arm_fir_decimate_f32.c:396-426, arm_fir_f32.c:947-978) ----
+        if constexpr (ND > 0) {
+            constexpr int NV = 2 * M * (G::HQ4 / 4);                  // float4 moves
+            float4 tmp[(NV + 63) / 64];
+#pragma unroll
+            for (int k = 0; k < (NV + 63) / 64; ++k) {
+                const int i = k * 64 + lane;
+                if (i < NV) {
+                    const int arr = i / (G::HQ4 / 4), v = i % (G::HQ4 / 4);
+                    tmp[k] = *reinterpret_cast<const float4 *>(S + arr * G::PS + G::P + 4 * v);
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < (NV + 63) / 64; ++k) {
+                const int i = k * 64 + lane;
+                if (i < NV) {
+                    const int arr = i / (G::HQ4 / 4), v = i % (G::HQ4 / 4);
+                    *reinterpret_cast<float4 *>(S + arr * G::PS + 4 * v) = tmp[k];
+                }
+            }
+        }
+        if constexpr (NH > 0) {
+            constexpr int NV = 2 * (G::HH4 / 4);
+            static_assert(NV <= 64, "Hilbert history move assumes <= 64 float4");
+            float4 tmp;
+            const int rail = lane / (G::HH4 / 4), v = lane % (G::HH4 / 4);
+            if (lane < NV) tmp = *reinterpret_cast<const float4 *>(D + rail * G::DLEN + G::P + 4 * v);
+            __syncthreads();
+            if (lane < NV) *reinterpret_cast<float4 *>(D + rail * G::DLEN + 4 * v) = tmp;
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: streaming state back to HBM ----
+    if constexpr (ND > 0) {
+        for (int i = lane; i < 2 * M * G::HQ4; i += kWave) {
+            const int rail = i / (M * G::HQ4), rem = i % (M * G::HQ4);
+            const int s = rem - G::F, pp = rem % M, m = rem / M;
+            if (s >= 0) p.dec_state[((size_t)c * 2 + rail) * (ND - 1) + s] = S[(rail * M + pp) * G::PS + m];
+        }
+    }
+    if constexpr (NH > 0) {
+        for (int i = lane; i < 2 * G::HH4; i += kWave) {
+            const int rail = i / G::HH4, m = i % G::HH4, s = m - G::FH;
+            if (s >= 0) p.fir_state[((size_t)c * 2 + rail) * G::HH + s] = D[rail * G::DLEN + m];
+        }
+    }
+    if (lane == 0) {
+        if (p.nco) p.phase[c] = ph0 + p.block_size * step;
+        if (p.agc) p.gain[c] = gain;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// host side: plan + dispatch
+// ------------------------------------------------------------------------------------------
+template <int ND, int M, int NH>
+static bool shape_is(const selenite_rx_config &g)
+{
+    return (int)g.nd_taps == ND && (int)g.decim == M && (int)g.nh_taps == NH;
+}
+
+template <int ND, int M, int NH>
+static hipError_t build_tables(const selenite_rx_config &g, FusedPlan &plan)
+{
+    using G = Geo<ND, M, NH>;
+    if constexpr (ND > 0) {
+        std::vector<float> cq((size_t)G::HQ4 * M + 4, 0.0f);
+        for (int k = 0; k < ND; ++k) cq[(size_t)k + G::F] = g.dec_coeffs[k];
+        hipError_t e = hipMalloc((void **)&plan.d_cq, cq.size() * sizeof(float));
+        if (e != hipSuccess) return e;
+        return hipMemcpy(plan.d_cq, cq.data(), cq.size() * sizeof(float), hipMemcpyHostToDevice);
+    }
+    return hipSuccess;
+}
+
+template <int ARITH, int ND, int M, int NH, typename TIn, typename TOut>
+static hipError_t launch_one(const RxParams &p, const FusedArgs &fa, const void *src, void *dst, hipStream_t st)
+{
+    using G = Geo<ND, M, NH>;
+    constexpr size_t lds = (size_t)G::total * sizeof(float);
+    auto k = k_ssb_fused<ARITH, ND, M, NH, TIn, TOut>;
+    if constexpr (lds > 48 * 1024) {
+        static bool once = false;
+        if (!once) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+            once = true;
+        }
+    }
+    hipLaunchKernelGGL(k, dim3(p.channels), dim3(64), lds, st, p, fa, static_cast<const TIn *>(src),
+                       static_cast<TOut *>(dst));
+    return hipGetLastError();
+}
+
+template <int ND, int M, int NH>
+static hipError_t launch_shape(const RxParams &p, const FusedArgs &fa, int arith, const void *src, bool src_q15,
+                               void *dst, bool dst_q15, hipStream_t st)
+{
+    if (src_q15 != dst_q15) return hipErrorNotSupported;
+    if (arith == SELENITE_ARITH_FMA) {
+        if (src_q15) return launch_one<1, ND, M, NH, int16_t, int16_t>(p, fa, src, dst, st);
+        return launch_one<1, ND, M, NH, float, float>(p, fa, src, dst, st);
+    }
+    if (src_q15) return launch_one<0, ND, M, NH, int16_t, int16_t>(p, fa, src, dst, st);
+    return launch_one<0, ND, M, NH, float, float>(p, fa, src, dst, st);
+}
+
+// the instantiated shapes: BASELINE.json cfg1 / cfg2 / cfg3 (+ cfg5 = cfg2 chain)
+#define SRX_SHAPES(X) X(256, 4, 63, 1) X(0, 1, 63, 2) X(0, 1, 127, 3)
+
+static bool fused_mode_ok(const selenite_rx_config &g)
+{
+    const uint32_t m = g.mode;
+    const bool ssb = m == SELENITE_MODE_USB || m == SELENITE_MODE_LSB || m == SELENITE_MODE_DIG || m == SELENITE_MODE_PKT;
+    const bool cw_plain = mode_is_cw(m) && g.n_biquad == 0;
+    return ssb || cw_plain;
+}
+
+hipError_t plan_fused(const selenite_rx_config &g, bool delay_is_impulse, int delay_index, bool hilb_odd_only,
+                      FusedPlan &plan)
+{
+    (void)delay_index;
+    plan.kind = 0;
+    plan.name = "generic";
+    if (!fused_mode_ok(g) || !g.nh_taps || !delay_is_impulse || !hilb_odd_only) return hipSuccess;
+    if (g.agc_enable && g.agc_global) return hipSuccess;
+    const uint32_t na = g.block / g.decim;
+    if (na < 4 || na > 256 || (na & (na - 1)) != 0) return hipSuccess;
+    int kind = 0;
+    const char *name = nullptr;
+#define X(ND_, M_, NH_, ID_) \
+    if (shape_is<ND_, M_, NH_>(g)) { kind = ID_; name = "k_ssb_fused<" #ND_ "," #M_ "," #NH_ ">"; }
+    SRX_SHAPES(X)
+#undef X
+    if (!kind) return hipSuccess;
+    if (!plan.tables_built) {
+        hipError_t e = hipSuccess;
+#define X(ND_, M_, NH_, ID_) if (kind == ID_) e = build_tables<ND_, M_, NH_>(g, plan);
+        SRX_SHAPES(X)
+#undef X
+        if (e != hipSuccess) return e;
+        plan.tables_built = true;
+    }
+    plan.kind = kind;
+    plan.name = name;
+    return hipSuccess;
+}
+
+void free_fused(FusedPlan &plan)
+{
+    if (plan.d_cq) (void)hipFree(plan.d_cq);
+    plan.d_cq = nullptr;
+    plan.tables_built = false;
+    plan.kind = 0;
+}
+
+bool fused_block_size_ok(const FusedPlan &plan, const selenite_rx_config &g, uint32_t block_size)
+{
+    (void)plan;
+    return (block_size / g.decim) % 256 == 0;       // whole passes only; otherwise the generic path runs
+}
+
+hipError_t launch_fused(const FusedPlan &plan, const RxParams &p, int arith, const void *src, bool src_q15,
+                        void *dst, bool dst_q15, int delay_index, hipStream_t st)
+{
+    FusedArgs fa;
+    fa.cq = plan.d_cq;
+    fa.delay_idx = (uint32_t)delay_index;
+    fa.upper = mode_is_upper(p.mode) ? 1u : 0u;
+    fa.group = (p.block / p.decim) / 4;
+#define X(ND_, M_, NH_, ID_) \
+    if (plan.kind == ID_) return launch_shape<ND_, M_, NH_>(p, fa, arith, src, src_q15, dst, dst_q15, st);
+    SRX_SHAPES(X)
+#undef X
     return hipErrorNotSupported;
 }
+
 }  // namespace srx
