@@ -6,9 +6,10 @@
 // wavefront turns 256*M complex input samples into 256 audio samples entirely on chip:
 //
 //   HBM --dwordx4, 1 KiB/wave-instr--> VGPR --NCO mix (arm_sin/cos table in LDS, cmplx_mult)-->
-//   LDS polyphase image (per rail M arrays S_p[m] = s[m*M+p], history of HQ4 phase-samples in
-//   front) --ds_read_b128, conflict free--> arm_fir_decimate taps (coefficients through SGPRs,
-//   4 adjacent outputs per lane so one b128 read feeds 16 MACs) --> LDS (decimated rails, NH-1
+//   LDS polyphase image (M arrays of (I,Q) pairs S_p[m] = s[m*M+p], history of HQ4 phase-samples
+//   in front, 48-byte lane groups) --ds_read_b128, conflict free--> arm_fir_decimate taps as
+//   v_pk_{mul,add,fma}_f32 on (I,Q) with the coefficient from v_readlane (4 adjacent outputs per
+//   lane, so one b128 read feeds 8 packed MACs) --> LDS (decimated rails, NH-1
 //   history) --> Hilbert FIR on Q (structurally-zero taps skipped), delay on I (unit impulse =
 //   one LDS read), arm_sub/arm_add --> AGC: |.| and max by 16-lane xor-shuffle, gain law,
 //   arm_scale --> one dwordx4 store per lane.
@@ -27,6 +28,8 @@
 
 namespace srx {
 
+typedef float v2f __attribute__((ext_vector_type(2)));
+
 template <int ND, int M, int NH>
 struct Geo {
     static constexpr int P = 256;                                   // decimated outputs per pass
@@ -34,23 +37,27 @@ struct Geo {
     static constexpr int HQ = ND ? (ND - 1 + M - 1) / M : 0;        // decimator history, phase-samples
     static constexpr int HQ4 = (HQ + 3) & ~3;
     static constexpr int F = ND ? (HQ4 * M + 1 - ND) : 0;           // leading zero-pad taps
-    static constexpr int PLEN = HQ4 + P;                            // one phase array
-    // phase stride: PLEN rounded up so that 2*PS % 32 == 16 -> the two phases a 32-lane group
-    // writes (p, p+2) fall on disjoint banks
-    static constexpr int PS = ((PLEN + 31) / 32) * 32 + 8;
+    static constexpr int NCQ = HQ4 * M + 1;                         // padded taps cq[0 .. HQ4*M]
+    static constexpr int NCR = (NCQ + 63) / 64;                     // coefficient VGPRs per lane
+    static constexpr int PLEN = HQ4 + P;                            // complex elements per phase
+    // Polyphase image: per phase p an array of (I,Q) float2 elements; each group of 4 elements
+    // (the 4 outputs one lane owns) occupies THREE 16-byte slots (48 B, last slot unused), so the
+    // ds_read_b128 of lane l at compile-time offset o is at 48*l + imm: lane stride 3 slots is
+    // conflict-free for every b128 lane group and needs no per-read address arithmetic.
+    static constexpr int PSF = 12 * (PLEN / 4);                     // floats per phase array
     static constexpr int HH = NH ? NH - 1 : 0;                      // Hilbert history
     static constexpr int HH4 = (HH + 3) & ~3;
     static constexpr int FH = HH4 - HH;                             // leading pad of the FIR window
     static constexpr int DLEN = HH4 + P + 4;
-    // LDS image (floats)
     static constexpr int oTab = 0;
-    static constexpr int oS = 516;                                  // [2 rails][M][PS]   (ND > 0)
-    static constexpr int oD = oS + (ND ? 2 * M * PS : 0);           // [2 rails][DLEN]
+    static constexpr int oS = 516;                                  // [M][PSF]          (ND > 0)
+    static constexpr int oD = oS + (ND ? M * PSF : 0);              // [2 rails][DLEN]
     static constexpr int total = oD + 2 * DLEN;
+    __host__ __device__ static constexpr int elem(int idx) { return 12 * (idx >> 2) + 2 * (idx & 3); }
 };
 
 struct FusedArgs {
-    const float *cq;        // padded decimator taps: cq[k'] = dec[k' - F] (k' >= F), else 0
+    const float *cq;        // padded decimator taps: cq[k'] = dec[k' - F] (k' >= F), else 0; 64*NCR floats
     uint32_t delay_idx;     // index of the unit tap in delay_coeffs
     uint32_t upper;         // 1: audio = I' - Q'   0: audio = I' + Q'
     uint32_t group;         // lanes per DSP block = (block / M) / 4
@@ -61,30 +68,74 @@ __device__ __forceinline__ float f4get(const float4 &v, int e)
     return e == 0 ? v.x : (e == 1 ? v.y : (e == 2 ? v.z : v.w));
 }
 
-// arm_fir_decimate_f32 for 4 adjacent outputs j = 4*lane + r of one rail.
-// sp: this rail's phase arrays.  Output j needs s[(j - HQ4 + q)*M + p] * cq[q*M + p], q = 0..HQ4.
+// (I,Q) += (I,Q) * c  -- one v_pk_fma_f32, or v_pk_mul_f32 + v_pk_add_f32 in the CMSIS arithmetic
+template <int ARITH>
+__device__ __forceinline__ v2f mac2(v2f acc, v2f w, float c)
+{
+    const v2f c2 = { c, c };
+    if constexpr (ARITH == 1) {
+        return __builtin_elementwise_fma(w, c2, acc);
+    } else {
+        const v2f p = w * c2;
+        return acc + p;
+    }
+}
+
+// raw global loads: two complex samples per lane per instruction
+template <typename TIn> struct Raw;
+template <> struct Raw<float> {
+    typedef float4 type;
+    static __device__ __forceinline__ type load(const float *src, size_t cplx_index)
+    {
+        return *reinterpret_cast<const float4 *>(src + 2 * cplx_index);
+    }
+    static __device__ __forceinline__ void unpack(const type &r, float2 &a, float2 &b)
+    {
+        a = make_float2(r.x, r.y); b = make_float2(r.z, r.w);
+    }
+};
+template <> struct Raw<int16_t> {
+    typedef short4 type;
+    static __device__ __forceinline__ type load(const int16_t *src, size_t cplx_index)
+    {
+        return *reinterpret_cast<const short4 *>(src + 2 * cplx_index);
+    }
+    static __device__ __forceinline__ void unpack(const type &r, float2 &a, float2 &b)
+    {
+        a = make_float2(q15_to_float(r.x), q15_to_float(r.y));
+        b = make_float2(q15_to_float(r.z), q15_to_float(r.w));
+    }
+};
+
+// arm_fir_decimate_f32 on BOTH rails for the 4 adjacent outputs j = 4*lane + r.
+// Output j needs s[(j - HQ4 + q)*M + p] * cq[q*M + p], q = 0..HQ4 ascending, p ascending: the
+// loops below visit (q, p) in exactly that order for every r, so each accumulator sees the
+// reference's tap order.  Coefficients live lane-distributed in creg and reach the SGPR file by
+// v_readlane (no scalar-memory latency, one fetch serves both rails and up to 4 outputs).
 template <int ARITH, int ND, int M, int NH>
-__device__ __forceinline__ void decim_quad(const float *sp, int lane, const float *__restrict__ cq,
-                                           float (&acc)[4])
+__device__ __forceinline__ void decim_quad(const float *S, int lane, const float (&creg)[Geo<ND, M, NH>::NCR],
+                                           v2f (&acc)[4])
 {
     using G = Geo<ND, M, NH>;
+    const float *base = S + 12 * lane;
 #pragma unroll
-    for (int t = 0; t <= G::HQ4 / 4; ++t) {
+    for (int o = 0; o < (G::HQ4 + 4) / 2; ++o) {
         float4 W[M];
 #pragma unroll
         for (int p = 0; p < M; ++p)
-            W[p] = *reinterpret_cast<const float4 *>(sp + p * G::PS + 4 * lane + 4 * t);
+            W[p] = *reinterpret_cast<const float4 *>(base + p * G::PSF + 4 * (3 * (o >> 1) + (o & 1)));
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
+        for (int e = 0; e < 2; ++e) {
 #pragma unroll
             for (int p = 0; p < M; ++p) {
-                const float w = f4get(W[p], e);
+                const v2f w = e ? v2f{ W[p].z, W[p].w } : v2f{ W[p].x, W[p].y };
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int q = 4 * t + e - r;
+                    const int q = 2 * o + e - r;
                     const int kk = q * M + p;
                     if (q < 0 || q > G::HQ4 || (q == G::HQ4 && p > 0) || kk < G::F) continue;
-                    acc[r] = mac<ARITH>(acc[r], w, cq[kk]);
+                    const float c = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(creg[kk >> 6]), kk & 63));
+                    acc[r] = mac2<ARITH>(acc[r], w, c);
                 }
             }
         }
@@ -116,11 +167,12 @@ __device__ __forceinline__ void hilbert_quad(const float *dq, int lane, const fl
 }
 
 template <int ARITH, int ND, int M, int NH, typename TIn, typename TOut>
-__global__ __launch_bounds__(64) void k_ssb_fused(RxParams p, FusedArgs fa, const TIn *__restrict__ src,
-                                                  TOut *__restrict__ dst)
+__global__ __launch_bounds__(64, 2) void k_ssb_fused(RxParams p, FusedArgs fa, const TIn *__restrict__ src,
+                                                     TOut *__restrict__ dst)
 {
     using G = Geo<ND, M, NH>;
-    static_assert(ND == 0 ? M == 1 : true, "decimation needs a decimator");
+    using R = Raw<TIn>;
+    static_assert(ND == 0 ? M == 1 : M == 4, "fused kernel: no decimator, or decimate by 4");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x;
     const uint32_t c = blockIdx.x;
@@ -128,19 +180,29 @@ __global__ __launch_bounds__(64) void k_ssb_fused(RxParams p, FusedArgs fa, cons
     float *S = lds + G::oS;
     float *D = lds + G::oD;
     float *dI = D, *dQ = D + G::DLEN;
+    constexpr int NLD = G::T / 128;                      // raw loads per lane per pass
 
-    // ---- prologue: tables and streaming state into LDS ----
+    const size_t in_base = (size_t)c * p.block_size, out_base = (size_t)c * p.nout;
+    const uint32_t npass = p.nout / G::P;
+    typename R::type raw[NLD];
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) raw[i] = R::load(src, in_base + 128u * i + 2u * lane);
+
+    // ---- prologue: tables and streaming state into LDS / registers ----
     if (p.nco)
         for (int i = lane; i < 513; i += kWave) tab[i] = p.sintab[i];
+    float creg[G::NCR > 0 ? G::NCR : 1];
     if constexpr (ND > 0) {
-        // history slot (phase pp, index m) holds sample s = (m*M + pp) - F of the CMSIS state
+#pragma unroll
+        for (int v = 0; v < G::NCR; ++v) creg[v] = fa.cq[64 * v + lane];
+        // history element (phase pp, index m) holds sample s = (m*M + pp) - F of the CMSIS state
         // (oldest first); slots before the state (s < 0) only ever meet zero-padded taps
         for (int i = lane; i < 2 * M * G::HQ4; i += kWave) {
             const int rail = i / (M * G::HQ4), rem = i % (M * G::HQ4);
             const int s = rem - G::F, pp = rem % M, m = rem / M;
             float v = 0.0f;
             if (s >= 0) v = p.dec_state[((size_t)c * 2 + rail) * (ND - 1) + s];
-            S[(rail * M + pp) * G::PS + m] = v;
+            S[pp * G::PSF + G::elem(m) + rail] = v;
         }
     }
     if constexpr (NH > 0) {
@@ -157,39 +219,40 @@ __global__ __launch_bounds__(64) void k_ssb_fused(RxParams p, FusedArgs fa, cons
     const int group = (int)fa.group;
     __syncthreads();
 
-    const size_t in_base = (size_t)c * p.block_size, out_base = (size_t)c * p.nout;
-    const uint32_t npass = p.nout / G::P;
     for (uint32_t pass = 0; pass < npass; ++pass) {
         const uint32_t n0 = pass * G::T;
-        // ---- 1. coalesced load (2 complex samples per lane per instruction), NCO mix, LDS ----
+        // ---- 1. NCO mix of the prefetched samples, scatter into the LDS image ----
 #pragma unroll
-        for (int i = 0; i < G::T / 128; ++i) {
+        for (int i = 0; i < NLD; ++i) {
             const uint32_t n = 128u * i + 2u * lane;                  // even sample index in the pass
-            float2 a = load_iq(src, in_base + n0 + n);
-            float2 b = load_iq(src, in_base + n0 + n + 1);
+            float2 a, b;
+            R::unpack(raw[i], a, b);
             if (p.nco) {
                 a = cmul<0>(a, nco_lo<0>(tab, ph0 + (n0 + n) * step));
                 b = cmul<0>(b, nco_lo<0>(tab, ph0 + (n0 + n + 1) * step));
             }
             if constexpr (ND > 0) {
-                const int m = G::HQ4 + (int)(n / M), pp = (int)(n % M);   // n even: pp in {0,2}, pp+1 valid
-                S[(0 * M + pp) * G::PS + m] = a.x;
-                S[(0 * M + pp + 1) * G::PS + m] = b.x;
-                S[(1 * M + pp) * G::PS + m] = a.y;
-                S[(1 * M + pp + 1) * G::PS + m] = b.y;
+                const int m = G::HQ4 + (int)(n / M), pp = (int)(n % M);   // n even: pp in {0,2}
+                float *d = S + pp * G::PSF + G::elem(m);
+                *reinterpret_cast<float2 *>(d) = a;
+                *reinterpret_cast<float2 *>(d + G::PSF) = b;
             } else {
                 *reinterpret_cast<float2 *>(dI + G::HH4 + n) = make_float2(a.x, b.x);
                 *reinterpret_cast<float2 *>(dQ + G::HH4 + n) = make_float2(a.y, b.y);
             }
         }
         __syncthreads();
+        // ---- prefetch the next pass while this one computes ----
+        if (pass + 1 < npass) {
+#pragma unroll
+            for (int i = 0; i < NLD; ++i) raw[i] = R::load(src, in_base + n0 + G::T + 128u * i + 2u * lane);
+        }
         // ---- 2. arm_fir_decimate_f32 on both rails, 4 adjacent outputs per lane ----
         if constexpr (ND > 0) {
-            float aI[4] = { 0.0f, 0.0f, 0.0f, 0.0f }, aQ[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
-            decim_quad<ARITH, ND, M, NH>(S, lane, fa.cq, aI);
-            decim_quad<ARITH, ND, M, NH>(S + M * G::PS, lane, fa.cq, aQ);
-            *reinterpret_cast<float4 *>(dI + G::HH4 + 4 * lane) = make_float4(aI[0], aI[1], aI[2], aI[3]);
-            *reinterpret_cast<float4 *>(dQ + G::HH4 + 4 * lane) = make_float4(aQ[0], aQ[1], aQ[2], aQ[3]);
+            v2f acc[4] = { { 0.0f, 0.0f }, { 0.0f, 0.0f }, { 0.0f, 0.0f }, { 0.0f, 0.0f } };
+            decim_quad<ARITH, ND, M, NH>(S, lane, creg, acc);
+            *reinterpret_cast<float4 *>(dI + G::HH4 + 4 * lane) = make_float4(acc[0].x, acc[1].x, acc[2].x, acc[3].x);
+            *reinterpret_cast<float4 *>(dQ + G::HH4 + 4 * lane) = make_float4(acc[0].y, acc[1].y, acc[2].y, acc[3].y);
             __syncthreads();
         }
         // ---- 3. Hilbert pair + sideband combine ----
@@ -237,23 +300,26 @@ __global__ __launch_bounds__(64) void k_ssb_fused(RxParams p, FusedArgs fa, cons
         __syncthreads();
         // ---- 6. history copy-back (arm_fir_decimate_f32.c:396-426, arm_fir_f32.c:947-978) ----
         if constexpr (ND > 0) {
-            constexpr int NV = 2 * M * (G::HQ4 / 4);                  // float4 moves
-            float4 tmp[(NV + 63) / 64];
+            constexpr int NG = M * (G::HQ4 / 4);                      // 48-byte groups to move
+            constexpr int NK = (NG + 63) / 64;
+            float4 t0[NK], t1[NK];
 #pragma unroll
-            for (int k = 0; k < (NV + 63) / 64; ++k) {
+            for (int k = 0; k < NK; ++k) {
                 const int i = k * 64 + lane;
-                if (i < NV) {
-                    const int arr = i / (G::HQ4 / 4), v = i % (G::HQ4 / 4);
-                    tmp[k] = *reinterpret_cast<const float4 *>(S + arr * G::PS + G::P + 4 * v);
+                if (i < NG) {
+                    const float *sp = S + (i / (G::HQ4 / 4)) * G::PSF + 12 * (G::P / 4 + i % (G::HQ4 / 4));
+                    t0[k] = *reinterpret_cast<const float4 *>(sp);
+                    t1[k] = *reinterpret_cast<const float4 *>(sp + 4);
                 }
             }
             __syncthreads();
 #pragma unroll
-            for (int k = 0; k < (NV + 63) / 64; ++k) {
+            for (int k = 0; k < NK; ++k) {
                 const int i = k * 64 + lane;
-                if (i < NV) {
-                    const int arr = i / (G::HQ4 / 4), v = i % (G::HQ4 / 4);
-                    *reinterpret_cast<float4 *>(S + arr * G::PS + 4 * v) = tmp[k];
+                if (i < NG) {
+                    float *dp = S + (i / (G::HQ4 / 4)) * G::PSF + 12 * (i % (G::HQ4 / 4));
+                    *reinterpret_cast<float4 *>(dp) = t0[k];
+                    *reinterpret_cast<float4 *>(dp + 4) = t1[k];
                 }
             }
         }
@@ -274,7 +340,7 @@ __global__ __launch_bounds__(64) void k_ssb_fused(RxParams p, FusedArgs fa, cons
         for (int i = lane; i < 2 * M * G::HQ4; i += kWave) {
             const int rail = i / (M * G::HQ4), rem = i % (M * G::HQ4);
             const int s = rem - G::F, pp = rem % M, m = rem / M;
-            if (s >= 0) p.dec_state[((size_t)c * 2 + rail) * (ND - 1) + s] = S[(rail * M + pp) * G::PS + m];
+            if (s >= 0) p.dec_state[((size_t)c * 2 + rail) * (ND - 1) + s] = S[pp * G::PSF + G::elem(m) + rail];
         }
     }
     if constexpr (NH > 0) {
@@ -303,7 +369,7 @@ static hipError_t build_tables(const selenite_rx_config &g, FusedPlan &plan)
 {
     using G = Geo<ND, M, NH>;
     if constexpr (ND > 0) {
-        std::vector<float> cq((size_t)G::HQ4 * M + 4, 0.0f);
+        std::vector<float> cq((size_t)64 * G::NCR, 0.0f);
         for (int k = 0; k < ND; ++k) cq[(size_t)k + G::F] = g.dec_coeffs[k];
         hipError_t e = hipMalloc((void **)&plan.d_cq, cq.size() * sizeof(float));
         if (e != hipSuccess) return e;
