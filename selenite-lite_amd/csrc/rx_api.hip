@@ -67,14 +67,14 @@ static hipError_t dev_upload(T **d, const T *h, size_t n)
     if (e != hipSuccess) return e;
     return hipMemcpy(*d, h, n * sizeof(T), hipMemcpyHostToDevice);
 }
+// allocation only: every state buffer is initialised by reset_state() on the instance's own stream
+// (a null-stream hipMemset here could land AFTER reset_state's writes: the streams do not order)
 template <typename T>
-static hipError_t dev_zero(T **d, size_t n)
+static hipError_t dev_alloc(T **d, size_t n)
 {
     *d = nullptr;
     if (n == 0) return hipSuccess;
-    hipError_t e = hipMalloc((void **)d, n * sizeof(T));
-    if (e != hipSuccess) return e;
-    return hipMemset(*d, 0, n * sizeof(T));
+    return hipMalloc((void **)d, n * sizeof(T));
 }
 
 static void classify_coeffs(selenite_rx_instance *S)
@@ -214,11 +214,11 @@ extern "C" int selenite_rx_init(selenite_rx_instance **out, const selenite_rx_co
     INITCHK(dev_upload(&S->d_biq_c, S->h_biq.data(), S->h_biq.size()));
     INITCHK(dev_upload(&S->d_sintab, host_sin_table(), (size_t)513));
     INITCHK(dev_upload(&S->d_step, S->h_step.data(), C));
-    INITCHK(dev_zero(&S->d_phase, C));
-    INITCHK(dev_zero(&S->d_dec_state, cfg->nd_taps > 1 ? C * 2 * (cfg->nd_taps - 1) : 0));
-    INITCHK(dev_zero(&S->d_fir_state, cfg->nh_taps > 1 ? C * 2 * (cfg->nh_taps - 1) : 0));
-    INITCHK(dev_zero(&S->d_biq_state, C * 4 * cfg->n_biquad));
-    INITCHK(dev_zero(&S->d_gain, C));
+    INITCHK(dev_alloc(&S->d_phase, C));
+    INITCHK(dev_alloc(&S->d_dec_state, cfg->nd_taps > 1 ? C * 2 * (cfg->nd_taps - 1) : 0));
+    INITCHK(dev_alloc(&S->d_fir_state, cfg->nh_taps > 1 ? C * 2 * (cfg->nh_taps - 1) : 0));
+    INITCHK(dev_alloc(&S->d_biq_state, C * 4 * cfg->n_biquad));
+    INITCHK(dev_alloc(&S->d_gain, C));
 #undef INITCHK
     classify_coeffs(S);
     if (plan_fused(S->cfg, S->delay_is_impulse, S->delay_index, S->hilb_odd_only, S->plan) != hipSuccess) {

@@ -116,6 +116,7 @@ class ChainSpec:
         g.agc_target, g.agc_attack, g.agc_decay = p["target"], p["attack"], p["decay"]
         g.agc_gain_min, g.agc_gain_max = p["gain_min"], p["gain_max"]
         g.agc_env_floor, g.agc_gain_init = p["env_floor"], p["gain_init"]
+        g._keepalive = self          # the struct only holds raw pointers into this spec's arrays
         return g
 
     def state_arrays(self):
@@ -179,6 +180,24 @@ def oracle_lib():
         L.orc_rx_get_state.argtypes = [C.c_void_p, C.POINTER(StateView)]
         L.orc_rx_set_state.argtypes = [C.c_void_p, C.POINTER(StateView)]
         L.orc_synth_iq.argtypes = [f32p, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint64]
+        u32, ci = C.c_uint32, C.c_int
+        L.orc_cmplx_mult_cmplx_f32.argtypes = [f32p, f32p, f32p, u32, ci]
+        L.orc_cmplx_mag_f32.argtypes = [f32p, f32p, u32, ci]
+        L.orc_fir_decimate_f32.argtypes = [f32p, u32, u32, f32p, f32p, f32p, u32, ci]
+        L.orc_fir_f32.argtypes = [f32p, u32, f32p, f32p, f32p, u32, ci]
+        L.orc_biquad_cascade_df1_f32.argtypes = [f32p, u32, f32p, f32p, f32p, u32, ci]
+        L.orc_add_f32.argtypes = [f32p, f32p, f32p, u32]
+        L.orc_sub_f32.argtypes = [f32p, f32p, f32p, u32]
+        L.orc_abs_f32.argtypes = [f32p, f32p, u32]
+        L.orc_max_f32.argtypes = [f32p, u32, f32p, u32p]
+        L.orc_scale_f32.argtypes = [f32p, C.c_float, f32p, u32]
+        L.orc_q15_to_float.argtypes = [i16p, f32p, u32]
+        L.orc_float_to_q15.argtypes = [f32p, i16p, u32]
+        for fn in ("orc_cmplx_mult_cmplx_f32", "orc_cmplx_mag_f32", "orc_fir_decimate_f32", "orc_fir_f32",
+                   "orc_biquad_cascade_df1_f32", "orc_add_f32", "orc_sub_f32", "orc_abs_f32", "orc_max_f32",
+                   "orc_scale_f32", "orc_q15_to_float", "orc_float_to_q15", "orc_synth_iq",
+                   "orc_rx_process_f32", "orc_rx_process_q15", "orc_rx_process_f32_env", "orc_rx_destroy"):
+            getattr(L, fn).restype = None
         _oracle = L
     return _oracle
 

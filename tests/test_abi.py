@@ -1,0 +1,118 @@
+"""CPU: the C-ABI library loads, exports every symbol include/selenite_rx.h declares, validates
+arguments the way the CMSIS init functions do, and refuses to run without a GPU (no CPU fallback).
+No compute call is made here."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import rxcommon as rc
+import selenite_rx as sr
+
+
+def header_symbols():
+    text = open(os.path.join(rc.ROOT, "include", "selenite_rx.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(selenite_rx_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    L = sr.lib()
+    names = header_symbols()
+    assert len(names) >= 30
+    for n in names:
+        assert hasattr(L, n), "libselenite_rx.so does not export %s" % n
+    assert sorted(sr.ABI_SYMBOLS) == names              # the Python face covers the whole header
+    assert L.selenite_rx_abi_version() == 1
+
+
+def test_config_struct_layout_matches_header():
+    # C layout of selenite_rx_config on LP64: 8 u32, 4 u8, u32, 5 pointers, 7 floats (+4 tail pad)
+    assert C.sizeof(sr.Config) == 8 * 4 + 4 + 4 + 5 * 8 + 7 * 4 + 4
+    assert sr.Config.dec_coeffs.offset == 40 and sr.Config.agc_target.offset == 80
+    assert C.sizeof(sr.StateView) == 40
+
+
+def has_gpu():
+    return sr.lib().selenite_rx_device_count() > 0
+
+
+def init_rc(spec, mutate=None):
+    cfg = spec.config()
+    if mutate:
+        mutate(cfg)
+    h = C.c_void_p()
+    code = sr.lib().selenite_rx_init(C.byref(h), C.byref(cfg))
+    if h:
+        sr.lib().selenite_rx_free(h)
+    return code
+
+
+def test_init_argument_validation_precedes_device_use():
+    ok = rc.baseline_spec("cfg3", 2)
+    assert init_rc(ok, lambda g: setattr(g, "struct_size", 12)) == rc.ARGUMENT_ERROR
+    assert init_rc(ok, lambda g: setattr(g, "channels", 0)) == rc.ARGUMENT_ERROR
+    assert init_rc(ok, lambda g: setattr(g, "mode", rc.MODE_FM)) == rc.ARGUMENT_ERROR
+    assert init_rc(ok, lambda g: setattr(g, "arith", 7)) == rc.ARGUMENT_ERROR
+    assert init_rc(ok, lambda g: setattr(g, "nd_taps", 0)) == rc.ARGUMENT_ERROR        # decim 4 without decimator
+    assert init_rc(ok, lambda g: setattr(g, "hilb_coeffs", None)) == rc.ARGUMENT_ERROR
+    # arm_fir_decimate_init_f32.c:74-97: blockSize % M != 0 -> ARM_MATH_LENGTH_ERROR (-2)
+    assert init_rc(ok, lambda g: setattr(g, "block", 255)) == rc.LENGTH_ERROR
+    assert sr.lib().selenite_rx_error_string(None)
+
+
+def test_no_cpu_fallback_without_gpu():
+    if has_gpu():
+        pytest.skip("a GPU is present")
+    with pytest.raises(sr.RxError) as e:
+        sr.Rx(rc.baseline_spec("cfg1", 1).config())
+    assert e.value.code == rc.DEVICE_ERROR and "no CPU fallback" in str(e.value)
+
+
+def test_null_instance_calls_are_safe():
+    L = sr.lib()
+    L.selenite_rx_free(None)
+    assert L.selenite_rx_status(None) == rc.ARGUMENT_ERROR
+    assert L.selenite_rx_set_mode(None, 1) == rc.ARGUMENT_ERROR
+    L.selenite_rx_process_f32(None, None, None, 256)
+
+
+def test_design_helpers_match_numpy_designs():
+    for n, fc in [(256, 0.1), (63, 0.2), (17, 0.05)]:
+        assert np.array_equal(sr.design_lowpass(n, fc), rc.design_lowpass(n, fc))
+    for n in (63, 127, 31):
+        h, d = sr.design_hilbert(n)
+        h2, d2 = rc.design_hilbert(n)
+        assert np.array_equal(h, h2) and np.array_equal(d, d2)
+        c = (n - 1) // 2
+        assert np.all(h[(np.arange(n) - c) % 2 == 0] == 0.0)          # type III: structural zeros
+        assert np.allclose(h, -h[::-1], atol=0) and d[c] == 1.0 and d.sum() == 1.0
+    assert np.array_equal(sr.design_bandpass(4, 500 / 48000, 4.0), rc.design_bandpass(4, 500 / 48000, 4.0))
+    lp = sr.design_lowpass(256, 0.1).astype(np.float64)
+    assert abs(lp.sum() - 1.0) < 1e-6 and np.allclose(lp, lp[::-1], atol=1e-9)
+    with pytest.raises(ValueError):
+        sr.design_hilbert(64)
+    with pytest.raises(ValueError):
+        sr.design_lowpass(64, 0.7)
+
+
+def test_host_synth_matches_oracle_synth_and_is_bounded():
+    a = sr.synth_iq_host(7, 5, 10 ** 9, 777, rc.SEED)
+    b = rc.synth_iq(7, 5, 10 ** 9, 777)
+    assert rc.bits_equal(a, b)
+    assert np.abs(a).max() < 0.8 and np.abs(a).std() > 0.1
+    # channel- and time-shift consistency (what channel sharding relies on)
+    full = rc.synth_iq(0, 8, 0, 512)
+    assert rc.bits_equal(full[3:6], rc.synth_iq(3, 3, 0, 512))
+    assert rc.bits_equal(full[:, 100:300], rc.synth_iq(0, 8, 100, 200))
+
+
+def test_algorithmic_bytes_formula():
+    spec = rc.baseline_spec("cfg3", 65536)
+    cfg = spec.config()
+    rd = C.c_uint64()
+    tot = sr.lib().selenite_rx_algorithmic_bytes(C.byref(cfg), 4096, C.byref(rd))
+    assert tot == 65536 * 41952                           # 41 952 B per channel-block
+    assert rd.value == 65536 * (8 * 4096 + 4 * (510 + 124) + 8)
