@@ -116,3 +116,13 @@ def test_algorithmic_bytes_formula():
     tot = sr.lib().selenite_rx_algorithmic_bytes(C.byref(cfg), 4096, C.byref(rd))
     assert tot == 65536 * 41952                           # 41 952 B per channel-block
     assert rd.value == 65536 * (8 * 4096 + 4 * (510 + 124) + 8)
+
+
+def test_pure_c_host_example_links_and_fails_loudly_without_gpu():
+    import subprocess
+    exe = os.path.join(rc.PKG_DIR, "host", "dsp_if_slot")
+    assert os.path.exists(exe), "make -C selenite-lite_amd builds host/dsp_if_slot"
+    if has_gpu():
+        pytest.skip("a GPU is present (covered by the gpu-marked test)")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 77 and "no CPU fallback" in r.stderr

@@ -65,3 +65,13 @@ def test_q15_fixture():
     q = np.clip(np.trunc(iq * 32768.0), -32768, 32767).astype(np.int16)
     gold = np.load(os.path.join(G, "chain_cfg3_q15.npz"))
     assert np.array_equal(rx.process_q15(q), gold["audio"])
+
+
+def test_pure_c_host_slot_example_runs():
+    """selenite-lite_amd/host/dsp_if_slot.c: C host code in the shape of the firmware's callback slot
+    (dsp_if.c:50-67), linked against the C-ABI only."""
+    import subprocess
+    exe = os.path.join(rc.PKG_DIR, "host", "dsp_if_slot")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.count("k_ssb_fused<256,4,63>") == 3
