@@ -109,7 +109,7 @@ static void free_device(selenite_rx_instance *S)
 {
     void *ptrs[] = { S->d_dec_c, S->d_hilb_c, S->d_delay_c, S->d_biq_c, S->d_sintab, S->d_step, S->d_phase,
                      S->d_dec_state, S->d_fir_state, S->d_biq_state, S->d_gain, S->d_scratch, S->d_env,
-                     S->d_io_in, S->d_io_out };
+                     S->d_io_in, S->d_io_out, S->d_lo };
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     free_fused(S->plan);
@@ -127,6 +127,8 @@ static int reset_state(selenite_rx_instance *S)
     std::vector<float> gi(C, g.agc_gain_init);
     HIPCHK(S, hipMemcpyAsync(S->d_gain, gi.data(), C * sizeof(float), hipMemcpyHostToDevice, S->stream));
     HIPCHK(S, hipStreamSynchronize(S->stream));
+    S->phase_uniform = true;
+    S->phase_host = 0;
     return SELENITE_RX_SUCCESS;
 }
 
@@ -190,8 +192,12 @@ extern "C" int selenite_rx_init(selenite_rx_instance **out, const selenite_rx_co
     S->cfg.dec_coeffs = S->h_dec.data(); S->cfg.hilb_coeffs = S->h_hilb.data();
     S->cfg.delay_coeffs = S->h_delay.data(); S->cfg.biquad_coeffs = S->h_biq.data();
     S->cfg.nco_step = S->h_step.data();
+    S->steps_uniform = true;
+    for (size_t c = 1; c < C; ++c) S->steps_uniform = S->steps_uniform && S->h_step[c] == S->h_step[0];
     const char *fg = std::getenv("SELENITE_RX_FORCE_GENERIC");
     S->force_generic = (fg && fg[0] == '1') ? 1 : 0;
+    const char *nl = std::getenv("SELENITE_RX_NO_SHARED_LO");
+    S->no_shared_lo = (nl && nl[0] == '1') ? 1 : 0;
 
 #define INITCHK(call)                                                                        \
     do {                                                                                     \
@@ -343,8 +349,20 @@ static int run_chain(selenite_rx_instance *S, const void *src, bool src_q15, voi
     const bool cw = mode_is_cw(g.mode) && g.n_biquad;
     hipStream_t st = S->stream;
 
+    // host copy of the common NCO phase (valid while every channel shares step and phase)
+    const uint32_t phase_now = S->phase_host;
+    if (phase != kPhase2 && g.nco_enable) S->phase_host += block_size * S->h_step[0];
+
     if (phase != kPhase2 && !global && !S->force_generic && S->plan.kind != 0 &&
         fused_block_size_ok(S->plan, g, block_size)) {
+        if (g.nco_enable && S->steps_uniform && S->phase_uniform && !S->no_shared_lo) {
+            // one LO for all channels: computed once per call, read from L2 by every wavefront
+            int rc = ensure(S, (void **)&S->d_lo, &S->lo_bytes, (size_t)block_size * sizeof(float2));
+            if (rc) return rc;
+            HIPCHK(S, launch_lo_table(S->d_lo, S->d_sintab, phase_now, S->h_step[0], block_size, st));
+            p.nco = 2;
+            p.lo = S->d_lo;
+        }
         HIPCHK(S, launch_fused(S->plan, p, arith, src, src_q15, dst, dst_q15, S->delay_index, st));
         return SELENITE_RX_SUCCESS;
     }
@@ -479,7 +497,12 @@ extern "C" int selenite_rx_set_state(selenite_rx_instance *S, const selenite_rx_
     if (v->biq_state && g.n_biquad)
         HIPCHK(S, hipMemcpy(S->d_biq_state, v->biq_state, C * 4 * g.n_biquad * sizeof(float), hipMemcpyHostToDevice));
     if (v->agc_gain) HIPCHK(S, hipMemcpy(S->d_gain, v->agc_gain, C * sizeof(float), hipMemcpyHostToDevice));
-    if (v->nco_phase) HIPCHK(S, hipMemcpy(S->d_phase, v->nco_phase, C * sizeof(uint32_t), hipMemcpyHostToDevice));
+    if (v->nco_phase) {
+        HIPCHK(S, hipMemcpy(S->d_phase, v->nco_phase, C * sizeof(uint32_t), hipMemcpyHostToDevice));
+        S->phase_uniform = true;
+        for (size_t c = 1; c < C; ++c) S->phase_uniform = S->phase_uniform && v->nco_phase[c] == v->nco_phase[0];
+        S->phase_host = v->nco_phase[0];
+    }
     return SELENITE_RX_SUCCESS;
 }
 

@@ -24,6 +24,8 @@
 // AGC with block/M in {4..256, power of two}.  Everything else runs on rx_generic.hip.
 #include "rx_internal.h"
 
+#include <cstdlib>
+
 #pragma clang fp contract(off)
 
 namespace srx {
@@ -62,6 +64,18 @@ struct FusedArgs {
     uint32_t upper;         // 1: audio = I' - Q'   0: audio = I' + Q'
     uint32_t group;         // lanes per DSP block = (block / M) / 4
 };
+
+// Workgroups of these kernels are ONE wavefront: LDS instructions of a wave execute in issue order,
+// so a store is visible to any lane's later load without s_barrier.  What is needed is only that
+// the compiler keeps the program order of LDS accesses: a wavefront-scope fence (emits nothing)
+// plus the wave_barrier scheduling fence.  __syncthreads() would add "s_waitcnt vmcnt(0)", which
+// drains the next pass's HBM prefetch and stalls the wave for a full memory latency per pass.
+__device__ __forceinline__ void wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
 __device__ __forceinline__ float f4get(const float4 &v, int e)
 {
@@ -166,7 +180,58 @@ __device__ __forceinline__ void hilbert_quad(const float *dq, int lane, const fl
     }
 }
 
-template <int ARITH, int ND, int M, int NH, typename TIn, typename TOut>
+// Steps 3-5 of a pass, shared by the VALU and the MFMA kernels: Hilbert FIR on Q (structural zeros
+// skipped) and unit-impulse delay on I from the decimated rails in LDS, sideband combine, AGC per
+// DSP block (group lanes), one 4-sample store per lane.
+template <int ARITH, int ND, int M, int NH, typename TOut>
+__device__ __forceinline__ void demod_agc_store(const RxParams &p, const FusedArgs &fa, const float *dI,
+                                                const float *dQ, int lane, int group, float &gain,
+                                                TOut *__restrict__ dst, size_t out_index)
+{
+    using G = Geo<ND, M, NH>;
+    float au[4];
+    if constexpr (NH > 0) {
+        float q2[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+        hilbert_quad<ARITH, ND, M, NH>(dQ, lane, p.hilb_c, q2);
+        const float *di = dI + G::FH + fa.delay_idx + 4 * lane;   // unit-impulse delay FIR
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float i2 = di[r] + 0.0f;                        // 0.0f + 1.0f*x of the dense loop
+            au[r] = fa.upper ? (i2 - q2[r]) : (i2 + q2[r]);       // arm_sub_f32 / arm_add_f32
+        }
+    } else {
+        const float4 v = *reinterpret_cast<const float4 *>(dI + 4 * lane);
+        au[0] = v.x; au[1] = v.y; au[2] = v.z; au[3] = v.w;
+    }
+    // AGC: arm_abs + arm_max per DSP block (group lanes), gain law, arm_scale
+    if (p.agc) {
+        float m = fmaxf(fmaxf(fabsf(au[0]), fabsf(au[1])), fmaxf(fabsf(au[2]), fabsf(au[3])));
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1)
+            if (off < group) m = fmaxf(m, __shfl_xor(m, off, 64));
+        float g = gain, mine = gain;
+        const int nblk = 64 / group, myblk = lane / group;
+        for (int b = 0; b < nblk; ++b) {
+            const float env = __shfl(m, b * group, 64);
+            g = agc_update<0>(p.agcp, g, env);
+            if (b == myblk) mine = g;
+        }
+        gain = g;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) au[r] = au[r] * mine;
+    }
+    const size_t o = out_index + 4 * lane;
+    if constexpr (sizeof(TOut) == 4) {
+        *reinterpret_cast<float4 *>(reinterpret_cast<float *>(dst) + o) = make_float4(au[0], au[1], au[2], au[3]);
+    } else {
+        short4 s4;
+        s4.x = float_to_q15(au[0]); s4.y = float_to_q15(au[1]);
+        s4.z = float_to_q15(au[2]); s4.w = float_to_q15(au[3]);
+        *reinterpret_cast<short4 *>(reinterpret_cast<int16_t *>(dst) + o) = s4;
+    }
+}
+
+template <int ARITH, int NCO, int ND, int M, int NH, typename TIn, typename TOut>
 __global__ __launch_bounds__(64, 2) void k_ssb_fused(RxParams p, FusedArgs fa, const TIn *__restrict__ src,
                                                      TOut *__restrict__ dst)
 {
@@ -189,7 +254,7 @@ __global__ __launch_bounds__(64, 2) void k_ssb_fused(RxParams p, FusedArgs fa, c
     for (int i = 0; i < NLD; ++i) raw[i] = R::load(src, in_base + 128u * i + 2u * lane);
 
     // ---- prologue: tables and streaming state into LDS / registers ----
-    if (p.nco)
+    if constexpr (NCO == 1)
         for (int i = lane; i < 513; i += kWave) tab[i] = p.sintab[i];
     float creg[G::NCR > 0 ? G::NCR : 1];
     if constexpr (ND > 0) {
@@ -213,21 +278,32 @@ __global__ __launch_bounds__(64, 2) void k_ssb_fused(RxParams p, FusedArgs fa, c
             D[rail * G::DLEN + m] = v;
         }
     }
-    const uint32_t ph0 = p.nco ? p.phase[c] : 0u;
-    const uint32_t step = p.nco ? p.step[c] : 0u;
+    const uint32_t ph0 = NCO ? p.phase[c] : 0u;
+    const uint32_t step = NCO ? p.step[c] : 0u;
     float gain = p.agc ? p.gain[c] : 1.0f;
     const int group = (int)fa.group;
-    __syncthreads();
+    wave_lds_sync();
 
     for (uint32_t pass = 0; pass < npass; ++pass) {
         const uint32_t n0 = pass * G::T;
         // ---- 1. NCO mix of the prefetched samples, scatter into the LDS image ----
+        float4 lo4[NLD];
+        if constexpr (NCO == 2) {                                     // shared LO table (L2 resident):
+#pragma unroll
+            for (int i = 0; i < NLD; ++i)                             // all loads of the pass in flight at once
+                lo4[i] = *reinterpret_cast<const float4 *>(p.lo + n0 + 128u * i + 2u * lane);
+            __builtin_amdgcn_sched_barrier(0);
+        }
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
             const uint32_t n = 128u * i + 2u * lane;                  // even sample index in the pass
             float2 a, b;
             R::unpack(raw[i], a, b);
-            if (p.nco) {
+            if constexpr (NCO == 2) {
+                const float4 l2 = lo4[i];
+                a = cmul<0>(a, make_float2(l2.x, l2.y));
+                b = cmul<0>(b, make_float2(l2.z, l2.w));
+            } else if constexpr (NCO == 1) {
                 a = cmul<0>(a, nco_lo<0>(tab, ph0 + (n0 + n) * step));
                 b = cmul<0>(b, nco_lo<0>(tab, ph0 + (n0 + n + 1) * step));
             }
@@ -241,7 +317,7 @@ __global__ __launch_bounds__(64, 2) void k_ssb_fused(RxParams p, FusedArgs fa, c
                 *reinterpret_cast<float2 *>(dQ + G::HH4 + n) = make_float2(a.y, b.y);
             }
         }
-        __syncthreads();
+        wave_lds_sync();
         // ---- prefetch the next pass while this one computes ----
         if (pass + 1 < npass) {
 #pragma unroll
@@ -253,51 +329,12 @@ __global__ __launch_bounds__(64, 2) void k_ssb_fused(RxParams p, FusedArgs fa, c
             decim_quad<ARITH, ND, M, NH>(S, lane, creg, acc);
             *reinterpret_cast<float4 *>(dI + G::HH4 + 4 * lane) = make_float4(acc[0].x, acc[1].x, acc[2].x, acc[3].x);
             *reinterpret_cast<float4 *>(dQ + G::HH4 + 4 * lane) = make_float4(acc[0].y, acc[1].y, acc[2].y, acc[3].y);
-            __syncthreads();
+            wave_lds_sync();
         }
-        // ---- 3. Hilbert pair + sideband combine ----
-        float au[4];
-        if constexpr (NH > 0) {
-            float q2[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
-            hilbert_quad<ARITH, ND, M, NH>(dQ, lane, p.hilb_c, q2);
-            const float *di = dI + G::FH + fa.delay_idx + 4 * lane;   // unit-impulse delay FIR
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float i2 = di[r] + 0.0f;                        // 0.0f + 1.0f*x of the dense loop
-                au[r] = fa.upper ? (i2 - q2[r]) : (i2 + q2[r]);       // arm_sub_f32 / arm_add_f32
-            }
-        } else {
-            const float4 v = *reinterpret_cast<const float4 *>(dI + 4 * lane);
-            au[0] = v.x; au[1] = v.y; au[2] = v.z; au[3] = v.w;
-        }
-        // ---- 4. AGC: arm_abs + arm_max per DSP block (group lanes), gain law, arm_scale ----
-        if (p.agc) {
-            float m = fmaxf(fmaxf(fabsf(au[0]), fabsf(au[1])), fmaxf(fabsf(au[2]), fabsf(au[3])));
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1)
-                if (off < group) m = fmaxf(m, __shfl_xor(m, off, 64));
-            float g = gain, mine = gain;
-            const int nblk = 64 / group, myblk = lane / group;
-            for (int b = 0; b < nblk; ++b) {
-                const float env = __shfl(m, b * group, 64);
-                g = agc_update<0>(p.agcp, g, env);
-                if (b == myblk) mine = g;
-            }
-            gain = g;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) au[r] = au[r] * mine;
-        }
-        // ---- 5. store: 4 adjacent audio samples per lane ----
-        const size_t o = out_base + (size_t)pass * G::P + 4 * lane;
-        if constexpr (sizeof(TOut) == 4) {
-            *reinterpret_cast<float4 *>(reinterpret_cast<float *>(dst) + o) = make_float4(au[0], au[1], au[2], au[3]);
-        } else {
-            short4 s4;
-            s4.x = float_to_q15(au[0]); s4.y = float_to_q15(au[1]);
-            s4.z = float_to_q15(au[2]); s4.w = float_to_q15(au[3]);
-            *reinterpret_cast<short4 *>(reinterpret_cast<int16_t *>(dst) + o) = s4;
-        }
-        __syncthreads();
+        // ---- 3-5. Hilbert pair + sideband, AGC, store ----
+        demod_agc_store<ARITH, ND, M, NH, TOut>(p, fa, dI, dQ, lane, group, gain, dst,
+                                                out_base + (size_t)pass * G::P);
+        wave_lds_sync();
         // ---- 6. history copy-back (arm_fir_decimate_f32.c:396-426, arm_fir_f32.c:947-978) ----
         if constexpr (ND > 0) {
             constexpr int NG = M * (G::HQ4 / 4);                      // 48-byte groups to move
@@ -312,7 +349,7 @@ __global__ __launch_bounds__(64, 2) void k_ssb_fused(RxParams p, FusedArgs fa, c
                     t1[k] = *reinterpret_cast<const float4 *>(sp + 4);
                 }
             }
-            __syncthreads();
+            wave_lds_sync();
 #pragma unroll
             for (int k = 0; k < NK; ++k) {
                 const int i = k * 64 + lane;
@@ -329,10 +366,10 @@ __global__ __launch_bounds__(64, 2) void k_ssb_fused(RxParams p, FusedArgs fa, c
             float4 tmp;
             const int rail = lane / (G::HH4 / 4), v = lane % (G::HH4 / 4);
             if (lane < NV) tmp = *reinterpret_cast<const float4 *>(D + rail * G::DLEN + G::P + 4 * v);
-            __syncthreads();
+            wave_lds_sync();
             if (lane < NV) *reinterpret_cast<float4 *>(D + rail * G::DLEN + 4 * v) = tmp;
         }
-        __syncthreads();
+        wave_lds_sync();
     }
 
     // ---- epilogue: streaming state back to HBM ----
@@ -350,9 +387,244 @@ __global__ __launch_bounds__(64, 2) void k_ssb_fused(RxParams p, FusedArgs fa, c
         }
     }
     if (lane == 0) {
-        if (p.nco) p.phase[c] = ph0 + p.block_size * step;
+        if constexpr (NCO != 0) p.phase[c] = ph0 + p.block_size * step;
         if (p.agc) p.gain[c] = gain;
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_ssb_mfma<ND, 4, NH, TIn, TOut> -- FMA-arithmetic variant with the decimator on the matrix
+// cores.  v_mfma_f32_16x16x4_f32 is bit-for-bit a k-ordered fmaf chain (cdna_hip_programming.md
+// section 3), i.e. exactly SELENITE_ARITH_FMA's contract, so this kernel is bit-exact against the
+// oracle's fmaf restatement.  The FIR is cast as a banded-Toeplitz product
+//     D[i][n] = sum_k A[i][k] * B[k][n],   A[i][k] = x[64*i + k],   B[k][n] = cq[k - 4*n]
+// rows i = 16 blocks of 16 consecutive outputs of one rail, columns n = the 16 outputs of a block,
+// k = 0 .. ND+60 (80 MFMA steps of 4; 256/320 = 80 % of the multiplies are on real taps; a zero
+// B entry adds fma(x, 0, acc) = acc exactly).  B (80 VGPRs) is loaded once per kernel; A is one
+// ds_read_b32 per MFMA from a flat per-rail LDS image whose 64-sample rows are padded by 2 dwords
+// (address = 66*(lane&15) + (lane>>4) + imm: conflict-free for both 32-lane groups).
+// The VALU (NCO, Hilbert, AGC, address math) runs beside the MFMA pipe instead of in front of it.
+// ------------------------------------------------------------------------------------------
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+template <int ND, int M, int NH>
+struct GeoM {
+    using G = Geo<ND, M, NH>;
+    static constexpr int HS = G::HQ4 * M;                 // history samples kept in front (>= ND-1)
+    static constexpr int XN = HS + G::T;                  // samples per rail in LDS
+    static constexpr int XROWS = XN / 64;
+    static constexpr int XLEN = 66 * XROWS;               // padded floats per rail
+    static constexpr int KTOT = ND + 4 * 15 + 1;          // padded taps 0..ND  +  shift of 15 outputs
+    static constexpr int KS = (KTOT + 3) / 4;             // MFMA k-steps
+    static constexpr int oTab = 0;
+    static constexpr int oX = 516;
+    static constexpr int oD = oX + 2 * XLEN;
+    static constexpr int total = oD + 2 * G::DLEN;
+    __host__ __device__ static constexpr int phys(int f) { return f + 2 * (f >> 6); }
+};
+
+template <int NCO, int ND, int M, int NH, typename TIn, typename TOut>
+__global__ __launch_bounds__(64, 2) void k_ssb_mfma(RxParams p, FusedArgs fa, const float *__restrict__ btab,
+                                                    const TIn *__restrict__ src, TOut *__restrict__ dst)
+{
+    using G = Geo<ND, M, NH>;
+    using GM = GeoM<ND, M, NH>;
+    using R = Raw<TIn>;
+    static_assert(ND > 0 && M == 4 && G::T % 64 == 0 && GM::HS % 64 == 0, "MFMA decimator: /4, 64-sample rows");
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x;
+    const uint32_t c = blockIdx.x;
+    float *tab = lds + GM::oTab;
+    float *XI = lds + GM::oX, *XQ = XI + GM::XLEN;
+    float *D = lds + GM::oD;
+    float *dI = D, *dQ = D + G::DLEN;
+    constexpr int NLD = G::T / 128;
+
+    const size_t in_base = (size_t)c * p.block_size, out_base = (size_t)c * p.nout;
+    const uint32_t npass = p.nout / G::P;
+    typename R::type raw[NLD];
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) raw[i] = R::load(src, in_base + 128u * i + 2u * lane);
+
+    // Toeplitz B operand: lane l holds B[k = 4*ks + (l>>4)][n = l&15] = cq[k - 4n]
+    float B[GM::KS];
+#pragma unroll
+    for (int ks = 0; ks < GM::KS; ++ks) B[ks] = btab[64 * ks + lane];
+
+    if constexpr (NCO == 1)
+        for (int i = lane; i < 513; i += kWave) tab[i] = p.sintab[i];
+    // history: flat sample f in [0, HS) is CMSIS state sample s = f - F (older slots meet zero taps)
+    for (int i = lane; i < 2 * GM::HS; i += kWave) {
+        const int rail = i / GM::HS, f = i % GM::HS, s = f - G::F;
+        float v = 0.0f;
+        if (s >= 0) v = p.dec_state[((size_t)c * 2 + rail) * (ND - 1) + s];
+        (rail ? XQ : XI)[GM::phys(f)] = v;
+    }
+    if constexpr (NH > 0) {
+        for (int i = lane; i < 2 * G::HH4; i += kWave) {
+            const int rail = i / G::HH4, m = i % G::HH4, s = m - G::FH;
+            float v = 0.0f;
+            if (s >= 0) v = p.fir_state[((size_t)c * 2 + rail) * G::HH + s];
+            D[rail * G::DLEN + m] = v;
+        }
+    }
+    const uint32_t ph0 = NCO ? p.phase[c] : 0u;
+    const uint32_t step = NCO ? p.step[c] : 0u;
+    float gain = p.agc ? p.gain[c] : 1.0f;
+    const int group = (int)fa.group;
+    const int abase = 66 * (lane & 15) + (lane >> 4);                 // A-operand lane base (dwords)
+    wave_lds_sync();
+
+    for (uint32_t pass = 0; pass < npass; ++pass) {
+        const uint32_t n0 = pass * G::T;
+        // ---- 1. NCO mix, write both rails into the flat padded image ----
+        float4 lo4[NLD];
+        if constexpr (NCO == 2) {                                     // shared LO table (L2 resident):
+#pragma unroll
+            for (int i = 0; i < NLD; ++i)                             // all loads of the pass in flight at once
+                lo4[i] = *reinterpret_cast<const float4 *>(p.lo + n0 + 128u * i + 2u * lane);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const uint32_t n = 128u * i + 2u * lane;
+            float2 a, b;
+            R::unpack(raw[i], a, b);
+            if constexpr (NCO == 2) {
+                const float4 l2 = lo4[i];
+                a = cmul<0>(a, make_float2(l2.x, l2.y));
+                b = cmul<0>(b, make_float2(l2.z, l2.w));
+            } else if constexpr (NCO == 1) {
+                a = cmul<0>(a, nco_lo<0>(tab, ph0 + (n0 + n) * step));
+                b = cmul<0>(b, nco_lo<0>(tab, ph0 + (n0 + n + 1) * step));
+            }
+            const int f = GM::HS + (int)n;                            // even: (f, f+1) share a row
+            const int ph = f + 2 * (f >> 6);
+            *reinterpret_cast<float2 *>(XI + ph) = make_float2(a.x, b.x);
+            *reinterpret_cast<float2 *>(XQ + ph) = make_float2(a.y, b.y);
+        }
+        wave_lds_sync();
+        if (pass + 1 < npass) {
+#pragma unroll
+            for (int i = 0; i < NLD; ++i) raw[i] = R::load(src, in_base + n0 + G::T + 128u * i + 2u * lane);
+        }
+        // ---- 2. decimator on the matrix cores: 2 accumulator tiles (I, Q), KS steps each ----
+        {
+            v4f accI = { 0.0f, 0.0f, 0.0f, 0.0f }, accQ = { 0.0f, 0.0f, 0.0f, 0.0f };
+            const float *aI = XI + abase, *aQ = XQ + abase;
+            // A operands are fetched one group (GK k-steps, both rails) ahead of the MFMAs that use
+            // them; the compiler-only memory barrier keeps the scheduler from sinking the ds_reads
+            // back next to their uses (which exposes a full LDS round trip per MFMA pair).
+            constexpr int GK = 4, NG = (GM::KS + GK - 1) / GK;
+            float bufI[2][GK], bufQ[2][GK];
+#pragma unroll
+            for (int j = 0; j < GK; ++j) {
+                const int off = 4 * j + 2 * ((4 * j) >> 6);
+                bufI[0][j] = aI[off];
+                bufQ[0][j] = aQ[off];
+            }
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                if (g + 1 < NG) {
+#pragma unroll
+                    for (int j = 0; j < GK; ++j) {
+                        const int ks = (g + 1) * GK + j;
+                        if (ks < GM::KS) {
+                            const int off = 4 * ks + 2 * ((4 * ks) >> 6);     // phys(k0), k0 = 4*ks
+                            bufI[(g + 1) & 1][j] = aI[off];
+                            bufQ[(g + 1) & 1][j] = aQ[off];
+                        }
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < GK; ++j) {
+                    const int ks = g * GK + j;
+                    if (ks < GM::KS) {
+                        accI = __builtin_amdgcn_mfma_f32_16x16x4f32(bufI[g & 1][j], B[ks], accI, 0, 0, 0);
+                        accQ = __builtin_amdgcn_mfma_f32_16x16x4f32(bufQ[g & 1][j], B[ks], accQ, 0, 0, 0);
+                    }
+                }
+            }
+            // D layout: lane holds rows (lane>>4)*4 + r, column lane&15 -> output 16*row + col
+            const int o0 = G::HH4 + 64 * (lane >> 4) + (lane & 15);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                dI[o0 + 16 * r] = accI[r];
+                dQ[o0 + 16 * r] = accQ[r];
+            }
+            wave_lds_sync();
+        }
+        // ---- 3-5. Hilbert pair + sideband, AGC, store ----
+        demod_agc_store<1, ND, M, NH, TOut>(p, fa, dI, dQ, lane, group, gain, dst, out_base + (size_t)pass * G::P);
+        wave_lds_sync();
+        // ---- 6. history copy-back: the last HS samples of each rail move to the front ----
+        {
+            constexpr int NV = 2 * GM::HS / 2;                        // float2 moves
+            constexpr int NK = (NV + 63) / 64;
+            float2 t[NK];
+#pragma unroll
+            for (int k = 0; k < NK; ++k) {
+                const int i = k * 64 + lane;
+                if (i < NV) {
+                    const int rail = i / (GM::HS / 2), f = 2 * (i % (GM::HS / 2));
+                    t[k] = *reinterpret_cast<const float2 *>((rail ? XQ : XI) + GM::phys(G::T + f));
+                }
+            }
+            wave_lds_sync();
+#pragma unroll
+            for (int k = 0; k < NK; ++k) {
+                const int i = k * 64 + lane;
+                if (i < NV) {
+                    const int rail = i / (GM::HS / 2), f = 2 * (i % (GM::HS / 2));
+                    *reinterpret_cast<float2 *>((rail ? XQ : XI) + GM::phys(f)) = t[k];
+                }
+            }
+        }
+        if constexpr (NH > 0) {
+            constexpr int NV = 2 * (G::HH4 / 4);
+            float4 tmp;
+            const int rail = lane / (G::HH4 / 4), v = lane % (G::HH4 / 4);
+            if (lane < NV) tmp = *reinterpret_cast<const float4 *>(D + rail * G::DLEN + G::P + 4 * v);
+            wave_lds_sync();
+            if (lane < NV) *reinterpret_cast<float4 *>(D + rail * G::DLEN + 4 * v) = tmp;
+        }
+        wave_lds_sync();
+    }
+
+    for (int i = lane; i < 2 * GM::HS; i += kWave) {
+        const int rail = i / GM::HS, f = i % GM::HS, s = f - G::F;
+        if (s >= 0) p.dec_state[((size_t)c * 2 + rail) * (ND - 1) + s] = (rail ? XQ : XI)[GM::phys(f)];
+    }
+    if constexpr (NH > 0) {
+        for (int i = lane; i < 2 * G::HH4; i += kWave) {
+            const int rail = i / G::HH4, m = i % G::HH4, s = m - G::FH;
+            if (s >= 0) p.fir_state[((size_t)c * 2 + rail) * G::HH + s] = D[rail * G::DLEN + m];
+        }
+    }
+    if (lane == 0) {
+        if constexpr (NCO != 0) p.phase[c] = ph0 + p.block_size * step;
+        if (p.agc) p.gain[c] = gain;
+    }
+}
+
+// LO[n] = (cos x, -sin x), x from the integer phase phase0 + n*step: the NCO of DESIGN.md section 2,
+// evaluated once per call when every channel shares step and phase.
+__global__ __launch_bounds__(256) void k_lo_table(float2 *lo, const float *sintab, uint32_t phase0, uint32_t step,
+                                                  uint32_t nsamp)
+{
+    __shared__ float tab[516];
+    for (uint32_t i = threadIdx.x; i < 513; i += blockDim.x) tab[i] = sintab[i];
+    __syncthreads();
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n < nsamp) lo[n] = nco_lo<0>(tab, phase0 + n * step);
+}
+
+hipError_t launch_lo_table(float2 *lo, const float *sintab, uint32_t phase0, uint32_t step, uint32_t nsamp,
+                           hipStream_t st)
+{
+    hipLaunchKernelGGL(k_lo_table, dim3((nsamp + 255) / 256), dim3(256), 0, st, lo, sintab, phase0, step, nsamp);
+    return hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------------------
@@ -373,7 +645,21 @@ static hipError_t build_tables(const selenite_rx_config &g, FusedPlan &plan)
         for (int k = 0; k < ND; ++k) cq[(size_t)k + G::F] = g.dec_coeffs[k];
         hipError_t e = hipMalloc((void **)&plan.d_cq, cq.size() * sizeof(float));
         if (e != hipSuccess) return e;
-        return hipMemcpy(plan.d_cq, cq.data(), cq.size() * sizeof(float), hipMemcpyHostToDevice);
+        e = hipMemcpy(plan.d_cq, cq.data(), cq.size() * sizeof(float), hipMemcpyHostToDevice);
+        if (e != hipSuccess) return e;
+        if constexpr (M == 4) {
+            // Toeplitz operand of k_ssb_mfma: btab[ks][lane] = cq[k - 4n], k = 4ks + (lane>>4), n = lane&15
+            using GM = GeoM<ND, M, NH>;
+            std::vector<float> bt((size_t)64 * GM::KS, 0.0f);
+            for (int ks = 0; ks < GM::KS; ++ks)
+                for (int l = 0; l < 64; ++l) {
+                    const int idx = 4 * ks + (l >> 4) - 4 * (l & 15);
+                    if (idx >= 0 && idx <= ND) bt[(size_t)64 * ks + l] = cq[idx];
+                }
+            e = hipMalloc((void **)&plan.d_btab, bt.size() * sizeof(float));
+            if (e != hipSuccess) return e;
+            return hipMemcpy(plan.d_btab, bt.data(), bt.size() * sizeof(float), hipMemcpyHostToDevice);
+        }
     }
     return hipSuccess;
 }
@@ -383,7 +669,8 @@ static hipError_t launch_one(const RxParams &p, const FusedArgs &fa, const void 
 {
     using G = Geo<ND, M, NH>;
     constexpr size_t lds = (size_t)G::total * sizeof(float);
-    auto k = k_ssb_fused<ARITH, ND, M, NH, TIn, TOut>;
+    auto k = p.nco == 2 ? k_ssb_fused<ARITH, 2, ND, M, NH, TIn, TOut>
+                        : (p.nco == 1 ? k_ssb_fused<ARITH, 1, ND, M, NH, TIn, TOut> : k_ssb_fused<ARITH, 0, ND, M, NH, TIn, TOut>);
     if constexpr (lds > 48 * 1024) {
         static bool once = false;
         if (!once) {
@@ -398,11 +685,31 @@ static hipError_t launch_one(const RxParams &p, const FusedArgs &fa, const void 
     return hipGetLastError();
 }
 
+template <int ND, int M, int NH, typename TIn, typename TOut>
+static hipError_t launch_mfma(const RxParams &p, const FusedArgs &fa, const float *btab, const void *src, void *dst,
+                              hipStream_t st)
+{
+    using GM = GeoM<ND, M, NH>;
+    constexpr size_t lds = (size_t)GM::total * sizeof(float);
+    static_assert(lds <= 48 * 1024, "k_ssb_mfma LDS image");
+    auto k = p.nco == 2 ? k_ssb_mfma<2, ND, M, NH, TIn, TOut>
+                        : (p.nco == 1 ? k_ssb_mfma<1, ND, M, NH, TIn, TOut> : k_ssb_mfma<0, ND, M, NH, TIn, TOut>);
+    hipLaunchKernelGGL(k, dim3(p.channels), dim3(64), lds, st, p, fa, btab, static_cast<const TIn *>(src),
+                       static_cast<TOut *>(dst));
+    return hipGetLastError();
+}
+
 template <int ND, int M, int NH>
-static hipError_t launch_shape(const RxParams &p, const FusedArgs &fa, int arith, const void *src, bool src_q15,
-                               void *dst, bool dst_q15, hipStream_t st)
+static hipError_t launch_shape(const RxParams &p, const FusedArgs &fa, const FusedPlan &plan, int arith,
+                               const void *src, bool src_q15, void *dst, bool dst_q15, hipStream_t st)
 {
     if (src_q15 != dst_q15) return hipErrorNotSupported;
+    if constexpr (ND > 0 && M == 4) {
+        if (arith == SELENITE_ARITH_FMA && plan.use_mfma) {
+            if (src_q15) return launch_mfma<ND, M, NH, int16_t, int16_t>(p, fa, plan.d_btab, src, dst, st);
+            return launch_mfma<ND, M, NH, float, float>(p, fa, plan.d_btab, src, dst, st);
+        }
+    }
     if (arith == SELENITE_ARITH_FMA) {
         if (src_q15) return launch_one<1, ND, M, NH, int16_t, int16_t>(p, fa, src, dst, st);
         return launch_one<1, ND, M, NH, float, float>(p, fa, src, dst, st);
@@ -449,13 +756,18 @@ hipError_t plan_fused(const selenite_rx_config &g, bool delay_is_impulse, int de
     }
     plan.kind = kind;
     plan.name = name;
+    const char *nm = std::getenv("SELENITE_RX_NO_MFMA");
+    plan.use_mfma = plan.d_btab != nullptr && !(nm && nm[0] == '1');
+    if (plan.use_mfma && g.arith == SELENITE_ARITH_FMA) plan.name = "k_ssb_mfma<256,4,63>";
     return hipSuccess;
 }
 
 void free_fused(FusedPlan &plan)
 {
     if (plan.d_cq) (void)hipFree(plan.d_cq);
+    if (plan.d_btab) (void)hipFree(plan.d_btab);
     plan.d_cq = nullptr;
+    plan.d_btab = nullptr;
     plan.tables_built = false;
     plan.kind = 0;
 }
@@ -475,7 +787,7 @@ hipError_t launch_fused(const FusedPlan &plan, const RxParams &p, int arith, con
     fa.upper = mode_is_upper(p.mode) ? 1u : 0u;
     fa.group = (p.block / p.decim) / 4;
 #define X(ND_, M_, NH_, ID_) \
-    if (plan.kind == ID_) return launch_shape<ND_, M_, NH_>(p, fa, arith, src, src_q15, dst, dst_q15, st);
+    if (plan.kind == ID_) return launch_shape<ND_, M_, NH_>(p, fa, plan, arith, src, src_q15, dst, dst_q15, st);
     SRX_SHAPES(X)
 #undef X
     return hipErrorNotSupported;

@@ -20,12 +20,13 @@ struct RxParams {
     uint32_t nh;           // Hilbert / delay taps (0 = none)
     uint32_t nbiq;         // biquad stages
     uint32_t mode;         // SELENITE_MODE_*
-    uint32_t nco;          // NCO enabled
+    uint32_t nco;          // 0 = off, 1 = per-channel LO computed in the kernel, 2 = shared LO table `lo`
     uint32_t agc;          // AGC enabled
     uint32_t block_size;   // input samples per channel in this call
     uint32_t nout;         // block_size / decim
     uint32_t pass_out;     // generic front kernel: decimated outputs per pass
     const float *dec_c, *hilb_c, *delay_c, *biq_c, *sintab;
+    const float2 *lo;      // nco == 2: LO[n] = (cos, -sin) for the samples of this call (all channels share it)
     const uint32_t *step;
     uint32_t *phase;
     float *dec_state;      // [C][2][nd-1]
@@ -61,6 +62,8 @@ struct FusedPlan {
     int kind = 0;                 // 0 = none
     const char *name = "generic";
     float *d_cq = nullptr;        // zero-padded decimator taps in the fused kernel's indexing
+    float *d_btab = nullptr;      // banded-Toeplitz B operand of the MFMA decimator
+    bool use_mfma = false;        // FMA arithmetic: decimator on the matrix cores
     bool tables_built = false;
 };
 hipError_t plan_fused(const selenite_rx_config &cfg, bool delay_is_impulse, int delay_index,
@@ -69,6 +72,10 @@ void free_fused(FusedPlan &plan);
 bool fused_block_size_ok(const FusedPlan &plan, const selenite_rx_config &cfg, uint32_t block_size);
 hipError_t launch_fused(const FusedPlan &plan, const RxParams &p, int arith, const void *src,
                         bool src_q15, void *dst, bool dst_q15, int delay_index, hipStream_t st);
+
+// shared local-oscillator table for one call (rx_fused.hip)
+hipError_t launch_lo_table(float2 *lo, const float *sintab, uint32_t phase0, uint32_t step, uint32_t nsamp,
+                           hipStream_t st);
 
 // ---- synthetic input (rx_synth.hip) ----
 hipError_t launch_synth(float *dIQ, const float *sintab, uint32_t first_channel, uint32_t nch,
@@ -94,8 +101,13 @@ struct selenite_rx_instance {
     float *d_env = nullptr;      size_t env_cap = 0;
     void *d_io_in = nullptr;     size_t io_in_bytes = 0;     // staging for the host-pointer entry points
     void *d_io_out = nullptr;    size_t io_out_bytes = 0;
+    float2 *d_lo = nullptr;      size_t lo_bytes = 0;        // shared LO table of the current call
+    bool steps_uniform = false;        // every channel has the same NCO step
+    bool phase_uniform = true;         // ... and the same phase (true after init/reset)
+    uint32_t phase_host = 0;           // that common phase, tracked on the host
     bool delay_is_impulse = false; int delay_index = 0; bool hilb_odd_only = false;
     srx::FusedPlan plan;
+    int no_shared_lo = 0;              // SELENITE_RX_NO_SHARED_LO=1: always compute the LO per channel
     int force_generic = 0;             // SELENITE_RX_FORCE_GENERIC=1 (tests cross-check both paths)
     int status = SELENITE_RX_SUCCESS;
     std::string err;

@@ -220,3 +220,36 @@ def test_generic_and_fused_paths_agree():
         assert gen.kernel_name() == "generic"
         for _ in range(2):
             assert bits_equal(fused.process(iq), gen.process(iq)), name
+
+
+def test_shared_lo_table_path_equals_per_channel_nco():
+    """When every channel shares step and phase the LO is computed once per call (L2 table); it must
+    be indistinguishable from the per-channel in-kernel NCO, also across set_state/reset."""
+    spec = baseline_spec("cfg3", 5)
+    shared = gpu_rx(spec)
+    os.environ["SELENITE_RX_NO_SHARED_LO"] = "1"
+    try:
+        per_ch = gpu_rx(spec)
+    finally:
+        del os.environ["SELENITE_RX_NO_SHARED_LO"]
+    o = CpuChain(spec, "orc")
+    for call in range(3):
+        iq = synth_iq(0, 5, call * 1024, 1024)
+        ya, yb, yo = shared.process(iq), per_ch.process(iq), o.process(iq)
+        assert bits_equal(ya, yo) and bits_equal(yb, yo)
+    assert_state_equal(shared, o)
+    # make the phases differ per channel: the library must fall back to the per-channel NCO
+    st = shared.state()
+    st["nco_phase"] = (st["nco_phase"] + np.arange(5, dtype=np.uint32) * np.uint32(0x10000000)).astype(np.uint32)
+    shared.set_state(st)
+    o.L.orc_rx_set_state(o.h, rc.C.byref(rc.state_view(st)))
+    iq = synth_iq(0, 5, 3072, 1024)
+    assert bits_equal(shared.process(iq), o.process(iq))
+    # and back to a common phase
+    st = shared.state()
+    st["nco_phase"][:] = 0x12345678
+    shared.set_state(st)
+    o.L.orc_rx_set_state(o.h, rc.C.byref(rc.state_view(st)))
+    iq = synth_iq(0, 5, 4096, 2048)
+    assert bits_equal(shared.process(iq), o.process(iq))
+    assert_state_equal(shared, o)
