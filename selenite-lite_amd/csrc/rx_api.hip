@@ -268,7 +268,10 @@ extern "C" const char *selenite_rx_error_string(const selenite_rx_instance *S)
 extern "C" const char *selenite_rx_kernel_name(const selenite_rx_instance *S)
 {
     if (!S) return "";
-    return (S->force_generic || S->plan.kind == 0) ? "generic" : S->plan.name;
+    if (S->force_generic) return "generic";
+    if (S->plan.kind != 0) return S->plan.name;
+    if (cw_fused_ok(S->cfg, S->cfg.block)) return "k_cw_fused<4,256>";
+    return "generic";
 }
 
 extern "C" int selenite_rx_set_stream(selenite_rx_instance *S, void *hip_stream)
@@ -353,8 +356,10 @@ static int run_chain(selenite_rx_instance *S, const void *src, bool src_q15, voi
     const uint32_t phase_now = S->phase_host;
     if (phase != kPhase2 && g.nco_enable) S->phase_host += block_size * S->h_step[0];
 
-    if (phase != kPhase2 && !global && !S->force_generic && S->plan.kind != 0 &&
-        fused_block_size_ok(S->plan, g, block_size)) {
+    const bool ssb_fused = phase != kPhase2 && !global && !S->force_generic && S->plan.kind != 0 &&
+                           fused_block_size_ok(S->plan, g, block_size);
+    const bool cw_fused = phase != kPhase2 && !global && !S->force_generic && cw_fused_ok(g, block_size);
+    if (ssb_fused || cw_fused) {
         if (g.nco_enable && S->steps_uniform && S->phase_uniform && !S->no_shared_lo) {
             // one LO for all channels: computed once per call, read from L2 by every wavefront
             int rc = ensure(S, (void **)&S->d_lo, &S->lo_bytes, (size_t)block_size * sizeof(float2));
@@ -363,7 +368,8 @@ static int run_chain(selenite_rx_instance *S, const void *src, bool src_q15, voi
             p.nco = 2;
             p.lo = S->d_lo;
         }
-        HIPCHK(S, launch_fused(S->plan, p, arith, src, src_q15, dst, dst_q15, S->delay_index, st));
+        if (ssb_fused) HIPCHK(S, launch_fused(S->plan, p, arith, src, src_q15, dst, dst_q15, S->delay_index, st));
+        else HIPCHK(S, launch_cw_fused(p, src, src_q15, dst, dst_q15, st));
         return SELENITE_RX_SUCCESS;
     }
 

@@ -73,6 +73,10 @@ bool fused_block_size_ok(const FusedPlan &plan, const selenite_rx_config &cfg, u
 hipError_t launch_fused(const FusedPlan &plan, const RxParams &p, int arith, const void *src,
                         bool src_q15, void *dst, bool dst_q15, int delay_index, hipStream_t st);
 
+// fused CW kernel (rx_cw.hip): NCO -> real part -> 4-stage biquad cascade -> AGC
+bool cw_fused_ok(const selenite_rx_config &cfg, uint32_t block_size);
+hipError_t launch_cw_fused(const RxParams &p, const void *src, bool src_q15, void *dst, bool dst_q15, hipStream_t st);
+
 // shared local-oscillator table for one call (rx_fused.hip)
 hipError_t launch_lo_table(float2 *lo, const float *sintab, uint32_t phase0, uint32_t step, uint32_t nsamp,
                            hipStream_t st);

@@ -253,3 +253,50 @@ def test_shared_lo_table_path_equals_per_channel_nco():
     iq = synth_iq(0, 5, 4096, 2048)
     assert bits_equal(shared.process(iq), o.process(iq))
     assert_state_equal(shared, o)
+
+
+@pytest.mark.parametrize("arith", [ARITH_CMSIS, ARITH_FMA])
+@pytest.mark.parametrize("variant", ["shared_lo", "per_channel_nco", "no_nco", "no_agc", "cwr"])
+def test_cw_fused_kernel_bit_exact(arith, variant):
+    """k_cw_fused (systolic 16 channels x 4 stages per wavefront) against the oracle."""
+    kw = dict(block=256, decim=1, nd_taps=0, nh_taps=0, n_biquad=4, mode=MODE_CW, arith=arith,
+              nco=True, nco_step_all=0x00800000, agc=True)
+    if variant == "per_channel_nco":
+        kw["nco_steps"] = (np.arange(48, dtype=np.uint32) * np.uint32(0x00123457) + np.uint32(0x00400000))
+    elif variant == "no_nco":
+        kw["nco"] = False
+    elif variant == "no_agc":
+        kw["agc"] = False
+    elif variant == "cwr":
+        kw["mode"] = MODE_CWR
+    spec = ChainSpec(48, **kw)
+    g, o = gpu_rx(spec), CpuChain(spec, "orc")
+    assert g.kernel_name() == "k_cw_fused<4,256>"
+    for call in range(3):
+        iq = synth_iq(0, 48, call * 768, 768)
+        yg, yo = g.process(iq), o.process(iq)
+        assert bits_equal(yg, yo), "%s call %d rel_err %g" % (variant, call, rel_err(yg, yo))
+    assert_state_equal(g, o)
+
+
+def test_cw_fused_q15_and_vs_generic_large():
+    spec = baseline_spec("cfg4", 64)
+    g, o = gpu_rx(spec), CpuChain(spec, "orc")
+    iq = synth_iq(0, 64, 0, 1024)
+    q = np.clip(np.trunc(iq * 32768.0), -32768, 32767).astype(np.int16)
+    assert np.array_equal(g.process_q15(q), o.process_q15(q))
+    # large: fused vs generic on the GPU
+    spec = baseline_spec("cfg4", 1024)
+    iq = synth_iq(0, 1024, 0, 2048)
+    fused = gpu_rx(spec)
+    os.environ["SELENITE_RX_FORCE_GENERIC"] = "1"
+    try:
+        gen = gpu_rx(spec)
+    finally:
+        del os.environ["SELENITE_RX_FORCE_GENERIC"]
+    assert fused.kernel_name() == "k_cw_fused<4,256>" and gen.kernel_name() == "generic"
+    for _ in range(2):
+        assert bits_equal(fused.process(iq), gen.process(iq))
+    sf, sg = fused.state(), gen.state()
+    for k in sf:
+        assert np.array_equal(sf[k].view(np.uint32), sg[k].view(np.uint32)), k
