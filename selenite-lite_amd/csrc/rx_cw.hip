@@ -65,7 +65,7 @@ __global__ __launch_bounds__(64) void k_cw_fused(RxParams p, const TIn *__restri
 {
     constexpr int RS = BLK + 4;                         // tile row stride (floats); rows stay 16 B aligned
     constexpr int NCHUNK = BLK / 64;                    // input chunks of 64 samples x 16 channels
-    __shared__ __attribute__((aligned(16))) float tile[kCwCh * RS + 64];
+    __shared__ __attribute__((aligned(16))) float tile[kCwCh * RS + 4 * 64];
     __shared__ float tab[NCO == 1 ? 516 : 4];
     const int lane = threadIdx.x;
     const int s = lane & 3, ch = lane >> 2;
@@ -82,87 +82,119 @@ __global__ __launch_bounds__(64) void k_cw_fused(RxParams p, const TIn *__restri
     float gain = p.agc ? p.gain[c] : 1.0f;
     // load-phase geometry: load j of a chunk covers channel 2j + (lane>>5), samples 2*(lane&31), +1
     const int lch = lane >> 5, lsm = 2 * (lane & 31);
-    uint32_t ph_a = 0, ph_b = 0, st_a = 0, st_b = 0;    // per-channel NCO of the two channels this lane loads
-    (void)ph_a; (void)ph_b; (void)st_a; (void)st_b;
     const uint32_t ph_own = NCO ? p.phase[c] : 0u, st_own = NCO ? p.step[c] : 0u;
-    // stage-3 lanes write y[n] at tile[ch][n]; other lanes write a private dummy word
-    float *wbase = (s == 3) ? (tile + ch * RS) : (tile + kCwCh * RS + lane);
+    // stage-3 lanes write y[4i..4i+3] at tile[ch][4i]; other lanes write a private dummy float4
+    float *wbase = (s == 3) ? (tile + ch * RS) : (tile + kCwCh * RS + 4 * lane);
     const int wstride = (s == 3) ? 1 : 0;
     const float *rbase = tile + ch * RS;
-    cw_lds_sync();
+
+    typedef typename CwRaw<TIn>::type raw_t;
+    raw_t raw[8];
+    float4 lo4 = make_float4(1.0f, 0.0f, 1.0f, 0.0f);
+    auto issue_loads = [&](uint32_t n_first) {          // chunk of 64 samples x 16 channels starting at n_first
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            raw[j] = CwRaw<TIn>::load(src, (size_t)(c0 + 2 * j + lch) * p.block_size + n_first + lsm);
+        if constexpr (NCO == 2) lo4 = *reinterpret_cast<const float4 *>(p.lo + n_first + lsm);
+    };
+    auto mix_write = [&](uint32_t n_first, int q) {      // NCO mix (real part) of the loaded chunk into the tile
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float2 a, b;
+            CwRaw<TIn>::unpack(raw[j], a, b);
+            float xa, xb;
+            if constexpr (NCO == 0) {
+                xa = a.x; xb = b.x;
+            } else {
+                float2 la, lb;
+                if constexpr (NCO == 2) {
+                    la = make_float2(lo4.x, lo4.y); lb = make_float2(lo4.z, lo4.w);
+                } else {
+                    const uint32_t cj = c0 + 2 * j + lch;
+                    const uint32_t phj = p.phase[cj], stj = p.step[cj];
+                    la = nco_lo<0>(tab, phj + (n_first + lsm) * stj);
+                    lb = nco_lo<0>(tab, phj + (n_first + lsm + 1) * stj);
+                }
+                xa = cmul<0>(a, la).x;                        // arm_cmplx_mult_cmplx_f32 real part: ac - bd
+                xb = cmul<0>(b, lb).x;
+            }
+            *reinterpret_cast<float2 *>(tile + (2 * j + lch) * RS + 64 * q + lsm) = make_float2(xa, xb);
+        }
+    };
+    // one DF1 step of this lane's stage; xs = stage-0 input of the step
+    auto step = [&](float xs) -> float {
+        const float prev = dpp_row_shr1(y1);
+        const float xin = (s == 0) ? xs : prev;
+        const float p0 = b0 * xin, p1 = b1 * x1, p2 = b2 * x2, p3 = a1 * y1, p4 = a2 * y2;
+        float y = p0 + p1;
+        y = y + p2;
+        y = y + p3;
+        y = y + p4;
+        x2 = x1; x1 = xin; y2 = y1; y1 = y;
+        return y;
+    };
+    // the same with the state update suppressed where stage s has no sample at step k (fill / drain)
+    auto step_masked = [&](float xs, int k) -> float {
+        const float ox1 = x1, ox2 = x2, oy1 = y1, oy2 = y2;
+        const float y = step(xs);
+        const bool valid = (k - s >= 0) && (k - s < BLK);
+        x1 = valid ? x1 : ox1; x2 = valid ? x2 : ox2; y1 = valid ? y1 : oy1; y2 = valid ? y2 : oy2;
+        return y;
+    };
 
     const uint32_t nblk = p.block_size / BLK;
+    issue_loads(0);
+    cw_lds_sync();
     for (uint32_t blk = 0; blk < nblk; ++blk) {
         const uint32_t n0 = blk * BLK;
-        // ---- 1. load + NCO mix (real part) into the tile ----
+        float m = 0.0f, ycarry = 0.0f;
 #pragma unroll 1
         for (int q = 0; q < NCHUNK; ++q) {
-            typename CwRaw<TIn>::type raw[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-                raw[j] = CwRaw<TIn>::load(src, (size_t)(c0 + 2 * j + lch) * p.block_size + n0 + 64 * q + lsm);
-            float4 lo4 = make_float4(1.0f, 0.0f, 1.0f, 0.0f);
-            if constexpr (NCO == 2) lo4 = *reinterpret_cast<const float4 *>(p.lo + n0 + 64 * q + lsm);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                float2 a, b;
-                CwRaw<TIn>::unpack(raw[j], a, b);
-                float xa, xb;
-                if constexpr (NCO == 0) {
-                    xa = a.x; xb = b.x;
-                } else {
-                    float2 la, lb;
-                    if constexpr (NCO == 2) {
-                        la = make_float2(lo4.x, lo4.y); lb = make_float2(lo4.z, lo4.w);
-                    } else {
-                        const uint32_t cj = c0 + 2 * j + lch;
-                        const uint32_t phj = p.phase[cj], stj = p.step[cj];
-                        la = nco_lo<0>(tab, phj + (n0 + 64 * q + lsm) * stj);
-                        lb = nco_lo<0>(tab, phj + (n0 + 64 * q + lsm + 1) * stj);
-                    }
-                    xa = cmul<0>(a, la).x;                    // arm_cmplx_mult_cmplx_f32 real part: ac - bd
-                    xb = cmul<0>(b, lb).x;
-                }
-                *reinterpret_cast<float2 *>(tile + (2 * j + lch) * RS + 64 * q + lsm) = make_float2(xa, xb);
+            // ---- 1. this chunk's input into the tile; next chunk's HBM loads in flight meanwhile ----
+            mix_write(n0 + 64 * q, q);
+            {
+                const uint32_t nxt = n0 + 64 * (q + 1);               // next chunk (may be the next block's first)
+                if (nxt < p.block_size) issue_loads(nxt);
             }
-        }
-        cw_lds_sync();
-        // ---- 2. systolic biquad cascade over the block ----
-        float m = 0.0f;
-        auto step = [&](int k, bool masked) {
-            const float xs = rbase[k < BLK ? k : BLK - 1];
-            const float prev = dpp_row_shr1(y1);
-            const float xin = (s == 0) ? xs : prev;
-            const float p0 = b0 * xin, p1 = b1 * x1, p2 = b2 * x2, p3 = a1 * y1, p4 = a2 * y2;
-            float y = p0 + p1;
-            y = y + p2;
-            y = y + p3;
-            y = y + p4;
-            if (masked) {
-                const bool valid = (k - s >= 0) && (k - s < BLK);
-                x2 = valid ? x1 : x2; x1 = valid ? xin : x1;
-                y2 = valid ? y1 : y2; y1 = valid ? y : y1;
-                if (k >= 3 && s == 3) { wbase[k - 3] = y; m = fmaxf(m, fabsf(y)); }
-            } else {
-                x2 = x1; x1 = xin; y2 = y1; y1 = y;
-                wbase[(k - 3) * wstride] = y;
-                m = fmaxf(m, fabsf(y));
+            cw_lds_sync();
+            // ---- 2. 16 trips of 4 systolic steps; stage-0 input is one aligned float4 per trip ----
+            int i = 16 * q;
+            float4 xq = *reinterpret_cast<const float4 *>(rbase + 4 * i);
+            if (q == 0) {                                             // block prologue: 3 fill steps + step 3
+                float4 xn = *reinterpret_cast<const float4 *>(rbase + 4);
+                (void)step_masked(xq.x, 0);
+                (void)step_masked(xq.y, 1);
+                (void)step_masked(xq.z, 2);
+                ycarry = step(xq.w);                                  // y[0] in stage-3 lanes
+                m = fmaxf(m, fabsf(ycarry));
+                xq = xn;
+                i = 1;
             }
-        };
-        step(0, true); step(1, true); step(2, true);
 #pragma unroll 1
-        for (int k = 3; k < BLK - 1; k += 4) {          // BLK-4 unmasked steps, 4 per trip
-            step(k, false); step(k + 1, false); step(k + 2, false); step(k + 3, false);
+            for (; i < 16 * q + 16; ++i) {
+                // prefetch the next trip's input (stays inside this chunk; harmless re-read at the end)
+                const int inext = (i + 1 < 16 * q + 16) ? i + 1 : i;
+                const float4 xn = *reinterpret_cast<const float4 *>(rbase + 4 * inext);
+                const float ya = step(xq.x), yb = step(xq.y), yc = step(xq.z), yd = step(xq.w);
+                // outputs y[4i-3 .. 4i]: the aligned group y[4i-4 .. 4i-1] is complete after yc
+                *reinterpret_cast<float4 *>(wbase + (4 * i - 4) * wstride) = make_float4(ycarry, ya, yb, yc);
+                m = fmaxf(fmaxf(m, fabsf(ya)), fmaxf(fabsf(yb), fmaxf(fabsf(yc), fabsf(yd))));
+                ycarry = yd;
+                xq = xn;
+            }
         }
-        step(BLK - 1, false);
-        step(BLK, true); step(BLK + 1, true); step(BLK + 2, true);
+        // ---- drain: stages 1..3 finish samples BLK-3 .. BLK-1 ----
+        {
+            const float ya = step_masked(0.0f, BLK), yb = step_masked(0.0f, BLK + 1), yc = step_masked(0.0f, BLK + 2);
+            *reinterpret_cast<float4 *>(wbase + (BLK - 4) * wstride) = make_float4(ycarry, ya, yb, yc);
+            m = fmaxf(fmaxf(m, fabsf(ya)), fmaxf(fabsf(yb), fabsf(yc)));
+        }
         cw_lds_sync();
         // ---- 3. AGC gain law (stage-3 lanes hold max|y| of their channel) and scaled store ----
         if (p.agc) gain = agc_update<0>(p.agcp, gain, m);
-#pragma unroll
+#pragma unroll 4
         for (int r = 0; r < kCwCh; ++r) {
-            const float g = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gain), 4 * r + 3));
-            // BLK samples of channel r: BLK/4 lanes of float4
+            const float g = __shfl(gain, 4 * r + 3, 64);
 #pragma unroll
             for (int h = 0; h < (BLK / 4 + 63) / 64; ++h) {
                 const int t = 4 * (lane + 64 * h);
