@@ -24,6 +24,7 @@
 // AGC with block/M in {4..256, power of two}.  Everything else runs on rx_generic.hip.
 #include "rx_internal.h"
 
+#include <cstdio>
 #include <cstdlib>
 
 #pragma clang fp contract(off)
@@ -63,6 +64,8 @@ struct FusedArgs {
     uint32_t delay_idx;     // index of the unit tap in delay_coeffs
     uint32_t upper;         // 1: audio = I' - Q'   0: audio = I' + Q'
     uint32_t group;         // lanes per DSP block = (block / M) / 4
+    uint32_t grp_shift;     // k_ssb_mfma: phase group of a wave = (wave >> grp_shift) & 1
+    unsigned long long *dbg; // diagnostics (SELENITE_RX_DEBUG_TIMING): s_memtime stamps of workgroup 0, else NULL
 };
 
 // Workgroups of these kernels are ONE wavefront: LDS instructions of a wave execute in issue order,
@@ -158,8 +161,11 @@ __device__ __forceinline__ void decim_quad(const float *S, int lane, const float
 
 // arm_fir_f32 with type-III Hilbert taps for 4 adjacent outputs n = 4*lane + r.
 // dq: decimated Q rail, new samples start at HH4.  y[n] = sum_k h[k] * dq[n + k + FH].
+// The taps live lane-distributed in hreg (lane k of hreg[k>>6] = h[k]), loaded ONCE per kernel and
+// fetched by v_readlane: reading them from memory inside the pass loop costs an L2 round trip per
+// pass (the compiler cannot hoist the loads above the audio stores it must assume may alias).
 template <int ARITH, int ND, int M, int NH>
-__device__ __forceinline__ void hilbert_quad(const float *dq, int lane, const float *__restrict__ h,
+__device__ __forceinline__ void hilbert_quad(const float *dq, int lane, const float (&hreg)[(NH + 63) / 64 ? (NH + 63) / 64 : 1],
                                              float (&acc)[4])
 {
     using G = Geo<ND, M, NH>;
@@ -174,7 +180,8 @@ __device__ __forceinline__ void hilbert_quad(const float *dq, int lane, const fl
             for (int r = 0; r < 4; ++r) {
                 const int k = 4 * t + e - r - G::FH;
                 if (k < 0 || k >= NH || (((k - C) & 1) == 0)) continue;   // structural zeros
-                acc[r] = mac<ARITH>(acc[r], w, h[k]);
+                const float hk = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(hreg[k >> 6]), k & 63));
+                acc[r] = mac<ARITH>(acc[r], w, hk);
             }
         }
     }
@@ -183,16 +190,20 @@ __device__ __forceinline__ void hilbert_quad(const float *dq, int lane, const fl
 // Steps 3-5 of a pass, shared by the VALU and the MFMA kernels: Hilbert FIR on Q (structural zeros
 // skipped) and unit-impulse delay on I from the decimated rails in LDS, sideband combine, AGC per
 // DSP block (group lanes), one 4-sample store per lane.
-template <int ARITH, int ND, int M, int NH, typename TOut>
+// GROUP = lanes per DSP block as a compile-time constant (16: 64-sample blocks, 64: 256-sample blocks;
+// 0 = runtime `group`): constant lane indices turn the block-envelope broadcasts into v_readlane and
+// the lane reductions into DPP instead of ds_bpermute round trips.
+template <int ARITH, int GROUP, int ND, int M, int NH, typename TOut>
 __device__ __forceinline__ void demod_agc_store(const RxParams &p, const FusedArgs &fa, const float *dI,
-                                                const float *dQ, int lane, int group, float &gain,
+                                                const float *dQ, int lane, int group,
+                                                const float (&hreg)[(NH + 63) / 64 ? (NH + 63) / 64 : 1], float &gain,
                                                 TOut *__restrict__ dst, size_t out_index)
 {
     using G = Geo<ND, M, NH>;
     float au[4];
     if constexpr (NH > 0) {
         float q2[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
-        hilbert_quad<ARITH, ND, M, NH>(dQ, lane, p.hilb_c, q2);
+        hilbert_quad<ARITH, ND, M, NH>(dQ, lane, hreg, q2);
         const float *di = dI + G::FH + fa.delay_idx + 4 * lane;   // unit-impulse delay FIR
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -206,15 +217,27 @@ __device__ __forceinline__ void demod_agc_store(const RxParams &p, const FusedAr
     // AGC: arm_abs + arm_max per DSP block (group lanes), gain law, arm_scale
     if (p.agc) {
         float m = fmaxf(fmaxf(fabsf(au[0]), fabsf(au[1])), fmaxf(fabsf(au[2]), fabsf(au[3])));
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1)
-            if (off < group) m = fmaxf(m, __shfl_xor(m, off, 64));
         float g = gain, mine = gain;
-        const int nblk = 64 / group, myblk = lane / group;
-        for (int b = 0; b < nblk; ++b) {
-            const float env = __shfl(m, b * group, 64);
-            g = agc_update<0>(p.agcp, g, env);
-            if (b == myblk) mine = g;
+        if constexpr (GROUP > 0) {
+#pragma unroll
+            for (int off = 1; off < GROUP; off <<= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+            const int myblk = lane / GROUP;
+#pragma unroll
+            for (int b = 0; b < 64 / GROUP; ++b) {
+                const float env = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(m), b * GROUP));
+                g = agc_update<0>(p.agcp, g, env);
+                mine = (b == myblk) ? g : mine;
+            }
+        } else {
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1)
+                if (off < group) m = fmaxf(m, __shfl_xor(m, off, 64));
+            const int nblk = 64 / group, myblk = lane / group;
+            for (int b = 0; b < nblk; ++b) {
+                const float env = __shfl(m, b * group, 64);
+                g = agc_update<0>(p.agcp, g, env);
+                if (b == myblk) mine = g;
+            }
         }
         gain = g;
 #pragma unroll
@@ -278,6 +301,9 @@ __global__ __launch_bounds__(64, 2) void k_ssb_fused(RxParams p, FusedArgs fa, c
             D[rail * G::DLEN + m] = v;
         }
     }
+    float hreg[(NH + 63) / 64 ? (NH + 63) / 64 : 1];
+#pragma unroll
+    for (int v = 0; v < (NH + 63) / 64; ++v) hreg[v] = (64 * v + lane < NH) ? p.hilb_c[64 * v + lane] : 0.0f;
     const uint32_t ph0 = NCO ? p.phase[c] : 0u;
     const uint32_t step = NCO ? p.step[c] : 0u;
     float gain = p.agc ? p.gain[c] : 1.0f;
@@ -332,8 +358,12 @@ __global__ __launch_bounds__(64, 2) void k_ssb_fused(RxParams p, FusedArgs fa, c
             wave_lds_sync();
         }
         // ---- 3-5. Hilbert pair + sideband, AGC, store ----
-        demod_agc_store<ARITH, ND, M, NH, TOut>(p, fa, dI, dQ, lane, group, gain, dst,
-                                                out_base + (size_t)pass * G::P);
+        if (group == 16)
+            demod_agc_store<ARITH, 16, ND, M, NH, TOut>(p, fa, dI, dQ, lane, group, hreg, gain, dst, out_base + (size_t)pass * G::P);
+        else if (group == 64)
+            demod_agc_store<ARITH, 64, ND, M, NH, TOut>(p, fa, dI, dQ, lane, group, hreg, gain, dst, out_base + (size_t)pass * G::P);
+        else
+            demod_agc_store<ARITH, 0, ND, M, NH, TOut>(p, fa, dI, dQ, lane, group, hreg, gain, dst, out_base + (size_t)pass * G::P);
         wave_lds_sync();
         // ---- 6. history copy-back (arm_fir_decimate_f32.c:396-426, arm_fir_f32.c:947-978) ----
         if constexpr (ND > 0) {
@@ -423,17 +453,29 @@ struct GeoM {
     __host__ __device__ static constexpr int phys(int f) { return f + 2 * (f >> 6); }
 };
 
+constexpr int kMfmaWaves = 1;      // waves (= channels) per workgroup of k_ssb_mfma (f32 MFMA shares the FP32 ALUs with the VALU, so anti-phased multi-wave groups bring nothing)
+
 template <int NCO, int ND, int M, int NH, typename TIn, typename TOut>
-__global__ __launch_bounds__(64, 2) void k_ssb_mfma(RxParams p, FusedArgs fa, const float *__restrict__ btab,
-                                                    const TIn *__restrict__ src, TOut *__restrict__ dst)
+__global__ __launch_bounds__(64 * kMfmaWaves, 2) void k_ssb_mfma(RxParams p, FusedArgs fa,
+                                                                 const float *__restrict__ btab,
+                                                                 const TIn *__restrict__ src, TOut *__restrict__ dst)
 {
     using G = Geo<ND, M, NH>;
     using GM = GeoM<ND, M, NH>;
     using R = Raw<TIn>;
     static_assert(ND > 0 && M == 4 && G::T % 64 == 0 && GM::HS % 64 == 0, "MFMA decimator: /4, 64-sample rows");
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int lane = threadIdx.x;
-    const uint32_t c = blockIdx.x;
+    extern __shared__ __attribute__((aligned(16))) float lds_all[];
+    // Eight independent wavefronts (one channel each) per workgroup.  A workgroup's waves are placed
+    // on the CU's SIMDs cyclically, so waves w and w+4 share a SIMD: the two halves of the workgroup
+    // run in ANTI-PHASE (s_barrier between half-steps): while waves 0-3 issue their MFMA chain, waves
+    // 4-7 do their VALU work (Hilbert/AGC/store of the finished pass, NCO staging of the next), then
+    // the roles swap.  No data is shared between waves -- the barrier only aligns the phases so the
+    // matrix pipe and the VALU of every SIMD are busy at the same time.
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int grp = (wave >> fa.grp_shift) & 1;                       // 0: MFMA on even half-steps, 1: on odd
+    float *lds = lds_all + wave * GM::total;
+    const uint32_t c = blockIdx.x * kMfmaWaves + wave;
     float *tab = lds + GM::oTab;
     float *XI = lds + GM::oX, *XQ = XI + GM::XLEN;
     float *D = lds + GM::oD;
@@ -468,20 +510,22 @@ __global__ __launch_bounds__(64, 2) void k_ssb_mfma(RxParams p, FusedArgs fa, co
             D[rail * G::DLEN + m] = v;
         }
     }
+    float hreg[(NH + 63) / 64 ? (NH + 63) / 64 : 1];
+#pragma unroll
+    for (int v = 0; v < (NH + 63) / 64; ++v) hreg[v] = (64 * v + lane < NH) ? p.hilb_c[64 * v + lane] : 0.0f;
     const uint32_t ph0 = NCO ? p.phase[c] : 0u;
     const uint32_t step = NCO ? p.step[c] : 0u;
     float gain = p.agc ? p.gain[c] : 1.0f;
     const int group = (int)fa.group;
     const int abase = 66 * (lane & 15) + (lane >> 4);                 // A-operand lane base (dwords)
-    wave_lds_sync();
 
-    for (uint32_t pass = 0; pass < npass; ++pass) {
+    // ---- V phase, part 2: NCO mix of the prefetched pass into the X image, then prefetch the next ----
+    auto stage = [&](uint32_t pass) {
         const uint32_t n0 = pass * G::T;
-        // ---- 1. NCO mix, write both rails into the flat padded image ----
         float4 lo4[NLD];
-        if constexpr (NCO == 2) {                                     // shared LO table (L2 resident):
+        if constexpr (NCO == 2) {
 #pragma unroll
-            for (int i = 0; i < NLD; ++i)                             // all loads of the pass in flight at once
+            for (int i = 0; i < NLD; ++i)
                 lo4[i] = *reinterpret_cast<const float4 *>(p.lo + n0 + 128u * i + 2u * lane);
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -508,57 +552,59 @@ __global__ __launch_bounds__(64, 2) void k_ssb_mfma(RxParams p, FusedArgs fa, co
 #pragma unroll
             for (int i = 0; i < NLD; ++i) raw[i] = R::load(src, in_base + n0 + G::T + 128u * i + 2u * lane);
         }
-        // ---- 2. decimator on the matrix cores: 2 accumulator tiles (I, Q), KS steps each ----
-        {
-            v4f accI = { 0.0f, 0.0f, 0.0f, 0.0f }, accQ = { 0.0f, 0.0f, 0.0f, 0.0f };
-            const float *aI = XI + abase, *aQ = XQ + abase;
-            // A operands are fetched one group (GK k-steps, both rails) ahead of the MFMAs that use
-            // them; the compiler-only memory barrier keeps the scheduler from sinking the ds_reads
-            // back next to their uses (which exposes a full LDS round trip per MFMA pair).
-            constexpr int GK = 4, NG = (GM::KS + GK - 1) / GK;
-            float bufI[2][GK], bufQ[2][GK];
+    };
+    // ---- M phase: decimator on the matrix cores, 2 accumulator tiles (I, Q), KS steps each ----
+    auto mfma_phase = [&]() {
+        v4f accI = { 0.0f, 0.0f, 0.0f, 0.0f }, accQ = { 0.0f, 0.0f, 0.0f, 0.0f };
+        const float *aI = XI + abase, *aQ = XQ + abase;
+        // A operands are fetched one group (GK k-steps, both rails) ahead of the MFMAs that use them
+        constexpr int GK = 4, NG = (GM::KS + GK - 1) / GK;
+        float bufI[2][GK], bufQ[2][GK];
 #pragma unroll
-            for (int j = 0; j < GK; ++j) {
-                const int off = 4 * j + 2 * ((4 * j) >> 6);
-                bufI[0][j] = aI[off];
-                bufQ[0][j] = aQ[off];
-            }
+        for (int j = 0; j < GK; ++j) {
+            const int off = 4 * j + 2 * ((4 * j) >> 6);
+            bufI[0][j] = aI[off];
+            bufQ[0][j] = aQ[off];
+        }
 #pragma unroll
-            for (int g = 0; g < NG; ++g) {
-                if (g + 1 < NG) {
-#pragma unroll
-                    for (int j = 0; j < GK; ++j) {
-                        const int ks = (g + 1) * GK + j;
-                        if (ks < GM::KS) {
-                            const int off = 4 * ks + 2 * ((4 * ks) >> 6);     // phys(k0), k0 = 4*ks
-                            bufI[(g + 1) & 1][j] = aI[off];
-                            bufQ[(g + 1) & 1][j] = aQ[off];
-                        }
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);
+        for (int g = 0; g < NG; ++g) {
+            if (g + 1 < NG) {
 #pragma unroll
                 for (int j = 0; j < GK; ++j) {
-                    const int ks = g * GK + j;
+                    const int ks = (g + 1) * GK + j;
                     if (ks < GM::KS) {
-                        accI = __builtin_amdgcn_mfma_f32_16x16x4f32(bufI[g & 1][j], B[ks], accI, 0, 0, 0);
-                        accQ = __builtin_amdgcn_mfma_f32_16x16x4f32(bufQ[g & 1][j], B[ks], accQ, 0, 0, 0);
+                        const int off = 4 * ks + 2 * ((4 * ks) >> 6);     // phys(k0), k0 = 4*ks
+                        bufI[(g + 1) & 1][j] = aI[off];
+                        bufQ[(g + 1) & 1][j] = aQ[off];
                     }
                 }
             }
-            // D layout: lane holds rows (lane>>4)*4 + r, column lane&15 -> output 16*row + col
-            const int o0 = G::HH4 + 64 * (lane >> 4) + (lane & 15);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                dI[o0 + 16 * r] = accI[r];
-                dQ[o0 + 16 * r] = accQ[r];
+            for (int j = 0; j < GK; ++j) {
+                const int ks = g * GK + j;
+                if (ks < GM::KS) {
+                    accI = __builtin_amdgcn_mfma_f32_16x16x4f32(bufI[g & 1][j], B[ks], accI, 0, 0, 0);
+                    accQ = __builtin_amdgcn_mfma_f32_16x16x4f32(bufQ[g & 1][j], B[ks], accQ, 0, 0, 0);
+                }
             }
-            wave_lds_sync();
         }
-        // ---- 3-5. Hilbert pair + sideband, AGC, store ----
-        demod_agc_store<1, ND, M, NH, TOut>(p, fa, dI, dQ, lane, group, gain, dst, out_base + (size_t)pass * G::P);
+        // D layout: lane holds rows (lane>>4)*4 + r, column lane&15 -> output 16*row + col
+        const int o0 = G::HH4 + 64 * (lane >> 4) + (lane & 15);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            dI[o0 + 16 * r] = accI[r];
+            dQ[o0 + 16 * r] = accQ[r];
+        }
         wave_lds_sync();
-        // ---- 6. history copy-back: the last HS samples of each rail move to the front ----
+    };
+    // ---- V phase, part 1: Hilbert pair + sideband, AGC, store; history copy-backs ----
+    auto finish = [&](uint32_t pass) {
+        if (group == 16)
+            demod_agc_store<1, 16, ND, M, NH, TOut>(p, fa, dI, dQ, lane, group, hreg, gain, dst, out_base + (size_t)pass * G::P);
+        else
+            demod_agc_store<1, 0, ND, M, NH, TOut>(p, fa, dI, dQ, lane, group, hreg, gain, dst, out_base + (size_t)pass * G::P);
+        wave_lds_sync();
         {
             constexpr int NV = 2 * GM::HS / 2;                        // float2 moves
             constexpr int NK = (NV + 63) / 64;
@@ -590,6 +636,34 @@ __global__ __launch_bounds__(64, 2) void k_ssb_mfma(RxParams p, FusedArgs fa, co
             if (lane < NV) *reinterpret_cast<float4 *>(D + rail * G::DLEN + 4 * v) = tmp;
         }
         wave_lds_sync();
+    };
+
+    wave_lds_sync();
+    stage(0);
+    // half-steps: group 0 runs M(k) at h = 2k and V(k) at h = 2k+1; group 1 one half-step later
+    const uint32_t nhalf = 2 * npass + 1;
+    // diagnostics: stamp slot s of half-step h for wave w at dbg[w*128 + h*8 + s] (workgroup 0 only)
+    uint32_t hcur = 0;
+    auto stamp = [&](int slot) {
+        if (fa.dbg && blockIdx.x == 0 && lane == 0) fa.dbg[wave * 128 + hcur * 8 + slot] = __builtin_amdgcn_s_memtime();
+    };
+    for (uint32_t h = 0; h < nhalf; ++h) {
+        hcur = h;
+        stamp(0);
+        if (h >= (uint32_t)grp) {
+            const uint32_t hh = h - grp, k = hh >> 1;
+            if (k < npass) {
+                if ((hh & 1) == 0) {
+                    mfma_phase();
+                } else {
+                    finish(k);
+                    stamp(3);
+                    if (k + 1 < npass) stage(k + 1);
+                }
+            }
+        }
+        stamp(7);
+        __builtin_amdgcn_s_barrier();                                 // timing alignment only: no shared data
     }
 
     for (int i = lane; i < 2 * GM::HS; i += kWave) {
@@ -690,12 +764,15 @@ static hipError_t launch_mfma(const RxParams &p, const FusedArgs &fa, const floa
                               hipStream_t st)
 {
     using GM = GeoM<ND, M, NH>;
-    constexpr size_t lds = (size_t)GM::total * sizeof(float);
-    static_assert(lds <= 48 * 1024, "k_ssb_mfma LDS image");
+    constexpr size_t lds = (size_t)kMfmaWaves * GM::total * sizeof(float);
+    static_assert(lds <= 160 * 1024, "k_ssb_mfma LDS image");
     auto k = p.nco == 2 ? k_ssb_mfma<2, ND, M, NH, TIn, TOut>
                         : (p.nco == 1 ? k_ssb_mfma<1, ND, M, NH, TIn, TOut> : k_ssb_mfma<0, ND, M, NH, TIn, TOut>);
-    hipLaunchKernelGGL(k, dim3(p.channels), dim3(64), lds, st, p, fa, btab, static_cast<const TIn *>(src),
-                       static_cast<TOut *>(dst));
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k, dim3(p.channels / kMfmaWaves), dim3(64 * kMfmaWaves), lds, st, p, fa, btab,
+                       static_cast<const TIn *>(src), static_cast<TOut *>(dst));
     return hipGetLastError();
 }
 
@@ -705,7 +782,7 @@ static hipError_t launch_shape(const RxParams &p, const FusedArgs &fa, const Fus
 {
     if (src_q15 != dst_q15) return hipErrorNotSupported;
     if constexpr (ND > 0 && M == 4) {
-        if (arith == SELENITE_ARITH_FMA && plan.use_mfma) {
+        if (arith == SELENITE_ARITH_FMA && plan.use_mfma && p.channels % kMfmaWaves == 0) {
             if (src_q15) return launch_mfma<ND, M, NH, int16_t, int16_t>(p, fa, plan.d_btab, src, dst, st);
             return launch_mfma<ND, M, NH, float, float>(p, fa, plan.d_btab, src, dst, st);
         }
@@ -786,6 +863,32 @@ hipError_t launch_fused(const FusedPlan &plan, const RxParams &p, int arith, con
     fa.delay_idx = (uint32_t)delay_index;
     fa.upper = mode_is_upper(p.mode) ? 1u : 0u;
     fa.group = (p.block / p.decim) / 4;
+    {
+        const char *e = std::getenv("SELENITE_RX_GRP_SHIFT");
+        fa.grp_shift = e ? (uint32_t)std::atoi(e) : 2u;
+        fa.dbg = nullptr;
+        static unsigned long long *dbg_buf = nullptr;
+        static int dbg_calls = 0;
+        if (std::getenv("SELENITE_RX_DEBUG_TIMING")) {        // phase timeline of workgroup 0 on stderr
+            if (!dbg_buf) { (void)hipMalloc((void **)&dbg_buf, 1024 * 8); (void)hipMemset(dbg_buf, 0, 1024 * 8); }
+            fa.dbg = dbg_buf;
+            if (++dbg_calls == 8) {
+                (void)hipDeviceSynchronize();
+                unsigned long long h[1024];
+                (void)hipMemcpy(h, dbg_buf, sizeof h, hipMemcpyDeviceToHost);
+                for (int w = 0; w < 8; w += 4) {
+                    fprintf(stderr, "wave %d:", w);
+                    for (int i = 0; i < 12; ++i)
+                        if (h[w * 128 + i * 8 + 7]) {
+                            fprintf(stderr, " [h%d @%llu", i, h[w * 128 + i * 8] - h[0]);
+                            if (h[w * 128 + i * 8 + 3]) fprintf(stderr, " fin %llu", h[w * 128 + i * 8 + 3] - h[w * 128 + i * 8]);
+                            fprintf(stderr, " tot %llu]", h[w * 128 + i * 8 + 7] - h[w * 128 + i * 8]);
+                        }
+                    fprintf(stderr, "\n");
+                }
+            }
+        }
+    }
 #define X(ND_, M_, NH_, ID_) \
     if (plan.kind == ID_) return launch_shape<ND_, M_, NH_>(p, fa, plan, arith, src, src_q15, dst, dst_q15, st);
     SRX_SHAPES(X)
