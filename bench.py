@@ -97,7 +97,7 @@ def main():
     ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
     ap.add_argument("--channels", type=int, default=0, help="channels per GPU (default: workload's)")
     ap.add_argument("--block-size", type=int, default=0)
-    ap.add_argument("--arith", default=os.environ.get("SELENITE_BENCH_ARITH", "fma"), choices=["cmsis", "fma"],
+    ap.add_argument("--arith", default=os.environ.get("SELENITE_BENCH_ARITH", "fma"), choices=["cmsis", "fma", "split16"],
                     help="fma (default): FIR tap loops fused, <=1e-5 rel vs CMSIS (north-star tolerance); "
                          "cmsis: bit-exact CMSIS-DSP arithmetic")
     ap.add_argument("--global-gain", action="store_true")
@@ -126,7 +126,7 @@ def main():
     import rxcommon as rc
     import selenite_rx as sr
 
-    arith = rc.ARITH_FMA if args.arith == "fma" else rc.ARITH_CMSIS
+    arith = {"fma": rc.ARITH_FMA, "cmsis": rc.ARITH_CMSIS, "split16": rc.ARITH_SPLIT16}[args.arith]
     cfg_name, channels, bs = WORKLOADS[args.workload]
     channels = args.channels or channels
     bs = args.block_size or bs
@@ -204,7 +204,8 @@ def main():
                             "cfg2": "127-tap Hilbert SSB (USB) + AGC",
                             "cfg4": "CW: NCO + 4-stage DF1 biquad @500 Hz + AGC",
                             "cfg5": "127-tap Hilbert SSB (USB) + AGC, cfg5 weak-scaling shape"}[args.workload]),
-                       "arith": "cmsis-exact (mul,add)" if arith == rc.ARITH_CMSIS else "fma (<=1e-5 rel vs CMSIS)",
+                       "arith": {rc.ARITH_CMSIS: "cmsis-exact (mul,add)", rc.ARITH_FMA: "fma (<=1e-5 rel vs CMSIS)",
+                                 rc.ARITH_SPLIT16: "split16 (f16 hi/lo x3 MFMA decimator, <=1e-5 rel vs CMSIS)"}[arith],
                        "kernel": rx.kernel_name(), "agc": "global" if args.global_gain else "per-channel",
                        "parallelism": "channels sharded x%d, no data-path collective" % world},
             "per_gpu_msamples_s": round(value / world, 2),
@@ -217,7 +218,7 @@ def main():
                          "unit": "TFLOP/s", "frac": round(fl / (k_ms * 1e-3) / 1e12 / F32_PEAK_TFLOPS, 4),
                          "flops_per_sample": flops_per_sample(spec)},
         }
-        if world == 1 and arith == rc.ARITH_FMA and not args.global_gain:
+        if world == 1 and arith != rc.ARITH_CMSIS and not args.global_gain:
             # same workload in the bit-exact CMSIS arithmetic, outside the timed region, for the record
             spec_x = rc.baseline_spec(cfg_name, channels, rc.ARITH_CMSIS)
             rx_x = sr.Rx(spec_x.config())

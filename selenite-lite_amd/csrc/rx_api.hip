@@ -157,7 +157,7 @@ extern "C" int selenite_rx_init(selenite_rx_instance **out, const selenite_rx_co
         return fail(nullptr, SELENITE_RX_ARGUMENT_ERROR, "selenite_rx_init: channels, block, decim must be non-zero");
     if (!mode_valid(cfg->mode))
         return fail(nullptr, SELENITE_RX_ARGUMENT_ERROR, "selenite_rx_init: unsupported mode (FM is not demodulated)");
-    if (cfg->arith != SELENITE_ARITH_CMSIS && cfg->arith != SELENITE_ARITH_FMA)
+    if (cfg->arith != SELENITE_ARITH_CMSIS && cfg->arith != SELENITE_ARITH_FMA && cfg->arith != SELENITE_ARITH_SPLIT16)
         return fail(nullptr, SELENITE_RX_ARGUMENT_ERROR, "selenite_rx_init: bad arith");
     if (cfg->nd_taps == 0 && cfg->decim != 1)
         return fail(nullptr, SELENITE_RX_ARGUMENT_ERROR, "selenite_rx_init: decim > 1 needs a decimator (nd_taps)");

@@ -24,6 +24,7 @@
 // AGC with block/M in {4..256, power of two}.  Everything else runs on rx_generic.hip.
 #include "rx_internal.h"
 
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 
@@ -65,6 +66,8 @@ struct FusedArgs {
     uint32_t upper;         // 1: audio = I' - Q'   0: audio = I' + Q'
     uint32_t group;         // lanes per DSP block = (block / M) / 4
     uint32_t grp_shift;     // k_ssb_mfma: phase group of a wave = (wave >> grp_shift) & 1
+    const void *btab16;     // k_ssb_split16: Toeplitz operand, f16 hi/lo fragments
+    float split_post;       // k_ssb_split16: exact power-of-two rescale of the MFMA result
     unsigned long long *dbg; // diagnostics (SELENITE_RX_DEBUG_TIMING): s_memtime stamps of workgroup 0, else NULL
 };
 
@@ -682,6 +685,225 @@ __global__ __launch_bounds__(64 * kMfmaWaves, 2) void k_ssb_mfma(RxParams p, Fus
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// k_ssb_split16<NCO, ND, 4, NH, TIn, TOut> -- SELENITE_ARITH_SPLIT16: the decimator as a
+// split-precision matrix product on the 16-bit matrix cores (v_mfma_f32_16x16x32_f16).
+//
+// f32 MFMA executes on the FP32 vector ALUs (it ADDS to the VALU time, measured: DESIGN.md 5.1), so
+// the only extra throughput on the chip is the separate 16-bit matrix pipe.  Each mixed sample x
+// (scaled by 2^8) and each tap c (scaled by 2^SC) is split exactly into f16 hi + lo,
+//     x' = xh + xl + O(2^-22 x'),    c' = ch + cl + O(2^-22 c'),
+// and the banded-Toeplitz product of k_ssb_mfma is evaluated as  xh*ch + (xh*cl + xl*ch)  with f32
+// accumulation inside the MFMA (f16 x f16 products are exact in f32); the dropped xl*cl term is
+// 2^-22 relative.  The big and the two small terms use separate accumulators.  The result is
+// rescaled by an exact power of two.  Error vs the CMSIS arithmetic: <2e-6 of the block maximum
+// (tests), against the north star's 1e-5.  NOT bit-reproducible by a CPU loop -- parity for this
+// mode is tolerance-based by construction.
+// LDS: four f16 images (I/Q x hi/lo), 64-sample rows padded to 80 halfs: the 16-byte A-fragment read
+// of lane l is at 160*(l&15) + 16*(l>>4) + imm, conflict-free for every b128 lane group.
+// The streaming state stays exact f32: the last ND-1 mixed samples of a call go to HBM as f32.
+// ------------------------------------------------------------------------------------------
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+
+template <int ND, int M, int NH>
+struct GeoS {
+    using G = Geo<ND, M, NH>;
+    static constexpr int HS = G::HQ4 * M;                 // history samples in front
+    static constexpr int XN = HS + G::T;
+    static constexpr int XROWS = XN / 64;
+    static constexpr int IMG = 80 * XROWS;                // halfs per image
+    static constexpr int KTOT = ND + 4 * 15 + 1;
+    static constexpr int KS = (KTOT + 31) / 32;           // MFMA k-steps of 32
+    static constexpr int oTab = 0;                        // floats
+    static constexpr int oX = 516;                        // 4 images of IMG halfs = 2*IMG floats
+    static constexpr int oD = oX + 2 * IMG;
+    static constexpr int total = oD + 2 * G::DLEN;
+    static constexpr int XSCALE = 8;                      // samples scaled by 2^8 before the split
+    __host__ __device__ static constexpr int phys(int f) { return 80 * (f >> 6) + (f & 63); }
+};
+
+template <int NCO, int ND, int M, int NH, typename TIn, typename TOut>
+__global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa, const TIn *__restrict__ src,
+                                                       TOut *__restrict__ dst)
+{
+    using G = Geo<ND, M, NH>;
+    using GS = GeoS<ND, M, NH>;
+    using R = Raw<TIn>;
+    static_assert(ND > 0 && M == 4 && NH > 0 && G::T % 64 == 0 && GS::HS % 64 == 0, "split16 decimator: /4 + Hilbert");
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x;
+    const uint32_t c = blockIdx.x;
+    float *tab = lds + GS::oTab;
+    _Float16 *X = reinterpret_cast<_Float16 *>(lds + GS::oX);     // [rail][hi/lo][IMG]
+    float *D = lds + GS::oD;
+    float *dI = D, *dQ = D + G::DLEN;
+    constexpr int NLD = G::T / 128;
+
+    const size_t in_base = (size_t)c * p.block_size, out_base = (size_t)c * p.nout;
+    const uint32_t npass = p.nout / G::P;
+    typename R::type raw[NLD];
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) raw[i] = R::load(src, in_base + 128u * i + 2u * lane);
+
+    // Toeplitz B fragments (8 halfs per lane): [kk][hi/lo]
+    h8 Bh[GS::KS], Bl[GS::KS];
+    {
+        const h8 *bt = static_cast<const h8 *>(fa.btab16);
+#pragma unroll
+        for (int kk = 0; kk < GS::KS; ++kk) {
+            Bh[kk] = bt[(2 * kk + 0) * 64 + lane];
+            Bl[kk] = bt[(2 * kk + 1) * 64 + lane];
+        }
+    }
+    float hreg[(NH + 63) / 64];
+#pragma unroll
+    for (int v = 0; v < (NH + 63) / 64; ++v) hreg[v] = (64 * v + lane < NH) ? p.hilb_c[64 * v + lane] : 0.0f;
+
+    if constexpr (NCO == 1)
+        for (int i = lane; i < 513; i += kWave) tab[i] = p.sintab[i];
+    const float xs = (float)(1 << GS::XSCALE);
+    auto put = [&](int rail, int f, float x0, float x1) {           // samples f (even), f+1 of one rail
+        const float a0 = x0 * xs, a1 = x1 * xs;
+        const _Float16 h0 = (_Float16)a0, h1 = (_Float16)a1;
+        const _Float16 l0 = (_Float16)(a0 - (float)h0), l1 = (_Float16)(a1 - (float)h1);
+        const int ph = GS::phys(f);
+        *reinterpret_cast<h2 *>(X + (2 * rail + 0) * GS::IMG + ph) = h2{ h0, h1 };
+        *reinterpret_cast<h2 *>(X + (2 * rail + 1) * GS::IMG + ph) = h2{ l0, l1 };
+    };
+    // history: flat sample f in [0, HS) is CMSIS state sample s = f - F (older slots meet zero taps)
+    for (int i = lane; i < 2 * (GS::HS / 2); i += kWave) {
+        const int rail = i / (GS::HS / 2), f = 2 * (i % (GS::HS / 2));
+        const int s0 = f - G::F, s1 = f + 1 - G::F;
+        const float *st = p.dec_state + ((size_t)c * 2 + rail) * (ND - 1);
+        put(rail, f, s0 >= 0 ? st[s0] : 0.0f, s1 >= 0 ? st[s1] : 0.0f);
+    }
+    for (int i = lane; i < 2 * G::HH4; i += kWave) {
+        const int rail = i / G::HH4, m = i % G::HH4, s = m - G::FH;
+        float v = 0.0f;
+        if (s >= 0) v = p.fir_state[((size_t)c * 2 + rail) * G::HH + s];
+        D[rail * G::DLEN + m] = v;
+    }
+    const uint32_t ph0 = NCO ? p.phase[c] : 0u;
+    const uint32_t step = NCO ? p.step[c] : 0u;
+    float gain = p.agc ? p.gain[c] : 1.0f;
+    const int group = (int)fa.group;
+    const int abase = 80 * (lane & 15) + 8 * (lane >> 4);             // A-fragment lane base (halfs)
+    wave_lds_sync();
+
+    for (uint32_t pass = 0; pass < npass; ++pass) {
+        const uint32_t n0 = pass * G::T;
+        const bool last = (pass + 1 == npass);
+        // ---- 1. NCO mix, f16 hi/lo split, four LDS images; exact f32 state from the last pass ----
+        float4 lo4[NLD];
+        if constexpr (NCO == 2) {
+#pragma unroll
+            for (int i = 0; i < NLD; ++i)
+                lo4[i] = *reinterpret_cast<const float4 *>(p.lo + n0 + 128u * i + 2u * lane);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const uint32_t n = 128u * i + 2u * lane;
+            float2 a, b;
+            R::unpack(raw[i], a, b);
+            if constexpr (NCO == 2) {
+                const float4 l2 = lo4[i];
+                a = cmul<0>(a, make_float2(l2.x, l2.y));
+                b = cmul<0>(b, make_float2(l2.z, l2.w));
+            } else if constexpr (NCO == 1) {
+                a = cmul<0>(a, nco_lo<0>(tab, ph0 + (n0 + n) * step));
+                b = cmul<0>(b, nco_lo<0>(tab, ph0 + (n0 + n + 1) * step));
+            }
+            put(0, GS::HS + (int)n, a.x, b.x);
+            put(1, GS::HS + (int)n, a.y, b.y);
+            if (last) {                                               // CMSIS pState: last ND-1 mixed samples, f32
+                const int s0 = (int)n - (G::T - (ND - 1));
+                float *stI = p.dec_state + ((size_t)c * 2 + 0) * (ND - 1), *stQ = stI + (ND - 1);
+                if (s0 >= 0) { stI[s0] = a.x; stQ[s0] = a.y; }
+                if (s0 + 1 >= 0) { stI[s0 + 1] = b.x; stQ[s0 + 1] = b.y; }
+            }
+        }
+        wave_lds_sync();
+        if (pass + 1 < npass) {
+#pragma unroll
+            for (int i = 0; i < NLD; ++i) raw[i] = R::load(src, in_base + n0 + G::T + 128u * i + 2u * lane);
+        }
+        // ---- 2. decimator: 3 f16 MFMAs per k-step and rail (hi*hi | hi*lo + lo*hi) ----
+        {
+            v4f bigI = { 0.0f, 0.0f, 0.0f, 0.0f }, smlI = { 0.0f, 0.0f, 0.0f, 0.0f };
+            v4f bigQ = { 0.0f, 0.0f, 0.0f, 0.0f }, smlQ = { 0.0f, 0.0f, 0.0f, 0.0f };
+            const _Float16 *xIh = X + 0 * GS::IMG + abase, *xIl = X + 1 * GS::IMG + abase;
+            const _Float16 *xQh = X + 2 * GS::IMG + abase, *xQl = X + 3 * GS::IMG + abase;
+#pragma unroll
+            for (int kk = 0; kk < GS::KS; ++kk) {
+                const int off = 80 * (kk >> 1) + 32 * (kk & 1);        // phys(32*kk): rows never straddle
+                const h8 aIh = *reinterpret_cast<const h8 *>(xIh + off), aIl = *reinterpret_cast<const h8 *>(xIl + off);
+                const h8 aQh = *reinterpret_cast<const h8 *>(xQh + off), aQl = *reinterpret_cast<const h8 *>(xQl + off);
+                bigI = __builtin_amdgcn_mfma_f32_16x16x32_f16(aIh, Bh[kk], bigI, 0, 0, 0);
+                bigQ = __builtin_amdgcn_mfma_f32_16x16x32_f16(aQh, Bh[kk], bigQ, 0, 0, 0);
+                smlI = __builtin_amdgcn_mfma_f32_16x16x32_f16(aIh, Bl[kk], smlI, 0, 0, 0);
+                smlQ = __builtin_amdgcn_mfma_f32_16x16x32_f16(aQh, Bl[kk], smlQ, 0, 0, 0);
+                smlI = __builtin_amdgcn_mfma_f32_16x16x32_f16(aIl, Bh[kk], smlI, 0, 0, 0);
+                smlQ = __builtin_amdgcn_mfma_f32_16x16x32_f16(aQl, Bh[kk], smlQ, 0, 0, 0);
+            }
+            const int o0 = G::HH4 + 64 * (lane >> 4) + (lane & 15);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                dI[o0 + 16 * r] = (bigI[r] + smlI[r]) * fa.split_post;
+                dQ[o0 + 16 * r] = (bigQ[r] + smlQ[r]) * fa.split_post;
+            }
+            wave_lds_sync();
+        }
+        // ---- 3-5. Hilbert pair + sideband, AGC, store ----
+        if (group == 16)
+            demod_agc_store<1, 16, ND, M, NH, TOut>(p, fa, dI, dQ, lane, group, hreg, gain, dst, out_base + (size_t)pass * G::P);
+        else
+            demod_agc_store<1, 0, ND, M, NH, TOut>(p, fa, dI, dQ, lane, group, hreg, gain, dst, out_base + (size_t)pass * G::P);
+        wave_lds_sync();
+        // ---- 6. history copy-back: last HS samples of every image to its front (8-byte moves) ----
+        {
+            constexpr int NV = 4 * (GS::HS / 4), NK = (NV + 63) / 64;
+            uint2 t[NK];
+#pragma unroll
+            for (int k = 0; k < NK; ++k) {
+                const int i = k * 64 + lane;
+                if (i < NV) {
+                    const int img = i / (GS::HS / 4), f = 4 * (i % (GS::HS / 4));
+                    t[k] = *reinterpret_cast<const uint2 *>(X + img * GS::IMG + GS::phys(G::T + f));
+                }
+            }
+            wave_lds_sync();
+#pragma unroll
+            for (int k = 0; k < NK; ++k) {
+                const int i = k * 64 + lane;
+                if (i < NV) {
+                    const int img = i / (GS::HS / 4), f = 4 * (i % (GS::HS / 4));
+                    *reinterpret_cast<uint2 *>(X + img * GS::IMG + GS::phys(f)) = t[k];
+                }
+            }
+        }
+        {
+            constexpr int NV = 2 * (G::HH4 / 4);
+            float4 tmp;
+            const int rail = lane / (G::HH4 / 4), v = lane % (G::HH4 / 4);
+            if (lane < NV) tmp = *reinterpret_cast<const float4 *>(D + rail * G::DLEN + G::P + 4 * v);
+            wave_lds_sync();
+            if (lane < NV) *reinterpret_cast<float4 *>(D + rail * G::DLEN + 4 * v) = tmp;
+        }
+        wave_lds_sync();
+    }
+
+    for (int i = lane; i < 2 * G::HH4; i += kWave) {
+        const int rail = i / G::HH4, m = i % G::HH4, s = m - G::FH;
+        if (s >= 0) p.fir_state[((size_t)c * 2 + rail) * G::HH + s] = D[rail * G::DLEN + m];
+    }
+    if (lane == 0) {
+        if constexpr (NCO != 0) p.phase[c] = ph0 + p.block_size * step;
+        if (p.agc) p.gain[c] = gain;
+    }
+}
+
 // LO[n] = (cos x, -sin x), x from the integer phase phase0 + n*step: the NCO of DESIGN.md section 2,
 // evaluated once per call when every channel shares step and phase.
 __global__ __launch_bounds__(256) void k_lo_table(float2 *lo, const float *sintab, uint32_t phase0, uint32_t step,
@@ -732,7 +954,36 @@ static hipError_t build_tables(const selenite_rx_config &g, FusedPlan &plan)
                 }
             e = hipMalloc((void **)&plan.d_btab, bt.size() * sizeof(float));
             if (e != hipSuccess) return e;
-            return hipMemcpy(plan.d_btab, bt.data(), bt.size() * sizeof(float), hipMemcpyHostToDevice);
+            e = hipMemcpy(plan.d_btab, bt.data(), bt.size() * sizeof(float), hipMemcpyHostToDevice);
+            if (e != hipSuccess) return e;
+            if constexpr (NH > 0) {
+                // SELENITE_ARITH_SPLIT16: taps scaled by 2^SC (largest |tap| lands in [2^9, 2^10)), split into
+                // f16 hi + lo; fragment of lane l at k-step kk: 8 halfs B[k = 32kk + 8(l>>4) + j][n = l&15]
+                using GS = GeoS<ND, M, NH>;
+                float cmax = 0.0f;
+                for (int k = 0; k < ND; ++k) cmax = std::fmax(cmax, std::fabs(g.dec_coeffs[k]));
+                int ex = 0;
+                if (cmax > 0.0f) std::frexp(cmax, &ex);                       // cmax = m * 2^ex, m in [0.5, 1)
+                const int SC = 10 - ex;
+                std::vector<_Float16> b16((size_t)GS::KS * 2 * 64 * 8, (_Float16)0.0f);
+                for (int kk = 0; kk < GS::KS; ++kk)
+                    for (int l = 0; l < 64; ++l)
+                        for (int j = 0; j < 8; ++j) {
+                            const int idx = 32 * kk + 8 * (l >> 4) + j - 4 * (l & 15);
+                            float cv = 0.0f;
+                            if (idx >= 0 && idx <= ND) cv = std::ldexp(cq[idx], SC);
+                            const _Float16 hi = (_Float16)cv;
+                            const _Float16 lo = (_Float16)(cv - (float)hi);
+                            b16[(((size_t)2 * kk + 0) * 64 + l) * 8 + j] = hi;
+                            b16[(((size_t)2 * kk + 1) * 64 + l) * 8 + j] = lo;
+                        }
+                e = hipMalloc(&plan.d_btab16, b16.size() * sizeof(_Float16));
+                if (e != hipSuccess) return e;
+                e = hipMemcpy(plan.d_btab16, b16.data(), b16.size() * sizeof(_Float16), hipMemcpyHostToDevice);
+                if (e != hipSuccess) return e;
+                plan.split_post = std::ldexp(1.0f, -(SC + GS::XSCALE));
+            }
+            return hipSuccess;
         }
     }
     return hipSuccess;
@@ -776,18 +1027,37 @@ static hipError_t launch_mfma(const RxParams &p, const FusedArgs &fa, const floa
     return hipGetLastError();
 }
 
+template <int ND, int M, int NH, typename TIn, typename TOut>
+static hipError_t launch_split16(const RxParams &p, const FusedArgs &fa, const void *src, void *dst, hipStream_t st)
+{
+    using GS = GeoS<ND, M, NH>;
+    constexpr size_t lds = (size_t)GS::total * sizeof(float);
+    static_assert(lds <= 48 * 1024, "k_ssb_split16 LDS image");
+    auto k = p.nco == 2 ? k_ssb_split16<2, ND, M, NH, TIn, TOut>
+                        : (p.nco == 1 ? k_ssb_split16<1, ND, M, NH, TIn, TOut> : k_ssb_split16<0, ND, M, NH, TIn, TOut>);
+    hipLaunchKernelGGL(k, dim3(p.channels), dim3(64), lds, st, p, fa, static_cast<const TIn *>(src),
+                       static_cast<TOut *>(dst));
+    return hipGetLastError();
+}
+
 template <int ND, int M, int NH>
 static hipError_t launch_shape(const RxParams &p, const FusedArgs &fa, const FusedPlan &plan, int arith,
                                const void *src, bool src_q15, void *dst, bool dst_q15, hipStream_t st)
 {
     if (src_q15 != dst_q15) return hipErrorNotSupported;
+    if constexpr (ND > 0 && M == 4 && NH > 0) {
+        if (arith == SELENITE_ARITH_SPLIT16 && plan.d_btab16) {
+            if (src_q15) return launch_split16<ND, M, NH, int16_t, int16_t>(p, fa, src, dst, st);
+            return launch_split16<ND, M, NH, float, float>(p, fa, src, dst, st);
+        }
+    }
     if constexpr (ND > 0 && M == 4) {
-        if (arith == SELENITE_ARITH_FMA && plan.use_mfma && p.channels % kMfmaWaves == 0) {
+        if (arith != SELENITE_ARITH_CMSIS && plan.use_mfma && p.channels % kMfmaWaves == 0) {
             if (src_q15) return launch_mfma<ND, M, NH, int16_t, int16_t>(p, fa, plan.d_btab, src, dst, st);
             return launch_mfma<ND, M, NH, float, float>(p, fa, plan.d_btab, src, dst, st);
         }
     }
-    if (arith == SELENITE_ARITH_FMA) {
+    if (arith != SELENITE_ARITH_CMSIS) {
         if (src_q15) return launch_one<1, ND, M, NH, int16_t, int16_t>(p, fa, src, dst, st);
         return launch_one<1, ND, M, NH, float, float>(p, fa, src, dst, st);
     }
@@ -836,6 +1106,7 @@ hipError_t plan_fused(const selenite_rx_config &g, bool delay_is_impulse, int de
     const char *nm = std::getenv("SELENITE_RX_NO_MFMA");
     plan.use_mfma = plan.d_btab != nullptr && !(nm && nm[0] == '1');
     if (plan.use_mfma && g.arith == SELENITE_ARITH_FMA) plan.name = "k_ssb_mfma<256,4,63>";
+    if (plan.d_btab16 && g.arith == SELENITE_ARITH_SPLIT16) plan.name = "k_ssb_split16<256,4,63>";
     return hipSuccess;
 }
 
@@ -843,6 +1114,8 @@ void free_fused(FusedPlan &plan)
 {
     if (plan.d_cq) (void)hipFree(plan.d_cq);
     if (plan.d_btab) (void)hipFree(plan.d_btab);
+    if (plan.d_btab16) (void)hipFree(plan.d_btab16);
+    plan.d_btab16 = nullptr;
     plan.d_cq = nullptr;
     plan.d_btab = nullptr;
     plan.tables_built = false;
@@ -863,6 +1136,8 @@ hipError_t launch_fused(const FusedPlan &plan, const RxParams &p, int arith, con
     fa.delay_idx = (uint32_t)delay_index;
     fa.upper = mode_is_upper(p.mode) ? 1u : 0u;
     fa.group = (p.block / p.decim) / 4;
+    fa.btab16 = plan.d_btab16;
+    fa.split_post = plan.split_post;
     {
         const char *e = std::getenv("SELENITE_RX_GRP_SHIFT");
         fa.grp_shift = e ? (uint32_t)std::atoi(e) : 2u;

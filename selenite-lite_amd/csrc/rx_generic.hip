@@ -241,7 +241,7 @@ static hipError_t front_launch(const RxParams &p, const void *src, float *audio,
 hipError_t launch_front_generic(const RxParams &p, int arith, const void *src, bool src_q15,
                                 float *audio, hipStream_t st)
 {
-    if (arith == SELENITE_ARITH_FMA)
+    if (arith != SELENITE_ARITH_CMSIS)
         return src_q15 ? front_launch<1, int16_t>(p, src, audio, st) : front_launch<1, float>(p, src, audio, st);
     return src_q15 ? front_launch<0, int16_t>(p, src, audio, st) : front_launch<0, float>(p, src, audio, st);
 }
@@ -249,7 +249,7 @@ hipError_t launch_front_generic(const RxParams &p, int arith, const void *src, b
 hipError_t launch_biquad_generic(const RxParams &p, int arith, float *audio, hipStream_t st)
 {
     const dim3 grid((p.channels + 63) / 64), blk(64);
-    if (arith == SELENITE_ARITH_FMA) hipLaunchKernelGGL(k_biquad_generic<1>, grid, blk, 0, st, p, audio);
+    if (arith != SELENITE_ARITH_CMSIS) hipLaunchKernelGGL(k_biquad_generic<1>, grid, blk, 0, st, p, audio);
     else hipLaunchKernelGGL(k_biquad_generic<0>, grid, blk, 0, st, p, audio);
     return hipGetLastError();
 }
@@ -258,7 +258,7 @@ hipError_t launch_agc_generic(const RxParams &p, int arith, const float *audio, 
                               bool dst_q15, hipStream_t st)
 {
     const dim3 grid(p.channels), blk(64);
-    if (arith == SELENITE_ARITH_FMA) {
+    if (arith != SELENITE_ARITH_CMSIS) {
         if (dst_q15) hipLaunchKernelGGL((k_agc_generic<1, int16_t>), grid, blk, 0, st, p, audio, (int16_t *)dst);
         else hipLaunchKernelGGL((k_agc_generic<1, float>), grid, blk, 0, st, p, audio, (float *)dst);
     } else {
@@ -280,7 +280,7 @@ hipError_t launch_agc_apply_global(const RxParams &p, int arith, const float *au
                                    void *dst, bool dst_q15, hipStream_t st)
 {
     const dim3 grid(p.channels), blk(64);
-    if (arith == SELENITE_ARITH_FMA) {
+    if (arith != SELENITE_ARITH_CMSIS) {
         if (dst_q15) hipLaunchKernelGGL((k_agc_apply_global<1, int16_t>), grid, blk, 0, st, p, audio, env, (int16_t *)dst);
         else hipLaunchKernelGGL((k_agc_apply_global<1, float>), grid, blk, 0, st, p, audio, env, (float *)dst);
     } else {

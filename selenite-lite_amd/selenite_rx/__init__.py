@@ -15,7 +15,7 @@ PKG_ROOT = os.path.dirname(_HERE)
 LIB_PATH = os.path.join(PKG_ROOT, "libselenite_rx.so")
 
 MODE_LSB, MODE_USB, MODE_CW, MODE_CWR, MODE_AM, MODE_FM, MODE_DIG, MODE_PKT = 0, 1, 2, 3, 4, 8, 0x0A, 0x0C
-ARITH_CMSIS, ARITH_FMA = 0, 1
+ARITH_CMSIS, ARITH_FMA, ARITH_SPLIT16 = 0, 1, 2
 SUCCESS, ARGUMENT_ERROR, LENGTH_ERROR, DEVICE_ERROR = 0, -1, -2, -7
 
 f32p = C.POINTER(C.c_float)

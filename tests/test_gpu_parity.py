@@ -300,3 +300,61 @@ def test_cw_fused_q15_and_vs_generic_large():
     sf, sg = fused.state(), gen.state()
     for k in sf:
         assert np.array_equal(sf[k].view(np.uint32), sg[k].view(np.uint32)), k
+
+
+def test_split16_mode_within_north_star_tolerance():
+    """SELENITE_ARITH_SPLIT16: decimator as f16 hi/lo split MFMA product.  Not bit-exact by
+    construction; the bar is the north star's: max|gpu-ref| <= 1e-5 * max|ref| per DSP block, against
+    the CMSIS arithmetic.  The f32 streaming state of the decimator must still be bit-exact."""
+    import selenite_rx as sr
+    nch = 96
+    spec_s = baseline_spec("cfg3", nch, rc.ARITH_SPLIT16)
+    spec_c = baseline_spec("cfg3", nch, ARITH_CMSIS)
+    g = gpu_rx(spec_s)
+    assert g.kernel_name() == "k_ssb_split16<256,4,63>"
+    o = CpuChain(spec_c, "orc")
+    worst = 0.0
+    na = spec_c.block // spec_c.decim
+    for call in range(3):
+        iq = synth_iq(0, nch, call * 4096, 4096)
+        yg, yo = g.process(iq), o.process(iq)
+        assert np.isfinite(yg).all()
+        for ch in range(nch):
+            for b in range(yo.shape[1] // na):
+                e = rel_err(yg[ch, b * na:(b + 1) * na], yo[ch, b * na:(b + 1) * na])
+                worst = max(worst, e)
+    print("split16 worst per-channel-block rel_err = %.3g" % worst)
+    assert worst <= TOL, worst
+    sg, so = g.state(), o.state()
+    assert bits_equal(sg["dec_state"], so["dec_state"])          # mixed samples are exact f32 in every mode
+    assert np.array_equal(sg["nco_phase"], so["nco_phase"])
+    assert rel_err(sg["fir_state"], so["fir_state"]) <= TOL
+    assert np.allclose(sg["agc_gain"], so["agc_gain"], rtol=1e-5, atol=0)
+
+
+def test_split16_full_scale_and_silence_and_q15():
+    spec_s = baseline_spec("cfg3", 8, rc.ARITH_SPLIT16)
+    spec_c = baseline_spec("cfg3", 8, ARITH_CMSIS)
+    g, o = gpu_rx(spec_s), CpuChain(spec_c, "orc")
+    z = np.zeros((8, 1024, 2), np.float32)
+    assert bits_equal(g.process(z), o.process(z))
+    full = np.ones((8, 2048, 2), np.float32)
+    full[:, ::3, :] = -1.0
+    yg, yo = g.process(full), o.process(full)
+    assert rel_err(yg, yo) <= TOL
+    g2, o2 = gpu_rx(spec_s), CpuChain(spec_c, "orc")
+    iq = synth_iq(0, 8, 0, 2048)
+    q = np.clip(np.trunc(iq * 32768.0), -32768, 32767).astype(np.int16)
+    a, b = g2.process_q15(q).astype(np.int32), o2.process_q15(q).astype(np.int32)
+    assert np.abs(a - b).max() <= 1                                   # one q15 LSB
+
+
+def test_mfma_fma_kernel_is_exercised_and_bit_exact():
+    """FMA mode with the f32 MFMA decimator (k_ssb_mfma): bit-exact vs the oracle's fmaf chain."""
+    spec = baseline_spec("cfg3", 24, ARITH_FMA)
+    g, o = gpu_rx(spec), CpuChain(spec, "orc")
+    assert g.kernel_name() == "k_ssb_mfma<256,4,63>"
+    for call in range(3):
+        iq = synth_iq(0, 24, call * 2048, 2048)
+        assert bits_equal(g.process(iq), o.process(iq))
+    assert_state_equal(g, o)
