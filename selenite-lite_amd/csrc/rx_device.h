@@ -131,6 +131,24 @@ __device__ __forceinline__ float agc_update(const AgcParams &p, float gain, floa
     return gain + q;
 }
 
+// the same law in two pieces (identical operations, identical order per block): the desired gain of a
+// block depends only on its envelope, the recurrence only on the previous gain
+__device__ __forceinline__ float agc_desired(const AgcParams &p, float env)
+{
+    float e = (env < p.env_floor) ? p.env_floor : env;
+    float d = __fdiv_rn(p.target, e);
+    if (d > p.gain_max) d = p.gain_max;
+    if (d < p.gain_min) d = p.gain_min;
+    return d;
+}
+__device__ __forceinline__ float agc_step(const AgcParams &p, float gain, float d)
+{
+    float diff = d - gain;
+    float rate = (diff < 0.0f) ? p.attack : p.decay;
+    float q = rate * diff;
+    return gain + q;
+}
+
 // SupportFunctions/arm_q15_to_float.c:87 and arm_float_to_q15.c:117 (ARM_MATH_ROUNDING off)
 __device__ __forceinline__ float q15_to_float(int16_t v) { return (float)v / 32768.0f; }
 __device__ __forceinline__ int16_t float_to_q15(float f)

@@ -225,10 +225,17 @@ __device__ __forceinline__ void demod_agc_store(const RxParams &p, const FusedAr
 #pragma unroll
             for (int off = 1; off < GROUP; off <<= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
             const int myblk = lane / GROUP;
+            // the divisions target/env of the blocks of this pass are independent of the gain
+            // recurrence: issue them together, then run the (cheap) recurrence
+            float dsr[64 / GROUP];
 #pragma unroll
             for (int b = 0; b < 64 / GROUP; ++b) {
                 const float env = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(m), b * GROUP));
-                g = agc_update<0>(p.agcp, g, env);
+                dsr[b] = agc_desired(p.agcp, env);
+            }
+#pragma unroll
+            for (int b = 0; b < 64 / GROUP; ++b) {
+                g = agc_step(p.agcp, g, dsr[b]);
                 mine = (b == myblk) ? g : mine;
             }
         } else {
