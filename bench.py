@@ -54,6 +54,23 @@ def flops_per_sample(spec):
     return f
 
 
+def pmc_traffic(workload, arith_name, kernel, channels, bs):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r1/traffic.json:
+    2*FETCH_SIZE*1024 + WRITE_SIZE*1024, separate --pmc passes, calibration in profiles/r1/README.md).
+    Only returned when the run is the profiled shape and kernel."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "r1", "traffic.json")))
+    except (OSError, ValueError):
+        return None
+    tag = workload if workload != "cfg3" else "cfg3_" + arith_name
+    e = t.get(tag)
+    if not e or (channels, bs) != WORKLOADS[workload][1:]:
+        return None
+    if kernel.split("<")[0] not in e["kernel"]:
+        return None
+    return int(e["hbm_bytes"])
+
+
 def cpu_baseline(name, arith, budget_s=12.0):
     """Oracle (kind 'port') on the host cores, bounded sample of the same workload."""
     import numpy as np
@@ -97,11 +114,13 @@ def main():
     ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
     ap.add_argument("--channels", type=int, default=0, help="channels per GPU (default: workload's)")
     ap.add_argument("--block-size", type=int, default=0)
-    ap.add_argument("--arith", default=os.environ.get("SELENITE_BENCH_ARITH", "fma"), choices=["cmsis", "fma", "split16"],
-                    help="fma (default): FIR tap loops fused, <=1e-5 rel vs CMSIS (north-star tolerance); "
-                         "cmsis: bit-exact CMSIS-DSP arithmetic")
+    ap.add_argument("--arith", default=os.environ.get("SELENITE_BENCH_ARITH", "split16"), choices=["cmsis", "fma", "split16"],
+                    help="split16 (default): decimator as f16 hi/lo split-precision MFMA product, <=1e-5 rel vs CMSIS "
+                         "(north-star tolerance; measured 1.6e-6); fma: FIR tap loops fused, bit-exact vs the fmaf "
+                         "oracle; cmsis: bit-exact CMSIS-DSP arithmetic")
     ap.add_argument("--global-gain", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--main-only", action="store_true", help="profiling runs: skip the cpu_baseline and other-arithmetic legs")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"])
     args = ap.parse_args()
 
@@ -210,7 +229,8 @@ def main():
                        "parallelism": "channels sharded x%d, no data-path collective" % world},
             "per_gpu_msamples_s": round(value / world, 2),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4),
+                         "traffic": pmc_traffic(args.workload, args.arith, rx.kernel_name(), channels, bs),
                          "algorithmic_bytes_per_launch": alg_bytes, "read_bytes_per_launch": rd_bytes,
                          "read_frac": round(rd_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                          "launch_ms_hip_events": round(k_ms, 4)},
@@ -218,17 +238,23 @@ def main():
                          "unit": "TFLOP/s", "frac": round(fl / (k_ms * 1e-3) / 1e12 / F32_PEAK_TFLOPS, 4),
                          "flops_per_sample": flops_per_sample(spec)},
         }
-        if world == 1 and arith != rc.ARITH_CMSIS and not args.global_gain:
-            # same workload in the bit-exact CMSIS arithmetic, outside the timed region, for the record
-            spec_x = rc.baseline_spec(cfg_name, channels, rc.ARITH_CMSIS)
-            rx_x = sr.Rx(spec_x.config())
-            rx_x.time_process(d_in.ptr, d_out.ptr, bs, 2)
-            ms_x = rx_x.time_process(d_in.ptr, d_out.ptr, bs, max(3, args.steps // 2))
-            out["cmsis_exact_mode"] = {"value": round(channels * bs / (ms_x * 1e-3) / 1e6, 2), "unit": "Msamples/s",
-                                       "ms_per_step": round(ms_x, 4), "kernel": rx_x.kernel_name(),
-                                       "note": "bit-exact vs CMSIS-DSP 1.5.3 arithmetic (0 ULP)"}
-            rx_x.close()
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.global_gain and not args.main_only:
+            # the same workload in the other arithmetic contracts, outside the timed region, for the record
+            others = {}
+            for nm, ar in (("fma", rc.ARITH_FMA), ("cmsis", rc.ARITH_CMSIS)):
+                if ar == arith:
+                    continue
+                spec_x = rc.baseline_spec(cfg_name, channels, ar)
+                rx_x = sr.Rx(spec_x.config())
+                rx_x.time_process(d_in.ptr, d_out.ptr, bs, 2)
+                ms_x = rx_x.time_process(d_in.ptr, d_out.ptr, bs, max(3, args.steps // 2))
+                others[nm] = {"value": round(channels * bs / (ms_x * 1e-3) / 1e6, 2), "unit": "Msamples/s",
+                              "ms_per_step": round(ms_x, 4), "kernel": rx_x.kernel_name()}
+                rx_x.close()
+            others["note"] = ("fma: bit-exact vs the oracle's fmaf restatement; cmsis: bit-exact (0 ULP) vs CMSIS-DSP 1.5.3 "
+                              "arithmetic; split16: tolerance-based, <=1e-5 relative per DSP block")
+            out["other_arith_modes"] = others
+        if world == 1 and not args.no_cpu_baseline and not args.main_only:
             out["cpu_baseline"] = cpu_baseline(args.workload, rc.ARITH_CMSIS)
         print(json.dumps(out), flush=True)
 
