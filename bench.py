@@ -130,7 +130,7 @@ def main():
     n_gpus = args.gpus
     dist = None
     torch = None
-    if world > 1:
+    if world > 1 or os.environ.get("SELENITE_BENCH_FORCE_DIST") == "1":   # (the env var lets a 1-GPU box exercise this path)
         # torch FIRST: its bundled libamdhip64 (same soname) then serves libselenite_rx.so too, so
         # the process holds exactly one HIP runtime.
         import torch
