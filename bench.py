@@ -169,14 +169,15 @@ def main():
     env_t = None
     if args.global_gain:
         env_t = torch.zeros(bs // spec.block, dtype=torch.float32, device="cuda:%d" % local_rank)
+        # kernels go on torch's current stream, so phase1 -> all-reduce -> phase2 are ordered on
+        # the device and a step needs no host synchronisation
+        rx.set_stream(torch.cuda.current_stream().cuda_stream)
 
     def step():
         if args.global_gain:
             rx.global_phase1(d_in.ptr, d_out.ptr, env_t.data_ptr(), bs)
-            rx.sync()
             if dist is not None:
                 dist.all_reduce(env_t, op=dist.ReduceOp.MAX)     # RCCL over xGMI: 4 B per DSP block
-                torch.cuda.synchronize()
             rx.global_phase2(d_out.ptr, env_t.data_ptr(), bs)
         else:
             rx.process_device(d_in.ptr, d_out.ptr, bs)

@@ -108,7 +108,7 @@ static void classify_coeffs(selenite_rx_instance *S)
 static void free_device(selenite_rx_instance *S)
 {
     void *ptrs[] = { S->d_dec_c, S->d_hilb_c, S->d_delay_c, S->d_biq_c, S->d_sintab, S->d_step, S->d_phase,
-                     S->d_dec_state, S->d_fir_state, S->d_biq_state, S->d_gain, S->d_scratch, S->d_env,
+                     S->d_dec_state, S->d_fir_state, S->d_biq_state, S->d_gain, S->d_scratch, S->d_env, S->d_env_part,
                      S->d_io_in, S->d_io_out, S->d_lo };
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -356,33 +356,38 @@ static int run_chain(selenite_rx_instance *S, const void *src, bool src_q15, voi
     const uint32_t phase_now = S->phase_host;
     if (phase != kPhase2 && g.nco_enable) S->phase_host += block_size * S->h_step[0];
 
-    const bool ssb_fused = phase != kPhase2 && !global && !S->force_generic && S->plan.kind != 0 &&
+    // Fused kernels serve the global-gain variant too: they run with their own AGC off (un-scaled
+    // audio out), then the envelope reduction and the gain pass below finish the call.
+    const bool ssb_fused = phase != kPhase2 && !S->force_generic && S->plan.kind != 0 &&
                            fused_block_size_ok(S->plan, g, block_size);
-    const bool cw_fused = phase != kPhase2 && !global && !S->force_generic && cw_fused_ok(g, block_size);
-    if (ssb_fused || cw_fused) {
-        if (g.nco_enable && S->steps_uniform && S->phase_uniform && !S->no_shared_lo) {
-            // one LO for all channels: computed once per call, read from L2 by every wavefront
-            int rc = ensure(S, (void **)&S->d_lo, &S->lo_bytes, (size_t)block_size * sizeof(float2));
-            if (rc) return rc;
-            HIPCHK(S, launch_lo_table(S->d_lo, S->d_sintab, phase_now, S->h_step[0], block_size, st));
-            p.nco = 2;
-            p.lo = S->d_lo;
-        }
-        if (ssb_fused) HIPCHK(S, launch_fused(S->plan, p, arith, src, src_q15, dst, dst_q15, S->delay_index, st));
-        else HIPCHK(S, launch_cw_fused(p, src, src_q15, dst, dst_q15, st));
-        return SELENITE_RX_SUCCESS;
-    }
-
-    // generic path: front -> [biquad] -> AGC / convert.  Un-scaled audio lives in dst itself when
-    // dst is f32, else in the scratch buffer.
-    float *audio = (float *)dst;
-    if (dst_q15) {
+    const bool cw_fused = phase != kPhase2 && !S->force_generic && cw_fused_ok(g, block_size);
+    float *audio = (float *)dst;      // un-scaled audio: dst itself when dst is f32, else scratch
+    if (dst_q15 && (global || !(ssb_fused || cw_fused))) {
         const size_t need = (size_t)g.channels * p.nout * sizeof(float);
         int rc = ensure(S, (void **)&S->d_scratch, &S->scratch_bytes, need);
         if (rc) return rc;
         audio = S->d_scratch;
     }
-    if (phase != kPhase2) {
+    if (ssb_fused || cw_fused) {
+        RxParams pf = p;
+        if (g.nco_enable && S->steps_uniform && S->phase_uniform && !S->no_shared_lo) {
+            // one LO for all channels: computed once per call, read from L2 by every wavefront
+            int rc = ensure(S, (void **)&S->d_lo, &S->lo_bytes, (size_t)block_size * sizeof(float2));
+            if (rc) return rc;
+            HIPCHK(S, launch_lo_table(S->d_lo, S->d_sintab, phase_now, S->h_step[0], block_size, st));
+            pf.nco = 2;
+            pf.lo = S->d_lo;
+        }
+        void *fdst = dst;
+        bool fq15 = dst_q15;
+        if (global) { pf.agc = 0; fdst = audio; fq15 = false; }
+        if (ssb_fused) HIPCHK(S, launch_fused(S->plan, pf, arith, src, src_q15, fdst, fq15, S->delay_index, st));
+        else HIPCHK(S, launch_cw_fused(pf, src, src_q15, fdst, fq15, st));
+        if (!global) return SELENITE_RX_SUCCESS;
+    }
+
+    // generic path: front -> [biquad] -> AGC / convert
+    if (phase != kPhase2 && !(ssb_fused || cw_fused)) {
         HIPCHK(S, launch_front_generic(p, arith, src, src_q15, audio, st));
         if (cw) HIPCHK(S, launch_biquad_generic(p, arith, audio, st));
     }
@@ -394,7 +399,12 @@ static int run_chain(selenite_rx_instance *S, const void *src, bool src_q15, voi
             if (rc) return rc;
             env = S->d_env;
         }
-        if (phase != kPhase2) HIPCHK(S, launch_env_global(p, audio, env, st));
+        if (phase != kPhase2) {
+            const size_t need = sizeof(float) * env_global_rows(p) * (block_size / g.block);
+            int rc = ensure(S, (void **)&S->d_env_part, &S->env_part_cap, need);
+            if (rc) return rc;
+            HIPCHK(S, launch_env_global(p, audio, S->d_env_part, env, st));
+        }
         if (phase != kPhase1) HIPCHK(S, launch_agc_apply_global(p, arith, audio, env, dst, dst_q15, st));
     } else if (g.agc_enable || dst_q15) {
         HIPCHK(S, launch_agc_generic(p, arith, audio, dst, dst_q15, st));

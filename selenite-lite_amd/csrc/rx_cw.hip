@@ -225,7 +225,7 @@ __global__ __launch_bounds__(64) void k_cw_fused(RxParams p, const TIn *__restri
 bool cw_fused_ok(const selenite_rx_config &g, uint32_t block_size)
 {
     return mode_is_cw(g.mode) && g.nd_taps == 0 && g.decim == 1 && g.nh_taps == 0 && g.n_biquad == kCwNs &&
-           !(g.agc_enable && g.agc_global) && g.block == 256 && g.channels % kCwCh == 0 &&
+           g.block == 256 && g.channels % kCwCh == 0 &&
            block_size % g.block == 0;
 }
 

@@ -1090,7 +1090,6 @@ hipError_t plan_fused(const selenite_rx_config &g, bool delay_is_impulse, int de
     plan.kind = 0;
     plan.name = "generic";
     if (!fused_mode_ok(g) || !g.nh_taps || !delay_is_impulse || !hilb_odd_only) return hipSuccess;
-    if (g.agc_enable && g.agc_global) return hipSuccess;
     const uint32_t na = g.block / g.decim;
     if (na < 4 || na > 256 || (na & (na - 1)) != 0) return hipSuccess;
     int kind = 0;

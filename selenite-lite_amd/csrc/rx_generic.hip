@@ -192,28 +192,122 @@ __global__ __launch_bounds__(64) void k_agc_generic(RxParams p, const float *aud
     if (p.agc && lane == 0) p.gain[c] = g;
 }
 
-// env[b] = max over channels; non-negative floats order like their bit patterns
-__global__ __launch_bounds__(64) void k_env_global(RxParams p, const float *audio, float *env)
+// Lane -> (channel, float4) mapping shared by the two global-gain kernels: a DSP block of one
+// channel is L = na/4 float4 (na % 4 == 0), and a wavefront covers cpw = max(1, 64 / L) channels
+// at a time so short blocks (cfg3: na = 64, L = 16) still use every lane.
+struct GlobalMap {
+    uint32_t L, cpw, sub, coff;
+    bool live;
+    __device__ GlobalMap(uint32_t na, int lane)
+    {
+        L = na / 4;
+        cpw = L >= kWave ? 1u : kWave / L;
+        sub = L >= kWave ? (uint32_t)lane : (uint32_t)lane % L;
+        coff = L >= kWave ? 0u : (uint32_t)lane / L;
+        live = coff < cpw;
+    }
+};
+
+// env[b] = max over channels, in two deterministic steps without atomics: every wavefront folds a
+// strided set of channels into part[wave][b]; k_env_fold then folds the waves.  (One atomicMax per
+// channel-block on nblk shared words cost ~1 ms at 65536 channels.)
+constexpr int kEnvWaves = 4;
+constexpr uint32_t kEnvMaxGrid = 1024;
+__global__ __launch_bounds__(64 * kEnvWaves) void k_env_global(RxParams p, const float *audio, float *part)
 {
-    const int lane = threadIdx.x;
-    const uint32_t c = blockIdx.x;
+    const int lane = threadIdx.x & 63;
+    const uint32_t w = blockIdx.x * kEnvWaves + (threadIdx.x >> 6), nw = gridDim.x * kEnvWaves;
     const uint32_t na = p.block / p.decim, nblk = p.block_size / p.block;
+    if (na % 4 == 0) {
+        const GlobalMap gm(na, lane);
+        for (uint32_t b = 0; b < nblk; ++b) {
+            float m = 0.0f;
+            for (uint32_t c = w * gm.cpw + gm.coff; c < p.channels && gm.live; c += nw * gm.cpw) {
+                const float *a = audio + (size_t)c * p.nout + (size_t)b * na;
+                for (uint32_t i = gm.sub; i < gm.L; i += kWave) {
+                    const float4 v = *reinterpret_cast<const float4 *>(a + 4 * i);
+                    m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+                }
+            }
+            m = wave_max(m);
+            if (lane == 0) part[(size_t)w * nblk + b] = m;
+        }
+        return;
+    }
     for (uint32_t b = 0; b < nblk; ++b) {
-        const size_t base = (size_t)c * p.nout + (size_t)b * na;
         float m = 0.0f;
-        for (uint32_t i = lane; i < na; i += kWave) m = fmaxf(m, fabsf(audio[base + i]));
+        for (uint32_t c = w; c < p.channels; c += nw) {
+            const size_t base = (size_t)c * p.nout + (size_t)b * na;
+            for (uint32_t i = lane; i < na; i += kWave) m = fmaxf(m, fabsf(audio[base + i]));
+        }
         m = wave_max(m);
-        if (lane == 0) atomicMax(reinterpret_cast<unsigned int *>(env) + b, __float_as_uint(m));
+        if (lane == 0) part[(size_t)w * nblk + b] = m;
     }
 }
 
+// env[b] = max over the n partial rows part[r][b]; one wavefront per DSP block
+__global__ __launch_bounds__(64) void k_env_fold(const float *part, float *env, uint32_t n, uint32_t nblk)
+{
+    const uint32_t b = blockIdx.x;
+    float m = 0.0f;
+    for (uint32_t r = threadIdx.x; r < n; r += kWave) m = fmaxf(m, part[(size_t)r * nblk + b]);
+    m = wave_max(m);
+    if (threadIdx.x == 0) env[b] = m;
+}
+
+// gain recurrence on the shared envelope + arm_scale_f32 of every channel.  grid: one wavefront
+// per GlobalMap::cpw channels when na % 4 == 0 (launch_agc_apply_global sizes it), else per channel.
 template <int ARITH, typename TOut>
 __global__ __launch_bounds__(64) void k_agc_apply_global(RxParams p, const float *audio,
                                                          const float *env, TOut *dst)
 {
     const int lane = threadIdx.x;
-    const uint32_t c = blockIdx.x;
     const uint32_t na = p.block / p.decim, nblk = p.block_size / p.block;
+    if (na % 4 == 0) {
+        const GlobalMap gm(na, lane);
+        const uint32_t c = blockIdx.x * gm.cpw + gm.coff;
+        if (!gm.live || c >= p.channels) return;
+        float g = p.gain[c];
+        auto put = [&](size_t at, const float4 &v, float gg) {
+            const float4 r = make_float4(v.x * gg, v.y * gg, v.z * gg, v.w * gg);
+            if constexpr (sizeof(TOut) == 4) {
+                *reinterpret_cast<float4 *>(reinterpret_cast<float *>(dst) + at) = r;
+            } else {
+                short4 s4;
+                s4.x = float_to_q15(r.x); s4.y = float_to_q15(r.y);
+                s4.z = float_to_q15(r.z); s4.w = float_to_q15(r.w);
+                *reinterpret_cast<short4 *>(reinterpret_cast<int16_t *>(dst) + at) = s4;
+            }
+        };
+        if (gm.L <= kWave) {
+            // audio may alias dst (in place), so the loads of a chunk of blocks are issued before
+            // the first store of the chunk to keep them in flight together
+            constexpr uint32_t CH = 8;
+            for (uint32_t b0 = 0; b0 < nblk; b0 += CH) {
+                float4 v[CH];
+#pragma unroll
+                for (uint32_t k = 0; k < CH; ++k)
+                    if (b0 + k < nblk && gm.sub < gm.L)
+                        v[k] = *reinterpret_cast<const float4 *>(audio + (size_t)c * p.nout + (size_t)(b0 + k) * na + 4 * gm.sub);
+#pragma unroll
+                for (uint32_t k = 0; k < CH; ++k)
+                    if (b0 + k < nblk) {
+                        g = agc_update<ARITH>(p.agcp, g, env[b0 + k]);
+                        if (gm.sub < gm.L) put((size_t)c * p.nout + (size_t)(b0 + k) * na + 4 * gm.sub, v[k], g);
+                    }
+            }
+        } else {
+            for (uint32_t b = 0; b < nblk; ++b) {
+                const size_t base = (size_t)c * p.nout + (size_t)b * na;
+                g = agc_update<ARITH>(p.agcp, g, env[b]);
+                for (uint32_t i = gm.sub; i < gm.L; i += kWave)
+                    put(base + 4 * i, *reinterpret_cast<const float4 *>(audio + base + 4 * i), g);
+            }
+        }
+        if (gm.sub == 0) p.gain[c] = g;
+        return;
+    }
+    const uint32_t c = blockIdx.x;
     float g = p.gain[c];
     for (uint32_t b = 0; b < nblk; ++b) {
         const size_t base = (size_t)c * p.nout + (size_t)b * na;
@@ -268,18 +362,27 @@ hipError_t launch_agc_generic(const RxParams &p, int arith, const float *audio, 
     return hipGetLastError();
 }
 
-hipError_t launch_env_global(const RxParams &p, const float *audio, float *env, hipStream_t st)
+uint32_t env_global_rows(const RxParams &p)
 {
-    hipError_t e = hipMemsetAsync(env, 0, sizeof(float) * (p.block_size / p.block), st);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_env_global, dim3(p.channels), dim3(64), 0, st, p, audio, env);
+    const uint32_t grid = (p.channels + kEnvWaves - 1) / kEnvWaves;
+    return (grid < kEnvMaxGrid ? grid : kEnvMaxGrid) * kEnvWaves;
+}
+
+// part: env_global_rows(p) * (block_size / block) floats of scratch
+hipError_t launch_env_global(const RxParams &p, const float *audio, float *part, float *env, hipStream_t st)
+{
+    const uint32_t rows = env_global_rows(p), nblk = p.block_size / p.block;
+    hipLaunchKernelGGL(k_env_global, dim3(rows / kEnvWaves), dim3(64 * kEnvWaves), 0, st, p, audio, part);
+    hipLaunchKernelGGL(k_env_fold, dim3(nblk), dim3(64), 0, st, part, env, rows, nblk);
     return hipGetLastError();
 }
 
 hipError_t launch_agc_apply_global(const RxParams &p, int arith, const float *audio, const float *env,
                                    void *dst, bool dst_q15, hipStream_t st)
 {
-    const dim3 grid(p.channels), blk(64);
+    const uint32_t na = p.block / p.decim;
+    const uint32_t cpw = (na % 4 == 0 && na / 4 < 64) ? 64 / (na / 4) : 1;
+    const dim3 grid((p.channels + cpw - 1) / cpw), blk(64);
     if (arith != SELENITE_ARITH_CMSIS) {
         if (dst_q15) hipLaunchKernelGGL((k_agc_apply_global<1, int16_t>), grid, blk, 0, st, p, audio, env, (int16_t *)dst);
         else hipLaunchKernelGGL((k_agc_apply_global<1, float>), grid, blk, 0, st, p, audio, env, (float *)dst);

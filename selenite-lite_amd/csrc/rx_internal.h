@@ -53,7 +53,8 @@ hipError_t launch_biquad_generic(const RxParams &p, int arith, float *audio, hip
 hipError_t launch_agc_generic(const RxParams &p, int arith, const float *audio, void *dst,
                               bool dst_q15, hipStream_t st);
 // global-gain AGC pieces: env[b] = max over channels of max|audio| in DSP block b
-hipError_t launch_env_global(const RxParams &p, const float *audio, float *env, hipStream_t st);
+uint32_t env_global_rows(const RxParams &p);
+hipError_t launch_env_global(const RxParams &p, const float *audio, float *part, float *env, hipStream_t st);
 hipError_t launch_agc_apply_global(const RxParams &p, int arith, const float *audio, const float *env,
                                    void *dst, bool dst_q15, hipStream_t st);
 
@@ -105,6 +106,7 @@ struct selenite_rx_instance {
     float *d_dec_state = nullptr, *d_fir_state = nullptr, *d_biq_state = nullptr, *d_gain = nullptr;
     float *d_scratch = nullptr;  size_t scratch_bytes = 0;   // intermediate f32 audio
     float *d_env = nullptr;      size_t env_cap = 0;
+    float *d_env_part = nullptr; size_t env_part_cap = 0;   // per-wavefront envelope maxima
     void *d_io_in = nullptr;     size_t io_in_bytes = 0;     // staging for the host-pointer entry points
     void *d_io_out = nullptr;    size_t io_out_bytes = 0;
     float2 *d_lo = nullptr;      size_t lo_bytes = 0;        // shared LO table of the current call

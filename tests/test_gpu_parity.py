@@ -358,3 +358,74 @@ def test_mfma_fma_kernel_is_exercised_and_bit_exact():
         iq = synth_iq(0, 24, call * 2048, 2048)
         assert bits_equal(g.process(iq), o.process(iq))
     assert_state_equal(g, o)
+
+
+# ---- global-gain variant (north_star (e): one envelope across every channel) on the fused kernels ----
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,arith,kernel", [
+    ("cfg3", ARITH_CMSIS, "k_ssb_fused<256,4,63>"),
+    ("cfg3", ARITH_FMA, "k_ssb_mfma<256,4,63>"),
+    ("cfg2", ARITH_CMSIS, "k_ssb_fused<0,1,127>"),
+    ("cfg4", ARITH_CMSIS, "k_cw_fused<4,256>"),
+    ("cfg4", ARITH_FMA, "k_cw_fused<4,256>"),
+])
+def test_global_gain_on_fused_kernels_bit_exact(name, arith, kernel):
+    spec = baseline_spec(name, 80, arith, agc_global=True)
+    g = gpu_rx(spec)
+    assert g.kernel_name() == kernel
+    o = CpuChain(spec, "orc")
+    for call in range(3):
+        iq = synth_iq(0, 80, call * 1024, 1024)
+        assert bits_equal(g.process(iq), o.process(iq)), "call %d" % call
+    assert_state_equal(g, o)
+    gains = g.state()["agc_gain"]
+    assert np.all(gains == gains[0])
+
+
+@pytest.mark.gpu
+def test_global_gain_q15_slots_and_split16():
+    spec = baseline_spec("cfg3", 33, ARITH_CMSIS, agc_global=True)
+    g, o = gpu_rx(spec), CpuChain(spec, "orc")
+    for call in range(2):
+        iq = synth_iq(0, 33, call * 512, 512)
+        q = np.clip(np.trunc(iq * 32768.0), -32768, 32767).astype(np.int16)
+        assert np.array_equal(g.process_q15(q), o.process_q15(q))
+    assert_state_equal(g, o)
+    # split16: tolerance-based like the per-channel variant
+    spec_s = baseline_spec("cfg3", 64, rc.ARITH_SPLIT16, agc_global=True)
+    gs, oc = gpu_rx(spec_s), CpuChain(baseline_spec("cfg3", 64, ARITH_CMSIS, agc_global=True), "orc")
+    assert gs.kernel_name() == "k_ssb_split16<256,4,63>"
+    for call in range(2):
+        iq = synth_iq(0, 64, call * 2048, 2048)
+        yg, yo = gs.process(iq), oc.process(iq)
+        for b in range(yo.shape[1] // 64):
+            assert rel_err(yg[:, b * 64:(b + 1) * 64], yo[:, b * 64:(b + 1) * 64]) <= TOL
+
+
+@pytest.mark.gpu
+def test_global_gain_two_shards_on_one_gpu_match_unsharded_oracle():
+    """Two instances own channels [0,40) and [40,80); the envelope exchange (an all-reduce MAX between
+    ranks in bench.py) is done on the host here.  Result must equal the unsharded oracle bit for bit."""
+    import selenite_rx as sr
+    nch, half, bs = 80, 40, 1024
+    spec_all = baseline_spec("cfg3", nch, ARITH_CMSIS, agc_global=True)
+    o = CpuChain(spec_all, "orc")
+    shards = [gpu_rx(baseline_spec("cfg3", half, ARITH_CMSIS, agc_global=True)) for _ in range(2)]
+    nblk = bs // spec_all.block
+    d_in = [sr.DeviceBuffer(half * bs * 8) for _ in range(2)]
+    d_out = [sr.DeviceBuffer(half * (bs // 4) * 4) for _ in range(2)]
+    d_env = [sr.DeviceBuffer(nblk * 4) for _ in range(2)]
+    for call in range(3):
+        iq = synth_iq(0, nch, call * bs, bs)
+        for r in range(2):
+            d_in[r].upload(iq[r * half:(r + 1) * half])
+            shards[r].global_phase1(d_in[r].ptr, d_out[r].ptr, d_env[r].ptr, bs)
+            shards[r].sync(); shards[r].check()
+        env = np.maximum(d_env[0].download((nblk,), np.float32), d_env[1].download((nblk,), np.float32))
+        ys = []
+        for r in range(2):
+            d_env[r].upload(env)
+            shards[r].global_phase2(d_out[r].ptr, d_env[r].ptr, bs)
+            shards[r].sync(); shards[r].check()
+            ys.append(d_out[r].download((half, bs // 4), np.float32))
+        assert bits_equal(np.concatenate(ys, axis=0), o.process(iq)), "call %d" % call
