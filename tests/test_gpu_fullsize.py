@@ -1,0 +1,117 @@
+"""Parity at BASELINE.json's full sizes (cfg3 65 536 ch x 4096, cfg4 65 536 ch x 4096,
+cfg2 4096 ch x ~1 s @ 48 k, cfg5's per-GPU shard 131 072 ch x 1024), through properties that do not
+need the oracle to chew through the whole batch:
+
+  * sampled channels: the oracle runs only a spread of channels (first, last, wavefront/workgroup
+    boundaries, a pseudo-random few) on the same synthetic input and must match the corresponding rows
+    of the full-size GPU result -- bit for bit in the exact modes, within the north-star tolerance in
+    split16 -- over two streamed calls, including the end-of-call state;
+  * determinism: a checksum of per-channel checksums is identical across two runs from reset;
+  * block-partition invariance: one call of B samples == B/1024 calls of 1024 samples.
+
+Inputs are generated on the device (selenite_rx_synth_iq_device, bit-identical to the oracle's
+generator: test_device_synth_matches_host / test_oracle_golden).
+"""
+import numpy as np
+import pytest
+
+import rxcommon as rc
+from rxcommon import ARITH_CMSIS, ARITH_FMA, CpuChain, baseline_spec, bits_equal, rel_err, synth_iq
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5   # north_star tolerance (split16 only)
+
+FULL = {
+    # name: (baseline chain, channels, samples per call)
+    "cfg3": ("cfg3", 65536, 4096),
+    "cfg4": ("cfg4", 65536, 4096),
+    "cfg2": ("cfg2", 4096, 48000 - 48000 % 256),
+    "cfg5": ("cfg2", 131072, 1024),
+}
+
+
+def sample_channels(nch, extra=24):
+    rng = np.random.default_rng(nch)
+    fixed = [0, 1, 15, 16, 63, 64, nch // 2 - 1, nch // 2, nch - 65, nch - 2, nch - 1]
+    return sorted(set(fixed) | set(int(x) for x in rng.integers(0, nch, extra)))
+
+
+def checksum(y):
+    u = np.ascontiguousarray(y).view(np.uint32).reshape(y.shape[0], -1).astype(np.uint64)
+    w = (np.arange(u.shape[1], dtype=np.uint64) * np.uint64(2654435761) + np.uint64(1)) & np.uint64(0xFFFFFFFF)
+    per_channel = (u * w).sum(axis=1, dtype=np.uint64)
+    return int(np.bitwise_xor.reduce(per_channel * (np.arange(len(per_channel), dtype=np.uint64) | np.uint64(1))))
+
+
+class FullRun:
+    def __init__(self, name, arith):
+        import selenite_rx as sr
+        self.sr = sr
+        chain, self.nch, self.bs = FULL[name]
+        self.chain, self.arith = chain, arith
+        self.spec = baseline_spec(chain, self.nch, arith)
+        self.rx = sr.Rx(self.spec.config())
+        self.nout = self.bs // self.spec.decim
+        self.d_in = sr.DeviceBuffer(self.nch * self.bs * 8)
+        self.d_out = sr.DeviceBuffer(self.nch * self.nout * 4)
+
+    def call(self, k, bs=None, first_sample=None):
+        bs = bs or self.bs
+        first = k * self.bs if first_sample is None else first_sample
+        self.rx.synth_device(self.d_in.ptr, 0, self.nch, first, bs, rc.SEED)
+        self.rx.process_device(self.d_in.ptr, self.d_out.ptr, bs)
+        self.rx.sync()
+        self.rx.check()
+        return self.d_out.download((self.nch, bs // self.spec.decim), np.float32)
+
+
+@pytest.mark.parametrize("name,arith", [
+    ("cfg3", ARITH_CMSIS), ("cfg3", ARITH_FMA), ("cfg3", rc.ARITH_SPLIT16),
+    ("cfg4", ARITH_CMSIS), ("cfg4", ARITH_FMA),
+    ("cfg2", ARITH_CMSIS), ("cfg2", ARITH_FMA),
+    ("cfg5", ARITH_CMSIS),
+])
+def test_full_size_sampled_channels_match_oracle(name, arith):
+    run = FullRun(name, arith)
+    assert run.rx.kernel_name() != "generic"
+    chans = sample_channels(run.nch)
+    ref_arith = ARITH_CMSIS if arith == rc.ARITH_SPLIT16 else arith
+    o = CpuChain(baseline_spec(run.chain, len(chans), ref_arith), "orc")
+    na = run.spec.block // run.spec.decim
+    for k in range(2):
+        y = run.call(k)
+        assert np.isfinite(y).all()
+        iq = np.concatenate([synth_iq(c, 1, k * run.bs, run.bs) for c in chans], axis=0)
+        yo = o.process(iq)
+        if arith == rc.ARITH_SPLIT16:
+            yg = y[chans]
+            for b in range(yo.shape[1] // na):
+                for i in range(len(chans)):
+                    assert rel_err(yg[i, b * na:(b + 1) * na], yo[i, b * na:(b + 1) * na]) <= TOL
+        else:
+            assert bits_equal(y[chans], yo), "call %d" % k
+    sg, so = run.rx.state(), o.state()
+    for key in sg:
+        a = sg[key][chans]
+        if arith == rc.ARITH_SPLIT16 and key in ("fir_state", "agc_gain"):
+            assert rel_err(a, so[key]) <= TOL, key
+        elif a.dtype == np.float32:
+            assert bits_equal(a, so[key]), key
+        else:
+            assert np.array_equal(a, so[key]), key
+
+
+@pytest.mark.parametrize("name,arith", [("cfg3", rc.ARITH_SPLIT16), ("cfg3", ARITH_CMSIS), ("cfg4", ARITH_CMSIS),
+                                        ("cfg5", ARITH_FMA)])
+def test_full_size_determinism_and_block_partition_invariance(name, arith):
+    run = FullRun(name, arith)
+    y1 = run.call(0)
+    c1 = checksum(y1)
+    run.rx.reset()
+    assert checksum(run.call(0)) == c1                       # same bits from the same state
+    run.rx.reset()
+    step = 1024 if run.bs > 1024 else 256
+    parts = [run.call(0, bs=step, first_sample=s) for s in range(0, run.bs, step)]
+    y2 = np.concatenate(parts, axis=1)
+    assert checksum(y2) == c1, "streaming in %d-sample calls changed the result" % step
+    assert bits_equal(y1, y2)
