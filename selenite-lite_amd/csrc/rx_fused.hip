@@ -101,6 +101,26 @@ __device__ __forceinline__ v2f mac2(v2f acc, v2f w, float c)
     }
 }
 
+// arm_cmplx_mult_cmplx_f32 on one (re, im) register pair: (a*c - b*d, a*d + b*c) with the four
+// products and the two sums rounded separately (ComplexMathFunctions/arm_cmplx_mult_cmplx_f32.c:186-187).
+// Three packed instructions: v_pk_mul_f32 x2 (operand halves picked by op_sel) + v_pk_add_f32.
+__device__ __forceinline__ v2f cmul_pk(v2f A, v2f L)
+{
+    // The compiler does not fold the half swaps into op_sel (it emits v_mov/v_xor pairs), hence asm:
+    //   t1 = (a*c, a*d)   t2 = (b*d, b*c)   r = (t1.lo - t2.lo, t1.hi + t2.hi)
+    // s_nop: packed-f32 results need one wait state before a non-packed consumer on gfx950 (the
+    // compiler inserts the same s_nop in its own code; it cannot see into the asm block).
+    v2f t1, t2, r;
+    asm("v_pk_mul_f32 %0, %3, %4 op_sel_hi:[0,1]\n\t"
+        "v_pk_mul_f32 %1, %3, %4 op_sel:[1,1] op_sel_hi:[1,0]\n\t"
+        "s_nop 0\n\t"
+        "v_pk_add_f32 %2, %0, %1 neg_lo:[0,1]\n\t"
+        "s_nop 0"
+        : "=&v"(t1), "=&v"(t2), "=v"(r)
+        : "v"(A), "v"(L));
+    return r;
+}
+
 // raw global loads: two complex samples per lane per instruction
 template <typename TIn> struct Raw;
 template <> struct Raw<float> {
@@ -228,11 +248,12 @@ __device__ __forceinline__ void demod_agc_store(const RxParams &p, const FusedAr
             // the divisions target/env of the blocks of this pass are independent of the gain
             // recurrence: issue them together, then run the (cheap) recurrence
             float dsr[64 / GROUP];
+            // every lane divides for its own block's envelope (one division sequence for the whole
+            // wavefront instead of one per block), then the per-block results are broadcast
+            const float mine_d = agc_desired(p.agcp, m);
 #pragma unroll
-            for (int b = 0; b < 64 / GROUP; ++b) {
-                const float env = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(m), b * GROUP));
-                dsr[b] = agc_desired(p.agcp, env);
-            }
+            for (int b = 0; b < 64 / GROUP; ++b)
+                dsr[b] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine_d), b * GROUP));
 #pragma unroll
             for (int b = 0; b < 64 / GROUP; ++b) {
                 g = agc_step(p.agcp, g, dsr[b]);
@@ -778,6 +799,20 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
         *reinterpret_cast<h2 *>(X + (2 * rail + 0) * GS::IMG + ph) = h2{ h0, h1 };
         *reinterpret_cast<h2 *>(X + (2 * rail + 1) * GS::IMG + ph) = h2{ l0, l1 };
     };
+    // two mixed samples (I, Q) -> four words, one per image.  Working on (I, Q) pairs keeps the
+    // complex multiply, the scaling and both conversions in packed instructions.
+    const v2f xs2 = { xs, xs };
+    auto put_iq = [&](int f, v2f ma, v2f mb) {                        // samples f (even) and f + 1
+        const v2f sa = ma * xs2, sb = mb * xs2;
+        const h2 ha = __builtin_convertvector(sa, h2), hb = __builtin_convertvector(sb, h2);
+        const h2 la = __builtin_convertvector(sa - __builtin_convertvector(ha, v2f), h2);
+        const h2 lb = __builtin_convertvector(sb - __builtin_convertvector(hb, v2f), h2);
+        const int ph = GS::phys(f);
+        *reinterpret_cast<h2 *>(X + 0 * GS::IMG + ph) = h2{ ha.x, hb.x };
+        *reinterpret_cast<h2 *>(X + 1 * GS::IMG + ph) = h2{ la.x, lb.x };
+        *reinterpret_cast<h2 *>(X + 2 * GS::IMG + ph) = h2{ ha.y, hb.y };
+        *reinterpret_cast<h2 *>(X + 3 * GS::IMG + ph) = h2{ la.y, lb.y };
+    };
     // history: flat sample f in [0, HS) is CMSIS state sample s = f - F (older slots meet zero taps)
     for (int i = lane; i < 2 * (GS::HS / 2); i += kWave) {
         const int rail = i / (GS::HS / 2), f = 2 * (i % (GS::HS / 2));
@@ -814,21 +849,25 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
             const uint32_t n = 128u * i + 2u * lane;
             float2 a, b;
             R::unpack(raw[i], a, b);
+            v2f ma, mb;                                               // mixed samples as (I, Q) pairs
             if constexpr (NCO == 2) {
                 const float4 l2 = lo4[i];
-                a = cmul<0>(a, make_float2(l2.x, l2.y));
-                b = cmul<0>(b, make_float2(l2.z, l2.w));
+                ma = cmul_pk(v2f{ a.x, a.y }, v2f{ l2.x, l2.y });
+                mb = cmul_pk(v2f{ b.x, b.y }, v2f{ l2.z, l2.w });
             } else if constexpr (NCO == 1) {
-                a = cmul<0>(a, nco_lo<0>(tab, ph0 + (n0 + n) * step));
-                b = cmul<0>(b, nco_lo<0>(tab, ph0 + (n0 + n + 1) * step));
+                const float2 la = nco_lo<0>(tab, ph0 + (n0 + n) * step), lb = nco_lo<0>(tab, ph0 + (n0 + n + 1) * step);
+                ma = cmul_pk(v2f{ a.x, a.y }, v2f{ la.x, la.y });
+                mb = cmul_pk(v2f{ b.x, b.y }, v2f{ lb.x, lb.y });
+            } else {
+                ma = v2f{ a.x, a.y };
+                mb = v2f{ b.x, b.y };
             }
-            put(0, GS::HS + (int)n, a.x, b.x);
-            put(1, GS::HS + (int)n, a.y, b.y);
+            put_iq(GS::HS + (int)n, ma, mb);
             if (last) {                                               // CMSIS pState: last ND-1 mixed samples, f32
                 const int s0 = (int)n - (G::T - (ND - 1));
                 float *stI = p.dec_state + ((size_t)c * 2 + 0) * (ND - 1), *stQ = stI + (ND - 1);
-                if (s0 >= 0) { stI[s0] = a.x; stQ[s0] = a.y; }
-                if (s0 + 1 >= 0) { stI[s0 + 1] = b.x; stQ[s0 + 1] = b.y; }
+                if (s0 >= 0) { stI[s0] = ma.x; stQ[s0] = ma.y; }
+                if (s0 + 1 >= 0) { stI[s0 + 1] = mb.x; stQ[s0 + 1] = mb.y; }
             }
         }
         wave_lds_sync();
