@@ -60,6 +60,16 @@ ABI_SYMBOLS = [
     "selenite_rx_abi_version",
 ]
 
+# every symbol include/selenite_ring.h declares
+RING_ABI_SYMBOLS = [
+    "selenite_ring_init", "selenite_ring_free", "selenite_ring_status", "selenite_ring_error_string",
+    "selenite_ring_set_stream", "selenite_ring_sync",
+    "selenite_ring_in_write_device", "selenite_ring_in_read_device",
+    "selenite_ring_out_write_device", "selenite_ring_out_read_device", "selenite_ring_mute",
+    "selenite_ring_in_write", "selenite_ring_in_read", "selenite_ring_out_write", "selenite_ring_out_read",
+    "selenite_ring_get_state", "selenite_ring_set_state", "selenite_ring_time_device",
+]
+
 _lib = None
 
 
@@ -321,6 +331,128 @@ class Rx:
     def close(self):
         if self.h:
             self.L.selenite_rx_free(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class RingStateView(C.Structure):
+    """struct selenite_ring_state_view."""
+    _fields_ = [("i", C.POINTER(C.c_int16)), ("q", C.POINTER(C.c_int16)), ("buff_enable", C.POINTER(C.c_uint8)),
+                ("rd_ptr", C.POINTER(C.c_uint16)), ("wr_ptr", C.POINTER(C.c_uint16))]
+
+
+class Ring:
+    """`channels` reference DSP_Buff_TypeDef rings in HBM (include/selenite_ring.h; dsp_if.c:83-340).
+    Method names and size units follow the reference functions they replace."""
+
+    def __init__(self, channels, frames=384):
+        self.L = lib()
+        L = self.L
+        vp = C.c_void_p
+        L.selenite_ring_init.argtypes = [C.POINTER(vp), C.c_uint32, C.c_uint32]
+        L.selenite_ring_free.argtypes = [vp]
+        L.selenite_ring_status.argtypes = [vp]
+        L.selenite_ring_error_string.argtypes = [vp]
+        L.selenite_ring_error_string.restype = C.c_char_p
+        L.selenite_ring_set_stream.argtypes = [vp, vp]
+        L.selenite_ring_sync.argtypes = [vp]
+        for n, a in (("in_write", C.c_uint16), ("in_read", C.c_uint32), ("out_write", C.c_uint32), ("out_read", C.c_uint16)):
+            getattr(L, "selenite_ring_%s" % n).argtypes = [vp, vp, a]
+            getattr(L, "selenite_ring_%s" % n).restype = None
+            getattr(L, "selenite_ring_%s_device" % n).argtypes = [vp, vp, a]
+            getattr(L, "selenite_ring_%s_device" % n).restype = None
+        L.selenite_ring_mute.argtypes = [vp]
+        L.selenite_ring_mute.restype = None
+        L.selenite_ring_get_state.argtypes = [vp, C.POINTER(RingStateView)]
+        L.selenite_ring_set_state.argtypes = [vp, C.POINTER(RingStateView)]
+        L.selenite_ring_time_device.argtypes = [vp, vp, vp, C.c_uint16, C.c_uint32, C.POINTER(C.c_float)]
+        self.channels, self.frames = int(channels), int(frames)
+        self.h = vp()
+        rc = L.selenite_ring_init(C.byref(self.h), self.channels, self.frames)
+        if rc:
+            raise RxError(rc, "selenite_ring_init failed (no GPU, or bad channels/frames)")
+
+    def check(self):
+        rc = self.L.selenite_ring_status(self.h)
+        if rc:
+            raise RxError(rc, self.L.selenite_ring_error_string(self.h).decode())
+
+    def _packet(self, arr, words):
+        arr = np.ascontiguousarray(arr, np.int16)
+        assert arr.shape == (self.channels, words), arr.shape
+        return arr
+
+    def in_write(self, pkt):                       # DSP_In_Buff_Write (words)
+        pkt = np.ascontiguousarray(pkt, np.int16)
+        self.L.selenite_ring_in_write(self.h, self._packet(pkt, pkt.shape[1]).ctypes.data, pkt.shape[1])
+        self.check()
+
+    def out_write(self, pkt):                      # DSP_Out_Buff_Write (bytes)
+        pkt = np.ascontiguousarray(pkt, np.int16)
+        self.L.selenite_ring_out_write(self.h, self._packet(pkt, pkt.shape[1]).ctypes.data, 2 * pkt.shape[1])
+        self.check()
+
+    def in_read(self, size_bytes):                 # DSP_In_Buff_Read (bytes)
+        out = np.empty((self.channels, size_bytes // 2), np.int16)
+        self.L.selenite_ring_in_read(self.h, out.ctypes.data, size_bytes)
+        self.check()
+        return out
+
+    def out_read(self, size_words):                # DSP_Out_Buff_Read (words)
+        out = np.empty((self.channels, size_words), np.int16)
+        self.L.selenite_ring_out_read(self.h, out.ctypes.data, size_words)
+        self.check()
+        return out
+
+    def mute(self):
+        self.L.selenite_ring_mute(self.h)
+        self.L.selenite_ring_sync(self.h)
+        self.check()
+
+    def _arrays(self):
+        return {"i": np.zeros((self.channels, self.frames), np.int16),
+                "q": np.zeros((self.channels, self.frames), np.int16),
+                "buff_enable": np.zeros(self.channels, np.uint8),
+                "rd_ptr": np.zeros(self.channels, np.uint16),
+                "wr_ptr": np.zeros(self.channels, np.uint16)}
+
+    @staticmethod
+    def _view(a):
+        return RingStateView(a["i"].ctypes.data_as(C.POINTER(C.c_int16)), a["q"].ctypes.data_as(C.POINTER(C.c_int16)),
+                             a["buff_enable"].ctypes.data_as(C.POINTER(C.c_uint8)),
+                             a["rd_ptr"].ctypes.data_as(C.POINTER(C.c_uint16)),
+                             a["wr_ptr"].ctypes.data_as(C.POINTER(C.c_uint16)))
+
+    def state(self):
+        a = self._arrays()
+        v = self._view(a)
+        rc = self.L.selenite_ring_get_state(self.h, C.byref(v))
+        if rc:
+            raise RxError(rc, self.L.selenite_ring_error_string(self.h).decode())
+        return a
+
+    def set_state(self, a):
+        a = {k: np.ascontiguousarray(v) for k, v in a.items()}
+        v = self._view(a)
+        rc = self.L.selenite_ring_set_state(self.h, C.byref(v))
+        if rc:
+            raise RxError(rc, self.L.selenite_ring_error_string(self.h).decode())
+
+    def time_pair(self, d_src, d_dst, size_words, iters):
+        ms = C.c_float()
+        rc = self.L.selenite_ring_time_device(self.h, d_src, d_dst, size_words, iters, C.byref(ms))
+        if rc:
+            raise RxError(rc, self.L.selenite_ring_error_string(self.h).decode())
+        return ms.value
+
+    def close(self):
+        if self.h:
+            self.L.selenite_ring_free(self.h)
             self.h = C.c_void_p()
 
     def __del__(self):

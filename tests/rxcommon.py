@@ -324,3 +324,83 @@ def baseline_spec(name, channels, arith=ARITH_CMSIS, **kw):
         return ChainSpec(channels, 256, 1, 0, 0, 4, MODE_CW, arith, nco=True,
                          nco_step_all=0x00800000, agc=True, **kw)
     raise KeyError(name)
+
+
+# ---- DSP ring buffer oracle (oracle/ring_oracle.c; parity unpinned, see its header) ----
+_ring_lib = None
+
+
+def ring_oracle_lib():
+    global _ring_lib
+    if _ring_lib is None:
+        path = os.path.join(ROOT, "oracle", "libring_oracle.so")
+        if not os.path.exists(path):
+            subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "libring_oracle.so"], check=True)
+        L = C.CDLL(path)
+        L.orc_ring_new.restype = C.c_void_p
+        L.orc_ring_new.argtypes = [C.c_uint32, C.c_uint32]
+        L.orc_ring_free.argtypes = [C.c_void_p]
+        L.orc_ring_in_write.argtypes = [C.c_void_p, C.c_void_p, C.c_uint16]
+        L.orc_ring_in_read.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
+        L.orc_ring_out_write.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
+        L.orc_ring_out_read.argtypes = [C.c_void_p, C.c_void_p, C.c_uint16]
+        L.orc_ring_mute.argtypes = [C.c_void_p]
+        for n, t in (("i", C.c_int16), ("q", C.c_int16), ("enable", C.c_uint8), ("rd", C.c_uint16), ("wr", C.c_uint16)):
+            getattr(L, "orc_ring_" + n).restype = C.POINTER(t)
+            getattr(L, "orc_ring_" + n).argtypes = [C.c_void_p]
+        _ring_lib = L
+    return _ring_lib
+
+
+class OracleRing:
+    """oracle/ring_oracle.c behind the same Python face as selenite_rx.Ring."""
+
+    def __init__(self, channels, frames=384):
+        self.L = ring_oracle_lib()
+        self.channels, self.frames = channels, frames
+        self.h = self.L.orc_ring_new(channels, frames)
+
+    def in_write(self, pkt):
+        pkt = np.ascontiguousarray(pkt, np.int16)
+        self.L.orc_ring_in_write(self.h, pkt.ctypes.data, pkt.shape[1])
+
+    def out_write(self, pkt):
+        pkt = np.ascontiguousarray(pkt, np.int16)
+        self.L.orc_ring_out_write(self.h, pkt.ctypes.data, 2 * pkt.shape[1])
+
+    def in_read(self, size_bytes):
+        out = np.empty((self.channels, size_bytes // 2), np.int16)
+        self.L.orc_ring_in_read(self.h, out.ctypes.data, size_bytes)
+        return out
+
+    def out_read(self, size_words):
+        out = np.empty((self.channels, size_words), np.int16)
+        self.L.orc_ring_out_read(self.h, out.ctypes.data, size_words)
+        return out
+
+    def mute(self):
+        self.L.orc_ring_mute(self.h)
+
+    def _np(self, name, shape, dtype):
+        ptr = getattr(self.L, "orc_ring_" + name)(self.h)
+        return np.ctypeslib.as_array(ptr, shape=shape).view(dtype)
+
+    def state(self):
+        C_, N = self.channels, self.frames
+        return {"i": self._np("i", (C_, N), np.int16).copy(), "q": self._np("q", (C_, N), np.int16).copy(),
+                "buff_enable": self._np("enable", (C_,), np.uint8).copy(),
+                "rd_ptr": self._np("rd", (C_,), np.uint16).copy(), "wr_ptr": self._np("wr", (C_,), np.uint16).copy()}
+
+    def set_state(self, a):
+        C_, N = self.channels, self.frames
+        self._np("i", (C_, N), np.int16)[...] = a["i"]
+        self._np("q", (C_, N), np.int16)[...] = a["q"]
+        self._np("enable", (C_,), np.uint8)[...] = a["buff_enable"]
+        self._np("rd", (C_,), np.uint16)[...] = a["rd_ptr"]
+        self._np("wr", (C_,), np.uint16)[...] = a["wr_ptr"]
+
+    def __del__(self):
+        try:
+            self.L.orc_ring_free(self.h)
+        except Exception:
+            pass

@@ -28,6 +28,25 @@ def test_library_exports_every_declared_symbol():
     assert L.selenite_rx_abi_version() == 1
 
 
+def test_ring_header_symbols_are_exported_and_bound():
+    text = open(os.path.join(rc.ROOT, "include", "selenite_ring.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = sorted(set(re.findall(r"\b(selenite_ring_[a-z0-9_]+)\s*\(", text)))
+    assert len(names) == 18
+    L = sr.lib()
+    for n in names:
+        assert hasattr(L, n), "libselenite_rx.so does not export %s" % n
+    assert sorted(sr.RING_ABI_SYMBOLS) == names
+
+
+def test_ring_refuses_to_run_without_a_gpu():
+    if has_gpu():
+        pytest.skip("GPU present")
+    h = C.c_void_p()
+    assert sr.lib().selenite_ring_init(C.byref(h), 4, 384) == rc.DEVICE_ERROR
+    assert not h
+
+
 def test_config_struct_layout_matches_header():
     # C layout of selenite_rx_config on LP64: 8 u32, 4 u8, u32, 5 pointers, 7 floats (+4 tail pad)
     assert C.sizeof(sr.Config) == 8 * 4 + 4 + 4 + 5 * 8 + 7 * 4 + 4
