@@ -358,9 +358,11 @@ static int run_chain(selenite_rx_instance *S, const void *src, bool src_q15, voi
 
     // Fused kernels serve the global-gain variant too: they run with their own AGC off (un-scaled
     // audio out), then the envelope reduction and the gain pass below finish the call.
-    const bool ssb_fused = phase != kPhase2 && !S->force_generic && S->plan.kind != 0 &&
-                           fused_block_size_ok(S->plan, g, block_size);
-    const bool cw_fused = phase != kPhase2 && !S->force_generic && cw_fused_ok(g, block_size);
+    // (the fused kernels convert in and out symmetrically: int16 slots with a global gain, which
+    // needs f32 audio between the two phases, stay on the generic kernels)
+    const bool fusable = phase != kPhase2 && !S->force_generic && !(global && src_q15);
+    const bool ssb_fused = fusable && S->plan.kind != 0 && fused_block_size_ok(S->plan, g, block_size);
+    const bool cw_fused = fusable && cw_fused_ok(g, block_size);
     float *audio = (float *)dst;      // un-scaled audio: dst itself when dst is f32, else scratch
     if (dst_q15 && (global || !(ssb_fused || cw_fused))) {
         const size_t need = (size_t)g.channels * p.nout * sizeof(float);

@@ -64,6 +64,7 @@ struct FusedArgs {
     const float *cq;        // padded decimator taps: cq[k'] = dec[k' - F] (k' >= F), else 0; 64*NCR floats
     uint32_t delay_idx;     // index of the unit tap in delay_coeffs
     uint32_t upper;         // 1: audio = I' - Q'   0: audio = I' + Q'
+    uint32_t am;            // 1: audio = |I + jQ| (arm_cmplx_mag_f32); the Hilbert pair and its state are untouched
     uint32_t group;         // lanes per DSP block = (block / M) / 4
     uint32_t grp_shift;     // k_ssb_mfma: phase group of a wave = (wave >> grp_shift) & 1
     const void *btab16;     // k_ssb_split16: Toeplitz operand, f16 hi/lo fragments
@@ -216,7 +217,7 @@ __device__ __forceinline__ void hilbert_quad(const float *dq, int lane, const fl
 // GROUP = lanes per DSP block as a compile-time constant (16: 64-sample blocks, 64: 256-sample blocks;
 // 0 = runtime `group`): constant lane indices turn the block-envelope broadcasts into v_readlane and
 // the lane reductions into DPP instead of ds_bpermute round trips.
-template <int ARITH, int GROUP, int ND, int M, int NH, typename TOut>
+template <int ARITH, int GROUP, int ND, int M, int NH, typename TOut, int AM = 0>
 __device__ __forceinline__ void demod_agc_store(const RxParams &p, const FusedArgs &fa, const float *dI,
                                                 const float *dQ, int lane, int group,
                                                 const float (&hreg)[(NH + 63) / 64 ? (NH + 63) / 64 : 1], float &gain,
@@ -224,7 +225,13 @@ __device__ __forceinline__ void demod_agc_store(const RxParams &p, const FusedAr
 {
     using G = Geo<ND, M, NH>;
     float au[4];
-    if constexpr (NH > 0) {
+    if constexpr (NH > 0 && AM != 0) {
+        // AM: envelope of the decimated rails; new sample n of a pass sits at HH4 + n
+        const float4 vi = *reinterpret_cast<const float4 *>(dI + G::HH4 + 4 * lane);
+        const float4 vq = *reinterpret_cast<const float4 *>(dQ + G::HH4 + 4 * lane);
+        au[0] = cmag<0>(vi.x, vq.x); au[1] = cmag<0>(vi.y, vq.y);
+        au[2] = cmag<0>(vi.z, vq.z); au[3] = cmag<0>(vi.w, vq.w);
+    } else if constexpr (NH > 0) {
         float q2[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
         hilbert_quad<ARITH, ND, M, NH>(dQ, lane, hreg, q2);
         const float *di = dI + G::FH + fa.delay_idx + 4 * lane;   // unit-impulse delay FIR
@@ -285,7 +292,7 @@ __device__ __forceinline__ void demod_agc_store(const RxParams &p, const FusedAr
     }
 }
 
-template <int ARITH, int NCO, int ND, int M, int NH, typename TIn, typename TOut>
+template <int ARITH, int NCO, int ND, int M, int NH, typename TIn, typename TOut, int AM = 0>
 __global__ __launch_bounds__(64, 2) void k_ssb_fused(RxParams p, FusedArgs fa, const TIn *__restrict__ src,
                                                      TOut *__restrict__ dst)
 {
@@ -390,11 +397,11 @@ __global__ __launch_bounds__(64, 2) void k_ssb_fused(RxParams p, FusedArgs fa, c
         }
         // ---- 3-5. Hilbert pair + sideband, AGC, store ----
         if (group == 16)
-            demod_agc_store<ARITH, 16, ND, M, NH, TOut>(p, fa, dI, dQ, lane, group, hreg, gain, dst, out_base + (size_t)pass * G::P);
+            demod_agc_store<ARITH, 16, ND, M, NH, TOut, AM>(p, fa, dI, dQ, lane, group, hreg, gain, dst, out_base + (size_t)pass * G::P);
         else if (group == 64)
-            demod_agc_store<ARITH, 64, ND, M, NH, TOut>(p, fa, dI, dQ, lane, group, hreg, gain, dst, out_base + (size_t)pass * G::P);
+            demod_agc_store<ARITH, 64, ND, M, NH, TOut, AM>(p, fa, dI, dQ, lane, group, hreg, gain, dst, out_base + (size_t)pass * G::P);
         else
-            demod_agc_store<ARITH, 0, ND, M, NH, TOut>(p, fa, dI, dQ, lane, group, hreg, gain, dst, out_base + (size_t)pass * G::P);
+            demod_agc_store<ARITH, 0, ND, M, NH, TOut, AM>(p, fa, dI, dQ, lane, group, hreg, gain, dst, out_base + (size_t)pass * G::P);
         wave_lds_sync();
         // ---- 6. history copy-back (arm_fir_decimate_f32.c:396-426, arm_fir_f32.c:947-978) ----
         if constexpr (ND > 0) {
@@ -442,9 +449,11 @@ __global__ __launch_bounds__(64, 2) void k_ssb_fused(RxParams p, FusedArgs fa, c
         }
     }
     if constexpr (NH > 0) {
-        for (int i = lane; i < 2 * G::HH4; i += kWave) {
-            const int rail = i / G::HH4, m = i % G::HH4, s = m - G::FH;
-            if (s >= 0) p.fir_state[((size_t)c * 2 + rail) * G::HH + s] = D[rail * G::DLEN + m];
+        if constexpr (AM == 0) {                                      // AM never ran the Hilbert pair: its state stays
+            for (int i = lane; i < 2 * G::HH4; i += kWave) {
+                const int rail = i / G::HH4, m = i % G::HH4, s = m - G::FH;
+                if (s >= 0) p.fir_state[((size_t)c * 2 + rail) * G::HH + s] = D[rail * G::DLEN + m];
+            }
         }
     }
     if (lane == 0) {
@@ -486,7 +495,7 @@ struct GeoM {
 
 constexpr int kMfmaWaves = 1;      // waves (= channels) per workgroup of k_ssb_mfma (f32 MFMA shares the FP32 ALUs with the VALU, so anti-phased multi-wave groups bring nothing)
 
-template <int NCO, int ND, int M, int NH, typename TIn, typename TOut>
+template <int NCO, int ND, int M, int NH, typename TIn, typename TOut, int AM = 0>
 __global__ __launch_bounds__(64 * kMfmaWaves, 2) void k_ssb_mfma(RxParams p, FusedArgs fa,
                                                                  const float *__restrict__ btab,
                                                                  const TIn *__restrict__ src, TOut *__restrict__ dst)
@@ -632,9 +641,9 @@ __global__ __launch_bounds__(64 * kMfmaWaves, 2) void k_ssb_mfma(RxParams p, Fus
     // ---- V phase, part 1: Hilbert pair + sideband, AGC, store; history copy-backs ----
     auto finish = [&](uint32_t pass) {
         if (group == 16)
-            demod_agc_store<1, 16, ND, M, NH, TOut>(p, fa, dI, dQ, lane, group, hreg, gain, dst, out_base + (size_t)pass * G::P);
+            demod_agc_store<1, 16, ND, M, NH, TOut, AM>(p, fa, dI, dQ, lane, group, hreg, gain, dst, out_base + (size_t)pass * G::P);
         else
-            demod_agc_store<1, 0, ND, M, NH, TOut>(p, fa, dI, dQ, lane, group, hreg, gain, dst, out_base + (size_t)pass * G::P);
+            demod_agc_store<1, 0, ND, M, NH, TOut, AM>(p, fa, dI, dQ, lane, group, hreg, gain, dst, out_base + (size_t)pass * G::P);
         wave_lds_sync();
         {
             constexpr int NV = 2 * GM::HS / 2;                        // float2 moves
@@ -702,9 +711,11 @@ __global__ __launch_bounds__(64 * kMfmaWaves, 2) void k_ssb_mfma(RxParams p, Fus
         if (s >= 0) p.dec_state[((size_t)c * 2 + rail) * (ND - 1) + s] = (rail ? XQ : XI)[GM::phys(f)];
     }
     if constexpr (NH > 0) {
-        for (int i = lane; i < 2 * G::HH4; i += kWave) {
-            const int rail = i / G::HH4, m = i % G::HH4, s = m - G::FH;
-            if (s >= 0) p.fir_state[((size_t)c * 2 + rail) * G::HH + s] = D[rail * G::DLEN + m];
+        if constexpr (AM == 0) {                                      // AM never ran the Hilbert pair: its state stays
+            for (int i = lane; i < 2 * G::HH4; i += kWave) {
+                const int rail = i / G::HH4, m = i % G::HH4, s = m - G::FH;
+                if (s >= 0) p.fir_state[((size_t)c * 2 + rail) * G::HH + s] = D[rail * G::DLEN + m];
+            }
         }
     }
     if (lane == 0) {
@@ -751,7 +762,7 @@ struct GeoS {
     __host__ __device__ static constexpr int phys(int f) { return 80 * (f >> 6) + (f & 63); }
 };
 
-template <int NCO, int ND, int M, int NH, typename TIn, typename TOut>
+template <int NCO, int ND, int M, int NH, typename TIn, typename TOut, int AM = 0>
 __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa, const TIn *__restrict__ src,
                                                        TOut *__restrict__ dst)
 {
@@ -903,9 +914,9 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
         }
         // ---- 3-5. Hilbert pair + sideband, AGC, store ----
         if (group == 16)
-            demod_agc_store<1, 16, ND, M, NH, TOut>(p, fa, dI, dQ, lane, group, hreg, gain, dst, out_base + (size_t)pass * G::P);
+            demod_agc_store<1, 16, ND, M, NH, TOut, AM>(p, fa, dI, dQ, lane, group, hreg, gain, dst, out_base + (size_t)pass * G::P);
         else
-            demod_agc_store<1, 0, ND, M, NH, TOut>(p, fa, dI, dQ, lane, group, hreg, gain, dst, out_base + (size_t)pass * G::P);
+            demod_agc_store<1, 0, ND, M, NH, TOut, AM>(p, fa, dI, dQ, lane, group, hreg, gain, dst, out_base + (size_t)pass * G::P);
         wave_lds_sync();
         // ---- 6. history copy-back: last HS samples of every image to its front (8-byte moves) ----
         {
@@ -940,9 +951,11 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
         wave_lds_sync();
     }
 
-    for (int i = lane; i < 2 * G::HH4; i += kWave) {
-        const int rail = i / G::HH4, m = i % G::HH4, s = m - G::FH;
-        if (s >= 0) p.fir_state[((size_t)c * 2 + rail) * G::HH + s] = D[rail * G::DLEN + m];
+    if constexpr (AM == 0) {                                          // AM never ran the Hilbert pair: its state stays
+        for (int i = lane; i < 2 * G::HH4; i += kWave) {
+            const int rail = i / G::HH4, m = i % G::HH4, s = m - G::FH;
+            if (s >= 0) p.fir_state[((size_t)c * 2 + rail) * G::HH + s] = D[rail * G::DLEN + m];
+        }
     }
     if (lane == 0) {
         if constexpr (NCO != 0) p.phase[c] = ph0 + p.block_size * step;
@@ -1040,8 +1053,10 @@ static hipError_t launch_one(const RxParams &p, const FusedArgs &fa, const void 
 {
     using G = Geo<ND, M, NH>;
     constexpr size_t lds = (size_t)G::total * sizeof(float);
-    auto k = p.nco == 2 ? k_ssb_fused<ARITH, 2, ND, M, NH, TIn, TOut>
-                        : (p.nco == 1 ? k_ssb_fused<ARITH, 1, ND, M, NH, TIn, TOut> : k_ssb_fused<ARITH, 0, ND, M, NH, TIn, TOut>);
+    auto k = fa.am ? (p.nco == 2 ? k_ssb_fused<ARITH, 2, ND, M, NH, TIn, TOut, 1>
+                         : (p.nco == 1 ? k_ssb_fused<ARITH, 1, ND, M, NH, TIn, TOut, 1> : k_ssb_fused<ARITH, 0, ND, M, NH, TIn, TOut, 1>))
+                   : (p.nco == 2 ? k_ssb_fused<ARITH, 2, ND, M, NH, TIn, TOut, 0>
+                         : (p.nco == 1 ? k_ssb_fused<ARITH, 1, ND, M, NH, TIn, TOut, 0> : k_ssb_fused<ARITH, 0, ND, M, NH, TIn, TOut, 0>));
     if constexpr (lds > 48 * 1024) {
         static bool once = false;
         if (!once) {
@@ -1063,8 +1078,10 @@ static hipError_t launch_mfma(const RxParams &p, const FusedArgs &fa, const floa
     using GM = GeoM<ND, M, NH>;
     constexpr size_t lds = (size_t)kMfmaWaves * GM::total * sizeof(float);
     static_assert(lds <= 160 * 1024, "k_ssb_mfma LDS image");
-    auto k = p.nco == 2 ? k_ssb_mfma<2, ND, M, NH, TIn, TOut>
-                        : (p.nco == 1 ? k_ssb_mfma<1, ND, M, NH, TIn, TOut> : k_ssb_mfma<0, ND, M, NH, TIn, TOut>);
+    auto k = fa.am ? (p.nco == 2 ? k_ssb_mfma<2, ND, M, NH, TIn, TOut, 1>
+                         : (p.nco == 1 ? k_ssb_mfma<1, ND, M, NH, TIn, TOut, 1> : k_ssb_mfma<0, ND, M, NH, TIn, TOut, 1>))
+                   : (p.nco == 2 ? k_ssb_mfma<2, ND, M, NH, TIn, TOut, 0>
+                         : (p.nco == 1 ? k_ssb_mfma<1, ND, M, NH, TIn, TOut, 0> : k_ssb_mfma<0, ND, M, NH, TIn, TOut, 0>));
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)lds);
     if (e != hipSuccess) return e;
@@ -1079,8 +1096,10 @@ static hipError_t launch_split16(const RxParams &p, const FusedArgs &fa, const v
     using GS = GeoS<ND, M, NH>;
     constexpr size_t lds = (size_t)GS::total * sizeof(float);
     static_assert(lds <= 48 * 1024, "k_ssb_split16 LDS image");
-    auto k = p.nco == 2 ? k_ssb_split16<2, ND, M, NH, TIn, TOut>
-                        : (p.nco == 1 ? k_ssb_split16<1, ND, M, NH, TIn, TOut> : k_ssb_split16<0, ND, M, NH, TIn, TOut>);
+    auto k = fa.am ? (p.nco == 2 ? k_ssb_split16<2, ND, M, NH, TIn, TOut, 1>
+                         : (p.nco == 1 ? k_ssb_split16<1, ND, M, NH, TIn, TOut, 1> : k_ssb_split16<0, ND, M, NH, TIn, TOut, 1>))
+                   : (p.nco == 2 ? k_ssb_split16<2, ND, M, NH, TIn, TOut, 0>
+                         : (p.nco == 1 ? k_ssb_split16<1, ND, M, NH, TIn, TOut, 0> : k_ssb_split16<0, ND, M, NH, TIn, TOut, 0>));
     hipLaunchKernelGGL(k, dim3(p.channels), dim3(64), lds, st, p, fa, static_cast<const TIn *>(src),
                        static_cast<TOut *>(dst));
     return hipGetLastError();
@@ -1119,7 +1138,7 @@ static bool fused_mode_ok(const selenite_rx_config &g)
     const uint32_t m = g.mode;
     const bool ssb = m == SELENITE_MODE_USB || m == SELENITE_MODE_LSB || m == SELENITE_MODE_DIG || m == SELENITE_MODE_PKT;
     const bool cw_plain = mode_is_cw(m) && g.n_biquad == 0;
-    return ssb || cw_plain;
+    return ssb || cw_plain || m == SELENITE_MODE_AM;
 }
 
 hipError_t plan_fused(const selenite_rx_config &g, bool delay_is_impulse, int delay_index, bool hilb_odd_only,
@@ -1180,6 +1199,7 @@ hipError_t launch_fused(const FusedPlan &plan, const RxParams &p, int arith, con
     fa.cq = plan.d_cq;
     fa.delay_idx = (uint32_t)delay_index;
     fa.upper = mode_is_upper(p.mode) ? 1u : 0u;
+    fa.am = p.mode == SELENITE_MODE_AM ? 1u : 0u;
     fa.group = (p.block / p.decim) / 4;
     fa.btab16 = plan.d_btab16;
     fa.split_post = plan.split_post;

@@ -386,8 +386,8 @@ def test_global_gain_on_fused_kernels_bit_exact(name, arith, kernel):
 def test_global_gain_q15_slots_and_split16():
     spec = baseline_spec("cfg3", 33, ARITH_CMSIS, agc_global=True)
     g, o = gpu_rx(spec), CpuChain(spec, "orc")
-    for call in range(2):
-        iq = synth_iq(0, 33, call * 512, 512)
+    for call, bs in enumerate((512, 1024, 2048)):
+        iq = synth_iq(0, 33, 4096 * call, bs)
         q = np.clip(np.trunc(iq * 32768.0), -32768, 32767).astype(np.int16)
         assert np.array_equal(g.process_q15(q), o.process_q15(q))
     assert_state_equal(g, o)
@@ -429,3 +429,31 @@ def test_global_gain_two_shards_on_one_gpu_match_unsharded_oracle():
             shards[r].sync(); shards[r].check()
             ys.append(d_out[r].download((half, bs // 4), np.float32))
         assert bits_equal(np.concatenate(ys, axis=0), o.process(iq)), "call %d" % call
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,arith,kernel", [
+    ("cfg3", ARITH_CMSIS, "k_ssb_fused<256,4,63>"), ("cfg3", ARITH_FMA, "k_ssb_mfma<256,4,63>"),
+    ("cfg2", ARITH_CMSIS, "k_ssb_fused<0,1,127>"), ("cfg1", ARITH_FMA, "k_ssb_fused<0,1,63>"),
+])
+def test_am_mode_on_fused_kernels_bit_exact_and_hilbert_state_untouched(name, arith, kernel):
+    """DSP_Set_Mode(MODE_AM) (rxtx_if.h:38): arm_cmplx_mag_f32 of the decimated rails.  The fused
+    kernels serve it; the Hilbert pair's state must stay exactly as the last SSB block left it, so
+    that USB -> AM -> USB continues like the CMSIS composition."""
+    spec = baseline_spec(name, 48, arith)
+    g, o = gpu_rx(spec), CpuChain(spec, "orc")
+    seq = [rc.MODE_USB, MODE_AM, MODE_AM, MODE_LSB, MODE_AM, MODE_USB]
+    for k, mode in enumerate(seq):
+        assert g.set_mode(mode) == 0 and o.set_mode(mode) == 0
+        assert g.kernel_name() == kernel
+        iq = synth_iq(0, 48, k * 1024, 1024)
+        assert bits_equal(g.process(iq), o.process(iq)), "step %d mode %d" % (k, mode)
+        assert_state_equal(g, o)
+    gs, oc = gpu_rx(baseline_spec("cfg3", 48, rc.ARITH_SPLIT16)), CpuChain(baseline_spec("cfg3", 48, ARITH_CMSIS), "orc")
+    assert gs.set_mode(MODE_AM) == 0 and oc.set_mode(MODE_AM) == 0
+    assert gs.kernel_name() == "k_ssb_split16<256,4,63>"
+    for k in range(2):
+        iq = synth_iq(0, 48, k * 2048, 2048)
+        yg, yo = gs.process(iq), oc.process(iq)
+        for b in range(yo.shape[1] // 64):
+            assert rel_err(yg[:, b * 64:(b + 1) * 64], yo[:, b * 64:(b + 1) * 64]) <= TOL
