@@ -824,18 +824,39 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
         *reinterpret_cast<h2 *>(X + 2 * GS::IMG + ph) = h2{ ha.y, hb.y };
         *reinterpret_cast<h2 *>(X + 3 * GS::IMG + ph) = h2{ la.y, lb.y };
     };
-    // history: flat sample f in [0, HS) is CMSIS state sample s = f - F (older slots meet zero taps)
-    for (int i = lane; i < 2 * (GS::HS / 2); i += kWave) {
-        const int rail = i / (GS::HS / 2), f = 2 * (i % (GS::HS / 2));
-        const int s0 = f - G::F, s1 = f + 1 - G::F;
-        const float *st = p.dec_state + ((size_t)c * 2 + rail) * (ND - 1);
-        put(rail, f, s0 >= 0 ? st[s0] : 0.0f, s1 >= 0 ? st[s1] : 0.0f);
-    }
-    for (int i = lane; i < 2 * G::HH4; i += kWave) {
-        const int rail = i / G::HH4, m = i % G::HH4, s = m - G::FH;
-        float v = 0.0f;
-        if (s >= 0) v = p.fir_state[((size_t)c * 2 + rail) * G::HH + s];
-        D[rail * G::DLEN + m] = v;
+    // history: flat sample f in [0, HS) is CMSIS state sample s = f - F (older slots meet zero taps).
+    // All state loads of the prologue are issued before the first use, so the workgroup pays one
+    // memory round trip for them instead of one per loop iteration.
+    {
+        constexpr int NHI = (2 * (GS::HS / 2) + kWave - 1) / kWave;      // pairs of history samples per lane
+        constexpr int NFI = (2 * G::HH4 + kWave - 1) / kWave;
+        float h0[NHI], h1[NHI], fv[NFI];
+#pragma unroll
+        for (int j = 0; j < NHI; ++j) {
+            const int i = j * kWave + lane;
+            const int rail = i / (GS::HS / 2), f = 2 * (i % (GS::HS / 2));
+            const int s0 = f - G::F, s1 = f + 1 - G::F;
+            const float *st = p.dec_state + ((size_t)c * 2 + rail) * (ND - 1);
+            const bool in = i < 2 * (GS::HS / 2);
+            h0[j] = (in && s0 >= 0) ? st[s0] : 0.0f;
+            h1[j] = (in && s1 >= 0) ? st[s1] : 0.0f;
+        }
+#pragma unroll
+        for (int j = 0; j < NFI; ++j) {
+            const int i = j * kWave + lane;
+            const int rail = i / G::HH4, m = i % G::HH4, s = m - G::FH;
+            fv[j] = (i < 2 * G::HH4 && s >= 0) ? p.fir_state[((size_t)c * 2 + rail) * G::HH + s] : 0.0f;
+        }
+#pragma unroll
+        for (int j = 0; j < NHI; ++j) {
+            const int i = j * kWave + lane;
+            if (i < 2 * (GS::HS / 2)) put(i / (GS::HS / 2), 2 * (i % (GS::HS / 2)), h0[j], h1[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < NFI; ++j) {
+            const int i = j * kWave + lane;
+            if (i < 2 * G::HH4) D[(i / G::HH4) * G::DLEN + i % G::HH4] = fv[j];
+        }
     }
     const uint32_t ph0 = NCO ? p.phase[c] : 0u;
     const uint32_t step = NCO ? p.step[c] : 0u;
@@ -874,7 +895,9 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
                 mb = v2f{ b.x, b.y };
             }
             put_iq(GS::HS + (int)n, ma, mb);
-            if (last) {                                               // CMSIS pState: last ND-1 mixed samples, f32
+            if (128 * (i + 1) > G::T - (ND - 1) && last) {            // CMSIS pState: last ND-1 mixed samples, f32
+                // (the first operand is a compile-time constant of the unrolled loop: load groups
+                // in front of the state window carry no store code at all)
                 const int s0 = (int)n - (G::T - (ND - 1));
                 float *stI = p.dec_state + ((size_t)c * 2 + 0) * (ND - 1), *stQ = stI + (ND - 1);
                 if (s0 >= 0) { stI[s0] = ma.x; stQ[s0] = ma.y; }
