@@ -84,6 +84,26 @@ __device__ __forceinline__ void wave_lds_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Prologue fill of N LDS words from HBM state: every load of the wavefront is issued before the
+// first store, so the N/64 round trips overlap instead of queueing behind one another (the compiler
+// does not hoist loads above LDS stores it cannot prove disjoint).
+template <int N, typename LoadFn, typename StoreFn>
+__device__ __forceinline__ void batched_fill(int lane, LoadFn load, StoreFn store)
+{
+    constexpr int NI = (N + 63) / 64;
+    float v[NI];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        const int i = j * 64 + lane;
+        v[j] = (i < N) ? load(i) : 0.0f;
+    }
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        const int i = j * 64 + lane;
+        if (i < N) store(i, v[j]);
+    }
+}
+
 __device__ __forceinline__ float f4get(const float4 &v, int e)
 {
     return e == 0 ? v.x : (e == 1 ? v.y : (e == 2 ? v.z : v.w));
@@ -323,21 +343,23 @@ __global__ __launch_bounds__(64, 2) void k_ssb_fused(RxParams p, FusedArgs fa, c
         for (int v = 0; v < G::NCR; ++v) creg[v] = fa.cq[64 * v + lane];
         // history element (phase pp, index m) holds sample s = (m*M + pp) - F of the CMSIS state
         // (oldest first); slots before the state (s < 0) only ever meet zero-padded taps
-        for (int i = lane; i < 2 * M * G::HQ4; i += kWave) {
-            const int rail = i / (M * G::HQ4), rem = i % (M * G::HQ4);
-            const int s = rem - G::F, pp = rem % M, m = rem / M;
-            float v = 0.0f;
-            if (s >= 0) v = p.dec_state[((size_t)c * 2 + rail) * (ND - 1) + s];
-            S[pp * G::PSF + G::elem(m) + rail] = v;
-        }
+        batched_fill<2 * M * G::HQ4>(lane,
+            [&](int i) {
+                const int rail = i / (M * G::HQ4), sidx = i % (M * G::HQ4) - G::F;
+                return sidx >= 0 ? p.dec_state[((size_t)c * 2 + rail) * (ND - 1) + sidx] : 0.0f;
+            },
+            [&](int i, float v) {
+                const int rail = i / (M * G::HQ4), rem = i % (M * G::HQ4);
+                S[(rem % M) * G::PSF + G::elem(rem / M) + rail] = v;
+            });
     }
     if constexpr (NH > 0) {
-        for (int i = lane; i < 2 * G::HH4; i += kWave) {
-            const int rail = i / G::HH4, m = i % G::HH4, s = m - G::FH;
-            float v = 0.0f;
-            if (s >= 0) v = p.fir_state[((size_t)c * 2 + rail) * G::HH + s];
-            D[rail * G::DLEN + m] = v;
-        }
+        batched_fill<2 * G::HH4>(lane,
+            [&](int i) {
+                const int rail = i / G::HH4, sidx = i % G::HH4 - G::FH;
+                return sidx >= 0 ? p.fir_state[((size_t)c * 2 + rail) * G::HH + sidx] : 0.0f;
+            },
+            [&](int i, float v) { D[(i / G::HH4) * G::DLEN + i % G::HH4] = v; });
     }
     float hreg[(NH + 63) / 64 ? (NH + 63) / 64 : 1];
 #pragma unroll
@@ -536,19 +558,19 @@ __global__ __launch_bounds__(64 * kMfmaWaves, 2) void k_ssb_mfma(RxParams p, Fus
     if constexpr (NCO == 1)
         for (int i = lane; i < 513; i += kWave) tab[i] = p.sintab[i];
     // history: flat sample f in [0, HS) is CMSIS state sample s = f - F (older slots meet zero taps)
-    for (int i = lane; i < 2 * GM::HS; i += kWave) {
-        const int rail = i / GM::HS, f = i % GM::HS, s = f - G::F;
-        float v = 0.0f;
-        if (s >= 0) v = p.dec_state[((size_t)c * 2 + rail) * (ND - 1) + s];
-        (rail ? XQ : XI)[GM::phys(f)] = v;
-    }
+    batched_fill<2 * GM::HS>(lane,
+        [&](int i) {
+            const int rail = i / GM::HS, sidx = i % GM::HS - G::F;
+            return sidx >= 0 ? p.dec_state[((size_t)c * 2 + rail) * (ND - 1) + sidx] : 0.0f;
+        },
+        [&](int i, float v) { (i / GM::HS ? XQ : XI)[GM::phys(i % GM::HS)] = v; });
     if constexpr (NH > 0) {
-        for (int i = lane; i < 2 * G::HH4; i += kWave) {
-            const int rail = i / G::HH4, m = i % G::HH4, s = m - G::FH;
-            float v = 0.0f;
-            if (s >= 0) v = p.fir_state[((size_t)c * 2 + rail) * G::HH + s];
-            D[rail * G::DLEN + m] = v;
-        }
+        batched_fill<2 * G::HH4>(lane,
+            [&](int i) {
+                const int rail = i / G::HH4, sidx = i % G::HH4 - G::FH;
+                return sidx >= 0 ? p.fir_state[((size_t)c * 2 + rail) * G::HH + sidx] : 0.0f;
+            },
+            [&](int i, float v) { D[(i / G::HH4) * G::DLEN + i % G::HH4] = v; });
     }
     float hreg[(NH + 63) / 64 ? (NH + 63) / 64 : 1];
 #pragma unroll
