@@ -109,8 +109,12 @@ def cpu_baseline(name, arith, budget_s=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--spinup-ms", type=float, default=300.0,
+                    help="untimed device spin-up before the W warmup steps: an idle MI355X sits at ~150 MHz and needs "
+                         "~60-100 ms of load to reach its sustained clocks (tools/clock_ramp.py); a streaming DSP "
+                         "service runs in that steady state.  0 disables it.")
     ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
     ap.add_argument("--channels", type=int, default=0, help="channels per GPU (default: workload's)")
     ap.add_argument("--block-size", type=int, default=0)
@@ -182,6 +186,13 @@ def main():
         else:
             rx.process_device(d_in.ptr, d_out.ptr, bs)
 
+    spin_t0 = time.perf_counter()
+    spin_calls = 0
+    while (time.perf_counter() - spin_t0) * 1e3 < args.spinup_ms:      # clock ramp, untimed (see --spinup-ms)
+        for _ in range(16):
+            step()
+        rx.sync()
+        spin_calls += 16
     for _ in range(args.warmup):
         step()
     barrier()
@@ -215,7 +226,7 @@ def main():
         out = {
             "metric": "Msamples/s complex I/Q through full RX chain (whole job)",
             "value": round(value, 2), "unit": "Msamples/s", "n_gpus": n_gpus, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+            "warmup": args.warmup, "spinup_ms": args.spinup_ms, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s: %d channels/GPU x %d complex samples/call, %s" % (
@@ -247,7 +258,7 @@ def main():
                     continue
                 spec_x = rc.baseline_spec(cfg_name, channels, ar)
                 rx_x = sr.Rx(spec_x.config())
-                rx_x.time_process(d_in.ptr, d_out.ptr, bs, 2)
+                rx_x.time_process(d_in.ptr, d_out.ptr, bs, max(2, args.warmup))
                 ms_x = rx_x.time_process(d_in.ptr, d_out.ptr, bs, max(3, args.steps // 2))
                 others[nm] = {"value": round(channels * bs / (ms_x * 1e-3) / 1e6, 2), "unit": "Msamples/s",
                               "ms_per_step": round(ms_x, 4), "kernel": rx_x.kernel_name()}

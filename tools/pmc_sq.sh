@@ -11,7 +11,7 @@ for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY 
            "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES" \
            "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_INSTS_WAVE32_LDS GRBM_GUI_ACTIVE"; do
   i=$((i+1))
-  rocprofv3 --pmc $set --output-format csv -d $OUT/p$i -o c -- python3 $R/bench.py --main-only --steps 2 --warmup 1 "$@" > /dev/null 2> $OUT/p$i.err
+  rocprofv3 --pmc $set --output-format csv -d $OUT/p$i -o c -- python3 $R/bench.py --main-only --spinup-ms 0 --steps 2 --warmup 1 "$@" > /dev/null 2> $OUT/p$i.err
 done
 python3 - "$OUT" <<'PY'
 import csv, glob, sys, collections
