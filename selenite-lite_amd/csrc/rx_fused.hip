@@ -153,7 +153,10 @@ template <> struct Raw<float> {
     typedef float4 type;
     static __device__ __forceinline__ type load(const float *src, size_t cplx_index)
     {
-        return *reinterpret_cast<const float4 *>(src + 2 * cplx_index);
+        // streamed once: non-temporal, so the shared LO / coefficient tables keep their cache lines
+        typedef float f4v __attribute__((ext_vector_type(4)));
+        const f4v v = __builtin_nontemporal_load(reinterpret_cast<const f4v *>(src + 2 * cplx_index));
+        return make_float4(v.x, v.y, v.z, v.w);
     }
     static __device__ __forceinline__ void unpack(const type &r, float2 &a, float2 &b)
     {
@@ -896,17 +899,18 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
     const int abase = 80 * (lane & 15) + 8 * (lane >> 4);             // A-fragment lane base (halfs)
     wave_lds_sync();
 
+    // shared LO of a pass (NCO == 2) is fetched from L2 one stage early -- pass 0 under the
+    // prologue, pass p+1 right behind the matrix stage of pass p (whose fragment and accumulator
+    // registers are dead by then) -- so the mix stage does not open with an exposed L2 round trip
+    float4 lo4[NLD];
+    if constexpr (NCO == 2) {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) lo4[i] = *reinterpret_cast<const float4 *>(p.lo + 128u * i + 2u * lane);
+    }
     for (uint32_t pass = 0; pass < npass; ++pass) {
         const uint32_t n0 = pass * G::T;
         const bool last = (pass + 1 == npass);
         // ---- 1. NCO mix, f16 hi/lo split, four LDS images; exact f32 state from the last pass ----
-        float4 lo4[NLD];
-        if constexpr (NCO == 2) {
-#pragma unroll
-            for (int i = 0; i < NLD; ++i)
-                lo4[i] = *reinterpret_cast<const float4 *>(p.lo + n0 + 128u * i + 2u * lane);
-            __builtin_amdgcn_sched_barrier(0);
-        }
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
             const uint32_t n = 128u * i + 2u * lane;
@@ -946,17 +950,30 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
             v4f bigQ = { 0.0f, 0.0f, 0.0f, 0.0f }, smlQ = { 0.0f, 0.0f, 0.0f, 0.0f };
             const _Float16 *xIh = X + 0 * GS::IMG + abase, *xIl = X + 1 * GS::IMG + abase;
             const _Float16 *xQh = X + 2 * GS::IMG + abase, *xQl = X + 3 * GS::IMG + abase;
+            // A fragments are read one k-step ahead of the MFMAs that consume them (explicit software
+            // pipeline + scheduling groups: left alone, the scheduler issues a fragment read right in
+            // front of its MFMA and the wave eats the LDS latency twice per k-step)
+            auto offA = [](int kk) { return 80 * (kk >> 1) + 32 * (kk & 1); };   // phys(32*kk): rows never straddle
+            h8 aIh = *reinterpret_cast<const h8 *>(xIh + offA(0)), aIl = *reinterpret_cast<const h8 *>(xIl + offA(0));
+            h8 aQh = *reinterpret_cast<const h8 *>(xQh + offA(0)), aQl = *reinterpret_cast<const h8 *>(xQl + offA(0));
+            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);                            // the 4 reads of k-step 0
 #pragma unroll
             for (int kk = 0; kk < GS::KS; ++kk) {
-                const int off = 80 * (kk >> 1) + 32 * (kk & 1);        // phys(32*kk): rows never straddle
-                const h8 aIh = *reinterpret_cast<const h8 *>(xIh + off), aIl = *reinterpret_cast<const h8 *>(xIl + off);
-                const h8 aQh = *reinterpret_cast<const h8 *>(xQh + off), aQl = *reinterpret_cast<const h8 *>(xQl + off);
+                h8 nIh = aIh, nIl = aIl, nQh = aQh, nQl = aQl;
+                if (kk + 1 < GS::KS) {
+                    const int off = offA(kk + 1);
+                    nIh = *reinterpret_cast<const h8 *>(xIh + off); nIl = *reinterpret_cast<const h8 *>(xIl + off);
+                    nQh = *reinterpret_cast<const h8 *>(xQh + off); nQl = *reinterpret_cast<const h8 *>(xQl + off);
+                }
                 bigI = __builtin_amdgcn_mfma_f32_16x16x32_f16(aIh, Bh[kk], bigI, 0, 0, 0);
                 bigQ = __builtin_amdgcn_mfma_f32_16x16x32_f16(aQh, Bh[kk], bigQ, 0, 0, 0);
                 smlI = __builtin_amdgcn_mfma_f32_16x16x32_f16(aIh, Bl[kk], smlI, 0, 0, 0);
                 smlQ = __builtin_amdgcn_mfma_f32_16x16x32_f16(aQh, Bl[kk], smlQ, 0, 0, 0);
                 smlI = __builtin_amdgcn_mfma_f32_16x16x32_f16(aIl, Bh[kk], smlI, 0, 0, 0);
                 smlQ = __builtin_amdgcn_mfma_f32_16x16x32_f16(aQl, Bh[kk], smlQ, 0, 0, 0);
+                if (kk + 1 < GS::KS) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);   // 4 DS reads (k-step kk+1)
+                __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);                        // 6 MFMAs (k-step kk)
+                aIh = nIh; aIl = nIl; aQh = nQh; aQl = nQl;
             }
             const int o0 = G::HH4 + 64 * (lane >> 4) + (lane & 15);
 #pragma unroll
@@ -965,6 +982,14 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
                 dQ[o0 + 16 * r] = (bigQ[r] + smlQ[r]) * fa.split_post;
             }
             wave_lds_sync();
+        }
+        if constexpr (NCO == 2) {
+            if (pass + 1 < npass) {
+#pragma unroll
+                for (int i = 0; i < NLD; ++i)
+                    lo4[i] = *reinterpret_cast<const float4 *>(p.lo + n0 + G::T + 128u * i + 2u * lane);
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
         // ---- 3-5. Hilbert pair + sideband, AGC, store ----
         if (group == 16)

@@ -13,6 +13,8 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 PKG_ROOT = os.path.dirname(_HERE)
 LIB_PATH = os.path.join(PKG_ROOT, "libselenite_rx.so")
+if os.environ.get("SELENITE_RX_LIB"):            # A/B experiments: another build of the same library
+    LIB_PATH = os.environ["SELENITE_RX_LIB"]
 
 MODE_LSB, MODE_USB, MODE_CW, MODE_CWR, MODE_AM, MODE_FM, MODE_DIG, MODE_PKT = 0, 1, 2, 3, 4, 8, 0x0A, 0x0C
 ARITH_CMSIS, ARITH_FMA, ARITH_SPLIT16 = 0, 1, 2
