@@ -123,6 +123,9 @@ def main():
                          "(north-star tolerance; measured 1.6e-6); fma: FIR tap loops fused, bit-exact vs the fmaf "
                          "oracle; cmsis: bit-exact CMSIS-DSP arithmetic")
     ap.add_argument("--global-gain", action="store_true")
+    ap.add_argument("--io", default="f32", choices=["f32", "q15"],
+                    help="f32: the canonical float I/Q in / float audio out signature (headline); q15: the firmware's "
+                         "int16 slot format either side (dsp_if.c:286-289, arm_q15_to_float / arm_float_to_q15 fused in)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--main-only", action="store_true", help="profiling runs: skip the cpu_baseline and other-arithmetic legs")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"])
@@ -162,6 +165,22 @@ def main():
     d_out = sr.DeviceBuffer(channels * nout * 4)
     rx.synth_device(d_in.ptr, rank * channels, channels, 0, bs, SEED)
     rx.sync()
+    q15 = args.io == "q15"
+    if q15:
+        if args.global_gain:
+            raise SystemExit("--io q15 with --global-gain is not a bench shape")
+        # int16 slots: the same synthetic signal through the reference's float->q15 rule
+        # (arm_float_to_q15.c:117: *32768, truncate, saturate), converted on the host chunk by chunk
+        d_in16 = sr.DeviceBuffer(channels * bs * 4)
+        chunk = max(1, min(channels, (64 << 20) // (bs * 8)))
+        for c0 in range(0, channels, chunk):
+            n = min(chunk, channels - c0)
+            f = np.empty((n, bs, 2), np.float32)
+            sr.lib().selenite_rx_memcpy_d2h(f.ctypes.data, d_in.ptr + c0 * bs * 8, f.nbytes)
+            q = np.clip(np.trunc(f * np.float32(32768.0)), -32768, 32767).astype(np.int16)
+            sr.lib().selenite_rx_memcpy_h2d(d_in16.ptr + c0 * bs * 4, q.ctypes.data, q.nbytes)
+        d_in.free()
+        d_in = d_in16
 
     def barrier():
         rx.sync()
@@ -183,6 +202,8 @@ def main():
             if dist is not None:
                 dist.all_reduce(env_t, op=dist.ReduceOp.MAX)     # RCCL over xGMI: 4 B per DSP block
             rx.global_phase2(d_out.ptr, env_t.data_ptr(), bs)
+        elif q15:
+            rx.process_q15_device(d_in.ptr, d_out.ptr, bs)
         else:
             rx.process_device(d_in.ptr, d_out.ptr, bs)
 
@@ -204,7 +225,7 @@ def main():
     else:
         # the K timed steps are issued by the library between two HIP events recorded on the
         # stream the kernels run on; the wall clock brackets the same region
-        ev_ms = rx.time_process(d_in.ptr, d_out.ptr, bs, args.steps)
+        ev_ms = (rx.time_process_q15 if q15 else rx.time_process)(d_in.ptr, d_out.ptr, bs, args.steps)
     barrier()
     t1 = time.perf_counter()
     rx.check()
@@ -220,6 +241,9 @@ def main():
         total_samples = float(world) * channels * bs * args.steps
         value = total_samples / elapsed / 1e6
         alg_bytes, rd_bytes = rx.algorithmic_bytes(bs)
+        if q15:     # int16 slots: 4 B per complex sample in, 2 B per audio sample out; state bytes unchanged
+            alg_bytes -= channels * (4 * bs + 2 * nout)
+            rd_bytes -= channels * 4 * bs
         k_ms = ev_ms if ev_ms is not None else ms_per_step
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9
         fl = flops_per_sample(spec) * channels * bs
@@ -228,7 +252,7 @@ def main():
             "value": round(value, 2), "unit": "Msamples/s", "n_gpus": n_gpus, "steps": args.steps,
             "warmup": args.warmup, "spinup_ms": args.spinup_ms, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32", "data": "synthetic", "io": args.io,
             "config": {"workload": "%s: %d channels/GPU x %d complex samples/call, %s" % (
                            args.workload, channels, bs,
                            {"cfg3": "NCO + 256-tap arm_fir_decimate/4 + 63-tap Hilbert SSB (USB) + AGC",
@@ -242,7 +266,7 @@ def main():
             "per_gpu_msamples_s": round(value / world, 2),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": pmc_traffic(args.workload, args.arith, rx.kernel_name(), channels, bs),
+                         "traffic": None if q15 else pmc_traffic(args.workload, args.arith, rx.kernel_name(), channels, bs),
                          "algorithmic_bytes_per_launch": alg_bytes, "read_bytes_per_launch": rd_bytes,
                          "read_frac": round(rd_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                          "launch_ms_hip_events": round(k_ms, 4)},
@@ -250,7 +274,7 @@ def main():
                          "unit": "TFLOP/s", "frac": round(fl / (k_ms * 1e-3) / 1e12 / F32_PEAK_TFLOPS, 4),
                          "flops_per_sample": flops_per_sample(spec)},
         }
-        if world == 1 and not args.global_gain and not args.main_only:
+        if world == 1 and not args.global_gain and not args.main_only and not q15:
             # the same workload in the other arithmetic contracts, outside the timed region, for the record
             others = {}
             for nm, ar in (("fma", rc.ARITH_FMA), ("cmsis", rc.ARITH_CMSIS)):

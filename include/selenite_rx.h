@@ -206,6 +206,10 @@ int  selenite_rx_synth_iq_device(selenite_rx_instance *S, float *dIQ, uint32_t f
 int  selenite_rx_time_process_device(selenite_rx_instance *S, const float *dSrcIQ,
                                      float *dDstAudio, uint32_t blockSize, uint32_t iters,
                                      float *ms_per_call);
+/* The same over the int16 slot format (selenite_rx_process_q15_device calls). */
+int  selenite_rx_time_process_q15_device(selenite_rx_instance *S, const int16_t *dSrcIQ,
+                                         int16_t *dDstAudio, uint32_t blockSize, uint32_t iters,
+                                         float *ms_per_call);
 
 /* Name of the kernel variant process_f32_device dispatches to for this instance
  * (e.g. "rx_ssb_fused<256,4,63>" or "generic"); for logs and profiles. */

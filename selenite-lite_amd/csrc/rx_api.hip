@@ -558,18 +558,18 @@ extern "C" int selenite_rx_synth_iq_device(selenite_rx_instance *S, float *dIQ, 
     return SELENITE_RX_SUCCESS;
 }
 
-extern "C" int selenite_rx_time_process_device(selenite_rx_instance *S, const float *dSrcIQ, float *dDstAudio,
-                                               uint32_t blockSize, uint32_t iters, float *ms_per_call)
+static int time_process(selenite_rx_instance *S, const void *src, void *dst, bool q15, uint32_t blockSize,
+                        uint32_t iters, float *ms_per_call, const char *who)
 {
     if (!S || !ms_per_call || iters == 0) return SELENITE_RX_ARGUMENT_ERROR;
-    if (!block_size_ok(S, blockSize, "selenite_rx_time_process_device")) return S->status;
+    if (!block_size_ok(S, blockSize, who)) return S->status;
     HIPCHK(S, hipSetDevice(S->device));
     hipEvent_t e0, e1;
     HIPCHK(S, hipEventCreate(&e0));
     HIPCHK(S, hipEventCreate(&e1));
     HIPCHK(S, hipEventRecord(e0, S->stream));
     for (uint32_t i = 0; i < iters; ++i) {
-        int rc = run_chain(S, dSrcIQ, false, dDstAudio, false, blockSize, kAll, nullptr);
+        int rc = run_chain(S, src, q15, dst, q15, blockSize, kAll, nullptr);
         if (rc) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return rc; }
     }
     HIPCHK(S, hipEventRecord(e1, S->stream));
@@ -580,6 +580,18 @@ extern "C" int selenite_rx_time_process_device(selenite_rx_instance *S, const fl
     (void)hipEventDestroy(e1);
     *ms_per_call = ms / (float)iters;
     return SELENITE_RX_SUCCESS;
+}
+
+extern "C" int selenite_rx_time_process_device(selenite_rx_instance *S, const float *dSrcIQ, float *dDstAudio,
+                                               uint32_t blockSize, uint32_t iters, float *ms_per_call)
+{
+    return time_process(S, dSrcIQ, dDstAudio, false, blockSize, iters, ms_per_call, "selenite_rx_time_process_device");
+}
+
+extern "C" int selenite_rx_time_process_q15_device(selenite_rx_instance *S, const int16_t *dSrcIQ, int16_t *dDstAudio,
+                                                   uint32_t blockSize, uint32_t iters, float *ms_per_call)
+{
+    return time_process(S, dSrcIQ, dDstAudio, true, blockSize, iters, ms_per_call, "selenite_rx_time_process_q15_device");
 }
 
 extern "C" uint64_t selenite_rx_algorithmic_bytes(const selenite_rx_config *g, uint32_t blockSize, uint64_t *read_bytes)

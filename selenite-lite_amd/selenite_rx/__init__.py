@@ -57,7 +57,7 @@ ABI_SYMBOLS = [
     "selenite_rx_reset", "selenite_rx_device_alloc", "selenite_rx_device_free",
     "selenite_rx_memcpy_h2d", "selenite_rx_memcpy_d2h", "selenite_rx_device_count",
     "selenite_rx_set_device", "selenite_rx_synth_iq_host", "selenite_rx_synth_iq_device",
-    "selenite_rx_time_process_device", "selenite_rx_kernel_name", "selenite_rx_algorithmic_bytes",
+    "selenite_rx_time_process_device", "selenite_rx_time_process_q15_device", "selenite_rx_kernel_name", "selenite_rx_algorithmic_bytes",
     "selenite_rx_design_lowpass", "selenite_rx_design_hilbert", "selenite_rx_design_bandpass",
     "selenite_rx_abi_version",
 ]
@@ -279,6 +279,15 @@ class Rx:
     def time_process(self, d_src, d_dst, block_size, iters):
         ms = C.c_float()
         rc = self.L.selenite_rx_time_process_device(self.h, d_src, d_dst, block_size, iters, C.byref(ms))
+        if rc:
+            raise RxError(rc, self.error())
+        return ms.value
+
+    def time_process_q15(self, d_src, d_dst, block_size, iters):
+        ms = C.c_float()
+        self.L.selenite_rx_time_process_q15_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32,
+                                                               C.c_uint32, C.POINTER(C.c_float)]
+        rc = self.L.selenite_rx_time_process_q15_device(self.h, d_src, d_dst, block_size, iters, C.byref(ms))
         if rc:
             raise RxError(rc, self.error())
         return ms.value
