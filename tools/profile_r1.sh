@@ -11,6 +11,6 @@ OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- python3 $R/bench.py --main-only "$@" > $OUT/bench_trace.json 2> $OUT/trace.err
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o f -- python3 $R/bench.py --main-only --spinup-ms 0 --steps 3 --warmup 1 "${@:5}" > $OUT/bench_pmc_fetch.json 2> $OUT/pmc_fetch.err
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o w -- python3 $R/bench.py --main-only --spinup-ms 0 --steps 3 --warmup 1 "${@:5}" > $OUT/bench_pmc_write.json 2> $OUT/pmc_write.err
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o f -- python3 $R/bench.py --main-only "$@" --spinup-ms 0 --steps 3 --warmup 1 > $OUT/bench_pmc_fetch.json 2> $OUT/pmc_fetch.err
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o w -- python3 $R/bench.py --main-only "$@" --spinup-ms 0 --steps 3 --warmup 1 > $OUT/bench_pmc_write.json 2> $OUT/pmc_write.err
 find $OUT -name "*.csv" | head -20
