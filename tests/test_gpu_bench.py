@@ -34,7 +34,8 @@ def test_bench_json_contract_default_shape():
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     assert r["algorithmic_bytes_per_launch"] == 1024 * 41952          # SURVEY.md 8d per channel-block figure
-    assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["launch_ms_hip_events"] * 1e-3) / 1e9) < 1.0
+    derived = r["algorithmic_bytes_per_launch"] / (r["launch_ms_hip_events"] * 1e-3) / 1e9
+    assert abs(r["achieved"] - derived) <= 0.02 * derived             # (launch_ms is rounded to 0.1 us in the JSON)
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
     assert d["value"] > 0 and d["ms_per_step"] > 0
