@@ -62,6 +62,33 @@ ABI_SYMBOLS = [
     "selenite_rx_abi_version",
 ]
 
+class TxConfig(C.Structure):
+    """struct selenite_tx_config (include/selenite_tx.h)."""
+    _fields_ = [
+        ("struct_size", C.c_uint32), ("channels", C.c_uint32), ("block", C.c_uint32),
+        ("interp", C.c_uint32), ("ni_taps", C.c_uint32), ("nh_taps", C.c_uint32),
+        ("arith", C.c_uint8), ("mode", C.c_uint8), ("nco_enable", C.c_uint8), ("alc_enable", C.c_uint8),
+        ("nco_step_all", C.c_uint32),
+        ("interp_coeffs", f32p), ("hilb_coeffs", f32p), ("delay_coeffs", f32p), ("nco_step", u32p),
+        ("alc_target", C.c_float), ("alc_attack", C.c_float), ("alc_decay", C.c_float),
+        ("alc_gain_min", C.c_float), ("alc_gain_max", C.c_float), ("alc_env_floor", C.c_float),
+        ("alc_gain_init", C.c_float),
+    ]
+
+
+class TxStateView(C.Structure):
+    """struct selenite_tx_state_view."""
+    _fields_ = [("fir_state", f32p), ("interp_state", f32p), ("alc_gain", f32p), ("nco_phase", u32p)]
+
+
+# every symbol include/selenite_tx.h declares
+TX_ABI_SYMBOLS = [
+    "selenite_tx_init", "selenite_tx_free", "selenite_tx_set_mode", "selenite_tx_status", "selenite_tx_error_string",
+    "selenite_tx_process_f32", "selenite_tx_process_q15", "selenite_tx_process_f32_device",
+    "selenite_tx_process_q15_device", "selenite_tx_set_stream", "selenite_tx_sync", "selenite_tx_get_state",
+    "selenite_tx_set_state", "selenite_tx_reset", "selenite_tx_time_process_device",
+]
+
 # every symbol include/selenite_ring.h declares
 RING_ABI_SYMBOLS = [
     "selenite_ring_init", "selenite_ring_free", "selenite_ring_status", "selenite_ring_error_string",
@@ -464,6 +491,116 @@ class Ring:
     def close(self):
         if self.h:
             self.L.selenite_ring_free(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Tx:
+    """One batched TX chain instance (include/selenite_tx.h); mirror of Rx."""
+
+    def __init__(self, cfg):
+        self.L = lib()
+        L = self.L
+        vp = C.c_void_p
+        L.selenite_tx_init.argtypes = [C.POINTER(vp), C.POINTER(TxConfig)]
+        L.selenite_tx_free.argtypes = [vp]
+        L.selenite_tx_set_mode.argtypes = [vp, C.c_uint8]
+        L.selenite_tx_status.argtypes = [vp]
+        L.selenite_tx_error_string.argtypes = [vp]
+        L.selenite_tx_error_string.restype = C.c_char_p
+        for n in ("process_f32", "process_q15", "process_f32_device", "process_q15_device"):
+            getattr(L, "selenite_tx_" + n).argtypes = [vp, vp, vp, C.c_uint32]
+            getattr(L, "selenite_tx_" + n).restype = None
+        L.selenite_tx_set_stream.argtypes = [vp, vp]
+        L.selenite_tx_sync.argtypes = [vp]
+        L.selenite_tx_get_state.argtypes = [vp, C.POINTER(TxStateView)]
+        L.selenite_tx_set_state.argtypes = [vp, C.POINTER(TxStateView)]
+        L.selenite_tx_reset.argtypes = [vp]
+        L.selenite_tx_time_process_device.argtypes = [vp, vp, vp, C.c_uint32, C.c_uint32, C.POINTER(C.c_float)]
+        self.cfg = cfg
+        self.h = vp()
+        rc = L.selenite_tx_init(C.byref(self.h), C.byref(cfg))
+        if rc:
+            raise RxError(rc, "selenite_tx_init failed")
+
+    def check(self):
+        rc = self.L.selenite_tx_status(self.h)
+        if rc:
+            raise RxError(rc, self.L.selenite_tx_error_string(self.h).decode())
+
+    def process(self, audio):
+        audio = np.ascontiguousarray(audio, np.float32)
+        c, bs = audio.shape
+        out = np.empty((c, bs * self.cfg.interp, 2), np.float32)
+        self.L.selenite_tx_process_f32(self.h, audio.ctypes.data, out.ctypes.data, bs)
+        self.check()
+        return out
+
+    def process_q15(self, audio):
+        audio = np.ascontiguousarray(audio, np.int16)
+        c, bs = audio.shape
+        out = np.empty((c, bs * self.cfg.interp, 2), np.int16)
+        self.L.selenite_tx_process_q15(self.h, audio.ctypes.data, out.ctypes.data, bs)
+        self.check()
+        return out
+
+    def process_device(self, d_src, d_dst, block_size):
+        self.L.selenite_tx_process_f32_device(self.h, d_src, d_dst, block_size)
+
+    def set_mode(self, mode):
+        return self.L.selenite_tx_set_mode(self.h, mode)
+
+    def sync(self):
+        return self.L.selenite_tx_sync(self.h)
+
+    def reset(self):
+        return self.L.selenite_tx_reset(self.h)
+
+    def _arrays(self):
+        g = self.cfg
+        return {"fir_state": np.zeros((g.channels, 2, max(g.nh_taps - 1, 0)), np.float32),
+                "interp_state": np.zeros((g.channels, 2, max(g.ni_taps // g.interp - 1, 0) if g.ni_taps else 0), np.float32),
+                "alc_gain": np.zeros(g.channels, np.float32), "nco_phase": np.zeros(g.channels, np.uint32)}
+
+    @staticmethod
+    def _view(a):
+        v = TxStateView()
+        v.fir_state = a["fir_state"].ctypes.data_as(f32p) if a["fir_state"].size else None
+        v.interp_state = a["interp_state"].ctypes.data_as(f32p) if a["interp_state"].size else None
+        v.alc_gain = a["alc_gain"].ctypes.data_as(f32p)
+        v.nco_phase = a["nco_phase"].ctypes.data_as(u32p)
+        return v
+
+    def state(self):
+        a = self._arrays()
+        v = self._view(a)
+        rc = self.L.selenite_tx_get_state(self.h, C.byref(v))
+        if rc:
+            raise RxError(rc, self.L.selenite_tx_error_string(self.h).decode())
+        return a
+
+    def set_state(self, a):
+        a = {k: np.ascontiguousarray(x) for k, x in a.items()}
+        v = self._view(a)
+        rc = self.L.selenite_tx_set_state(self.h, C.byref(v))
+        if rc:
+            raise RxError(rc, self.L.selenite_tx_error_string(self.h).decode())
+
+    def time_process(self, d_src, d_dst, block_size, iters):
+        ms = C.c_float()
+        rc = self.L.selenite_tx_time_process_device(self.h, d_src, d_dst, block_size, iters, C.byref(ms))
+        if rc:
+            raise RxError(rc, self.L.selenite_tx_error_string(self.h).decode())
+        return ms.value
+
+    def close(self):
+        if self.h:
+            self.L.selenite_tx_free(self.h)
             self.h = C.c_void_p()
 
     def __del__(self):

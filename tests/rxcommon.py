@@ -27,7 +27,7 @@ u32p = C.POINTER(C.c_uint32)
 i16p = C.POINTER(C.c_int16)
 
 
-from selenite_rx import Config, StateView  # noqa: E402  (ctypes structs of include/selenite_rx.h)
+from selenite_rx import Config, StateView, TxConfig, TxStateView  # noqa: E402  (ctypes structs of include/selenite_rx.h)
 
 
 def fptr(a):
@@ -402,5 +402,108 @@ class OracleRing:
     def __del__(self):
         try:
             self.L.orc_ring_free(self.h)
+        except Exception:
+            pass
+
+
+# ---- TX chain (include/selenite_tx.h): spec, oracle (tx_oracle.c) and real-CMSIS harness (ref_tx.c) ----
+class TxSpec:
+    """Python-side description of one TX instance; keeps the numpy arrays alive for ctypes."""
+
+    def __init__(self, channels, block=64, interp=4, ni_taps=256, nh_taps=63, mode=MODE_USB, arith=ARITH_CMSIS,
+                 nco=True, nco_step_all=0x01000000, nco_steps=None, alc=True, interp_cutoff=None, alc_params=None):
+        self.channels, self.block, self.interp = channels, block, interp
+        self.ni_taps, self.nh_taps, self.mode, self.arith = ni_taps, nh_taps, mode, arith
+        self.nco, self.nco_step_all, self.alc = nco, nco_step_all, alc
+        self.nco_steps = None if nco_steps is None else np.ascontiguousarray(nco_steps, dtype=np.uint32)
+        if interp_cutoff is None:
+            interp_cutoff = 0.4 / interp
+        # interpolation low-pass with gain L so that the pass-band level survives zero stuffing
+        self.ic = (design_lowpass(ni_taps, interp_cutoff) * np.float32(interp)).astype(np.float32) if ni_taps else None
+        self.hilb, self.delay = design_hilbert(nh_taps) if nh_taps else (None, None)
+        self.alc_params = dict(target=0.5, attack=0.5, decay=0.05, gain_min=1e-3, gain_max=1e2,
+                               env_floor=1e-6, gain_init=1.0)
+        if alc_params:
+            self.alc_params.update(alc_params)
+
+    def config(self):
+        g = TxConfig()
+        g.struct_size = C.sizeof(TxConfig)
+        g.channels, g.block, g.interp = self.channels, self.block, self.interp
+        g.ni_taps, g.nh_taps, g.arith, g.mode = self.ni_taps, self.nh_taps, self.arith, self.mode
+        g.nco_enable, g.alc_enable, g.nco_step_all = int(self.nco), int(self.alc), self.nco_step_all
+        g.interp_coeffs, g.hilb_coeffs, g.delay_coeffs = fptr(self.ic), fptr(self.hilb), fptr(self.delay)
+        g.nco_step = self.nco_steps.ctypes.data_as(u32p) if self.nco_steps is not None else None
+        p = self.alc_params
+        g.alc_target, g.alc_attack, g.alc_decay = p["target"], p["attack"], p["decay"]
+        g.alc_gain_min, g.alc_gain_max = p["gain_min"], p["gain_max"]
+        g.alc_env_floor, g.alc_gain_init = p["env_floor"], p["gain_init"]
+        g._keepalive = self
+        return g
+
+    def state_arrays(self):
+        c = self.channels
+        return {"fir_state": np.zeros((c, 2, max(self.nh_taps - 1, 0)), np.float32),
+                "interp_state": np.zeros((c, 2, max(self.ni_taps // self.interp - 1, 0) if self.ni_taps else 0), np.float32),
+                "alc_gain": np.zeros(c, np.float32), "nco_phase": np.zeros(c, np.uint32)}
+
+
+def synth_audio(first_channel, nch, first_sample, nsamp):
+    """Test audio: the I rail of the synthetic RX input (three tones + noise, |x| < 1)."""
+    return np.ascontiguousarray(synth_iq(first_channel, nch, first_sample, nsamp)[:, :, 0])
+
+
+class TxCpuChain:
+    """tx_oracle.c ('orc') or the real-CMSIS composition ref_tx.c ('ref') behind one face."""
+
+    def __init__(self, spec, which="orc"):
+        self.spec, self.which = spec, which
+        self.L = oracle_lib() if which == "orc" else ref_lib()
+        self.cfg = spec.config()
+        self.h = C.c_void_p()
+        pre = which + "_tx_"
+        getattr(self.L, pre + "create").argtypes = [C.POINTER(C.c_void_p), C.POINTER(TxConfig)]
+        for n in ("process_f32", "process_q15"):
+            getattr(self.L, pre + n).argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
+            getattr(self.L, pre + n).restype = None
+        getattr(self.L, pre + "get_state").argtypes = [C.c_void_p, C.POINTER(TxStateView)]
+        getattr(self.L, pre + "set_mode").argtypes = [C.c_void_p, C.c_uint8]
+        getattr(self.L, pre + "destroy").argtypes = [C.c_void_p]
+        self.rc = getattr(self.L, pre + "create")(C.byref(self.h), C.byref(self.cfg))
+
+    def ok(self):
+        return self.rc == 0 and bool(self.h)
+
+    def set_mode(self, mode):
+        return getattr(self.L, self.which + "_tx_set_mode")(self.h, mode)
+
+    def process(self, audio):
+        audio = np.ascontiguousarray(audio, np.float32)
+        c, bs = audio.shape
+        out = np.empty((c, bs * self.spec.interp, 2), np.float32)
+        getattr(self.L, self.which + "_tx_process_f32")(self.h, audio.ctypes.data, out.ctypes.data, bs)
+        return out
+
+    def process_q15(self, audio):
+        audio = np.ascontiguousarray(audio, np.int16)
+        c, bs = audio.shape
+        out = np.empty((c, bs * self.spec.interp, 2), np.int16)
+        getattr(self.L, self.which + "_tx_process_q15")(self.h, audio.ctypes.data, out.ctypes.data, bs)
+        return out
+
+    def state(self):
+        a = self.spec.state_arrays()
+        v = TxStateView()
+        v.fir_state = fptr(a["fir_state"]) if a["fir_state"].size else None
+        v.interp_state = fptr(a["interp_state"]) if a["interp_state"].size else None
+        v.alc_gain = fptr(a["alc_gain"])
+        v.nco_phase = a["nco_phase"].ctypes.data_as(u32p)
+        getattr(self.L, self.which + "_tx_get_state")(self.h, C.byref(v))
+        return a
+
+    def __del__(self):
+        try:
+            if self.h:
+                getattr(self.L, self.which + "_tx_destroy")(self.h)
         except Exception:
             pass
