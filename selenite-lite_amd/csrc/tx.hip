@@ -1,0 +1,439 @@
+// tx.hip -- batched TX chain (include/selenite_tx.h): ALC -> Hilbert pair -> sideband select ->
+// arm_fir_interpolate_f32 by L -> NCO up-mix, one wavefront per channel, ALC block by ALC block.
+// Arithmetic contract as in rx_device.h: every step keeps the CMSIS-DSP 1.5.3 operation order
+// (oracle/tx_oracle.c restates it, oracle/ref_tx.c composes the real functions); SELENITE_ARITH_FMA
+// fuses the FIR tap loops only.  This is the "any configuration" kernel of the TX direction (the
+// counterpart of rx_generic.hip): plain LDS arrays, runtime tap loops, coalesced 8-byte I/Q stores.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "../../include/selenite_tx.h"
+#include "rx_device.h"
+#include "rx_internal.h"
+
+struct selenite_tx_instance {
+    selenite_tx_config cfg;
+    int device = 0;
+    float *d_ic = nullptr, *d_hc = nullptr, *d_dc = nullptr, *d_sintab = nullptr;
+    uint32_t *d_step = nullptr, *d_phase = nullptr;
+    float *d_fir_state = nullptr, *d_int_state = nullptr, *d_gain = nullptr;
+    void *d_io_in = nullptr, *d_io_out = nullptr;
+    size_t io_in_bytes = 0, io_out_bytes = 0;
+    std::vector<uint32_t> h_step;
+    hipStream_t stream = nullptr, own_stream = nullptr;
+    int status = 0;
+    std::string err;
+};
+
+namespace {
+
+using namespace srx;
+
+struct TxParams {
+    uint32_t channels, block, L, ni, P, nh, mode, nco, alc, block_size;
+    const float *ic, *hc, *dc, *sintab;
+    const uint32_t *step;
+    uint32_t *phase;
+    float *fir_state;      // [C][2][nh-1]
+    float *int_state;      // [C][2][P-1]
+    float *gain;
+    AgcParams alcp;
+};
+
+__device__ __forceinline__ float load_audio(const float *p, size_t i) { return p[i]; }
+__device__ __forceinline__ float load_audio(const int16_t *p, size_t i) { return q15_to_float(p[i]); }
+__device__ __forceinline__ void store_iq(float *p, size_t i, float re, float im)
+{
+    reinterpret_cast<float2 *>(p)[i] = make_float2(re, im);
+}
+__device__ __forceinline__ void store_iq(int16_t *p, size_t i, float re, float im)
+{
+    short2 v;
+    v.x = float_to_q15(re);
+    v.y = float_to_q15(im);
+    reinterpret_cast<short2 *>(p)[i] = v;
+}
+
+size_t tx_lds_bytes(const TxParams &p)
+{
+    const size_t nh1 = p.nh ? p.nh - 1 : 0;
+    return sizeof(float) * (516 + 2 * (nh1 + p.block) + 2 * ((p.P - 1) + p.block));
+}
+
+template <int ARITH, typename TIn, typename TOut>
+__global__ __launch_bounds__(64) void k_tx_generic(TxParams p, const TIn *__restrict__ src, TOut *__restrict__ dst)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x;
+    const uint32_t c = blockIdx.x;
+    const uint32_t nb = p.block, L = p.L, P = p.P, nh = p.nh, nh1 = nh ? nh - 1 : 0, p1 = P - 1;
+    float *tab = lds;
+    float *HI = lds + 516, *HQ = HI + (nh1 + nb);            // arm_fir_f32 pState of the delay / Hilbert instance
+    float *ZI = HQ + (nh1 + nb), *ZQ = ZI + (p1 + nb);       // arm_fir_interpolate_f32 pState of the I / Q rail
+    if (p.nco)
+        for (int i = lane; i < 513; i += kWave) tab[i] = p.sintab[i];
+    for (uint32_t i = lane; i < 2 * nh1; i += kWave) (i < nh1 ? HI : HQ - nh1)[i] = p.fir_state[(size_t)c * 2 * nh1 + i];
+    for (uint32_t i = lane; i < 2 * p1; i += kWave) (i < p1 ? ZI : ZQ - p1)[i] = p.int_state[(size_t)c * 2 * p1 + i];
+    float gain = p.alc ? p.gain[c] : 1.0f;
+    const uint32_t ph0 = p.nco ? p.phase[c] : 0u, step = p.nco ? p.step[c] : 0u;
+    const bool am = p.mode == SELENITE_MODE_AM, up = mode_is_upper(p.mode);
+    const uint32_t nblk = p.block_size / nb;
+    __syncthreads();
+
+    for (uint32_t b = 0; b < nblk; ++b) {
+        // 1. ALC: arm_abs_f32 + arm_max_f32 -> gain law -> arm_scale_f32
+        const size_t ib = (size_t)c * p.block_size + (size_t)b * nb;
+        float m = 0.0f;
+        for (uint32_t i = lane; i < nb; i += kWave) m = fmaxf(m, fabsf(load_audio(src, ib + i)));
+        if (p.alc) {
+            m = wave_max(m);
+            gain = agc_update<0>(p.alcp, gain, m);
+        }
+        for (uint32_t i = lane; i < nb; i += kWave) {
+            float a = load_audio(src, ib + i);
+            if (p.alc) a = a * gain;
+            if (nh) { HI[nh1 + i] = a; HQ[nh1 + i] = a; }
+            else { ZI[p1 + i] = a; ZQ[p1 + i] = 0.0f; }
+        }
+        __syncthreads();
+        // 2.-3. Hilbert pair (arm_fir_f32 x2) and sideband select
+        if (nh) {
+            for (uint32_t i = lane; i < nb; i += kWave) {
+                float ri = 0.0f, rq = 0.0f;
+                for (uint32_t k = 0; k < nh; ++k) {
+                    ri = mac<ARITH>(ri, HI[i + k], p.dc[k]);
+                    rq = mac<ARITH>(rq, HQ[i + k], p.hc[k]);
+                }
+                ZI[p1 + i] = ri;
+                ZQ[p1 + i] = rq;
+            }
+            __syncthreads();
+            float ti = 0.0f, tq = 0.0f;                        // history tails: nh1 <= ... moved in 64-wide slices
+            for (uint32_t i0 = 0; i0 < nh1; i0 += kWave) {
+                const uint32_t i = i0 + lane;
+                if (i < nh1) { ti = HI[nb + i]; tq = HQ[nb + i]; }
+                __syncthreads();
+                if (i < nh1) { HI[i] = ti; HQ[i] = tq; }
+                __syncthreads();
+            }
+        }
+        for (uint32_t i = lane; i < nb; i += kWave) {
+            float ri = ZI[p1 + i], rq = ZQ[p1 + i];
+            if (am) {                                          // arm_scale_f32(0.5) then arm_offset_f32(0.5); Q = 0
+                const float t = ri * 0.5f;
+                ri = t + 0.5f;
+                rq = 0.0f;
+            } else if (!up) {
+                rq = -rq;                                      // arm_negate_f32
+            }
+            ZI[p1 + i] = ri;
+            ZQ[p1 + i] = rq;
+        }
+        __syncthreads();
+        // 4.-5. interpolator on both rails, NCO up-mix, store
+        const size_t ob = ((size_t)c * p.block_size + (size_t)b * nb) * L;
+        for (uint32_t o = lane; o < nb * L; o += kWave) {
+            const uint32_t n = o / L, phs = o % L;
+            float ui, uq;
+            if (p.ni) {
+                ui = 0.0f; uq = 0.0f;
+                const float *cf = p.ic + (L - 1 - phs);
+                for (uint32_t t = 0; t < P; ++t) {
+                    const float cc = cf[t * L];
+                    ui = mac<ARITH>(ui, ZI[n + t], cc);
+                    uq = mac<ARITH>(uq, ZQ[n + t], cc);
+                }
+            } else {
+                ui = ZI[n]; uq = ZQ[n];
+            }
+            float re = ui, im = uq;
+            if (p.nco) {
+                const uint32_t phase = ph0 + (uint32_t)(b * nb * L + o) * step;
+                const float x = (float)(phase >> 8) * kNcoK;
+                const float lc = cos_f32<0>(tab, x), ls = sin_f32<0>(tab, x);
+                const float2 r = cmul<0>(make_float2(ui, uq), make_float2(lc, ls));
+                re = r.x; im = r.y;
+            }
+            store_iq(dst, ob + o, re, im);
+        }
+        __syncthreads();
+        if (p.ni) {
+            float ti = 0.0f, tq = 0.0f;
+            for (uint32_t i0 = 0; i0 < p1; i0 += kWave) {
+                const uint32_t i = i0 + lane;
+                if (i < p1) { ti = ZI[nb + i]; tq = ZQ[nb + i]; }
+                __syncthreads();
+                if (i < p1) { ZI[i] = ti; ZQ[i] = tq; }
+                __syncthreads();
+            }
+        }
+    }
+    for (uint32_t i = lane; i < 2 * nh1; i += kWave) p.fir_state[(size_t)c * 2 * nh1 + i] = (i < nh1 ? HI : HQ - nh1)[i];
+    for (uint32_t i = lane; i < 2 * p1; i += kWave) p.int_state[(size_t)c * 2 * p1 + i] = (i < p1 ? ZI : ZQ - p1)[i];
+    if (lane == 0) {
+        if (p.alc) p.gain[c] = gain;
+        if (p.nco) p.phase[c] = ph0 + p.block_size * L * step;
+    }
+}
+
+int fail(selenite_tx_instance *S, int code, const std::string &msg)
+{
+    if (S && S->status == 0) { S->status = code; S->err = msg; }
+    return code;
+}
+
+#define TCHK(S, call)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (call);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return fail((S), SELENITE_RX_DEVICE_ERROR, std::string(#call ": ") + hipGetErrorString(e_)); \
+    } while (0)
+
+bool tx_mode_ok(uint8_t m)
+{
+    return m == SELENITE_MODE_LSB || m == SELENITE_MODE_USB || m == SELENITE_MODE_CW || m == SELENITE_MODE_CWR ||
+           m == SELENITE_MODE_AM || m == SELENITE_MODE_DIG || m == SELENITE_MODE_PKT;
+}
+
+TxParams make_params(const selenite_tx_instance *S, uint32_t block_size)
+{
+    const selenite_tx_config &g = S->cfg;
+    TxParams p{};
+    p.channels = g.channels; p.block = g.block; p.L = g.interp; p.ni = g.ni_taps;
+    p.P = g.ni_taps ? g.ni_taps / g.interp : 1; p.nh = g.nh_taps; p.mode = g.mode;
+    p.nco = g.nco_enable ? 1 : 0; p.alc = g.alc_enable ? 1 : 0; p.block_size = block_size;
+    p.ic = S->d_ic; p.hc = S->d_hc; p.dc = S->d_dc; p.sintab = S->d_sintab;
+    p.step = S->d_step; p.phase = S->d_phase;
+    p.fir_state = S->d_fir_state; p.int_state = S->d_int_state; p.gain = S->d_gain;
+    p.alcp = AgcParams{ g.alc_target, g.alc_attack, g.alc_decay, g.alc_gain_min, g.alc_gain_max, g.alc_env_floor };
+    return p;
+}
+
+template <int ARITH, typename TIn, typename TOut>
+hipError_t launch(const TxParams &p, const void *src, void *dst, hipStream_t st)
+{
+    const size_t lds = tx_lds_bytes(p);
+    auto k = k_tx_generic<ARITH, TIn, TOut>;
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(k, dim3(p.channels), dim3(64), lds, st, p, static_cast<const TIn *>(src), static_cast<TOut *>(dst));
+    return hipGetLastError();
+}
+
+bool block_size_ok(selenite_tx_instance *S, uint32_t bs, const char *who)
+{
+    if (!S) return false;
+    if (bs == 0 || bs % S->cfg.block != 0) {
+        fail(S, SELENITE_RX_LENGTH_ERROR, std::string(who) + ": blockSize is not a non-zero multiple of cfg.block");
+        return false;
+    }
+    return true;
+}
+
+int run(selenite_tx_instance *S, const void *src, void *dst, bool q15, uint32_t bs)
+{
+    TCHK(S, hipSetDevice(S->device));
+    const TxParams p = make_params(S, bs);
+    if (tx_lds_bytes(p) > 64 * 1024) return fail(S, SELENITE_RX_LENGTH_ERROR, "filter lengths exceed the LDS budget of the TX kernel");
+    const bool fma = S->cfg.arith != SELENITE_ARITH_CMSIS;
+    hipError_t e;
+    if (q15) e = fma ? launch<1, int16_t, int16_t>(p, src, dst, S->stream) : launch<0, int16_t, int16_t>(p, src, dst, S->stream);
+    else e = fma ? launch<1, float, float>(p, src, dst, S->stream) : launch<0, float, float>(p, src, dst, S->stream);
+    TCHK(S, e);
+    return 0;
+}
+
+template <typename T>
+int upload(selenite_tx_instance *S, T **dp, const T *h, size_t n)
+{
+    *dp = nullptr;
+    if (!n) return 0;
+    TCHK(S, hipMalloc((void **)dp, n * sizeof(T)));
+    if (h) TCHK(S, hipMemcpy(*dp, h, n * sizeof(T), hipMemcpyHostToDevice));
+    return 0;
+}
+
+int reset_state(selenite_tx_instance *S)
+{
+    const selenite_tx_config &g = S->cfg;
+    const size_t C = g.channels, nh1 = g.nh_taps ? g.nh_taps - 1 : 0, p1 = g.ni_taps ? g.ni_taps / g.interp - 1 : 0;
+    if (nh1) TCHK(S, hipMemsetAsync(S->d_fir_state, 0, C * 2 * nh1 * sizeof(float), S->stream));
+    if (p1) TCHK(S, hipMemsetAsync(S->d_int_state, 0, C * 2 * p1 * sizeof(float), S->stream));
+    TCHK(S, hipMemsetAsync(S->d_phase, 0, C * sizeof(uint32_t), S->stream));
+    std::vector<float> gi(C, g.alc_gain_init);
+    TCHK(S, hipMemcpyAsync(S->d_gain, gi.data(), C * sizeof(float), hipMemcpyHostToDevice, S->stream));
+    TCHK(S, hipStreamSynchronize(S->stream));
+    return 0;
+}
+
+int ensure(selenite_tx_instance *S, void **buf, size_t *cap, size_t need)
+{
+    if (*cap >= need) return 0;
+    TCHK(S, hipStreamSynchronize(S->stream));
+    if (*buf) (void)hipFree(*buf);
+    *buf = nullptr; *cap = 0;
+    TCHK(S, hipMalloc(buf, need));
+    *cap = need;
+    return 0;
+}
+
+void process_host(selenite_tx_instance *S, const void *src, void *dst, uint32_t bs, bool q15, const char *who)
+{
+    if (!block_size_ok(S, bs, who)) return;
+    const selenite_tx_config &g = S->cfg;
+    const size_t esz = q15 ? sizeof(int16_t) : sizeof(float);
+    const size_t nin = (size_t)g.channels * bs * esz, nout = (size_t)g.channels * bs * g.interp * 2 * esz;
+    if (hipSetDevice(S->device) != hipSuccess) { fail(S, SELENITE_RX_DEVICE_ERROR, "hipSetDevice"); return; }
+    if (ensure(S, &S->d_io_in, &S->io_in_bytes, nin) || ensure(S, &S->d_io_out, &S->io_out_bytes, nout)) return;
+    if (hipMemcpyAsync(S->d_io_in, src, nin, hipMemcpyHostToDevice, S->stream) != hipSuccess) { fail(S, SELENITE_RX_DEVICE_ERROR, "H2D copy failed"); return; }
+    if (run(S, S->d_io_in, S->d_io_out, q15, bs)) return;
+    if (hipMemcpyAsync(dst, S->d_io_out, nout, hipMemcpyDeviceToHost, S->stream) != hipSuccess ||
+        hipStreamSynchronize(S->stream) != hipSuccess)
+        fail(S, SELENITE_RX_DEVICE_ERROR, "D2H copy failed");
+}
+
+}  // namespace
+
+extern "C" int selenite_tx_init(selenite_tx_instance **out, const selenite_tx_config *g)
+{
+    if (!out) return SELENITE_RX_ARGUMENT_ERROR;
+    *out = nullptr;
+    if (!g || g->struct_size != sizeof(*g) || !g->channels || !g->block || !g->interp || !tx_mode_ok(g->mode) ||
+        g->arith > SELENITE_ARITH_SPLIT16)
+        return SELENITE_RX_ARGUMENT_ERROR;
+    if ((g->interp > 1) != (g->ni_taps > 0)) return SELENITE_RX_ARGUMENT_ERROR;
+    if (g->ni_taps && !g->interp_coeffs) return SELENITE_RX_ARGUMENT_ERROR;
+    if (g->nh_taps && (!g->hilb_coeffs || !g->delay_coeffs)) return SELENITE_RX_ARGUMENT_ERROR;
+    if (g->ni_taps % g->interp) return SELENITE_RX_LENGTH_ERROR;        // arm_fir_interpolate_init_f32.c:91-96
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return SELENITE_RX_DEVICE_ERROR;   // no CPU fallback
+    selenite_tx_instance *S = new selenite_tx_instance;
+    S->cfg = *g;
+    S->cfg.interp_coeffs = S->cfg.hilb_coeffs = S->cfg.delay_coeffs = nullptr;
+    S->cfg.nco_step = nullptr;
+    auto bail = [&](int code) { selenite_tx_free(S); return code; };
+    if (hipGetDevice(&S->device) != hipSuccess) return bail(SELENITE_RX_DEVICE_ERROR);
+    if (hipStreamCreateWithFlags(&S->own_stream, hipStreamNonBlocking) != hipSuccess) return bail(SELENITE_RX_DEVICE_ERROR);
+    S->stream = S->own_stream;
+    const size_t C = g->channels, nh1 = g->nh_taps ? g->nh_taps - 1 : 0, p1 = g->ni_taps ? g->ni_taps / g->interp - 1 : 0;
+    S->h_step.resize(C);
+    for (size_t c = 0; c < C; ++c) S->h_step[c] = g->nco_step ? g->nco_step[c] : g->nco_step_all;
+    if (upload(S, &S->d_ic, g->interp_coeffs, (size_t)g->ni_taps) || upload(S, &S->d_hc, g->hilb_coeffs, (size_t)g->nh_taps) ||
+        upload(S, &S->d_dc, g->delay_coeffs, (size_t)g->nh_taps) || upload(S, &S->d_sintab, srx::host_sin_table(), (size_t)513) ||
+        upload(S, &S->d_step, S->h_step.data(), C) || upload<uint32_t>(S, &S->d_phase, nullptr, C) ||
+        upload<float>(S, &S->d_fir_state, nullptr, C * 2 * nh1) || upload<float>(S, &S->d_int_state, nullptr, C * 2 * p1) ||
+        upload<float>(S, &S->d_gain, nullptr, C))
+        return bail(SELENITE_RX_DEVICE_ERROR);
+    if (reset_state(S)) return bail(SELENITE_RX_DEVICE_ERROR);
+    *out = S;
+    return SELENITE_RX_SUCCESS;
+}
+
+extern "C" void selenite_tx_free(selenite_tx_instance *S)
+{
+    if (!S) return;
+    void *ptrs[] = { S->d_ic, S->d_hc, S->d_dc, S->d_sintab, S->d_step, S->d_phase, S->d_fir_state, S->d_int_state,
+                     S->d_gain, S->d_io_in, S->d_io_out };
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    if (S->own_stream) (void)hipStreamDestroy(S->own_stream);
+    delete S;
+}
+
+extern "C" int selenite_tx_set_mode(selenite_tx_instance *S, uint8_t mode)
+{
+    if (!S || !tx_mode_ok(mode)) return SELENITE_RX_ARGUMENT_ERROR;     // instance stays usable in its old mode
+    S->cfg.mode = mode;
+    return SELENITE_RX_SUCCESS;
+}
+
+extern "C" int selenite_tx_status(const selenite_tx_instance *S) { return S ? S->status : SELENITE_RX_ARGUMENT_ERROR; }
+extern "C" const char *selenite_tx_error_string(const selenite_tx_instance *S) { return S ? S->err.c_str() : "null instance"; }
+
+extern "C" void selenite_tx_process_f32(selenite_tx_instance *S, const float *src, float *dst, uint32_t bs)
+{
+    process_host(S, src, dst, bs, false, "selenite_tx_process_f32");
+}
+extern "C" void selenite_tx_process_q15(selenite_tx_instance *S, const int16_t *src, int16_t *dst, uint32_t bs)
+{
+    process_host(S, src, dst, bs, true, "selenite_tx_process_q15");
+}
+extern "C" void selenite_tx_process_f32_device(selenite_tx_instance *S, const float *src, float *dst, uint32_t bs)
+{
+    if (block_size_ok(S, bs, "selenite_tx_process_f32_device")) run(S, src, dst, false, bs);
+}
+extern "C" void selenite_tx_process_q15_device(selenite_tx_instance *S, const int16_t *src, int16_t *dst, uint32_t bs)
+{
+    if (block_size_ok(S, bs, "selenite_tx_process_q15_device")) run(S, src, dst, true, bs);
+}
+
+extern "C" int selenite_tx_set_stream(selenite_tx_instance *S, void *hip_stream)
+{
+    if (!S) return SELENITE_RX_ARGUMENT_ERROR;
+    S->stream = hip_stream ? (hipStream_t)hip_stream : S->own_stream;
+    return SELENITE_RX_SUCCESS;
+}
+
+extern "C" int selenite_tx_sync(selenite_tx_instance *S)
+{
+    if (!S) return SELENITE_RX_ARGUMENT_ERROR;
+    TCHK(S, hipStreamSynchronize(S->stream));
+    return S->status;
+}
+
+extern "C" int selenite_tx_get_state(selenite_tx_instance *S, const selenite_tx_state_view *v)
+{
+    if (!S || !v) return SELENITE_RX_ARGUMENT_ERROR;
+    const selenite_tx_config &g = S->cfg;
+    const size_t C = g.channels, nh1 = g.nh_taps ? g.nh_taps - 1 : 0, p1 = g.ni_taps ? g.ni_taps / g.interp - 1 : 0;
+    TCHK(S, hipStreamSynchronize(S->stream));
+    if (v->fir_state && nh1) TCHK(S, hipMemcpy(v->fir_state, S->d_fir_state, C * 2 * nh1 * sizeof(float), hipMemcpyDeviceToHost));
+    if (v->interp_state && p1) TCHK(S, hipMemcpy(v->interp_state, S->d_int_state, C * 2 * p1 * sizeof(float), hipMemcpyDeviceToHost));
+    if (v->alc_gain) TCHK(S, hipMemcpy(v->alc_gain, S->d_gain, C * sizeof(float), hipMemcpyDeviceToHost));
+    if (v->nco_phase) TCHK(S, hipMemcpy(v->nco_phase, S->d_phase, C * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int selenite_tx_set_state(selenite_tx_instance *S, const selenite_tx_state_view *v)
+{
+    if (!S || !v) return SELENITE_RX_ARGUMENT_ERROR;
+    const selenite_tx_config &g = S->cfg;
+    const size_t C = g.channels, nh1 = g.nh_taps ? g.nh_taps - 1 : 0, p1 = g.ni_taps ? g.ni_taps / g.interp - 1 : 0;
+    TCHK(S, hipStreamSynchronize(S->stream));
+    if (v->fir_state && nh1) TCHK(S, hipMemcpy(S->d_fir_state, v->fir_state, C * 2 * nh1 * sizeof(float), hipMemcpyHostToDevice));
+    if (v->interp_state && p1) TCHK(S, hipMemcpy(S->d_int_state, v->interp_state, C * 2 * p1 * sizeof(float), hipMemcpyHostToDevice));
+    if (v->alc_gain) TCHK(S, hipMemcpy(S->d_gain, v->alc_gain, C * sizeof(float), hipMemcpyHostToDevice));
+    if (v->nco_phase) TCHK(S, hipMemcpy(S->d_phase, v->nco_phase, C * sizeof(uint32_t), hipMemcpyHostToDevice));
+    return 0;
+}
+
+extern "C" int selenite_tx_reset(selenite_tx_instance *S)
+{
+    if (!S) return SELENITE_RX_ARGUMENT_ERROR;
+    return reset_state(S);
+}
+
+extern "C" int selenite_tx_time_process_device(selenite_tx_instance *S, const float *src, float *dst, uint32_t bs,
+                                               uint32_t iters, float *ms_per_call)
+{
+    if (!S || !ms_per_call || iters == 0) return SELENITE_RX_ARGUMENT_ERROR;
+    if (!block_size_ok(S, bs, "selenite_tx_time_process_device")) return S->status;
+    hipEvent_t e0, e1;
+    TCHK(S, hipEventCreate(&e0));
+    TCHK(S, hipEventCreate(&e1));
+    TCHK(S, hipEventRecord(e0, S->stream));
+    for (uint32_t i = 0; i < iters; ++i)
+        if (run(S, src, dst, false, bs)) return S->status;
+    TCHK(S, hipEventRecord(e1, S->stream));
+    TCHK(S, hipEventSynchronize(e1));
+    float ms = 0.0f;
+    TCHK(S, hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *ms_per_call = ms / (float)iters;
+    return 0;
+}

@@ -39,6 +39,41 @@ def test_ring_header_symbols_are_exported_and_bound():
     assert sorted(sr.RING_ABI_SYMBOLS) == names
 
 
+def test_tx_header_symbols_are_exported_and_bound_and_struct_layout():
+    text = open(os.path.join(rc.ROOT, "include", "selenite_tx.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = sorted(set(re.findall(r"\b(selenite_tx_[a-z0-9_]+)\s*\(", text)))
+    assert len(names) == 15
+    L = sr.lib()
+    for n in names:
+        assert hasattr(L, n), "libselenite_rx.so does not export %s" % n
+    assert sorted(sr.TX_ABI_SYMBOLS) == names
+    # C layout on LP64: 6 u32, 4 u8, u32, 4 pointers, 7 floats (+4 tail pad)
+    assert C.sizeof(sr.TxConfig) == 6 * 4 + 4 + 4 + 4 * 8 + 7 * 4 + 4
+    assert sr.TxConfig.interp_coeffs.offset == 32 and sr.TxConfig.alc_target.offset == 64
+    assert C.sizeof(sr.TxStateView) == 32
+
+
+def test_tx_init_validation_and_no_cpu_fallback():
+    def code(mutate):
+        g = rc.TxSpec(2).config()
+        mutate(g)
+        h = C.c_void_p()
+        sr.lib().selenite_tx_init.argtypes = [C.POINTER(C.c_void_p), C.POINTER(sr.TxConfig)]
+        r = sr.lib().selenite_tx_init(C.byref(h), C.byref(g))
+        if h:
+            sr.lib().selenite_tx_free.argtypes = [C.c_void_p]
+            sr.lib().selenite_tx_free(h)
+        return r
+    assert code(lambda g: setattr(g, "struct_size", 8)) == rc.ARGUMENT_ERROR
+    assert code(lambda g: setattr(g, "channels", 0)) == rc.ARGUMENT_ERROR
+    assert code(lambda g: setattr(g, "mode", rc.MODE_FM)) == rc.ARGUMENT_ERROR
+    assert code(lambda g: setattr(g, "interp", 1)) == rc.ARGUMENT_ERROR          # taps without an interpolator
+    assert code(lambda g: setattr(g, "ni_taps", 255)) == rc.LENGTH_ERROR         # arm_fir_interpolate_init_f32.c:91-96
+    if not has_gpu():
+        assert code(lambda g: None) == rc.DEVICE_ERROR
+
+
 def test_ring_refuses_to_run_without_a_gpu():
     if has_gpu():
         pytest.skip("GPU present")
