@@ -64,6 +64,8 @@ int  selenite_tx_init(selenite_tx_instance **S, const selenite_tx_config *cfg);
 void selenite_tx_free(selenite_tx_instance *S);
 int  selenite_tx_set_mode(selenite_tx_instance *S, uint8_t mode);     /* DSP_Set_Mode, dsp_if.c:367-370 */
 int  selenite_tx_status(const selenite_tx_instance *S);
+/* which kernel serves calls whose blockSize is a multiple of 256: "k_tx_fused<4,256,63>" or "k_tx_generic" */
+const char *selenite_tx_kernel_name(const selenite_tx_instance *S);
 const char *selenite_tx_error_string(const selenite_tx_instance *S);
 
 /* host buffers (copied in and out, synchronous) */

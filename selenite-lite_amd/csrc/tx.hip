@@ -6,12 +6,15 @@
 // counterpart of rx_generic.hip): plain LDS arrays, runtime tap loops, coalesced 8-byte I/Q stores.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <cmath>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
 #include "../../include/selenite_tx.h"
 #include "rx_device.h"
 #include "rx_internal.h"
+#include "tx_internal.h"
 
 struct selenite_tx_instance {
     selenite_tx_config cfg;
@@ -22,6 +25,11 @@ struct selenite_tx_instance {
     void *d_io_in = nullptr, *d_io_out = nullptr;
     size_t io_in_bytes = 0, io_out_bytes = 0;
     std::vector<uint32_t> h_step;
+    // fused-kernel planning (tx_fused.hip) and the shared LO of a call
+    bool delay_is_impulse = false, hilb_odd_only = false, phase_uniform = true, steps_same = true, force_generic = false;
+    uint32_t delay_index = 0, phase_host = 0;
+    float2 *d_lo = nullptr;
+    size_t lo_bytes = 0;
     hipStream_t stream = nullptr, own_stream = nullptr;
     int status = 0;
     std::string err;
@@ -30,17 +38,6 @@ struct selenite_tx_instance {
 namespace {
 
 using namespace srx;
-
-struct TxParams {
-    uint32_t channels, block, L, ni, P, nh, mode, nco, alc, block_size;
-    const float *ic, *hc, *dc, *sintab;
-    const uint32_t *step;
-    uint32_t *phase;
-    float *fir_state;      // [C][2][nh-1]
-    float *int_state;      // [C][2][P-1]
-    float *gain;
-    AgcParams alcp;
-};
 
 __device__ __forceinline__ float load_audio(const float *p, size_t i) { return p[i]; }
 __device__ __forceinline__ float load_audio(const int16_t *p, size_t i) { return q15_to_float(p[i]); }
@@ -234,12 +231,28 @@ bool block_size_ok(selenite_tx_instance *S, uint32_t bs, const char *who)
     return true;
 }
 
+int ensure(selenite_tx_instance *S, void **buf, size_t *cap, size_t need);
+
 int run(selenite_tx_instance *S, const void *src, void *dst, bool q15, uint32_t bs)
 {
     TCHK(S, hipSetDevice(S->device));
+    const selenite_tx_config &g = S->cfg;
     const TxParams p = make_params(S, bs);
+    const uint32_t phase_now = S->phase_host;
+    if (g.nco_enable) S->phase_host += bs * g.interp * S->h_step[0];
+    if (!S->force_generic && tx_fused_ok(g, S->delay_is_impulse, S->hilb_odd_only, bs)) {
+        const float2 *lo = nullptr;
+        if (g.nco_enable && S->phase_uniform) {
+            // every channel shares step and phase: one LO per call, read from L2 by every wavefront
+            if (ensure(S, (void **)&S->d_lo, &S->lo_bytes, (size_t)bs * g.interp * sizeof(float2))) return S->status;
+            TCHK(S, launch_lo_table(S->d_lo, S->d_sintab, phase_now, S->h_step[0], bs * g.interp, S->stream));
+            lo = S->d_lo;
+        }
+        TCHK(S, launch_tx_fused(p, (int)g.arith, S->delay_index, lo, src, q15, dst, S->stream));
+        return 0;
+    }
     if (tx_lds_bytes(p) > 64 * 1024) return fail(S, SELENITE_RX_LENGTH_ERROR, "filter lengths exceed the LDS budget of the TX kernel");
-    const bool fma = S->cfg.arith != SELENITE_ARITH_CMSIS;
+    const bool fma = g.arith != SELENITE_ARITH_CMSIS;
     hipError_t e;
     if (q15) e = fma ? launch<1, int16_t, int16_t>(p, src, dst, S->stream) : launch<0, int16_t, int16_t>(p, src, dst, S->stream);
     else e = fma ? launch<1, float, float>(p, src, dst, S->stream) : launch<0, float, float>(p, src, dst, S->stream);
@@ -267,6 +280,8 @@ int reset_state(selenite_tx_instance *S)
     std::vector<float> gi(C, g.alc_gain_init);
     TCHK(S, hipMemcpyAsync(S->d_gain, gi.data(), C * sizeof(float), hipMemcpyHostToDevice, S->stream));
     TCHK(S, hipStreamSynchronize(S->stream));
+    S->phase_host = 0;
+    S->phase_uniform = S->steps_same;
     return 0;
 }
 
@@ -322,6 +337,32 @@ extern "C" int selenite_tx_init(selenite_tx_instance **out, const selenite_tx_co
     const size_t C = g->channels, nh1 = g->nh_taps ? g->nh_taps - 1 : 0, p1 = g->ni_taps ? g->ni_taps / g->interp - 1 : 0;
     S->h_step.resize(C);
     for (size_t c = 0; c < C; ++c) S->h_step[c] = g->nco_step ? g->nco_step[c] : g->nco_step_all;
+    S->steps_same = true;
+    for (size_t c = 1; c < C; ++c) S->steps_same = S->steps_same && S->h_step[c] == S->h_step[0];
+    {   // what tx_fused.hip relies on: a unit-impulse delay FIR and a type-III Hilbert (taps at even
+        // distance from the centre exactly +0.0f) -- same classification as the RX side (rx_api.hip)
+        const uint32_t nh = g->nh_taps;
+        int ones = 0, idx = -1;
+        bool rest_zero = true;
+        for (uint32_t k = 0; k < nh; ++k) {
+            const float v = g->delay_coeffs[k];
+            if (v == 1.0f) { ++ones; idx = (int)k; }
+            else if (!(v == 0.0f && !std::signbit(v))) rest_zero = false;
+        }
+        if (nh && ones == 1 && rest_zero) { S->delay_is_impulse = true; S->delay_index = (uint32_t)idx; }
+        if (nh % 2 == 1) {
+            const int cc = (int)(nh - 1) / 2;
+            bool ok = true;
+            for (uint32_t k = 0; k < nh && ok; ++k)
+                if ((((int)k - cc) & 1) == 0) {
+                    const float v = g->hilb_coeffs[k];
+                    if (!(v == 0.0f && !std::signbit(v))) ok = false;
+                }
+            S->hilb_odd_only = ok;
+        }
+        const char *fg = std::getenv("SELENITE_TX_FORCE_GENERIC");
+        S->force_generic = fg && fg[0] == '1';
+    }
     if (upload(S, &S->d_ic, g->interp_coeffs, (size_t)g->ni_taps) || upload(S, &S->d_hc, g->hilb_coeffs, (size_t)g->nh_taps) ||
         upload(S, &S->d_dc, g->delay_coeffs, (size_t)g->nh_taps) || upload(S, &S->d_sintab, srx::host_sin_table(), (size_t)513) ||
         upload(S, &S->d_step, S->h_step.data(), C) || upload<uint32_t>(S, &S->d_phase, nullptr, C) ||
@@ -337,7 +378,7 @@ extern "C" void selenite_tx_free(selenite_tx_instance *S)
 {
     if (!S) return;
     void *ptrs[] = { S->d_ic, S->d_hc, S->d_dc, S->d_sintab, S->d_step, S->d_phase, S->d_fir_state, S->d_int_state,
-                     S->d_gain, S->d_io_in, S->d_io_out };
+                     S->d_gain, S->d_io_in, S->d_io_out, S->d_lo };
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (S->own_stream) (void)hipStreamDestroy(S->own_stream);
@@ -349,6 +390,12 @@ extern "C" int selenite_tx_set_mode(selenite_tx_instance *S, uint8_t mode)
     if (!S || !tx_mode_ok(mode)) return SELENITE_RX_ARGUMENT_ERROR;     // instance stays usable in its old mode
     S->cfg.mode = mode;
     return SELENITE_RX_SUCCESS;
+}
+
+extern "C" const char *selenite_tx_kernel_name(const selenite_tx_instance *S)
+{
+    if (!S) return "";
+    return (!S->force_generic && tx_fused_ok(S->cfg, S->delay_is_impulse, S->hilb_odd_only, 256)) ? "k_tx_fused<4,256,63>" : "k_tx_generic";
 }
 
 extern "C" int selenite_tx_status(const selenite_tx_instance *S) { return S ? S->status : SELENITE_RX_ARGUMENT_ERROR; }
@@ -407,7 +454,13 @@ extern "C" int selenite_tx_set_state(selenite_tx_instance *S, const selenite_tx_
     if (v->fir_state && nh1) TCHK(S, hipMemcpy(S->d_fir_state, v->fir_state, C * 2 * nh1 * sizeof(float), hipMemcpyHostToDevice));
     if (v->interp_state && p1) TCHK(S, hipMemcpy(S->d_int_state, v->interp_state, C * 2 * p1 * sizeof(float), hipMemcpyHostToDevice));
     if (v->alc_gain) TCHK(S, hipMemcpy(S->d_gain, v->alc_gain, C * sizeof(float), hipMemcpyHostToDevice));
-    if (v->nco_phase) TCHK(S, hipMemcpy(S->d_phase, v->nco_phase, C * sizeof(uint32_t), hipMemcpyHostToDevice));
+    if (v->nco_phase) {
+        TCHK(S, hipMemcpy(S->d_phase, v->nco_phase, C * sizeof(uint32_t), hipMemcpyHostToDevice));
+        bool same = S->steps_same;
+        for (size_t c = 1; c < C; ++c) same = same && v->nco_phase[c] == v->nco_phase[0];
+        S->phase_uniform = same;
+        S->phase_host = v->nco_phase[0];
+    }
     return 0;
 }
 

@@ -1,0 +1,287 @@
+// tx_fused.hip -- fused TX kernel for the BASELINE-like shape: ALC block 64, L = 4, 256-tap
+// interpolator (P = 64 taps per phase), 63-tap Hilbert pair (unit-impulse delay, type-III Hilbert).
+// One wavefront per channel, passes of 256 audio samples -> 1024 complex output samples.
+//
+// The interpolator is the RX decimator's twin (128 MAC per complex output sample).  Both rails use
+// the same tap, so the interpolator state lives in LDS as (I, Q) pairs and every MAC is one
+// v_pk_fma_f32 (or v_pk_mul + v_pk_add in the CMSIS arithmetic) with the tap in an SGPR fetched by
+// v_readlane from four lane-distributed VGPRs.  Lane l owns input samples l, l+64, l+128, l+192 of
+// the pass: its four outputs per sample (the L phases) are 32 contiguous bytes and the lanes of a
+// wavefront store 2 KB contiguous -- coalesced without a transpose.  Per output the taps are visited
+// in the reference's order (t ascending, arm_fir_interpolate_f32.c:389-440), single accumulator.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "rx_internal.h"
+#include "tx_internal.h"
+
+namespace srx {
+
+namespace {
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+constexpr int kL = 4, kNI = 256, kP = kNI / kL, kNH = 63, kBlk = 64, kPass = 256;
+constexpr int kHH = kNH - 1, kHH4 = (kHH + 3) & ~3, kFH = kHH4 - kHH;        // Hilbert history 62 -> 64, lead pad 2
+constexpr int kHLen = kHH4 + kPass + 4;
+constexpr int kZH = 64;                                                       // interpolator history slots (63 used)
+constexpr int oTab = 0, oHI = 516, oHQ = oHI + kHLen, oZ = oHQ + kHLen, kTotal = oZ + 2 * (kZH + kPass);
+
+__device__ __forceinline__ void wave_lds_sync()      // single-wave workgroup: program order is enough (rx_fused.hip)
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <int ARITH>
+__device__ __forceinline__ v2f mac2(v2f acc, v2f w, float c)
+{
+    const v2f c2 = { c, c };
+    if constexpr (ARITH == 1) return __builtin_elementwise_fma(w, c2, acc);
+    else { const v2f pr = w * c2; return acc + pr; }
+}
+
+__device__ __forceinline__ float lane_bcast(float v, int l)
+{
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+}
+
+template <typename T> struct AudioIO;
+template <> struct AudioIO<float> {
+    typedef float4 raw;
+    static __device__ __forceinline__ raw load(const float *p, size_t i) { return *reinterpret_cast<const float4 *>(p + i); }
+    static __device__ __forceinline__ void unpack(const raw &r, float (&a)[4]) { a[0] = r.x; a[1] = r.y; a[2] = r.z; a[3] = r.w; }
+    static __device__ __forceinline__ void store4(float *p, size_t cplx, const v2f (&o)[4])
+    {
+        float4 *d = reinterpret_cast<float4 *>(p + 2 * cplx);
+        d[0] = make_float4(o[0].x, o[0].y, o[1].x, o[1].y);
+        d[1] = make_float4(o[2].x, o[2].y, o[3].x, o[3].y);
+    }
+};
+template <> struct AudioIO<int16_t> {
+    typedef short4 raw;
+    static __device__ __forceinline__ raw load(const int16_t *p, size_t i) { return *reinterpret_cast<const short4 *>(p + i); }
+    static __device__ __forceinline__ void unpack(const raw &r, float (&a)[4])
+    {
+        a[0] = q15_to_float(r.x); a[1] = q15_to_float(r.y); a[2] = q15_to_float(r.z); a[3] = q15_to_float(r.w);
+    }
+    static __device__ __forceinline__ void store4(int16_t *p, size_t cplx, const v2f (&o)[4])
+    {
+        short4 a, b;
+        a.x = float_to_q15(o[0].x); a.y = float_to_q15(o[0].y); a.z = float_to_q15(o[1].x); a.w = float_to_q15(o[1].y);
+        b.x = float_to_q15(o[2].x); b.y = float_to_q15(o[2].y); b.z = float_to_q15(o[3].x); b.w = float_to_q15(o[3].y);
+        short4 *d = reinterpret_cast<short4 *>(p + 2 * cplx);
+        d[0] = a; d[1] = b;
+    }
+};
+
+// NCO: 0 off, 1 per-channel LO computed here, 2 shared LO table (cos, -sin) of the call in `lo`
+template <int ARITH, int NCO, typename TIn, typename TOut>
+__global__ __launch_bounds__(64, 2) void k_tx_fused(TxParams p, uint32_t delay_idx, const float2 *__restrict__ lo,
+                                                    const TIn *__restrict__ src, TOut *__restrict__ dst)
+{
+    using IO = AudioIO<TIn>;
+    using OO = AudioIO<TOut>;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x;
+    const uint32_t c = blockIdx.x;
+    float *tab = lds + oTab, *HI = lds + oHI, *HQ = lds + oHQ;
+    v2f *Z = reinterpret_cast<v2f *>(lds + oZ);                   // Z[kZH + n]: n-th new (I,Q) of the pass; state[j] = Z[1 + j]
+    const size_t in_base = (size_t)c * p.block_size, out_base = (size_t)c * p.block_size * kL;
+    const uint32_t npass = p.block_size / kPass;
+    typename IO::raw raw = IO::load(src, in_base + 4u * lane);
+
+    // taps: interpolator lane-distributed (4 VGPRs), Hilbert (1 VGPR), fetched by v_readlane
+    float creg[kNI / 64];
+#pragma unroll
+    for (int v = 0; v < kNI / 64; ++v) creg[v] = p.ic[64 * v + lane];
+    const float hreg = (lane < kNH) ? p.hc[lane] : 0.0f;
+    if constexpr (NCO == 1)
+        for (int i = lane; i < 513; i += kWave) tab[i] = p.sintab[i];
+    // state: branch-free loads (clamped index, masked value), all issued before the first LDS store
+    {
+        const float *stF = p.fir_state + (size_t)c * 2 * kHH, *stZ = p.int_state + (size_t)c * 2 * (kP - 1);
+        float f[2], z[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {                            // 2 x 64 slots: rail j, slot lane
+            const int sidx = lane - kFH;
+            const float x = stF[j * kHH + (sidx < 0 ? 0 : sidx)];
+            f[j] = sidx < 0 ? 0.0f : x;
+            const int zi = lane - 1;
+            const float y = stZ[j * (kP - 1) + (zi < 0 ? 0 : zi)];
+            z[j] = zi < 0 ? 0.0f : y;
+        }
+        HI[lane] = f[0]; HQ[lane] = f[1];
+        Z[lane] = v2f{ z[0], z[1] };
+    }
+    float gain = p.alc ? p.gain[c] : 1.0f;
+    const uint32_t ph0 = NCO ? p.phase[c] : 0u, step = NCO ? p.step[c] : 0u;
+    const bool am = p.mode == SELENITE_MODE_AM, up = mode_is_upper(p.mode);
+    wave_lds_sync();
+
+    for (uint32_t pass = 0; pass < npass; ++pass) {
+        // ---- 1. ALC on the 4 blocks of the pass (16 lanes each): abs/max, gain law, scale ----
+        float a[4];
+        IO::unpack(raw, a);
+        if (pass + 1 < npass) raw = IO::load(src, in_base + (size_t)(pass + 1) * kPass + 4u * lane);
+        if (p.alc) {
+            float m = fmaxf(fmaxf(fabsf(a[0]), fabsf(a[1])), fmaxf(fabsf(a[2]), fabsf(a[3])));
+#pragma unroll
+            for (int off = 1; off < 16; off <<= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+            const float dmine = agc_desired(p.alcp, m);
+            float g = gain, mine = gain;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                g = agc_step(p.alcp, g, lane_bcast(dmine, 16 * b));
+                mine = (b == (lane >> 4)) ? g : mine;
+            }
+            gain = g;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) a[r] = a[r] * mine;
+        }
+        *reinterpret_cast<float4 *>(HI + kHH4 + 4 * lane) = make_float4(a[0], a[1], a[2], a[3]);
+        *reinterpret_cast<float4 *>(HQ + kHH4 + 4 * lane) = make_float4(a[0], a[1], a[2], a[3]);
+        wave_lds_sync();
+        // ---- 2.-3. Hilbert pair on the lane's 4 samples, sideband select, (I,Q) pairs into Z ----
+        {
+            float q2[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+            constexpr int C = (kNH - 1) / 2;
+#pragma unroll
+            for (int t = 0; t <= (kHH4 + 3) / 4; ++t) {
+                const float4 W = *reinterpret_cast<const float4 *>(HQ + 4 * lane + 4 * t);
+                const float w[4] = { W.x, W.y, W.z, W.w };
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int k = 4 * t + e - r - kFH;
+                        if (k < 0 || k >= kNH || (((k - C) & 1) == 0)) continue;      // structural zeros (exact for finite data)
+                        q2[r] = mac<ARITH>(q2[r], w[e], lane_bcast(hreg, k));
+                    }
+            }
+            const float *di = HI + kFH + delay_idx + 4 * lane;       // unit-impulse delay FIR
+            v2f z[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float ri = di[r] + 0.0f, rq = q2[r];
+                if (am) { const float t = ri * 0.5f; ri = t + 0.5f; rq = 0.0f; }
+                else if (!up) rq = -rq;
+                z[r] = v2f{ ri, rq };
+            }
+            float4 *zp = reinterpret_cast<float4 *>(Z + kZH + 4 * lane);
+            zp[0] = make_float4(z[0].x, z[0].y, z[1].x, z[1].y);
+            zp[1] = make_float4(z[2].x, z[2].y, z[3].x, z[3].y);
+        }
+        wave_lds_sync();
+        {   // Hilbert-pair history: last 64 slots to the front
+            const float ti = HI[kPass + lane], tq = HQ[kPass + lane];
+            wave_lds_sync();
+            HI[lane] = ti; HQ[lane] = tq;
+        }
+        // ---- 4. interpolator: samples lane + 64 s, phases 0..3, taps t ascending ----
+        v2f acc[4][kL];
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int ph = 0; ph < kL; ++ph) acc[s][ph] = v2f{ 0.0f, 0.0f };
+        const v2f *zb = Z + 1 + lane;                               // state[n + t] = Z[1 + n + t]
+#pragma unroll
+        for (int t = 0; t < kP; ++t) {
+            float cf[kL];
+#pragma unroll
+            for (int ph = 0; ph < kL; ++ph) {
+                const int k = (kL - 1 - ph) + kL * t;               // pCoeffs[(L - j) + t L], j = ph + 1
+                cf[ph] = lane_bcast(creg[k >> 6], k & 63);
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const v2f w = zb[64 * s + t];
+#pragma unroll
+                for (int ph = 0; ph < kL; ++ph) acc[s][ph] = mac2<ARITH>(acc[s][ph], w, cf[ph]);
+            }
+        }
+        // ---- 5. NCO up-mix (LO = (cos, +sin)) and store: 4 complex samples per (lane, s) ----
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const uint32_t o = kL * (lane + 64 * s);                // first output sample of this quad in the pass
+            v2f out[kL];
+            if constexpr (NCO == 2) {
+                const float4 *lp = reinterpret_cast<const float4 *>(lo + (size_t)pass * kPass * kL + o);
+                const float4 l01 = lp[0], l23 = lp[1];
+                const float2 l[4] = { make_float2(l01.x, -l01.y), make_float2(l01.z, -l01.w),
+                                      make_float2(l23.x, -l23.y), make_float2(l23.z, -l23.w) };   // conj of the RX LO: exact
+#pragma unroll
+                for (int ph = 0; ph < kL; ++ph) {
+                    const float2 r = cmul<0>(make_float2(acc[s][ph].x, acc[s][ph].y), l[ph]);
+                    out[ph] = v2f{ r.x, r.y };
+                }
+            } else if constexpr (NCO == 1) {
+#pragma unroll
+                for (int ph = 0; ph < kL; ++ph) {
+                    const uint32_t phase = ph0 + (pass * kPass * kL + o + ph) * step;
+                    const float x = (float)(phase >> 8) * kNcoK;
+                    const float2 r = cmul<0>(make_float2(acc[s][ph].x, acc[s][ph].y),
+                                             make_float2(cos_f32<0>(tab, x), sin_f32<0>(tab, x)));
+                    out[ph] = v2f{ r.x, r.y };
+                }
+            } else {
+#pragma unroll
+                for (int ph = 0; ph < kL; ++ph) out[ph] = acc[s][ph];
+            }
+            OO::store4(dst, out_base + (size_t)pass * kPass * kL + o, out);
+        }
+        wave_lds_sync();
+        {   // interpolator history: last 64 pairs to the front
+            const v2f tz = Z[kPass + lane];
+            wave_lds_sync();
+            Z[lane] = tz;
+        }
+        wave_lds_sync();
+    }
+
+    if (lane >= kFH) {
+        p.fir_state[(size_t)c * 2 * kHH + (lane - kFH)] = HI[lane];
+        p.fir_state[(size_t)c * 2 * kHH + kHH + (lane - kFH)] = HQ[lane];
+    }
+    if (lane >= 1) {
+        const v2f z = Z[lane];
+        p.int_state[(size_t)c * 2 * (kP - 1) + (lane - 1)] = z.x;
+        p.int_state[(size_t)c * 2 * (kP - 1) + (kP - 1) + (lane - 1)] = z.y;
+    }
+    if (lane == 0) {
+        if (p.alc) p.gain[c] = gain;
+        if constexpr (NCO != 0) p.phase[c] = ph0 + p.block_size * kL * step;
+    }
+}
+
+template <int ARITH, typename TIn, typename TOut>
+hipError_t launch_a(const TxParams &p, uint32_t delay_idx, const float2 *lo, const void *src, void *dst, hipStream_t st)
+{
+    constexpr size_t lds = (size_t)kTotal * sizeof(float);
+    const dim3 grid(p.channels), blk(64);
+    const TIn *s = static_cast<const TIn *>(src);
+    TOut *d = static_cast<TOut *>(dst);
+    if (!p.nco) hipLaunchKernelGGL((k_tx_fused<ARITH, 0, TIn, TOut>), grid, blk, lds, st, p, delay_idx, lo, s, d);
+    else if (lo) hipLaunchKernelGGL((k_tx_fused<ARITH, 2, TIn, TOut>), grid, blk, lds, st, p, delay_idx, lo, s, d);
+    else hipLaunchKernelGGL((k_tx_fused<ARITH, 1, TIn, TOut>), grid, blk, lds, st, p, delay_idx, lo, s, d);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+bool tx_fused_ok(const selenite_tx_config &g, bool delay_is_impulse, bool hilb_odd_only, uint32_t block_size)
+{
+    return g.interp == kL && g.ni_taps == kNI && g.nh_taps == kNH && g.block == kBlk && delay_is_impulse &&
+           hilb_odd_only && block_size % kPass == 0;
+}
+
+hipError_t launch_tx_fused(const TxParams &p, int arith, uint32_t delay_idx, const float2 *lo, const void *src, bool q15,
+                           void *dst, hipStream_t st)
+{
+    if (arith != SELENITE_ARITH_CMSIS)
+        return q15 ? launch_a<1, int16_t, int16_t>(p, delay_idx, lo, src, dst, st) : launch_a<1, float, float>(p, delay_idx, lo, src, dst, st);
+    return q15 ? launch_a<0, int16_t, int16_t>(p, delay_idx, lo, src, dst, st) : launch_a<0, float, float>(p, delay_idx, lo, src, dst, st);
+}
+
+}  // namespace srx

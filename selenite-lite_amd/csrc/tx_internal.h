@@ -1,0 +1,30 @@
+// tx_internal.h -- kernel parameter block and launch interfaces shared by tx.hip and tx_fused.hip.
+// Not part of the C-ABI (include/selenite_tx.h is).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/selenite_tx.h"
+#include "rx_device.h"
+
+namespace srx {
+
+struct TxParams {
+    uint32_t channels, block, L, ni, P, nh, mode, nco, alc, block_size;
+    const float *ic, *hc, *dc, *sintab;
+    const uint32_t *step;
+    uint32_t *phase;
+    float *fir_state;      // [C][2][nh-1]
+    float *int_state;      // [C][2][P-1]
+    float *gain;
+    AgcParams alcp;
+};
+
+// tx_fused.hip: the BASELINE-like shape (ALC block 64, L = 4, 256-tap interpolator, 63-tap Hilbert
+// pair with a unit-impulse delay and a type-III Hilbert).  `lo` = shared LO of the call as produced by
+// launch_lo_table (cos, -sin) or NULL (per-channel NCO in the kernel).
+bool tx_fused_ok(const selenite_tx_config &g, bool delay_is_impulse, bool hilb_odd_only, uint32_t block_size);
+hipError_t launch_tx_fused(const TxParams &p, int arith, uint32_t delay_idx, const float2 *lo, const void *src, bool q15,
+                           void *dst, hipStream_t st);
+
+}  // namespace srx

@@ -84,6 +84,7 @@ class TxStateView(C.Structure):
 # every symbol include/selenite_tx.h declares
 TX_ABI_SYMBOLS = [
     "selenite_tx_init", "selenite_tx_free", "selenite_tx_set_mode", "selenite_tx_status", "selenite_tx_error_string",
+    "selenite_tx_kernel_name",
     "selenite_tx_process_f32", "selenite_tx_process_q15", "selenite_tx_process_f32_device",
     "selenite_tx_process_q15_device", "selenite_tx_set_stream", "selenite_tx_sync", "selenite_tx_get_state",
     "selenite_tx_set_state", "selenite_tx_reset", "selenite_tx_time_process_device",
@@ -551,6 +552,11 @@ class Tx:
 
     def process_device(self, d_src, d_dst, block_size):
         self.L.selenite_tx_process_f32_device(self.h, d_src, d_dst, block_size)
+
+    def kernel_name(self):
+        self.L.selenite_tx_kernel_name.argtypes = [C.c_void_p]
+        self.L.selenite_tx_kernel_name.restype = C.c_char_p
+        return self.L.selenite_tx_kernel_name(self.h).decode()
 
     def set_mode(self, mode):
         return self.L.selenite_tx_set_mode(self.h, mode)

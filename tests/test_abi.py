@@ -43,7 +43,7 @@ def test_tx_header_symbols_are_exported_and_bound_and_struct_layout():
     text = open(os.path.join(rc.ROOT, "include", "selenite_tx.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     names = sorted(set(re.findall(r"\b(selenite_tx_[a-z0-9_]+)\s*\(", text)))
-    assert len(names) == 15
+    assert len(names) == 16
     L = sr.lib()
     for n in names:
         assert hasattr(L, n), "libselenite_rx.so does not export %s" % n

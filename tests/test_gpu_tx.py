@@ -131,3 +131,54 @@ def test_tx_large_batch_sampled_channels_and_rx_loopback():
     a = audio[5000]
     best = max(abs(np.corrcoef(a[:bs - 300], y[s:s + bs - 300])[0, 1]) for s in range(60, 260))
     assert best > 0.98
+
+
+@pytest.mark.parametrize("arith", [ARITH_CMSIS, ARITH_FMA])
+@pytest.mark.parametrize("variant", ["shared_lo", "per_channel_nco", "no_nco", "no_alc", "am", "lsb"])
+def test_tx_fused_kernel_bit_exact(variant, arith):
+    """k_tx_fused (csrc/tx_fused.hip): every NCO flavour, ALC on and off, the sideband variants."""
+    kw = dict(arith=arith)
+    if variant == "per_channel_nco":
+        kw["nco_steps"] = (np.arange(70, dtype=np.uint64) * 0x00100101 + 0x00400000).astype(np.uint32)
+    if variant == "no_nco":
+        kw["nco"] = False
+    if variant == "no_alc":
+        kw["alc"] = False
+    if variant == "am":
+        kw["mode"] = rc.MODE_AM
+    if variant == "lsb":
+        kw["mode"] = rc.MODE_LSB
+    spec = rc.TxSpec(70, **kw)
+    g, o = gpu_tx(spec), rc.TxCpuChain(spec, "orc")
+    assert g.kernel_name() == "k_tx_fused<4,256,63>"
+    for k, bs in enumerate((256, 1024, 512)):
+        a = rc.synth_audio(0, 70, 2048 * k, bs)
+        assert bits_equal(g.process(a), o.process(a)), "call %d" % k
+    assert_state_equal(g, o)
+    a = rc.synth_audio(0, 70, 9000, 192)                    # not a multiple of 256: generic kernel, same stream
+    assert bits_equal(g.process(a), o.process(a))
+    assert_state_equal(g, o)
+
+
+def test_tx_fused_q15_and_against_generic_large():
+    import selenite_rx as sr
+    spec = rc.TxSpec(33)
+    g, o = gpu_tx(spec), rc.TxCpuChain(spec, "orc")
+    for k in range(2):
+        aq = np.clip(np.trunc(rc.synth_audio(0, 33, k * 512, 512) * 32768.0), -32768, 32767).astype(np.int16)
+        assert np.array_equal(g.process_q15(aq), o.process_q15(aq))
+    nch, bs = 4096, 1024
+    big = rc.TxSpec(nch)
+    fused = gpu_tx(big)
+    os.environ["SELENITE_TX_FORCE_GENERIC"] = "1"
+    try:
+        gen = gpu_tx(big)
+    finally:
+        del os.environ["SELENITE_TX_FORCE_GENERIC"]
+    assert fused.kernel_name() == "k_tx_fused<4,256,63>" and gen.kernel_name() == "k_tx_generic"
+    a = np.concatenate([rc.synth_audio(c0, 512, 0, bs) for c0 in range(0, nch, 512)], axis=0)
+    for _ in range(2):
+        assert bits_equal(fused.process(a), gen.process(a))
+    sf, sg = fused.state(), gen.state()
+    for k in sf:
+        assert np.array_equal(sf[k].view(np.uint32), sg[k].view(np.uint32)), k

@@ -38,4 +38,4 @@ bytes_call = a.channels * (4 * a.block_size + 8 * a.block_size * L + 2 * state)
 print(json.dumps({"metric": "TX chain, complex output Msamples/s", "value": round(a.channels * a.block_size * L / ms / 1e3, 1),
                   "channels": a.channels, "audio_samples_per_call": a.block_size, "interp": L, "arith": a.arith,
                   "ms_per_call": round(ms, 4), "algorithmic_GBps": round(bytes_call / ms / 1e6, 1), "hbm_peak_GBps": 8000,
-                  "kernel": "k_tx_generic"}))
+                  "kernel": tx.kernel_name()}))
