@@ -1042,6 +1042,189 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// k_hilb_split16<NCO, NH, TIn, TOut, AM> -- SELENITE_ARITH_SPLIT16 for the no-decimator shapes
+// (BASELINE cfg1 / cfg2 / cfg5: M = 1, DSP block 256): the Hilbert FIR on the 16-bit matrix pipe.
+// Those shapes are VALU-bound by the Hilbert tap loop (64 non-zero taps of 127 per output); as a
+// banded-Toeplitz product  D[i][m] = sum_k A[i][k] B[k][m],  A[i][k] = st[16 i + k],  B[k][m] = h[k - m]
+// (st = [NH-1 history | 256 new samples] of the Q rail, 16 rows of 16 outputs, K = NH + 15) it is
+// 3 MFMAs per k-step of 32 with the f16 hi/lo split of k_ssb_split16 (samples x 2^8, taps x 2^SC,
+// xh*ch + xh*cl + xl*ch, f32 accumulation): 15 v_mfma_f32_16x16x32_f16 per pass instead of 128
+// v_pk_fma + 64 v_readlane.  The I rail is a pure delay (unit-impulse FIR) and stays f32; the
+// streaming state is written from the f32 mixed samples in registers, so it stays bit-exact.
+// The MFMA result layout (lane holds outputs 64(l>>4) + 16 r + (l&15)) goes through a 1 KB LDS
+// transpose so the audio leaves as one coalesced float4 per lane.  Tolerance-based like k_ssb_split16.
+// ------------------------------------------------------------------------------------------
+template <int NH>
+struct GeoH {
+    static constexpr int HH = NH - 1;                              // history samples (even)
+    static constexpr int KS = (NH + 15 + 31) / 32;                 // MFMA k-steps of 32
+    static constexpr int XN = 240 + 32 * KS;                       // highest image index read + 1
+    __host__ __device__ static constexpr int phys(int u) { return u + 8 * (u >> 7); }   // 16 B pad per 128 samples
+    static constexpr int IMG = ((XN + 8 * (XN >> 7) + 8) + 7) & ~7;  // halfs per image
+    static constexpr int DIL = HH + 256;                           // f32 I rail: [history | new]
+    static constexpr int oTab = 0, oX = 516, oDI = oX + IMG /* 2 images of IMG halfs */, oO = oDI + DIL + 2, total = oO + 256;
+    static_assert(HH % 2 == 0 && HH <= 256, "Hilbert history");
+};
+
+template <int NCO, int NH, typename TIn, typename TOut, int AM = 0>
+__global__ __launch_bounds__(64, 2) void k_hilb_split16(RxParams p, FusedArgs fa, const TIn *__restrict__ src,
+                                                        TOut *__restrict__ dst)
+{
+    using GH = GeoH<NH>;
+    using R = Raw<TIn>;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x;
+    const uint32_t c = blockIdx.x;
+    float *tab = lds + GH::oTab;
+    _Float16 *Xh = reinterpret_cast<_Float16 *>(lds + GH::oX), *Xl = Xh + GH::IMG;
+    float *dI = lds + GH::oDI, *O = lds + GH::oO;
+    const size_t in_base = (size_t)c * p.block_size, out_base = (size_t)c * p.nout;
+    const uint32_t npass = p.nout / 256;
+    typename R::type raw[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) raw[i] = R::load(src, in_base + 128u * i + 2u * lane);
+
+    h8 Bh[GH::KS], Bl[GH::KS];
+    {
+        const h8 *bt = static_cast<const h8 *>(fa.btab16);
+#pragma unroll
+        for (int kk = 0; kk < GH::KS; ++kk) {
+            Bh[kk] = bt[(2 * kk + 0) * 64 + lane];
+            Bl[kk] = bt[(2 * kk + 1) * 64 + lane];
+        }
+    }
+    if constexpr (NCO == 1)
+        for (int i = lane; i < 513; i += kWave) tab[i] = p.sintab[i];
+    const float xs = (float)(1 << 8);
+    auto put = [&](int u, float x0, float x1) {                     // image slots u (even), u + 1 of the Q rail
+        const float a0 = x0 * xs, a1 = x1 * xs;
+        const _Float16 h0 = (_Float16)a0, h1 = (_Float16)a1;
+        const _Float16 l0 = (_Float16)(a0 - (float)h0), l1 = (_Float16)(a1 - (float)h1);
+        const int ph = GH::phys(u);
+        *reinterpret_cast<h2 *>(Xh + ph) = h2{ h0, h1 };
+        *reinterpret_cast<h2 *>(Xl + ph) = h2{ l0, l1 };
+    };
+    // the read-only slack behind the samples meets zero taps only, but must hold finite numbers
+    for (int u = GH::HH + 256 + 2 * lane; u < GH::XN; u += 2 * kWave) put(u, 0.0f, 0.0f);
+    {   // state: I history (f32), Q history (split); branch-free loads (batched_fill)
+        const float *stI = p.fir_state + (size_t)c * 2 * GH::HH, *stQ = stI + GH::HH;
+        const int u = 2 * lane < GH::HH ? 2 * lane : GH::HH - 2;
+        const float i0 = stI[u], i1 = stI[u + 1], q0 = stQ[u], q1 = stQ[u + 1];
+        if (2 * lane < GH::HH) {
+            *reinterpret_cast<float2 *>(dI + u) = make_float2(i0, i1);
+            put(u, q0, q1);
+        }
+    }
+    const uint32_t ph0 = NCO ? p.phase[c] : 0u, step = NCO ? p.step[c] : 0u;
+    float gain = p.agc ? p.gain[c] : 1.0f;
+    const int mcol = lane & 15, rg = lane >> 4;
+    wave_lds_sync();
+
+    for (uint32_t pass = 0; pass < npass; ++pass) {
+        const uint32_t n0 = pass * 256u;
+        const bool last = (pass + 1 == npass);
+        // ---- 1. NCO mix; I rail f32, Q rail split into the f16 images; exact f32 state from the last pass ----
+        float4 lo4[2];
+        if constexpr (NCO == 2) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) lo4[i] = *reinterpret_cast<const float4 *>(p.lo + n0 + 128u * i + 2u * lane);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const uint32_t n = 128u * i + 2u * lane;
+            float2 a, b;
+            R::unpack(raw[i], a, b);
+            if constexpr (NCO == 2) {
+                a = cmul<0>(a, make_float2(lo4[i].x, lo4[i].y));
+                b = cmul<0>(b, make_float2(lo4[i].z, lo4[i].w));
+            } else if constexpr (NCO == 1) {
+                a = cmul<0>(a, nco_lo<0>(tab, ph0 + (n0 + n) * step));
+                b = cmul<0>(b, nco_lo<0>(tab, ph0 + (n0 + n + 1) * step));
+            }
+            if constexpr (AM != 0) {
+                *reinterpret_cast<float2 *>(O + n) = make_float2(cmag<0>(a.x, a.y), cmag<0>(b.x, b.y));
+            } else {
+                *reinterpret_cast<float2 *>(dI + GH::HH + n) = make_float2(a.x, b.x);
+                put(GH::HH + (int)n, a.y, b.y);
+                if (128 * (i + 1) > 256 - GH::HH && last) {            // arm_fir_f32 pState tails: last NH-1 samples, f32
+                    const int s0 = (int)n - (256 - GH::HH);
+                    float *stI = p.fir_state + (size_t)c * 2 * GH::HH, *stQ = stI + GH::HH;
+                    if (s0 >= 0) { stI[s0] = a.x; stQ[s0] = a.y; stI[s0 + 1] = b.x; stQ[s0 + 1] = b.y; }
+                }
+            }
+        }
+        wave_lds_sync();
+        if (pass + 1 < npass) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) raw[i] = R::load(src, in_base + n0 + 256u + 128u * i + 2u * lane);
+        }
+        if constexpr (AM == 0) {
+            // ---- 2. Hilbert FIR of the Q rail: 3 f16 MFMAs per k-step ----
+            v4f big = { 0.0f, 0.0f, 0.0f, 0.0f }, sml = { 0.0f, 0.0f, 0.0f, 0.0f };
+#pragma unroll
+            for (int kk = 0; kk < GH::KS; ++kk) {
+                const int u = 16 * mcol + 8 * rg + 32 * kk;                // A[i = l&15][k = 32kk + 8(l>>4) ..+7] = st[16 i + k]
+                const int ph = u + 8 * (u >> 7);
+                const h8 ah = *reinterpret_cast<const h8 *>(Xh + ph), al = *reinterpret_cast<const h8 *>(Xl + ph);
+                big = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, Bh[kk], big, 0, 0, 0);
+                sml = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, Bl[kk], sml, 0, 0, 0);
+                sml = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, Bh[kk], sml, 0, 0, 0);
+            }
+            // ---- 3. delay on I, sideband combine; transpose through LDS ----
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = 64 * rg + 16 * r + mcol;                     // D[row 4 rg + r][col mcol]
+                const float q2 = (big[r] + sml[r]) * fa.split_post;
+                const float i2 = dI[n + fa.delay_idx] + 0.0f;
+                O[n] = fa.upper ? (i2 - q2) : (i2 + q2);
+            }
+            wave_lds_sync();
+        }
+        // ---- 4.-5. AGC on the DSP block (= the pass), coalesced store ----
+        const float4 o4 = *reinterpret_cast<const float4 *>(O + 4 * lane);
+        float au[4] = { o4.x, o4.y, o4.z, o4.w };
+        if (p.agc) {
+            float m = fmaxf(fmaxf(fabsf(au[0]), fabsf(au[1])), fmaxf(fabsf(au[2]), fabsf(au[3])));
+            m = wave_max(m);
+            gain = agc_update<0>(p.agcp, gain, m);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) au[r] = au[r] * gain;
+        }
+        const size_t o = out_base + (size_t)n0 + 4 * lane;
+        if constexpr (sizeof(TOut) == 4) {
+            *reinterpret_cast<float4 *>(reinterpret_cast<float *>(dst) + o) = make_float4(au[0], au[1], au[2], au[3]);
+        } else {
+            short4 s4;
+            s4.x = float_to_q15(au[0]); s4.y = float_to_q15(au[1]);
+            s4.z = float_to_q15(au[2]); s4.w = float_to_q15(au[3]);
+            *reinterpret_cast<short4 *>(reinterpret_cast<int16_t *>(dst) + o) = s4;
+        }
+        // ---- 6. history: last NH-1 samples of the I rail and of both images to the front ----
+        if constexpr (AM == 0) {
+            float2 ti = make_float2(0.0f, 0.0f);
+            uint32_t th = 0, tl = 0;
+            const int v = 2 * lane;                                         // pair (v, v+1), v < HH
+            if (v < GH::HH) {
+                ti = *reinterpret_cast<const float2 *>(dI + 256 + v);
+                th = *reinterpret_cast<const uint32_t *>(Xh + GH::phys(256 + v));
+                tl = *reinterpret_cast<const uint32_t *>(Xl + GH::phys(256 + v));
+            }
+            wave_lds_sync();
+            if (v < GH::HH) {
+                *reinterpret_cast<float2 *>(dI + v) = ti;
+                *reinterpret_cast<uint32_t *>(Xh + GH::phys(v)) = th;
+                *reinterpret_cast<uint32_t *>(Xl + GH::phys(v)) = tl;
+            }
+        }
+        wave_lds_sync();
+    }
+    if (lane == 0) {
+        if constexpr (NCO != 0) p.phase[c] = ph0 + p.block_size * step;
+        if (p.agc) p.gain[c] = gain;
+    }
+}
+
 // LO[n] = (cos x, -sin x), x from the integer phase phase0 + n*step: the NCO of DESIGN.md section 2,
 // evaluated once per call when every channel shares step and phase.
 __global__ __launch_bounds__(256) void k_lo_table(float2 *lo, const float *sintab, uint32_t phase0, uint32_t step,
@@ -1124,6 +1307,33 @@ static hipError_t build_tables(const selenite_rx_config &g, FusedPlan &plan)
             return hipSuccess;
         }
     }
+    if constexpr (ND == 0 && M == 1 && NH > 0) {
+        // k_hilb_split16: Hilbert taps scaled by 2^SC, f16 hi + lo; fragment of lane l at k-step kk:
+        // 8 halfs B[k = 32kk + 8(l>>4) + j][m = l&15] = h[k - m]
+        using GH = GeoH<NH>;
+        float cmax = 0.0f;
+        for (int k = 0; k < NH; ++k) cmax = std::fmax(cmax, std::fabs(g.hilb_coeffs[k]));
+        int ex = 0;
+        if (cmax > 0.0f) std::frexp(cmax, &ex);
+        const int SC = 10 - ex;
+        std::vector<_Float16> b16((size_t)GH::KS * 2 * 64 * 8, (_Float16)0.0f);
+        for (int kk = 0; kk < GH::KS; ++kk)
+            for (int l = 0; l < 64; ++l)
+                for (int j = 0; j < 8; ++j) {
+                    const int idx = 32 * kk + 8 * (l >> 4) + j - (l & 15);
+                    float cv = 0.0f;
+                    if (idx >= 0 && idx < NH) cv = std::ldexp(g.hilb_coeffs[idx], SC);
+                    const _Float16 hi = (_Float16)cv;
+                    const _Float16 lo = (_Float16)(cv - (float)hi);
+                    b16[(((size_t)2 * kk + 0) * 64 + l) * 8 + j] = hi;
+                    b16[(((size_t)2 * kk + 1) * 64 + l) * 8 + j] = lo;
+                }
+        hipError_t e = hipMalloc(&plan.d_btab16, b16.size() * sizeof(_Float16));
+        if (e != hipSuccess) return e;
+        e = hipMemcpy(plan.d_btab16, b16.data(), b16.size() * sizeof(_Float16), hipMemcpyHostToDevice);
+        if (e != hipSuccess) return e;
+        plan.split_post = std::ldexp(1.0f, -(SC + 8));
+    }
     return hipSuccess;
 }
 
@@ -1184,6 +1394,21 @@ static hipError_t launch_split16(const RxParams &p, const FusedArgs &fa, const v
     return hipGetLastError();
 }
 
+template <int NH, typename TIn, typename TOut>
+static hipError_t launch_hilb16(const RxParams &p, const FusedArgs &fa, const void *src, void *dst, hipStream_t st)
+{
+    using GH = GeoH<NH>;
+    constexpr size_t lds = (size_t)GH::total * sizeof(float);
+    static_assert(lds <= 48 * 1024, "k_hilb_split16 LDS image");
+    auto k = fa.am ? (p.nco == 2 ? k_hilb_split16<2, NH, TIn, TOut, 1>
+                                 : (p.nco == 1 ? k_hilb_split16<1, NH, TIn, TOut, 1> : k_hilb_split16<0, NH, TIn, TOut, 1>))
+                   : (p.nco == 2 ? k_hilb_split16<2, NH, TIn, TOut, 0>
+                                 : (p.nco == 1 ? k_hilb_split16<1, NH, TIn, TOut, 0> : k_hilb_split16<0, NH, TIn, TOut, 0>));
+    hipLaunchKernelGGL(k, dim3(p.channels), dim3(64), lds, st, p, fa, static_cast<const TIn *>(src),
+                       static_cast<TOut *>(dst));
+    return hipGetLastError();
+}
+
 template <int ND, int M, int NH>
 static hipError_t launch_shape(const RxParams &p, const FusedArgs &fa, const FusedPlan &plan, int arith,
                                const void *src, bool src_q15, void *dst, bool dst_q15, hipStream_t st)
@@ -1193,6 +1418,12 @@ static hipError_t launch_shape(const RxParams &p, const FusedArgs &fa, const Fus
         if (arith == SELENITE_ARITH_SPLIT16 && plan.d_btab16) {
             if (src_q15) return launch_split16<ND, M, NH, int16_t, int16_t>(p, fa, src, dst, st);
             return launch_split16<ND, M, NH, float, float>(p, fa, src, dst, st);
+        }
+    }
+    if constexpr (ND == 0 && M == 1 && NH > 0) {
+        if (arith == SELENITE_ARITH_SPLIT16 && plan.d_btab16 && fa.group == 64) {
+            if (src_q15) return launch_hilb16<NH, int16_t, int16_t>(p, fa, src, dst, st);
+            return launch_hilb16<NH, float, float>(p, fa, src, dst, st);
         }
     }
     if constexpr (ND > 0 && M == 4) {
@@ -1249,7 +1480,10 @@ hipError_t plan_fused(const selenite_rx_config &g, bool delay_is_impulse, int de
     const char *nm = std::getenv("SELENITE_RX_NO_MFMA");
     plan.use_mfma = plan.d_btab != nullptr && !(nm && nm[0] == '1');
     if (plan.use_mfma && g.arith == SELENITE_ARITH_FMA) plan.name = "k_ssb_mfma<256,4,63>";
-    if (plan.d_btab16 && g.arith == SELENITE_ARITH_SPLIT16) plan.name = "k_ssb_split16<256,4,63>";
+    if (plan.d_btab16 && g.arith == SELENITE_ARITH_SPLIT16) {
+        if (g.nd_taps) plan.name = "k_ssb_split16<256,4,63>";
+        else if (na == 256) plan.name = g.nh_taps == 127 ? "k_hilb_split16<127>" : "k_hilb_split16<63>";
+    }
     return hipSuccess;
 }
 

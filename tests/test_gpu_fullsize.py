@@ -68,8 +68,8 @@ class FullRun:
 @pytest.mark.parametrize("name,arith", [
     ("cfg3", ARITH_CMSIS), ("cfg3", ARITH_FMA), ("cfg3", rc.ARITH_SPLIT16),
     ("cfg4", ARITH_CMSIS), ("cfg4", ARITH_FMA),
-    ("cfg2", ARITH_CMSIS), ("cfg2", ARITH_FMA),
-    ("cfg5", ARITH_CMSIS),
+    ("cfg2", ARITH_CMSIS), ("cfg2", ARITH_FMA), ("cfg2", rc.ARITH_SPLIT16),
+    ("cfg5", ARITH_CMSIS), ("cfg5", rc.ARITH_SPLIT16),
 ])
 def test_full_size_sampled_channels_match_oracle(name, arith):
     run = FullRun(name, arith)
@@ -93,7 +93,7 @@ def test_full_size_sampled_channels_match_oracle(name, arith):
     sg, so = run.rx.state(), o.state()
     for key in sg:
         a = sg[key][chans]
-        if arith == rc.ARITH_SPLIT16 and key in ("fir_state", "agc_gain"):
+        if arith == rc.ARITH_SPLIT16 and key in ("fir_state", "agc_gain") and not (key == "fir_state" and run.spec.nd_taps == 0):
             assert rel_err(a, so[key]) <= TOL, key
         elif a.dtype == np.float32:
             assert bits_equal(a, so[key]), key
