@@ -62,8 +62,7 @@ def pmc_traffic(workload, arith_name, kernel, channels, bs):
         t = json.load(open(os.path.join(ROOT, "profiles", "r1", "traffic.json")))
     except (OSError, ValueError):
         return None
-    tag = workload if workload != "cfg3" else "cfg3_" + arith_name
-    e = t.get(tag)
+    e = t.get(workload + "_" + arith_name) or t.get(workload)
     if not e or (channels, bs) != WORKLOADS[workload][1:]:
         return None
     if kernel.split("<")[0] not in e["kernel"]:

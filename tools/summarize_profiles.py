@@ -23,7 +23,7 @@ for d in sorted(glob.glob(os.path.join(root, "gpurun_out", "prof_*"))):
             continue
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"]
-            if r["Counter_Name"] == name and ("k_ssb" in k or "k_cw" in k or "generic" in k):
+            if r["Counter_Name"] == name and ("k_ssb" in k or "k_cw" in k or "k_hilb" in k or "generic" in k):
                 rows.append((k.split("(")[0], name, r["Dispatch_Id"], r["Counter_Value"], r["VGPR_Count"], r["LDS_Block_Size"]))
                 per.setdefault((k.split("(")[0], name), []).append(float(r["Counter_Value"]))
     with open(os.path.join(out, tag + "_pmc.csv"), "w") as fo:
