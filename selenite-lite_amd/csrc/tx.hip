@@ -30,6 +30,8 @@ struct selenite_tx_instance {
     uint32_t delay_index = 0, phase_host = 0;
     float2 *d_lo = nullptr;
     size_t lo_bytes = 0;
+    void *d_ttab16 = nullptr;     // k_tx_split16: Toeplitz fragments of the interpolator phases
+    float tpost = 1.0f;
     hipStream_t stream = nullptr, own_stream = nullptr;
     int status = 0;
     std::string err;
@@ -248,7 +250,10 @@ int run(selenite_tx_instance *S, const void *src, void *dst, bool q15, uint32_t 
             TCHK(S, launch_lo_table(S->d_lo, S->d_sintab, phase_now, S->h_step[0], bs * g.interp, S->stream));
             lo = S->d_lo;
         }
-        TCHK(S, launch_tx_fused(p, (int)g.arith, S->delay_index, lo, src, q15, dst, S->stream));
+        if (g.arith == SELENITE_ARITH_SPLIT16 && S->d_ttab16)
+            TCHK(S, launch_tx_split16(p, S->delay_index, lo, S->d_ttab16, S->tpost, src, q15, dst, S->stream));
+        else
+            TCHK(S, launch_tx_fused(p, (int)g.arith, S->delay_index, lo, src, q15, dst, S->stream));
         return 0;
     }
     if (tx_lds_bytes(p) > 64 * 1024) return fail(S, SELENITE_RX_LENGTH_ERROR, "filter lengths exceed the LDS budget of the TX kernel");
@@ -363,6 +368,9 @@ extern "C" int selenite_tx_init(selenite_tx_instance **out, const selenite_tx_co
         const char *fg = std::getenv("SELENITE_TX_FORCE_GENERIC");
         S->force_generic = fg && fg[0] == '1';
     }
+    if (g->arith == SELENITE_ARITH_SPLIT16 && tx_fused_ok(*g, S->delay_is_impulse, S->hilb_odd_only, 256) &&
+        build_tx_split16_table(g->interp_coeffs, &S->d_ttab16, &S->tpost) != hipSuccess)
+        return bail(SELENITE_RX_DEVICE_ERROR);
     if (upload(S, &S->d_ic, g->interp_coeffs, (size_t)g->ni_taps) || upload(S, &S->d_hc, g->hilb_coeffs, (size_t)g->nh_taps) ||
         upload(S, &S->d_dc, g->delay_coeffs, (size_t)g->nh_taps) || upload(S, &S->d_sintab, srx::host_sin_table(), (size_t)513) ||
         upload(S, &S->d_step, S->h_step.data(), C) || upload<uint32_t>(S, &S->d_phase, nullptr, C) ||
@@ -378,7 +386,7 @@ extern "C" void selenite_tx_free(selenite_tx_instance *S)
 {
     if (!S) return;
     void *ptrs[] = { S->d_ic, S->d_hc, S->d_dc, S->d_sintab, S->d_step, S->d_phase, S->d_fir_state, S->d_int_state,
-                     S->d_gain, S->d_io_in, S->d_io_out, S->d_lo };
+                     S->d_gain, S->d_io_in, S->d_io_out, S->d_lo, S->d_ttab16 };
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (S->own_stream) (void)hipStreamDestroy(S->own_stream);
@@ -395,7 +403,8 @@ extern "C" int selenite_tx_set_mode(selenite_tx_instance *S, uint8_t mode)
 extern "C" const char *selenite_tx_kernel_name(const selenite_tx_instance *S)
 {
     if (!S) return "";
-    return (!S->force_generic && tx_fused_ok(S->cfg, S->delay_is_impulse, S->hilb_odd_only, 256)) ? "k_tx_fused<4,256,63>" : "k_tx_generic";
+    if (S->force_generic || !tx_fused_ok(S->cfg, S->delay_is_impulse, S->hilb_odd_only, 256)) return "k_tx_generic";
+    return (S->cfg.arith == SELENITE_ARITH_SPLIT16 && S->d_ttab16) ? "k_tx_split16<4,256,63>" : "k_tx_fused<4,256,63>";
 }
 
 extern "C" int selenite_tx_status(const selenite_tx_instance *S) { return S ? S->status : SELENITE_RX_ARGUMENT_ERROR; }

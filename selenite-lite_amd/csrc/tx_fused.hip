@@ -11,6 +11,8 @@
 // in the reference's order (t ascending, arm_fir_interpolate_f32.c:389-440), single accumulator.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <cmath>
+#include <vector>
 
 #include "rx_internal.h"
 #include "tx_internal.h"
@@ -255,6 +257,253 @@ __global__ __launch_bounds__(64, 2) void k_tx_fused(TxParams p, uint32_t delay_i
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// k_tx_split16<NCO, TIn, TOut> -- SELENITE_ARITH_SPLIT16: the interpolator on the 16-bit matrix pipe.
+// Phase ph of the polyphase interpolator is a plain 64-tap FIR over the state (taps c[(3-ph) + 4t]),
+// i.e. the banded-Toeplitz product of rx_fused.hip's k_hilb_split16:  D_ph[i][m] = sum_k st'[16 i + k]
+// B_ph[k][m],  B_ph[k][m] = c'_ph[k - m],  where st' = [0 | 63 history | 256 new] carries one extra
+// oldest slot under a zero tap so that the new samples start 16-byte aligned (c'_ph[0] = 0,
+// c'_ph[t + 1] = c[(3-ph) + 4t]; K = 65 + 15 -> 3 k-steps of 32).  Samples (I', Q' x 2^8) and taps
+// (x 2^SC) are split into f16 hi + lo; xh*ch + xh*cl + xl*ch with f32 accumulation: 72
+// v_mfma_f32_16x16x32_f16 per 256-sample pass instead of 1024 v_pk_fma + 256 v_readlane.  The four
+// A fragments of a k-step serve all four phases.  The MFMA result layout gives every lane the four
+// phases of four input samples = 32 contiguous output bytes each.  ALC, Hilbert pair and NCO stay f32
+// VALU code as in k_tx_fused; the interpolator state is written from the f32 samples in registers and
+// stays bit-exact.  Output is tolerance-based (<= 1e-5 relative per ALC block against the CMSIS chain).
+// ------------------------------------------------------------------------------------------
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+constexpr int kZS = 64;                                            // image slots in front of the new samples
+constexpr int kKS = 3;                                             // k-steps of 32 (K = 80 <= 96)
+constexpr int kZN = 240 + 32 * kKS;                                // highest image index read + 1
+__host__ __device__ constexpr int zphys(int u) { return u + 8 * (u >> 7); }      // 16 B pad per 128 samples
+constexpr int kZIMG = ((kZN + 8 * (kZN >> 7) + 8) + 7) & ~7;       // halfs per image
+constexpr int oZ16 = oHQ + kHLen, kTotal16 = oZ16 + 2 * kZIMG;     // 4 images of kZIMG halfs = 2 kZIMG floats
+
+template <int NCO, typename TIn, typename TOut>
+__global__ __launch_bounds__(64, 2) void k_tx_split16(TxParams p, uint32_t delay_idx, const float2 *__restrict__ lo,
+                                                      const void *__restrict__ ttab16, float post,
+                                                      const TIn *__restrict__ src, TOut *__restrict__ dst)
+{
+    using IO = AudioIO<TIn>;
+    using OO = AudioIO<TOut>;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x;
+    const uint32_t c = blockIdx.x;
+    float *tab = lds + oTab, *HI = lds + oHI, *HQ = lds + oHQ;
+    _Float16 *ZI = reinterpret_cast<_Float16 *>(lds + oZ16);       // [I hi | I lo | Q hi | Q lo]
+    const size_t in_base = (size_t)c * p.block_size, out_base = (size_t)c * p.block_size * kL;
+    const uint32_t npass = p.block_size / kPass;
+    typename IO::raw raw = IO::load(src, in_base + 4u * lane);
+
+    h8 Bh[kL][kKS], Bl[kL][kKS];                                   // 96 VGPRs of Toeplitz fragments
+    {
+        const h8 *bt = static_cast<const h8 *>(ttab16);
+#pragma unroll
+        for (int ph = 0; ph < kL; ++ph)
+#pragma unroll
+            for (int kk = 0; kk < kKS; ++kk) {
+                Bh[ph][kk] = bt[((ph * kKS + kk) * 2 + 0) * 64 + lane];
+                Bl[ph][kk] = bt[((ph * kKS + kk) * 2 + 1) * 64 + lane];
+            }
+    }
+    const float hreg = (lane < kNH) ? p.hc[lane] : 0.0f;
+    if constexpr (NCO == 1)
+        for (int i = lane; i < 513; i += kWave) tab[i] = p.sintab[i];
+    const float xs = 256.0f;
+    auto putz = [&](int u, float i0, float q0, float i1, float q1) {     // image slots u (even), u + 1, both rails
+        const float a[4] = { i0 * xs, i1 * xs, q0 * xs, q1 * xs };
+        _Float16 h[4], l[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { h[j] = (_Float16)a[j]; l[j] = (_Float16)(a[j] - (float)h[j]); }
+        const int ph = zphys(u);
+        *reinterpret_cast<h2 *>(ZI + 0 * kZIMG + ph) = h2{ h[0], h[1] };
+        *reinterpret_cast<h2 *>(ZI + 1 * kZIMG + ph) = h2{ l[0], l[1] };
+        *reinterpret_cast<h2 *>(ZI + 2 * kZIMG + ph) = h2{ h[2], h[3] };
+        *reinterpret_cast<h2 *>(ZI + 3 * kZIMG + ph) = h2{ l[2], l[3] };
+    };
+    for (int u = kZS + kPass + 2 * lane; u < kZN; u += 2 * kWave) putz(u, 0.0f, 0.0f, 0.0f, 0.0f);   // finite slack under zero taps
+    {   // state, branch-free: Hilbert-pair histories (f32) and the interpolator history (split)
+        const float *stF = p.fir_state + (size_t)c * 2 * kHH, *stZ = p.int_state + (size_t)c * 2 * (kP - 1);
+        float f[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int sidx = lane - kFH;
+            const float x = stF[j * kHH + (sidx < 0 ? 0 : sidx)];
+            f[j] = sidx < 0 ? 0.0f : x;
+        }
+        HI[lane] = f[0]; HQ[lane] = f[1];
+        // image slot u = 1 + state index; lane < 32 owns slots 2 lane, 2 lane + 1 (slot 0 = the extra zero)
+        const int u = 2 * (lane & 31);
+        const int s0 = u - 1, s1 = u;                              // state indices, s0 = -1 for slot 0
+        const float zi0 = stZ[s0 < 0 ? 0 : s0], zi1 = stZ[s1 > kP - 2 ? kP - 2 : s1];
+        const float zq0 = stZ[(kP - 1) + (s0 < 0 ? 0 : s0)], zq1 = stZ[(kP - 1) + (s1 > kP - 2 ? kP - 2 : s1)];
+        if (lane < 32) putz(u, s0 < 0 ? 0.0f : zi0, s0 < 0 ? 0.0f : zq0, zi1, zq1);
+    }
+    float gain = p.alc ? p.gain[c] : 1.0f;
+    const uint32_t ph0 = NCO ? p.phase[c] : 0u, step = NCO ? p.step[c] : 0u;
+    const bool am = p.mode == SELENITE_MODE_AM, up = mode_is_upper(p.mode);
+    const int mcol = lane & 15, rg = lane >> 4;
+    wave_lds_sync();
+
+    for (uint32_t pass = 0; pass < npass; ++pass) {
+        const bool last = (pass + 1 == npass);
+        // ---- 1. ALC ----
+        float a[4];
+        IO::unpack(raw, a);
+        if (pass + 1 < npass) raw = IO::load(src, in_base + (size_t)(pass + 1) * kPass + 4u * lane);
+        if (p.alc) {
+            float m = fmaxf(fmaxf(fabsf(a[0]), fabsf(a[1])), fmaxf(fabsf(a[2]), fabsf(a[3])));
+#pragma unroll
+            for (int off = 1; off < 16; off <<= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+            const float dmine = agc_desired(p.alcp, m);
+            float g = gain, mine = gain;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                g = agc_step(p.alcp, g, lane_bcast(dmine, 16 * b));
+                mine = (b == (lane >> 4)) ? g : mine;
+            }
+            gain = g;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) a[r] = a[r] * mine;
+        }
+        *reinterpret_cast<float4 *>(HI + kHH4 + 4 * lane) = make_float4(a[0], a[1], a[2], a[3]);
+        *reinterpret_cast<float4 *>(HQ + kHH4 + 4 * lane) = make_float4(a[0], a[1], a[2], a[3]);
+        wave_lds_sync();
+        // ---- 2.-3. Hilbert pair (f32 VALU), sideband select, split into the four images ----
+        {
+            float q2[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+            constexpr int C = (kNH - 1) / 2;
+#pragma unroll
+            for (int t = 0; t <= (kHH4 + 3) / 4; ++t) {
+                const float4 W = *reinterpret_cast<const float4 *>(HQ + 4 * lane + 4 * t);
+                const float w[4] = { W.x, W.y, W.z, W.w };
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int k = 4 * t + e - r - kFH;
+                        if (k < 0 || k >= kNH || (((k - C) & 1) == 0)) continue;
+                        q2[r] = mac<1>(q2[r], w[e], lane_bcast(hreg, k));
+                    }
+            }
+            const float *di = HI + kFH + delay_idx + 4 * lane;
+            float zi[4], zq[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float ri = di[r] + 0.0f, rq = q2[r];
+                if (am) { const float t = ri * 0.5f; ri = t + 0.5f; rq = 0.0f; }
+                else if (!up) rq = -rq;
+                zi[r] = ri; zq[r] = rq;
+            }
+            putz(kZS + 4 * lane, zi[0], zq[0], zi[1], zq[1]);
+            putz(kZS + 4 * lane + 2, zi[2], zq[2], zi[3], zq[3]);
+            if (last) {                                            // arm_fir_interpolate_f32 pState tails, exact f32
+                float *stI = p.int_state + (size_t)c * 2 * (kP - 1), *stQ = stI + (kP - 1);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int sidx = 4 * lane + r - (kPass - (kP - 1));
+                    if (sidx >= 0) { stI[sidx] = zi[r]; stQ[sidx] = zq[r]; }
+                }
+            }
+        }
+        wave_lds_sync();
+        {   // Hilbert-pair history
+            const float ti = HI[kPass + lane], tq = HQ[kPass + lane];
+            wave_lds_sync();
+            HI[lane] = ti; HQ[lane] = tq;
+        }
+        // ---- 4. interpolator: 4 phases x 2 rails x 3 k-steps x 3 MFMAs ----
+        v4f aI[kL], aQ[kL];
+#pragma unroll
+        for (int ph = 0; ph < kL; ++ph) { aI[ph] = v4f{ 0.0f, 0.0f, 0.0f, 0.0f }; aQ[ph] = v4f{ 0.0f, 0.0f, 0.0f, 0.0f }; }
+#pragma unroll
+        for (int kk = 0; kk < kKS; ++kk) {
+            const int u = 16 * mcol + 8 * rg + 32 * kk;
+            const int pz = u + 8 * (u >> 7);
+            const h8 xIh = *reinterpret_cast<const h8 *>(ZI + 0 * kZIMG + pz), xIl = *reinterpret_cast<const h8 *>(ZI + 1 * kZIMG + pz);
+            const h8 xQh = *reinterpret_cast<const h8 *>(ZI + 2 * kZIMG + pz), xQl = *reinterpret_cast<const h8 *>(ZI + 3 * kZIMG + pz);
+#pragma unroll
+            for (int ph = 0; ph < kL; ++ph) {
+                aI[ph] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xIh, Bh[ph][kk], aI[ph], 0, 0, 0);
+                aQ[ph] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xQh, Bh[ph][kk], aQ[ph], 0, 0, 0);
+                aI[ph] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xIh, Bl[ph][kk], aI[ph], 0, 0, 0);
+                aQ[ph] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xQh, Bl[ph][kk], aQ[ph], 0, 0, 0);
+                aI[ph] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xIl, Bh[ph][kk], aI[ph], 0, 0, 0);
+                aQ[ph] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xQl, Bh[ph][kk], aQ[ph], 0, 0, 0);
+            }
+        }
+        // ---- 5. NCO up-mix and store: lane holds the 4 phases of input samples 64 rg + 16 r + mcol ----
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const uint32_t o = kL * (64 * rg + 16 * r + mcol);
+            v2f out[kL];
+#pragma unroll
+            for (int ph = 0; ph < kL; ++ph) out[ph] = v2f{ aI[ph][r] * post, aQ[ph][r] * post };
+            if constexpr (NCO == 2) {
+                const float4 *lp = reinterpret_cast<const float4 *>(lo + (size_t)pass * kPass * kL + o);
+                const float4 l01 = lp[0], l23 = lp[1];
+                const float2 l[4] = { make_float2(l01.x, -l01.y), make_float2(l01.z, -l01.w),
+                                      make_float2(l23.x, -l23.y), make_float2(l23.z, -l23.w) };
+#pragma unroll
+                for (int ph = 0; ph < kL; ++ph) {
+                    const float2 m2 = cmul<0>(make_float2(out[ph].x, out[ph].y), l[ph]);
+                    out[ph] = v2f{ m2.x, m2.y };
+                }
+            } else if constexpr (NCO == 1) {
+#pragma unroll
+                for (int ph = 0; ph < kL; ++ph) {
+                    const uint32_t phase = ph0 + (pass * kPass * kL + o + ph) * step;
+                    const float x = (float)(phase >> 8) * kNcoK;
+                    const float2 m2 = cmul<0>(make_float2(out[ph].x, out[ph].y), make_float2(cos_f32<0>(tab, x), sin_f32<0>(tab, x)));
+                    out[ph] = v2f{ m2.x, m2.y };
+                }
+            }
+            OO::store4(dst, out_base + (size_t)pass * kPass * kL + o, out);
+        }
+        wave_lds_sync();
+        {   // image history: slots [256, 320) -> [0, 64) of all four images (32-bit moves)
+            uint32_t t4[4] = { 0, 0, 0, 0 };
+            const int u = 2 * (lane & 31);
+            if (lane < 32) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) t4[j] = *reinterpret_cast<const uint32_t *>(ZI + j * kZIMG + zphys(kPass + u));
+            }
+            wave_lds_sync();
+            if (lane < 32) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) *reinterpret_cast<uint32_t *>(ZI + j * kZIMG + zphys(u)) = t4[j];
+            }
+        }
+        wave_lds_sync();
+    }
+
+    if (lane >= kFH) {
+        p.fir_state[(size_t)c * 2 * kHH + (lane - kFH)] = HI[lane];
+        p.fir_state[(size_t)c * 2 * kHH + kHH + (lane - kFH)] = HQ[lane];
+    }
+    if (lane == 0) {
+        if (p.alc) p.gain[c] = gain;
+        if constexpr (NCO != 0) p.phase[c] = ph0 + p.block_size * kL * step;
+    }
+}
+
+template <typename TIn, typename TOut>
+hipError_t launch_s16(const TxParams &p, uint32_t delay_idx, const float2 *lo, const void *ttab16, float post, const void *src,
+                      void *dst, hipStream_t st)
+{
+    constexpr size_t lds = (size_t)kTotal16 * sizeof(float);
+    const dim3 grid(p.channels), blk(64);
+    const TIn *s = static_cast<const TIn *>(src);
+    TOut *d = static_cast<TOut *>(dst);
+    if (!p.nco) hipLaunchKernelGGL((k_tx_split16<0, TIn, TOut>), grid, blk, lds, st, p, delay_idx, lo, ttab16, post, s, d);
+    else if (lo) hipLaunchKernelGGL((k_tx_split16<2, TIn, TOut>), grid, blk, lds, st, p, delay_idx, lo, ttab16, post, s, d);
+    else hipLaunchKernelGGL((k_tx_split16<1, TIn, TOut>), grid, blk, lds, st, p, delay_idx, lo, ttab16, post, s, d);
+    return hipGetLastError();
+}
+
 template <int ARITH, typename TIn, typename TOut>
 hipError_t launch_a(const TxParams &p, uint32_t delay_idx, const float2 *lo, const void *src, void *dst, hipStream_t st)
 {
@@ -274,6 +523,42 @@ bool tx_fused_ok(const selenite_tx_config &g, bool delay_is_impulse, bool hilb_o
 {
     return g.interp == kL && g.ni_taps == kNI && g.nh_taps == kNH && g.block == kBlk && delay_is_impulse &&
            hilb_odd_only && block_size % kPass == 0;
+}
+
+// Toeplitz fragments of the four interpolator phases for k_tx_split16 (f16 hi / lo, taps x 2^SC);
+// *post = 2^-(8 + SC).  Layout: [phase][k-step][hi, lo][lane][8 halfs].
+hipError_t build_tx_split16_table(const float *interp_coeffs, void **d_table, float *post)
+{
+    float cmax = 0.0f;
+    for (int k = 0; k < kNI; ++k) cmax = std::fmax(cmax, std::fabs(interp_coeffs[k]));
+    int ex = 0;
+    if (cmax > 0.0f) std::frexp(cmax, &ex);
+    const int SC = 10 - ex;
+    std::vector<_Float16> b16((size_t)kL * kKS * 2 * 64 * 8, (_Float16)0.0f);
+    for (int ph = 0; ph < kL; ++ph)
+        for (int kk = 0; kk < kKS; ++kk)
+            for (int l = 0; l < 64; ++l)
+                for (int j = 0; j < 8; ++j) {
+                    const int tp = 32 * kk + 8 * (l >> 4) + j - (l & 15);       // c'_ph index: 0 = the extra zero tap
+                    float cv = 0.0f;
+                    if (tp >= 1 && tp <= kP) cv = std::ldexp(interp_coeffs[(kL - 1 - ph) + kL * (tp - 1)], SC);
+                    const _Float16 hi = (_Float16)cv;
+                    const _Float16 lo = (_Float16)(cv - (float)hi);
+                    b16[((((size_t)ph * kKS + kk) * 2 + 0) * 64 + l) * 8 + j] = hi;
+                    b16[((((size_t)ph * kKS + kk) * 2 + 1) * 64 + l) * 8 + j] = lo;
+                }
+    hipError_t e = hipMalloc(d_table, b16.size() * sizeof(_Float16));
+    if (e != hipSuccess) return e;
+    e = hipMemcpy(*d_table, b16.data(), b16.size() * sizeof(_Float16), hipMemcpyHostToDevice);
+    *post = std::ldexp(1.0f, -(8 + SC));
+    return e;
+}
+
+hipError_t launch_tx_split16(const TxParams &p, uint32_t delay_idx, const float2 *lo, const void *ttab16, float post,
+                             const void *src, bool q15, void *dst, hipStream_t st)
+{
+    return q15 ? launch_s16<int16_t, int16_t>(p, delay_idx, lo, ttab16, post, src, dst, st)
+               : launch_s16<float, float>(p, delay_idx, lo, ttab16, post, src, dst, st);
 }
 
 hipError_t launch_tx_fused(const TxParams &p, int arith, uint32_t delay_idx, const float2 *lo, const void *src, bool q15,

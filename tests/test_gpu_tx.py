@@ -182,3 +182,54 @@ def test_tx_fused_q15_and_against_generic_large():
     sf, sg = fused.state(), gen.state()
     for k in sf:
         assert np.array_equal(sf[k].view(np.uint32), sg[k].view(np.uint32)), k
+
+
+@pytest.mark.parametrize("variant", ["shared_lo", "per_channel_nco", "no_nco", "no_alc", "am", "lsb"])
+def test_tx_split16_interpolator_on_the_matrix_pipe(variant):
+    """SELENITE_ARITH_SPLIT16 for TX (k_tx_split16): tolerance-based output (1e-5 relative per ALC block
+    of 256 output samples against the CMSIS arithmetic); ALC gain, NCO phase and both filter states are
+    computed from exact f32 data and must match the FMA-mode oracle / CMSIS chain as stated."""
+    kw = {}
+    if variant == "per_channel_nco":
+        kw["nco_steps"] = (np.arange(70, dtype=np.uint64) * 0x00100101 + 0x00400000).astype(np.uint32)
+    if variant == "no_nco":
+        kw["nco"] = False
+    if variant == "no_alc":
+        kw["alc"] = False
+    if variant == "am":
+        kw["mode"] = rc.MODE_AM
+    if variant == "lsb":
+        kw["mode"] = rc.MODE_LSB
+    g = gpu_tx(rc.TxSpec(70, arith=rc.ARITH_SPLIT16, **kw))
+    o = rc.TxCpuChain(rc.TxSpec(70, arith=ARITH_CMSIS, **kw), "orc")
+    of = rc.TxCpuChain(rc.TxSpec(70, arith=ARITH_FMA, **kw), "orc")
+    assert g.kernel_name() == "k_tx_split16<4,256,63>"
+    worst = 0.0
+    for k, bs in enumerate((256, 1024, 512)):
+        a = rc.synth_audio(0, 70, 2048 * k, bs)
+        yg, yo = g.process(a), o.process(a)
+        of.process(a)
+        assert np.isfinite(yg).all()
+        for b in range(0, yo.shape[1], 256):
+            for ch in range(70):
+                worst = max(worst, rel_err(yg[ch, b:b + 256], yo[ch, b:b + 256]))
+    print("tx split16 %s worst rel_err %.3g" % (variant, worst))
+    assert worst <= TOL, worst
+    sg, so, sf = g.state(), o.state(), of.state()
+    assert bits_equal(sg["alc_gain"], so["alc_gain"]) and np.array_equal(sg["nco_phase"], so["nco_phase"])
+    assert bits_equal(sg["fir_state"], so["fir_state"])
+    assert bits_equal(sg["interp_state"], sf["interp_state"])          # Hilbert pair runs fused (FMA) in this mode
+    assert rel_err(sg["interp_state"], so["interp_state"]) <= TOL
+
+
+def test_tx_split16_q15_silence_and_full_scale():
+    g = gpu_tx(rc.TxSpec(9, arith=rc.ARITH_SPLIT16))
+    o = rc.TxCpuChain(rc.TxSpec(9), "orc")
+    z = np.zeros((9, 512), np.float32)
+    assert bits_equal(g.process(z), o.process(z))                      # silence stays exact zero
+    full = np.ones((9, 512), np.float32)
+    full[:, ::2] = -1.0
+    assert rel_err(g.process(full), o.process(full)) <= TOL
+    gq, oq = gpu_tx(rc.TxSpec(9, arith=rc.ARITH_SPLIT16)), rc.TxCpuChain(rc.TxSpec(9), "orc")
+    aq = np.clip(np.trunc(rc.synth_audio(0, 9, 0, 512) * 32768.0), -32768, 32767).astype(np.int16)
+    assert np.max(np.abs(gq.process_q15(aq).astype(np.int32) - oq.process_q15(aq).astype(np.int32))) <= 1

@@ -17,10 +17,10 @@ import selenite_rx as sr  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--channels", type=int, default=65536)
 ap.add_argument("--block-size", type=int, default=1024, help="audio samples per channel and call")
-ap.add_argument("--arith", default="fma", choices=["fma", "cmsis"])
+ap.add_argument("--arith", default="split16", choices=["split16", "fma", "cmsis"])
 ap.add_argument("--iters", type=int, default=50)
 a = ap.parse_args()
-spec = rc.TxSpec(a.channels, arith=rc.ARITH_FMA if a.arith == "fma" else rc.ARITH_CMSIS)
+spec = rc.TxSpec(a.channels, arith={"fma": rc.ARITH_FMA, "cmsis": rc.ARITH_CMSIS, "split16": rc.ARITH_SPLIT16}[a.arith])
 tx = sr.Tx(spec.config())
 L = spec.interp
 d_a, d_iq = sr.DeviceBuffer(a.channels * a.block_size * 4), sr.DeviceBuffer(a.channels * a.block_size * L * 8)
