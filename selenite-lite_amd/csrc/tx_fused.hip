@@ -288,7 +288,6 @@ __global__ __launch_bounds__(64, 2) void k_tx_split16(TxParams p, uint32_t delay
                                                       const TIn *__restrict__ src, TOut *__restrict__ dst)
 {
     using IO = AudioIO<TIn>;
-    using OO = AudioIO<TOut>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x;
     const uint32_t c = blockIdx.x;
@@ -435,33 +434,41 @@ __global__ __launch_bounds__(64, 2) void k_tx_split16(TxParams p, uint32_t delay
                 aQ[ph] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xQl, Bh[ph][kk], aQ[ph], 0, 0, 0);
             }
         }
-        // ---- 5. NCO up-mix and store: lane holds the 4 phases of input samples 64 rg + 16 r + mcol ----
+        // ---- 5. transpose through LDS (lane holds the 4 phases of input samples 64 rg + 16 r + mcol), then
+        //         NCO up-mix and store with every wave instruction covering 1 KB of contiguous output ----
+        {
+            float *T = lds + kTotal16;                                  // [1024][2] un-mixed output tile of the pass
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const uint32_t o = kL * (64 * rg + 16 * r + mcol);
-            v2f out[kL];
+            for (int r = 0; r < 4; ++r) {
+                float4 *tp = reinterpret_cast<float4 *>(T + 2 * kL * (64 * rg + 16 * r + mcol));
+                tp[0] = make_float4(aI[0][r] * post, aQ[0][r] * post, aI[1][r] * post, aQ[1][r] * post);
+                tp[1] = make_float4(aI[2][r] * post, aQ[2][r] * post, aI[3][r] * post, aQ[3][r] * post);
+            }
+            wave_lds_sync();
 #pragma unroll
-            for (int ph = 0; ph < kL; ++ph) out[ph] = v2f{ aI[ph][r] * post, aQ[ph][r] * post };
-            if constexpr (NCO == 2) {
-                const float4 *lp = reinterpret_cast<const float4 *>(lo + (size_t)pass * kPass * kL + o);
-                const float4 l01 = lp[0], l23 = lp[1];
-                const float2 l[4] = { make_float2(l01.x, -l01.y), make_float2(l01.z, -l01.w),
-                                      make_float2(l23.x, -l23.y), make_float2(l23.z, -l23.w) };
-#pragma unroll
-                for (int ph = 0; ph < kL; ++ph) {
-                    const float2 m2 = cmul<0>(make_float2(out[ph].x, out[ph].y), l[ph]);
-                    out[ph] = v2f{ m2.x, m2.y };
+            for (int j = 0; j < 8; ++j) {
+                const uint32_t o = 2u * (64u * j + lane);                 // two complex outputs per lane and step
+                const float4 t = *reinterpret_cast<const float4 *>(T + 2 * o);
+                float2 y0 = make_float2(t.x, t.y), y1 = make_float2(t.z, t.w);
+                if constexpr (NCO == 2) {
+                    const float4 l = *reinterpret_cast<const float4 *>(lo + (size_t)pass * kPass * kL + o);
+                    y0 = cmul<0>(y0, make_float2(l.x, -l.y));
+                    y1 = cmul<0>(y1, make_float2(l.z, -l.w));
+                } else if constexpr (NCO == 1) {
+                    const uint32_t phase = ph0 + (pass * kPass * kL + o) * step;
+                    const float x0 = (float)(phase >> 8) * kNcoK, x1 = (float)((phase + step) >> 8) * kNcoK;
+                    y0 = cmul<0>(y0, make_float2(cos_f32<0>(tab, x0), sin_f32<0>(tab, x0)));
+                    y1 = cmul<0>(y1, make_float2(cos_f32<0>(tab, x1), sin_f32<0>(tab, x1)));
                 }
-            } else if constexpr (NCO == 1) {
-#pragma unroll
-                for (int ph = 0; ph < kL; ++ph) {
-                    const uint32_t phase = ph0 + (pass * kPass * kL + o + ph) * step;
-                    const float x = (float)(phase >> 8) * kNcoK;
-                    const float2 m2 = cmul<0>(make_float2(out[ph].x, out[ph].y), make_float2(cos_f32<0>(tab, x), sin_f32<0>(tab, x)));
-                    out[ph] = v2f{ m2.x, m2.y };
+                const size_t at = out_base + (size_t)pass * kPass * kL + o;
+                if constexpr (sizeof(TOut) == 4) {
+                    *reinterpret_cast<float4 *>(reinterpret_cast<float *>(dst) + 2 * at) = make_float4(y0.x, y0.y, y1.x, y1.y);
+                } else {
+                    short4 q;
+                    q.x = float_to_q15(y0.x); q.y = float_to_q15(y0.y); q.z = float_to_q15(y1.x); q.w = float_to_q15(y1.y);
+                    *reinterpret_cast<short4 *>(reinterpret_cast<int16_t *>(dst) + 2 * at) = q;
                 }
             }
-            OO::store4(dst, out_base + (size_t)pass * kPass * kL + o, out);
         }
         wave_lds_sync();
         {   // image history: slots [256, 320) -> [0, 64) of all four images (32-bit moves)
@@ -494,7 +501,7 @@ template <typename TIn, typename TOut>
 hipError_t launch_s16(const TxParams &p, uint32_t delay_idx, const float2 *lo, const void *ttab16, float post, const void *src,
                       void *dst, hipStream_t st)
 {
-    constexpr size_t lds = (size_t)kTotal16 * sizeof(float);
+    constexpr size_t lds = (size_t)(kTotal16 + 2 * kPass * kL) * sizeof(float);      // + the 8 KB output tile
     const dim3 grid(p.channels), blk(64);
     const TIn *s = static_cast<const TIn *>(src);
     TOut *d = static_cast<TOut *>(dst);
