@@ -509,3 +509,37 @@ def test_hilbert_split16_modes_q15_silence_full_scale():
     q = np.clip(np.trunc(iq * 32768.0), -32768, 32767).astype(np.int16)
     gq, oq = gpu_rx(baseline_spec("cfg2", 4, rc.ARITH_SPLIT16)), CpuChain(baseline_spec("cfg2", 4, ARITH_CMSIS), "orc")
     assert np.max(np.abs(gq.process_q15(q).astype(np.int32) - oq.process_q15(q).astype(np.int32))) <= 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("arith", [ARITH_CMSIS, rc.ARITH_SPLIT16])
+def test_eight_way_channel_sharding_equals_the_unsharded_run_on_4096_channels(arith):
+    """the result of a channel-sharded job (8 ranks, contiguous channel ranges from
+    selenite_rx.shard.channel_range) equals the 1-GPU result bit for bit -- channels share nothing but
+    read-only taps.  Eight instances on one device stand in for the eight ranks; also in the split16
+    arithmetic, whose result depends on nothing but the channel's own samples."""
+    import selenite_rx as sr
+    from selenite_rx.shard import channel_range
+    nch, bs, world = 4096, 2048, 8
+    d_in, d_out = sr.DeviceBuffer(nch * bs * 8), sr.DeviceBuffer(nch * (bs // 4) * 4)
+    whole = gpu_rx(baseline_spec("cfg3", nch, arith))
+    shards = []
+    for r in range(world):
+        c0, cnt = channel_range(nch, r, world)
+        shards.append((c0, c0 + cnt, gpu_rx(baseline_spec("cfg3", cnt, arith))))
+    for call in range(2):
+        whole.synth_device(d_in.ptr, 0, nch, call * bs, bs, rc.SEED)
+        whole.process_device(d_in.ptr, d_out.ptr, bs)
+        whole.sync(); whole.check()
+        y = d_out.download((nch, bs // 4), np.float32)
+        parts = []
+        for c0, c1, g in shards:
+            g.process_device(d_in.ptr + c0 * bs * 8, d_out.ptr + c0 * (bs // 4) * 4, bs)
+            g.sync(); g.check()
+        y2 = d_out.download((nch, bs // 4), np.float32)
+        assert bits_equal(y, y2), "call %d" % call
+    sw = whole.state()
+    for c0, c1, g in shards:
+        ss = g.state()
+        for k in ss:
+            assert np.array_equal(ss[k].view(np.uint32), sw[k][c0:c1].view(np.uint32)), k
