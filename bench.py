@@ -132,6 +132,8 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("SELENITE_BENCH_SHARE_GPU") == "1":      # test rig: several ranks on one device (gloo only)
+        local_rank = 0
     world = int(os.environ.get("WORLD_SIZE", "1"))
     n_gpus = args.gpus
     dist = None
