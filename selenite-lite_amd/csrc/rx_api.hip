@@ -303,6 +303,7 @@ static RxParams make_params(selenite_rx_instance *S, uint32_t block_size)
     p.nd = g.nd_taps; p.nh = g.nh_taps; p.nbiq = g.n_biquad; p.mode = g.mode;
     p.nco = g.nco_enable ? 1 : 0; p.agc = g.agc_enable ? 1 : 0;
     p.block_size = block_size; p.nout = block_size / g.decim;
+    p.in_stride = p.block_size; p.out_stride = p.nout;
     p.dec_c = S->d_dec_c; p.hilb_c = S->d_hilb_c; p.delay_c = S->d_delay_c; p.biq_c = S->d_biq_c;
     p.sintab = S->d_sintab; p.step = S->d_step; p.phase = S->d_phase;
     p.dec_state = S->d_dec_state; p.fir_state = S->d_fir_state; p.biq_state = S->d_biq_state;
@@ -339,12 +340,13 @@ static bool block_size_ok(selenite_rx_instance *S, uint32_t block_size, const ch
 enum Phase { kAll, kPhase1, kPhase2 };
 
 // The one dispatcher behind every process entry point.
-static int run_chain(selenite_rx_instance *S, const void *src, bool src_q15, void *dst, bool dst_q15,
-                     uint32_t block_size, Phase phase, float *ext_env)
+static int run_part(selenite_rx_instance *S, const void *src, bool src_q15, void *dst, bool dst_q15,
+                    uint32_t block_size, Phase phase, float *ext_env, uint32_t in_stride, uint32_t out_stride)
 {
     const selenite_rx_config &g = S->cfg;
     HIPCHK(S, hipSetDevice(S->device));
     RxParams p = make_params(S, block_size);
+    p.in_stride = in_stride; p.out_stride = out_stride;
     if (front_generic_lds_bytes(p) > 64 * 1024 && (S->force_generic || S->plan.kind == 0))
         return fail(S, SELENITE_RX_LENGTH_ERROR, "filter lengths exceed the LDS budget of the generic kernel");
     const int arith = (int)g.arith;
@@ -365,7 +367,7 @@ static int run_chain(selenite_rx_instance *S, const void *src, bool src_q15, voi
     const bool cw_fused = fusable && cw_fused_ok(g, block_size);
     float *audio = (float *)dst;      // un-scaled audio: dst itself when dst is f32, else scratch
     if (dst_q15 && (global || !(ssb_fused || cw_fused))) {
-        const size_t need = (size_t)g.channels * p.nout * sizeof(float);
+        const size_t need = (size_t)g.channels * p.out_stride * sizeof(float);
         int rc = ensure(S, (void **)&S->d_scratch, &S->scratch_bytes, need);
         if (rc) return rc;
         audio = S->d_scratch;
@@ -412,6 +414,31 @@ static int run_chain(selenite_rx_instance *S, const void *src, bool src_q15, voi
         HIPCHK(S, launch_agc_generic(p, arith, audio, dst, dst_q15, st));
     }
     return SELENITE_RX_SUCCESS;
+}
+
+// Entry of every process call.  The decimating fused kernels work in passes of 256 outputs; a call
+// whose length is a multiple of cfg.block but not of a pass is split: the whole passes go through the
+// fused kernel, the remaining DSP blocks through the generic kernels on the same streaming state (both
+// parts address the caller's buffers with the full per-channel stride).
+static int run_chain(selenite_rx_instance *S, const void *src, bool src_q15, void *dst, bool dst_q15,
+                     uint32_t block_size, Phase phase, float *ext_env)
+{
+    const selenite_rx_config &g = S->cfg;
+    const uint32_t nout = block_size / g.decim;
+    const bool global = g.agc_enable && g.agc_global;
+    if (phase == kAll && !global && !S->force_generic && S->plan.kind != 0 && g.nd_taps &&
+        !fused_block_size_ok(S->plan, g, block_size)) {
+        const uint32_t unit = 256u * g.decim, bs1 = block_size / unit * unit;
+        if (bs1 > 0) {
+            int rc = run_part(S, src, src_q15, dst, dst_q15, bs1, kAll, nullptr, block_size, nout);
+            if (rc) return rc;
+            const size_t ein = src_q15 ? sizeof(int16_t) : sizeof(float), eout = dst_q15 ? sizeof(int16_t) : sizeof(float);
+            const char *src2 = static_cast<const char *>(src) + (size_t)bs1 * 2 * ein;
+            char *dst2 = static_cast<char *>(dst) + (size_t)(bs1 / g.decim) * eout;
+            return run_part(S, src2, src_q15, dst2, dst_q15, block_size - bs1, kAll, nullptr, block_size, nout);
+        }
+    }
+    return run_part(S, src, src_q15, dst, dst_q15, block_size, phase, ext_env, block_size, nout);
 }
 
 extern "C" void selenite_rx_process_f32_device(selenite_rx_instance *S, const float *dSrcIQ,

@@ -94,7 +94,7 @@ __global__ __launch_bounds__(64) void k_cw_fused(RxParams p, const TIn *__restri
     auto issue_loads = [&](uint32_t n_first) {          // chunk of 64 samples x 16 channels starting at n_first
 #pragma unroll
         for (int j = 0; j < 8; ++j)
-            raw[j] = CwRaw<TIn>::load(src, (size_t)(c0 + 2 * j + lch) * p.block_size + n_first + lsm);
+            raw[j] = CwRaw<TIn>::load(src, (size_t)(c0 + 2 * j + lch) * p.in_stride + n_first + lsm);
         if constexpr (NCO == 2) lo4 = *reinterpret_cast<const float4 *>(p.lo + n_first + lsm);
     };
     auto mix_write = [&](uint32_t n_first, int q) {      // NCO mix (real part) of the loaded chunk into the tile
@@ -201,7 +201,7 @@ __global__ __launch_bounds__(64) void k_cw_fused(RxParams p, const TIn *__restri
                 if (t < BLK) {
                     float4 v = *reinterpret_cast<const float4 *>(tile + r * RS + t);
                     v.x = v.x * g; v.y = v.y * g; v.z = v.z * g; v.w = v.w * g;
-                    const size_t o = (size_t)(c0 + r) * p.nout + n0 + t;
+                    const size_t o = (size_t)(c0 + r) * p.out_stride + n0 + t;
                     if constexpr (sizeof(TOut) == 4) {
                         *reinterpret_cast<float4 *>(reinterpret_cast<float *>(dst) + o) = v;
                     } else {

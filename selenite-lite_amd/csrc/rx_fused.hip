@@ -336,7 +336,7 @@ __global__ __launch_bounds__(64, 2) void k_ssb_fused(RxParams p, FusedArgs fa, c
     float *dI = D, *dQ = D + G::DLEN;
     constexpr int NLD = G::T / 128;                      // raw loads per lane per pass
 
-    const size_t in_base = (size_t)c * p.block_size, out_base = (size_t)c * p.nout;
+    const size_t in_base = (size_t)c * p.in_stride, out_base = (size_t)c * p.out_stride;
     const uint32_t npass = p.nout / G::P;
     typename R::type raw[NLD];
 #pragma unroll
@@ -552,7 +552,7 @@ __global__ __launch_bounds__(64 * kMfmaWaves, 2) void k_ssb_mfma(RxParams p, Fus
     float *dI = D, *dQ = D + G::DLEN;
     constexpr int NLD = G::T / 128;
 
-    const size_t in_base = (size_t)c * p.block_size, out_base = (size_t)c * p.nout;
+    const size_t in_base = (size_t)c * p.in_stride, out_base = (size_t)c * p.out_stride;
     const uint32_t npass = p.nout / G::P;
     typename R::type raw[NLD];
 #pragma unroll
@@ -809,7 +809,7 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
     float *dI = D, *dQ = D + G::DLEN;
     constexpr int NLD = G::T / 128;
 
-    const size_t in_base = (size_t)c * p.block_size, out_base = (size_t)c * p.nout;
+    const size_t in_base = (size_t)c * p.in_stride, out_base = (size_t)c * p.out_stride;
     const uint32_t npass = p.nout / G::P;
     typename R::type raw[NLD];
 #pragma unroll
@@ -1079,7 +1079,7 @@ __global__ __launch_bounds__(64, 2) void k_hilb_split16(RxParams p, FusedArgs fa
     float *tab = lds + GH::oTab;
     _Float16 *Xh = reinterpret_cast<_Float16 *>(lds + GH::oX), *Xl = Xh + GH::IMG;
     float *dI = lds + GH::oDI, *O = lds + GH::oO;
-    const size_t in_base = (size_t)c * p.block_size, out_base = (size_t)c * p.nout;
+    const size_t in_base = (size_t)c * p.in_stride, out_base = (size_t)c * p.out_stride;
     const uint32_t npass = p.nout / 256;
     typename R::type raw[2];
 #pragma unroll

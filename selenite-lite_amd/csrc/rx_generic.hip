@@ -89,7 +89,7 @@ __global__ __launch_bounds__(64) void k_front_generic(RxParams p, const TIn *__r
     const uint32_t fo = use_fir ? Hh : 0u;     // where new decimated samples start in dI/dQ
     __syncthreads();
 
-    const size_t in_base = (size_t)c * p.block_size, out_base = (size_t)c * p.nout;
+    const size_t in_base = (size_t)c * p.in_stride, out_base = (size_t)c * p.out_stride;
     for (uint32_t o0 = 0; o0 < p.nout; o0 += P) {
         const uint32_t cnt = (p.nout - o0 < P) ? (p.nout - o0) : P;
         const uint32_t tin = cnt * M, n0 = o0 * M;
@@ -158,7 +158,7 @@ __global__ __launch_bounds__(64) void k_biquad_generic(RxParams p, float *__rest
 {
     const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= p.channels) return;
-    float *a = audio + (size_t)c * p.nout;
+    float *a = audio + (size_t)c * p.out_stride;
     for (uint32_t s = 0; s < p.nbiq; ++s) {
         const float b0 = p.biq_c[5 * s], b1 = p.biq_c[5 * s + 1], b2 = p.biq_c[5 * s + 2];
         const float a1 = p.biq_c[5 * s + 3], a2 = p.biq_c[5 * s + 4];
@@ -178,7 +178,7 @@ __global__ __launch_bounds__(64) void k_agc_generic(RxParams p, const float *aud
     const uint32_t na = p.block / p.decim, nblk = p.block_size / p.block;
     float g = p.agc ? p.gain[c] : 1.0f;
     for (uint32_t b = 0; b < nblk; ++b) {
-        const size_t base = (size_t)c * p.nout + (size_t)b * na;
+        const size_t base = (size_t)c * p.out_stride + (size_t)b * na;
         if (p.agc) {
             float m = 0.0f;
             for (uint32_t i = lane; i < na; i += kWave) m = fmaxf(m, fabsf(audio[base + i]));
@@ -223,7 +223,7 @@ __global__ __launch_bounds__(64 * kEnvWaves) void k_env_global(RxParams p, const
         for (uint32_t b = 0; b < nblk; ++b) {
             float m = 0.0f;
             for (uint32_t c = w * gm.cpw + gm.coff; c < p.channels && gm.live; c += nw * gm.cpw) {
-                const float *a = audio + (size_t)c * p.nout + (size_t)b * na;
+                const float *a = audio + (size_t)c * p.out_stride + (size_t)b * na;
                 for (uint32_t i = gm.sub; i < gm.L; i += kWave) {
                     const float4 v = *reinterpret_cast<const float4 *>(a + 4 * i);
                     m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
@@ -237,7 +237,7 @@ __global__ __launch_bounds__(64 * kEnvWaves) void k_env_global(RxParams p, const
     for (uint32_t b = 0; b < nblk; ++b) {
         float m = 0.0f;
         for (uint32_t c = w; c < p.channels; c += nw) {
-            const size_t base = (size_t)c * p.nout + (size_t)b * na;
+            const size_t base = (size_t)c * p.out_stride + (size_t)b * na;
             for (uint32_t i = lane; i < na; i += kWave) m = fmaxf(m, fabsf(audio[base + i]));
         }
         m = wave_max(m);
@@ -288,17 +288,17 @@ __global__ __launch_bounds__(64) void k_agc_apply_global(RxParams p, const float
 #pragma unroll
                 for (uint32_t k = 0; k < CH; ++k)
                     if (b0 + k < nblk && gm.sub < gm.L)
-                        v[k] = *reinterpret_cast<const float4 *>(audio + (size_t)c * p.nout + (size_t)(b0 + k) * na + 4 * gm.sub);
+                        v[k] = *reinterpret_cast<const float4 *>(audio + (size_t)c * p.out_stride + (size_t)(b0 + k) * na + 4 * gm.sub);
 #pragma unroll
                 for (uint32_t k = 0; k < CH; ++k)
                     if (b0 + k < nblk) {
                         g = agc_update<ARITH>(p.agcp, g, env[b0 + k]);
-                        if (gm.sub < gm.L) put((size_t)c * p.nout + (size_t)(b0 + k) * na + 4 * gm.sub, v[k], g);
+                        if (gm.sub < gm.L) put((size_t)c * p.out_stride + (size_t)(b0 + k) * na + 4 * gm.sub, v[k], g);
                     }
             }
         } else {
             for (uint32_t b = 0; b < nblk; ++b) {
-                const size_t base = (size_t)c * p.nout + (size_t)b * na;
+                const size_t base = (size_t)c * p.out_stride + (size_t)b * na;
                 g = agc_update<ARITH>(p.agcp, g, env[b]);
                 for (uint32_t i = gm.sub; i < gm.L; i += kWave)
                     put(base + 4 * i, *reinterpret_cast<const float4 *>(audio + base + 4 * i), g);
@@ -310,7 +310,7 @@ __global__ __launch_bounds__(64) void k_agc_apply_global(RxParams p, const float
     const uint32_t c = blockIdx.x;
     float g = p.gain[c];
     for (uint32_t b = 0; b < nblk; ++b) {
-        const size_t base = (size_t)c * p.nout + (size_t)b * na;
+        const size_t base = (size_t)c * p.out_stride + (size_t)b * na;
         g = agc_update<ARITH>(p.agcp, g, env[b]);
         for (uint32_t i = lane; i < na; i += kWave) store_audio(dst, base + i, audio[base + i] * g);
     }

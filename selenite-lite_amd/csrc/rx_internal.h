@@ -24,6 +24,8 @@ struct RxParams {
     uint32_t agc;          // AGC enabled
     uint32_t block_size;   // input samples per channel in this call
     uint32_t nout;         // block_size / decim
+    uint32_t in_stride;    // complex samples between consecutive channels in the source buffer (>= block_size)
+    uint32_t out_stride;   // audio samples between consecutive channels in the destination buffer (>= nout)
     uint32_t pass_out;     // generic front kernel: decimated outputs per pass
     const float *dec_c, *hilb_c, *delay_c, *biq_c, *sintab;
     const float2 *lo;      // nco == 2: LO[n] = (cos, -sin) for the samples of this call (all channels share it)

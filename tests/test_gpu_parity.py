@@ -543,3 +543,32 @@ def test_eight_way_channel_sharding_equals_the_unsharded_run_on_4096_channels(ar
         ss = g.state()
         for k in ss:
             assert np.array_equal(ss[k].view(np.uint32), sw[k][c0:c1].view(np.uint32)), k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("arith", [ARITH_CMSIS, ARITH_FMA, rc.ARITH_SPLIT16])
+def test_call_lengths_that_are_not_whole_passes_split_into_fused_plus_generic(arith):
+    """blockSize only has to be a multiple of cfg.block (256).  The decimating fused kernels work in
+    passes of 1024 inputs; other lengths run the whole passes fused and the remaining DSP blocks on the
+    generic kernels, on the same streaming state, addressing the caller's buffers with the full stride."""
+    nch = 40
+    g = gpu_rx(baseline_spec("cfg3", nch, arith))
+    ref_arith = ARITH_CMSIS if arith == rc.ARITH_SPLIT16 else arith
+    o = CpuChain(baseline_spec("cfg3", nch, ref_arith), "orc")
+    pos = 0
+    for bs in (1280, 256, 1024, 1792, 768, 2048 + 512):
+        iq = synth_iq(0, nch, pos, bs)
+        pos += bs
+        yg, yo = g.process(iq), o.process(iq)
+        if arith == rc.ARITH_SPLIT16:
+            for b in range(bs // 256):
+                assert rel_err(yg[:, 64 * b:64 * b + 64], yo[:, 64 * b:64 * b + 64]) <= TOL, bs
+        else:
+            assert bits_equal(yg, yo), bs
+    sg, so = g.state(), o.state()
+    assert bits_equal(sg["dec_state"], so["dec_state"]) and np.array_equal(sg["nco_phase"], so["nco_phase"])
+    if arith != rc.ARITH_SPLIT16:
+        assert bits_equal(sg["fir_state"], so["fir_state"]) and bits_equal(sg["agc_gain"], so["agc_gain"])
+    q = np.clip(np.trunc(synth_iq(0, nch, 0, 1280) * 32768.0), -32768, 32767).astype(np.int16)
+    gq, oq = gpu_rx(baseline_spec("cfg3", nch, ARITH_CMSIS)), CpuChain(baseline_spec("cfg3", nch, ARITH_CMSIS), "orc")
+    assert np.array_equal(gq.process_q15(q), oq.process_q15(q))
