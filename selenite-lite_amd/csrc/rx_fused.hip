@@ -1440,8 +1440,9 @@ static hipError_t launch_shape(const RxParams &p, const FusedArgs &fa, const Fus
     return launch_one<0, ND, M, NH, float, float>(p, fa, src, dst, st);
 }
 
-// the instantiated shapes: BASELINE.json cfg1 / cfg2 / cfg3 (+ cfg5 = cfg2 chain)
-#define SRX_SHAPES(X) X(256, 4, 63, 1) X(0, 1, 63, 2) X(0, 1, 127, 3)
+// the instantiated shapes: BASELINE.json cfg1 / cfg2 / cfg3 (+ cfg5 = cfg2 chain), and two neighbours of
+// cfg3 (half the decimator taps; the long Hilbert) to show the kernels are not tied to one tap count
+#define SRX_SHAPES(X) X(256, 4, 63, 1) X(0, 1, 63, 2) X(0, 1, 127, 3) X(128, 4, 63, 4) X(256, 4, 127, 5)
 
 static bool fused_mode_ok(const selenite_rx_config &g)
 {
@@ -1476,14 +1477,17 @@ hipError_t plan_fused(const selenite_rx_config &g, bool delay_is_impulse, int de
         plan.tables_built = true;
     }
     plan.kind = kind;
-    plan.name = name;
     const char *nm = std::getenv("SELENITE_RX_NO_MFMA");
     plan.use_mfma = plan.d_btab != nullptr && !(nm && nm[0] == '1');
-    if (plan.use_mfma && g.arith == SELENITE_ARITH_FMA) plan.name = "k_ssb_mfma<256,4,63>";
+    const std::string shape = "<" + std::to_string(g.nd_taps) + "," + std::to_string(g.decim) + "," + std::to_string(g.nh_taps) + ">";
+    plan.name_buf = "k_ssb_fused" + shape;
+    (void)name;
+    if (plan.use_mfma && g.arith == SELENITE_ARITH_FMA) plan.name_buf = "k_ssb_mfma" + shape;
     if (plan.d_btab16 && g.arith == SELENITE_ARITH_SPLIT16) {
-        if (g.nd_taps) plan.name = "k_ssb_split16<256,4,63>";
-        else if (na == 256) plan.name = g.nh_taps == 127 ? "k_hilb_split16<127>" : "k_hilb_split16<63>";
+        if (g.nd_taps) plan.name_buf = "k_ssb_split16" + shape;
+        else if (na == 256) plan.name_buf = "k_hilb_split16<" + std::to_string(g.nh_taps) + ">";
     }
+    plan.name = plan.name_buf.c_str();
     return hipSuccess;
 }
 

@@ -64,6 +64,7 @@ hipError_t launch_agc_apply_global(const RxParams &p, int arith, const float *au
 struct FusedPlan {
     int kind = 0;                 // 0 = none
     const char *name = "generic";
+    std::string name_buf;         // storage behind `name` for the composed kernel names
     float *d_cq = nullptr;        // zero-padded decimator taps in the fused kernel's indexing
     float *d_btab = nullptr;      // banded-Toeplitz B operand of the MFMA decimator
     void *d_btab16 = nullptr;     // same operand split into f16 hi / lo parts (SELENITE_ARITH_SPLIT16)

@@ -572,3 +572,29 @@ def test_call_lengths_that_are_not_whole_passes_split_into_fused_plus_generic(ar
     q = np.clip(np.trunc(synth_iq(0, nch, 0, 1280) * 32768.0), -32768, 32767).astype(np.int16)
     gq, oq = gpu_rx(baseline_spec("cfg3", nch, ARITH_CMSIS)), CpuChain(baseline_spec("cfg3", nch, ARITH_CMSIS), "orc")
     assert np.array_equal(gq.process_q15(q), oq.process_q15(q))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nd,nh", [(128, 63), (256, 127)])
+@pytest.mark.parametrize("arith", [ARITH_CMSIS, ARITH_FMA, rc.ARITH_SPLIT16])
+def test_neighbour_shapes_of_cfg3_run_the_fused_kernels(nd, nh, arith):
+    """The decimating kernels are templates: besides the BASELINE shape the library instantiates a
+    128-tap decimator and a 127-tap Hilbert variant.  Same parity contract per arithmetic mode."""
+    nch = 48
+    kw = dict(nco=True, nco_step_all=0x01000000, agc=True)
+    g = gpu_rx(rc.ChainSpec(nch, 256, 4, nd, nh, 0, rc.MODE_LSB, arith, **kw))
+    ref_arith = ARITH_CMSIS if arith == rc.ARITH_SPLIT16 else arith
+    o = CpuChain(rc.ChainSpec(nch, 256, 4, nd, nh, 0, rc.MODE_LSB, ref_arith, **kw), "orc")
+    want = {ARITH_CMSIS: "k_ssb_fused", ARITH_FMA: "k_ssb_mfma", rc.ARITH_SPLIT16: "k_ssb_split16"}[arith]
+    assert g.kernel_name() == "%s<%d,4,%d>" % (want, nd, nh)
+    for call in range(2):
+        iq = synth_iq(0, nch, 2048 * call, 2048)
+        yg, yo = g.process(iq), o.process(iq)
+        if arith == rc.ARITH_SPLIT16:
+            for b in range(8):
+                assert rel_err(yg[:, 64 * b:64 * b + 64], yo[:, 64 * b:64 * b + 64]) <= TOL
+        else:
+            assert bits_equal(yg, yo)
+    assert bits_equal(g.state()["dec_state"], o.state()["dec_state"])
+    if arith != rc.ARITH_SPLIT16:
+        assert_state_equal(g, o)
