@@ -27,7 +27,8 @@ d_a, d_iq = sr.DeviceBuffer(a.channels * a.block_size * 4), sr.DeviceBuffer(a.ch
 chunk = 4096
 for c0 in range(0, a.channels, chunk):
     n = min(chunk, a.channels - c0)
-    x = rc.synth_audio(c0, n, 0, a.block_size)
+    # audio = I rail of the library's own synthetic generator (the oracle is test infrastructure only)
+    x = np.ascontiguousarray(sr.synth_iq_host(c0, n, 0, a.block_size, rc.SEED)[:, :, 0])
     sr.lib().selenite_rx_memcpy_h2d(d_a.ptr + c0 * a.block_size * 4, x.ctypes.data, x.nbytes)
 t0 = time.perf_counter()
 while time.perf_counter() - t0 < 0.3:
