@@ -70,7 +70,10 @@ __global__ __launch_bounds__(64) void k_cw_fused(RxParams p, const TIn *__restri
     const int lane = threadIdx.x;
     const int s = lane & 3, ch = lane >> 2;
     const uint32_t c0 = blockIdx.x * kCwCh;
-    const uint32_t c = c0 + ch;
+    // the last workgroup of a channel count that is not a multiple of 16: lanes past the end work on a
+    // copy of the last channel (every load index is clamped) and none of their stores is issued
+    const bool live = c0 + ch < p.channels;
+    const uint32_t c = live ? c0 + ch : p.channels - 1;
 
     if constexpr (NCO == 1)
         for (int i = lane; i < 513; i += kWave) tab[i] = p.sintab[i];
@@ -94,7 +97,7 @@ __global__ __launch_bounds__(64) void k_cw_fused(RxParams p, const TIn *__restri
     auto issue_loads = [&](uint32_t n_first) {          // chunk of 64 samples x 16 channels starting at n_first
 #pragma unroll
         for (int j = 0; j < 8; ++j)
-            raw[j] = CwRaw<TIn>::load(src, (size_t)(c0 + 2 * j + lch) * p.in_stride + n_first + lsm);
+            raw[j] = CwRaw<TIn>::load(src, (size_t)min(c0 + 2 * j + lch, p.channels - 1) * p.in_stride + n_first + lsm);
         if constexpr (NCO == 2) lo4 = *reinterpret_cast<const float4 *>(p.lo + n_first + lsm);
     };
     auto mix_write = [&](uint32_t n_first, int q) {      // NCO mix (real part) of the loaded chunk into the tile
@@ -110,7 +113,7 @@ __global__ __launch_bounds__(64) void k_cw_fused(RxParams p, const TIn *__restri
                 if constexpr (NCO == 2) {
                     la = make_float2(lo4.x, lo4.y); lb = make_float2(lo4.z, lo4.w);
                 } else {
-                    const uint32_t cj = c0 + 2 * j + lch;
+                    const uint32_t cj = min(c0 + 2 * j + lch, p.channels - 1);
                     const uint32_t phj = p.phase[cj], stj = p.step[cj];
                     la = nco_lo<0>(tab, phj + (n_first + lsm) * stj);
                     lb = nco_lo<0>(tab, phj + (n_first + lsm + 1) * stj);
@@ -198,7 +201,7 @@ __global__ __launch_bounds__(64) void k_cw_fused(RxParams p, const TIn *__restri
 #pragma unroll
             for (int h = 0; h < (BLK / 4 + 63) / 64; ++h) {
                 const int t = 4 * (lane + 64 * h);
-                if (t < BLK) {
+                if (t < BLK && c0 + r < p.channels) {
                     float4 v = *reinterpret_cast<const float4 *>(tile + r * RS + t);
                     v.x = v.x * g; v.y = v.y * g; v.z = v.z * g; v.w = v.w * g;
                     const size_t o = (size_t)(c0 + r) * p.out_stride + n0 + t;
@@ -215,6 +218,7 @@ __global__ __launch_bounds__(64) void k_cw_fused(RxParams p, const TIn *__restri
         }
         cw_lds_sync();
     }
+    if (!live) return;
     *reinterpret_cast<float4 *>(p.biq_state + ((size_t)c * kCwNs + s) * 4) = make_float4(x1, x2, y1, y2);
     if (s == 3) {
         if (p.agc) p.gain[c] = gain;
@@ -225,14 +229,13 @@ __global__ __launch_bounds__(64) void k_cw_fused(RxParams p, const TIn *__restri
 bool cw_fused_ok(const selenite_rx_config &g, uint32_t block_size)
 {
     return mode_is_cw(g.mode) && g.nd_taps == 0 && g.decim == 1 && g.nh_taps == 0 && g.n_biquad == kCwNs &&
-           g.block == 256 && g.channels % kCwCh == 0 &&
-           block_size % g.block == 0;
+           g.block == 256 && block_size % g.block == 0;
 }
 
 template <int NCO, typename TIn, typename TOut>
 static hipError_t cw_launch(const RxParams &p, const void *src, void *dst, hipStream_t st)
 {
-    hipLaunchKernelGGL((k_cw_fused<NCO, 256, TIn, TOut>), dim3(p.channels / kCwCh), dim3(64), 0, st, p,
+    hipLaunchKernelGGL((k_cw_fused<NCO, 256, TIn, TOut>), dim3((p.channels + kCwCh - 1) / kCwCh), dim3(64), 0, st, p,
                        static_cast<const TIn *>(src), static_cast<TOut *>(dst));
     return hipGetLastError();
 }

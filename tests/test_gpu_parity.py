@@ -598,3 +598,17 @@ def test_neighbour_shapes_of_cfg3_run_the_fused_kernels(nd, nh, arith):
     assert bits_equal(g.state()["dec_state"], o.state()["dec_state"])
     if arith != rc.ARITH_SPLIT16:
         assert_state_equal(g, o)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nch", [1, 15, 17, 37])
+def test_cw_fused_kernel_any_channel_count(nch):
+    """k_cw_fused packs 16 channels per wavefront; counts that are not a multiple of 16 run it too
+    (clamped loads, masked stores in the last workgroup)."""
+    spec = baseline_spec("cfg4", nch, ARITH_CMSIS)
+    g, o = gpu_rx(spec), CpuChain(spec, "orc")
+    assert g.kernel_name() == "k_cw_fused<4,256>"
+    for call in range(3):
+        iq = synth_iq(0, nch, 512 * call, 512)
+        assert bits_equal(g.process(iq), o.process(iq))
+    assert_state_equal(g, o)
