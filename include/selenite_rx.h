@@ -64,13 +64,15 @@ extern "C" {
 #define SELENITE_ARITH_FMA   1   /* same operation order, the multiply-add of the FIR tap loops fused (fmaf);
                                     NCO, biquad recurrence and AGC keep the reference rounding.  Bit-exact
                                     vs the oracle's fmaf restatement, <=1e-5 relative vs CMSIS */
-#define SELENITE_ARITH_SPLIT16 2 /* decimator as a split-precision matrix product on the 16-bit matrix cores:
-                                    samples and taps are split into f16 hi + lo parts, the three significant
-                                    products (hi*hi, hi*lo, lo*hi) are accumulated in f32 by MFMA.  NOT bit-exact
-                                    against any CPU order; <=1e-5 relative vs CMSIS per DSP block (measured
-                                    <2e-6).  Requires |mixed sample| < 255.  Everything outside the
-                                    decimator (and every configuration without the fused decimator) runs as
-                                    SELENITE_ARITH_FMA.  Streaming state stays exact f32. */
+#define SELENITE_ARITH_SPLIT16 2 /* the many-tap FIR of the shape as a split-precision matrix product on the 16-bit
+                                    matrix cores (decimator of the /4 shapes; Hilbert FIR of the no-decimator
+                                    shapes; TX interpolator): samples and taps are split into f16 hi + lo
+                                    parts, the three significant products (hi*hi, hi*lo, lo*hi) are
+                                    accumulated in f32 by MFMA.  NOT bit-exact against any CPU order; <=1e-5
+                                    relative vs CMSIS per DSP block (measured <2e-6).  Requires
+                                    |sample| < 255 at the FIR input (int16 slots always are).  Everything else,
+                                    and every configuration without such a kernel, runs as SELENITE_ARITH_FMA.
+                                    Streaming filter state stays exact f32. */
 
 typedef struct selenite_rx_config {
     uint32_t struct_size;     /* = sizeof(selenite_rx_config) */
