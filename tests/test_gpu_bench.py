@@ -49,3 +49,13 @@ def test_bench_q15_slots_cw_shape_and_global_gain():
     assert cw["config"]["kernel"] == "k_cw_fused<4,256>"
     g = run_bench("--global-gain", "--no-cpu-baseline", "--main-only")
     assert g["config"]["agc"] == "global" and g["config"]["kernel"] == "k_ssb_split16<256,4,63>"
+
+
+def test_pure_c_host_benchmark_agrees_with_the_python_driven_one():
+    """selenite-lite_amd/host/bench_rx.c: the north star's "host code stays C" call pattern, measured."""
+    exe = os.path.join(rc.PKG_DIR, "host", "bench_rx")
+    out = subprocess.run([exe, "4096", "4096", "20"], check=True, capture_output=True, text=True, timeout=300)
+    d = json.loads(out.stdout.strip().splitlines()[-1])
+    assert d["host"] == "C" and d["kernel"] == "k_ssb_split16<256,4,63>" and d["channels"] == 4096
+    derived = 4096 * 41952 / d["ms_per_call"] / 1e6
+    assert d["msamples_per_s"] > 0 and abs(d["algorithmic_GBps"] - derived) <= 0.02 * derived
