@@ -18,22 +18,29 @@ namespace srx {
 
 static __host__ __device__ inline uint32_t up4(uint32_t v) { return (v + 3u) & ~3u; }
 
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+// LDS layout of k_front_generic (offsets in floats).  Both rails travel together as (I, Q) pairs: one
+// ds_read_b64 and one packed MAC serve both.  The decimator input is kept POLYPHASE -- phase array
+// pp holds the samples u' = m*M + pp of the padded state [F zeros | nd-1 history | new] -- so that the
+// lanes of a wavefront (consecutive outputs j) read consecutive pairs S[pp][j + q] for tap k' = q*M + pp
+// instead of pairs M apart (bank conflicts M-fold in the flat layout).
 struct FrontLds {
-    uint32_t tab, cd, ch, cdl, sI, sQ, dI, dQ, total;   // offsets in floats
+    uint32_t tab, cd, chd, S, D, Hq, F, PL, total;
 };
 static __host__ __device__ inline FrontLds front_layout(uint32_t nd, uint32_t nh, uint32_t M, uint32_t P, bool nco)
 {
     FrontLds L;
-    const uint32_t Hd = nd ? nd - 1 : 0, Hh = nh ? nh - 1 : 0;
+    const uint32_t Hh = nh ? nh - 1 : 0;
+    L.Hq = nd ? (nd - 1 + M - 1) / M : 0;                 // history length per phase
+    L.F = nd ? L.Hq * M - (nd - 1) : 0;                   // leading pad of the padded state
+    L.PL = L.Hq + P;                                      // pairs per phase array
     uint32_t o = 0;
     L.tab = o; o += nco ? 516u : 0u;
     L.cd = o;  o += up4(nd);
-    L.ch = o;  o += up4(nh);
-    L.cdl = o; o += up4(nh);
-    L.sI = o;  o += up4(Hd + P * M);
-    L.sQ = o;  o += up4(Hd + P * M);
-    L.dI = o;  o += up4(Hh + P);
-    L.dQ = o;  o += up4(Hh + P);
+    L.chd = o; o += up4(2 * nh);                          // (delay tap, Hilbert tap) pairs
+    L.S = o;   o += nd ? up4(2 * M * L.PL) : 0u;
+    L.D = o;   o += up4(2 * (Hh + P));
     L.total = o;
     return L;
 }
@@ -44,15 +51,29 @@ size_t front_generic_lds_bytes(const RxParams &p)
 }
 
 // move s[adv .. adv+H) down to s[0 .. H) (history copy-back, arm_fir_decimate_f32.c:396-426)
-__device__ __forceinline__ void shift_down(float *s, uint32_t H, uint32_t adv, int lane)
+__device__ __forceinline__ void shift_down2(v2f *s, uint32_t H, uint32_t adv, int lane)
 {
     for (uint32_t base = 0; base < H; base += kWave) {
-        uint32_t i = base + lane;
-        float t = (i < H) ? s[adv + i] : 0.0f;
+        const uint32_t i = base + lane;
+        const v2f t = (i < H) ? s[adv + i] : v2f{ 0.0f, 0.0f };
         __syncthreads();
         if (i < H) s[i] = t;
         __syncthreads();
     }
+}
+
+template <int ARITH>
+__device__ __forceinline__ v2f mac2s(v2f acc, v2f w, float c)       // both rails, one tap
+{
+    const v2f c2 = { c, c };
+    if constexpr (ARITH == 1) return __builtin_elementwise_fma(w, c2, acc);
+    else { const v2f pr = w * c2; return acc + pr; }
+}
+template <int ARITH>
+__device__ __forceinline__ v2f mac2v(v2f acc, v2f w, v2f c2)        // (I, Q) with a tap of its own per rail
+{
+    if constexpr (ARITH == 1) return __builtin_elementwise_fma(w, c2, acc);
+    else { const v2f pr = w * c2; return acc + pr; }
 }
 
 template <int ARITH, typename TIn>
@@ -68,87 +89,90 @@ __global__ __launch_bounds__(64) void k_front_generic(RxParams p, const TIn *__r
     const bool use_fir = nh && !am;
     const bool upper = mode_is_upper(p.mode);
     const FrontLds L = front_layout(nd, nh, M, P, p.nco != 0);
-    float *tab = lds + L.tab, *cd = lds + L.cd, *ch = lds + L.ch, *cdl = lds + L.cdl;
-    float *sI = lds + L.sI, *sQ = lds + L.sQ, *dI = lds + L.dI, *dQ = lds + L.dQ;
+    float *tab = lds + L.tab, *cd = lds + L.cd;
+    v2f *chd = reinterpret_cast<v2f *>(lds + L.chd), *S = reinterpret_cast<v2f *>(lds + L.S), *D = reinterpret_cast<v2f *>(lds + L.D);
+    const uint32_t Hq = L.Hq, F = L.F, PL = L.PL;
 
     if (p.nco)
         for (uint32_t i = lane; i < 513; i += kWave) tab[i] = p.sintab[i];
     for (uint32_t i = lane; i < nd; i += kWave) cd[i] = p.dec_c[i];
-    for (uint32_t i = lane; i < nh; i += kWave) { ch[i] = p.hilb_c[i]; cdl[i] = p.delay_c[i]; }
-    for (uint32_t i = lane; i < Hd; i += kWave) {
-        sI[i] = p.dec_state[((size_t)c * 2 + 0) * Hd + i];
-        sQ[i] = p.dec_state[((size_t)c * 2 + 1) * Hd + i];
+    for (uint32_t i = lane; i < nh; i += kWave) chd[i] = v2f{ p.delay_c[i], p.hilb_c[i] };
+    for (uint32_t i = lane; i < Hd; i += kWave) {            // CMSIS state sample i sits at padded index i + F
+        const uint32_t u = i + F;
+        S[(u % M) * PL + u / M] = v2f{ p.dec_state[((size_t)c * 2 + 0) * Hd + i], p.dec_state[((size_t)c * 2 + 1) * Hd + i] };
     }
     if (use_fir)
-        for (uint32_t i = lane; i < Hh; i += kWave) {
-            dI[i] = p.fir_state[((size_t)c * 2 + 0) * Hh + i];
-            dQ[i] = p.fir_state[((size_t)c * 2 + 1) * Hh + i];
-        }
+        for (uint32_t i = lane; i < Hh; i += kWave)
+            D[i] = v2f{ p.fir_state[((size_t)c * 2 + 0) * Hh + i], p.fir_state[((size_t)c * 2 + 1) * Hh + i] };
     const uint32_t ph0 = p.nco ? p.phase[c] : 0u;
     const uint32_t step = p.nco ? p.step[c] : 0u;
-    const uint32_t fo = use_fir ? Hh : 0u;     // where new decimated samples start in dI/dQ
+    const uint32_t fo = use_fir ? Hh : 0u;     // where new decimated samples start in D
     __syncthreads();
 
     const size_t in_base = (size_t)c * p.in_stride, out_base = (size_t)c * p.out_stride;
     for (uint32_t o0 = 0; o0 < p.nout; o0 += P) {
         const uint32_t cnt = (p.nout - o0 < P) ? (p.nout - o0) : P;
         const uint32_t tin = cnt * M, n0 = o0 * M;
-        // 1. load + NCO mix
+        // 1. load + NCO mix; new sample i of the pass is padded-state index Hq*M + i
         for (uint32_t i = lane; i < tin; i += kWave) {
             float2 v = load_iq(src, in_base + n0 + i);
             if (p.nco) v = cmul<ARITH>(v, nco_lo<ARITH>(tab, ph0 + (n0 + i) * step));
-            sI[Hd + i] = v.x;
-            sQ[Hd + i] = v.y;
+            if (nd) S[(i % M) * PL + Hq + i / M] = v2f{ v.x, v.y };
+            else D[fo + i] = v2f{ v.x, v.y };
         }
         __syncthreads();
-        // 2. decimating FIR, both rails (arm_fir_decimate_f32: y[j] = sum_k c[k] s[jM+k])
-        for (uint32_t j = lane; j < cnt; j += kWave) {
-            float aI, aQ;
-            if (nd) {
-                aI = 0.0f; aQ = 0.0f;
-                const uint32_t b = j * M;
+        // 2. decimating FIR on both rails (arm_fir_decimate_f32: y[j] = sum_k c[k] s[jM+k]), four outputs per
+        //    lane share every tap fetch; taps ascending for every output
+        if (nd) {
+            for (uint32_t j0 = 0; j0 < cnt; j0 += 4 * kWave) {
+                v2f acc[4] = { { 0.0f, 0.0f }, { 0.0f, 0.0f }, { 0.0f, 0.0f }, { 0.0f, 0.0f } };
+                const uint32_t jb = j0 + lane;
+                uint32_t pp = F % M, q = F / M;
+                const v2f *row = S + pp * PL + q + jb;
                 for (uint32_t k = 0; k < nd; ++k) {
                     const float ck = cd[k];
-                    aI = mac<ARITH>(aI, sI[b + k], ck);
-                    aQ = mac<ARITH>(aQ, sQ[b + k], ck);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[r] = mac2s<ARITH>(acc[r], row[64 * r], ck);   // slack reads stay inside S/D
+                    if (++pp == M) { pp = 0; row += 1 - (M - 1) * PL; } else row += PL;
                 }
-            } else {
-                aI = sI[j]; aQ = sQ[j];
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (jb + 64 * r < cnt) D[fo + jb + 64 * r] = acc[r];
             }
-            dI[fo + j] = aI;
-            dQ[fo + j] = aQ;
+            __syncthreads();
         }
-        __syncthreads();
         // 3. demodulator
         for (uint32_t j = lane; j < cnt; j += kWave) {
             float a;
             if (am) {
-                a = cmag<ARITH>(dI[fo + j], dQ[fo + j]);
+                const v2f d = D[fo + j];
+                a = cmag<ARITH>(d.x, d.y);
             } else if (use_fir) {
-                float i2 = 0.0f, q2 = 0.0f;            // arm_fir_f32: y[n] = sum_k c[k] s[n+k]
-                for (uint32_t k = 0; k < nh; ++k) {
-                    i2 = mac<ARITH>(i2, dI[j + k], cdl[k]);
-                    q2 = mac<ARITH>(q2, dQ[j + k], ch[k]);
-                }
-                a = upper ? (i2 - q2) : (i2 + q2);     // arm_sub_f32 / arm_add_f32
+                v2f acc = { 0.0f, 0.0f };                   // arm_fir_f32 x2: y[n] = sum_k c[k] s[n+k]; I: delay taps, Q: Hilbert taps
+#pragma unroll 4
+                for (uint32_t k = 0; k < nh; ++k) acc = mac2v<ARITH>(acc, D[j + k], chd[k]);
+                a = upper ? (acc.x - acc.y) : (acc.x + acc.y);     // arm_sub_f32 / arm_add_f32
             } else {
-                a = dI[j];
+                a = D[j].x;
             }
             audio[out_base + o0 + j] = a;
         }
         __syncthreads();
         // 4. history copy-back
-        if (Hd) { shift_down(sI, Hd, tin, lane); shift_down(sQ, Hd, tin, lane); }
-        if (use_fir && Hh) { shift_down(dI, Hh, cnt, lane); shift_down(dQ, Hh, cnt, lane); }
+        if (Hq)
+            for (uint32_t ppi = 0; ppi < M; ++ppi) shift_down2(S + ppi * PL, Hq, cnt, lane);
+        if (use_fir && Hh) shift_down2(D, Hh, cnt, lane);
     }
     for (uint32_t i = lane; i < Hd; i += kWave) {
-        p.dec_state[((size_t)c * 2 + 0) * Hd + i] = sI[i];
-        p.dec_state[((size_t)c * 2 + 1) * Hd + i] = sQ[i];
+        const uint32_t u = i + F;
+        const v2f v = S[(u % M) * PL + u / M];
+        p.dec_state[((size_t)c * 2 + 0) * Hd + i] = v.x;
+        p.dec_state[((size_t)c * 2 + 1) * Hd + i] = v.y;
     }
     if (use_fir)
         for (uint32_t i = lane; i < Hh; i += kWave) {
-            p.fir_state[((size_t)c * 2 + 0) * Hh + i] = dI[i];
-            p.fir_state[((size_t)c * 2 + 1) * Hh + i] = dQ[i];
+            p.fir_state[((size_t)c * 2 + 0) * Hh + i] = D[i].x;
+            p.fir_state[((size_t)c * 2 + 1) * Hh + i] = D[i].y;
         }
     if (p.nco && lane == 0) p.phase[c] = ph0 + p.block_size * step;
 }
