@@ -12,6 +12,8 @@
 //                     arm_scale, optional arm_float_to_q15 on the store
 #include "rx_internal.h"
 
+#include <type_traits>
+
 #pragma clang fp contract(off)
 
 namespace srx {
@@ -124,20 +126,27 @@ __global__ __launch_bounds__(64) void k_front_generic(RxParams p, const TIn *__r
         // 2. decimating FIR on both rails (arm_fir_decimate_f32: y[j] = sum_k c[k] s[jM+k]), four outputs per
         //    lane share every tap fetch; taps ascending for every output
         if (nd) {
-            for (uint32_t j0 = 0; j0 < cnt; j0 += 4 * kWave) {
-                v2f acc[4] = { { 0.0f, 0.0f }, { 0.0f, 0.0f }, { 0.0f, 0.0f }, { 0.0f, 0.0f } };
+            auto run = [&](auto rc, uint32_t j0) {            // R outputs per lane: j0 + lane + 64 r
+                constexpr int R = decltype(rc)::value;
+                v2f acc[R];
+#pragma unroll
+                for (int r = 0; r < R; ++r) acc[r] = v2f{ 0.0f, 0.0f };
                 const uint32_t jb = j0 + lane;
-                uint32_t pp = F % M, q = F / M;
-                const v2f *row = S + pp * PL + q + jb;
+                uint32_t pp = F % M;
+                const v2f *row = S + pp * PL + F / M + jb;
                 for (uint32_t k = 0; k < nd; ++k) {
                     const float ck = cd[k];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) acc[r] = mac2s<ARITH>(acc[r], row[64 * r], ck);   // slack reads stay inside S/D
+                    for (int r = 0; r < R; ++r) acc[r] = mac2s<ARITH>(acc[r], row[64 * r], ck);   // slack reads stay inside LDS
                     if (++pp == M) { pp = 0; row += 1 - (M - 1) * PL; } else row += PL;
                 }
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
+                for (int r = 0; r < R; ++r)
                     if (jb + 64 * r < cnt) D[fo + jb + 64 * r] = acc[r];
+            };
+            for (uint32_t j0 = 0; j0 < cnt;) {
+                if (cnt - j0 > kWave) { run(std::integral_constant<int, 4>{}, j0); j0 += 4 * kWave; }
+                else { run(std::integral_constant<int, 1>{}, j0); j0 += kWave; }
             }
             __syncthreads();
         }
