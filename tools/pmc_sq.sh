@@ -18,7 +18,7 @@ import csv, glob, sys, collections
 agg=collections.defaultdict(list)
 for f in glob.glob(sys.argv[1]+"/p*/*counter_collection.csv"):
     for r in csv.DictReader(open(f)):
-        if "k_ssb" in r["Kernel_Name"] or "k_cw" in r["Kernel_Name"]:
+        if any(t in r["Kernel_Name"] for t in ("k_ssb", "k_cw", "k_hilb", "k_tx")):
             agg[(r["Kernel_Name"].split("(")[0][-40:], r["Counter_Name"])].append(float(r["Counter_Value"]))
 for k in sorted(agg): print(k[0], k[1], sum(agg[k])/len(agg[k]))
 PY
