@@ -55,10 +55,38 @@ __device__ __forceinline__ void store_iq(int16_t *p, size_t i, float re, float i
     reinterpret_cast<short2 *>(p)[i] = v;
 }
 
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+static __host__ __device__ inline uint32_t up4(uint32_t v) { return (v + 3u) & ~3u; }
+
+// LDS of k_tx_generic, in floats: sine table | interpolator taps | (delay, Hilbert) tap pairs |
+// (delay-instance, Hilbert-instance) state pairs | (I, Q) interpolator state pairs.  Pairs: one
+// ds_read_b64 and one packed MAC serve both members.
+struct TxLds { uint32_t tab, ci, chd, H, Z, total; };
+static __host__ __device__ inline TxLds tx_layout(uint32_t ni, uint32_t nh, uint32_t P, uint32_t nb)
+{
+    TxLds L;
+    const uint32_t nh1 = nh ? nh - 1 : 0;
+    uint32_t o = 0;
+    L.tab = o; o += 516;
+    L.ci = o;  o += up4(ni);
+    L.chd = o; o += up4(2 * nh);
+    L.H = o;   o += up4(2 * (nh1 + nb));
+    L.Z = o;   o += up4(2 * ((P - 1) + nb));
+    L.total = o;
+    return L;
+}
+
 size_t tx_lds_bytes(const TxParams &p)
 {
-    const size_t nh1 = p.nh ? p.nh - 1 : 0;
-    return sizeof(float) * (516 + 2 * (nh1 + p.block) + 2 * ((p.P - 1) + p.block));
+    return sizeof(float) * tx_layout(p.ni, p.nh, p.P, p.block).total;
+}
+
+template <int ARITH>
+__device__ __forceinline__ v2f tx_mac2(v2f acc, v2f w, v2f c2)
+{
+    if constexpr (ARITH == 1) return __builtin_elementwise_fma(w, c2, acc);
+    else { const v2f pr = w * c2; return acc + pr; }
 }
 
 template <int ARITH, typename TIn, typename TOut>
@@ -68,13 +96,19 @@ __global__ __launch_bounds__(64) void k_tx_generic(TxParams p, const TIn *__rest
     const int lane = threadIdx.x;
     const uint32_t c = blockIdx.x;
     const uint32_t nb = p.block, L = p.L, P = p.P, nh = p.nh, nh1 = nh ? nh - 1 : 0, p1 = P - 1;
-    float *tab = lds;
-    float *HI = lds + 516, *HQ = HI + (nh1 + nb);            // arm_fir_f32 pState of the delay / Hilbert instance
-    float *ZI = HQ + (nh1 + nb), *ZQ = ZI + (p1 + nb);       // arm_fir_interpolate_f32 pState of the I / Q rail
+    const TxLds Y = tx_layout(p.ni, nh, P, nb);
+    float *tab = lds + Y.tab, *ci = lds + Y.ci;
+    v2f *chd = reinterpret_cast<v2f *>(lds + Y.chd);             // (delay tap, Hilbert tap)
+    v2f *H = reinterpret_cast<v2f *>(lds + Y.H);                 // arm_fir_f32 pState of the (delay, Hilbert) instances
+    v2f *Z = reinterpret_cast<v2f *>(lds + Y.Z);                 // arm_fir_interpolate_f32 pState of the (I, Q) rails
     if (p.nco)
         for (int i = lane; i < 513; i += kWave) tab[i] = p.sintab[i];
-    for (uint32_t i = lane; i < 2 * nh1; i += kWave) (i < nh1 ? HI : HQ - nh1)[i] = p.fir_state[(size_t)c * 2 * nh1 + i];
-    for (uint32_t i = lane; i < 2 * p1; i += kWave) (i < p1 ? ZI : ZQ - p1)[i] = p.int_state[(size_t)c * 2 * p1 + i];
+    for (uint32_t i = lane; i < p.ni; i += kWave) ci[i] = p.ic[i];
+    for (uint32_t i = lane; i < nh; i += kWave) chd[i] = v2f{ p.dc[i], p.hc[i] };
+    for (uint32_t i = lane; i < nh1; i += kWave)
+        H[i] = v2f{ p.fir_state[(size_t)c * 2 * nh1 + i], p.fir_state[(size_t)c * 2 * nh1 + nh1 + i] };
+    for (uint32_t i = lane; i < p1; i += kWave)
+        Z[i] = v2f{ p.int_state[(size_t)c * 2 * p1 + i], p.int_state[(size_t)c * 2 * p1 + p1 + i] };
     float gain = p.alc ? p.gain[c] : 1.0f;
     const uint32_t ph0 = p.nco ? p.phase[c] : 0u, step = p.nco ? p.step[c] : 0u;
     const bool am = p.mode == SELENITE_MODE_AM, up = mode_is_upper(p.mode);
@@ -93,84 +127,83 @@ __global__ __launch_bounds__(64) void k_tx_generic(TxParams p, const TIn *__rest
         for (uint32_t i = lane; i < nb; i += kWave) {
             float a = load_audio(src, ib + i);
             if (p.alc) a = a * gain;
-            if (nh) { HI[nh1 + i] = a; HQ[nh1 + i] = a; }
-            else { ZI[p1 + i] = a; ZQ[p1 + i] = 0.0f; }
+            if (nh) H[nh1 + i] = v2f{ a, a };
+            else Z[p1 + i] = v2f{ a, 0.0f };
         }
         __syncthreads();
-        // 2.-3. Hilbert pair (arm_fir_f32 x2) and sideband select
+        // 2.-3. Hilbert pair (arm_fir_f32 x2 as one packed tap loop) and sideband select
         if (nh) {
             for (uint32_t i = lane; i < nb; i += kWave) {
-                float ri = 0.0f, rq = 0.0f;
-                for (uint32_t k = 0; k < nh; ++k) {
-                    ri = mac<ARITH>(ri, HI[i + k], p.dc[k]);
-                    rq = mac<ARITH>(rq, HQ[i + k], p.hc[k]);
-                }
-                ZI[p1 + i] = ri;
-                ZQ[p1 + i] = rq;
+                v2f r = { 0.0f, 0.0f };
+#pragma unroll 4
+                for (uint32_t k = 0; k < nh; ++k) r = tx_mac2<ARITH>(r, H[i + k], chd[k]);
+                Z[p1 + i] = r;
             }
             __syncthreads();
-            float ti = 0.0f, tq = 0.0f;                        // history tails: nh1 <= ... moved in 64-wide slices
-            for (uint32_t i0 = 0; i0 < nh1; i0 += kWave) {
+            for (uint32_t i0 = 0; i0 < nh1; i0 += kWave) {     // history tails, 64-wide slices
                 const uint32_t i = i0 + lane;
-                if (i < nh1) { ti = HI[nb + i]; tq = HQ[nb + i]; }
+                const v2f t = (i < nh1) ? H[nb + i] : v2f{ 0.0f, 0.0f };
                 __syncthreads();
-                if (i < nh1) { HI[i] = ti; HQ[i] = tq; }
+                if (i < nh1) H[i] = t;
                 __syncthreads();
             }
         }
         for (uint32_t i = lane; i < nb; i += kWave) {
-            float ri = ZI[p1 + i], rq = ZQ[p1 + i];
+            v2f z = Z[p1 + i];
             if (am) {                                          // arm_scale_f32(0.5) then arm_offset_f32(0.5); Q = 0
-                const float t = ri * 0.5f;
-                ri = t + 0.5f;
-                rq = 0.0f;
+                const float t = z.x * 0.5f;
+                z = v2f{ t + 0.5f, 0.0f };
             } else if (!up) {
-                rq = -rq;                                      // arm_negate_f32
+                z.y = -z.y;                                    // arm_negate_f32
             }
-            ZI[p1 + i] = ri;
-            ZQ[p1 + i] = rq;
+            Z[p1 + i] = z;
         }
         __syncthreads();
-        // 4.-5. interpolator on both rails, NCO up-mix, store
+        // 4.-5. interpolator on both rails (one packed MAC per tap), NCO up-mix, store
         const size_t ob = ((size_t)c * p.block_size + (size_t)b * nb) * L;
         for (uint32_t o = lane; o < nb * L; o += kWave) {
             const uint32_t n = o / L, phs = o % L;
-            float ui, uq;
+            v2f u;
             if (p.ni) {
-                ui = 0.0f; uq = 0.0f;
-                const float *cf = p.ic + (L - 1 - phs);
+                u = v2f{ 0.0f, 0.0f };
+                const float *cf = ci + (L - 1 - phs);
+#pragma unroll 4
                 for (uint32_t t = 0; t < P; ++t) {
                     const float cc = cf[t * L];
-                    ui = mac<ARITH>(ui, ZI[n + t], cc);
-                    uq = mac<ARITH>(uq, ZQ[n + t], cc);
+                    u = tx_mac2<ARITH>(u, Z[n + t], v2f{ cc, cc });
                 }
             } else {
-                ui = ZI[n]; uq = ZQ[n];
+                u = Z[n];
             }
-            float re = ui, im = uq;
+            float re = u.x, im = u.y;
             if (p.nco) {
                 const uint32_t phase = ph0 + (uint32_t)(b * nb * L + o) * step;
                 const float x = (float)(phase >> 8) * kNcoK;
                 const float lc = cos_f32<0>(tab, x), ls = sin_f32<0>(tab, x);
-                const float2 r = cmul<0>(make_float2(ui, uq), make_float2(lc, ls));
+                const float2 r = cmul<0>(make_float2(u.x, u.y), make_float2(lc, ls));
                 re = r.x; im = r.y;
             }
             store_iq(dst, ob + o, re, im);
         }
         __syncthreads();
         if (p.ni) {
-            float ti = 0.0f, tq = 0.0f;
             for (uint32_t i0 = 0; i0 < p1; i0 += kWave) {
                 const uint32_t i = i0 + lane;
-                if (i < p1) { ti = ZI[nb + i]; tq = ZQ[nb + i]; }
+                const v2f t = (i < p1) ? Z[nb + i] : v2f{ 0.0f, 0.0f };
                 __syncthreads();
-                if (i < p1) { ZI[i] = ti; ZQ[i] = tq; }
+                if (i < p1) Z[i] = t;
                 __syncthreads();
             }
         }
     }
-    for (uint32_t i = lane; i < 2 * nh1; i += kWave) p.fir_state[(size_t)c * 2 * nh1 + i] = (i < nh1 ? HI : HQ - nh1)[i];
-    for (uint32_t i = lane; i < 2 * p1; i += kWave) p.int_state[(size_t)c * 2 * p1 + i] = (i < p1 ? ZI : ZQ - p1)[i];
+    for (uint32_t i = lane; i < nh1; i += kWave) {
+        p.fir_state[(size_t)c * 2 * nh1 + i] = H[i].x;
+        p.fir_state[(size_t)c * 2 * nh1 + nh1 + i] = H[i].y;
+    }
+    for (uint32_t i = lane; i < p1; i += kWave) {
+        p.int_state[(size_t)c * 2 * p1 + i] = Z[i].x;
+        p.int_state[(size_t)c * 2 * p1 + p1 + i] = Z[i].y;
+    }
     if (lane == 0) {
         if (p.alc) p.gain[c] = gain;
         if (p.nco) p.phase[c] = ph0 + p.block_size * L * step;
