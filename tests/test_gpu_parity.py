@@ -612,3 +612,38 @@ def test_cw_fused_kernel_any_channel_count(nch):
         iq = synth_iq(0, nch, 512 * call, 512)
         assert bits_equal(g.process(iq), o.process(iq))
     assert_state_equal(g, o)
+
+
+@pytest.mark.gpu
+def test_instances_run_concurrently_on_their_own_streams():
+    """Distinct instances are independent (SURVEY.md 8b "Threading"): each has its own stream; calls
+    issued back to back without synchronisation in between must give what sequential runs give."""
+    import selenite_rx as sr
+    nch, bs = 512, 2048
+    specs = [baseline_spec("cfg3", nch, ARITH_CMSIS), baseline_spec("cfg4", nch, ARITH_CMSIS),
+             baseline_spec("cfg2", nch, ARITH_FMA), baseline_spec("cfg3", nch, ARITH_FMA)]
+    inst = [gpu_rx(s) for s in specs]
+    ring, oring = sr.Ring(nch), rc.OracleRing(nch)
+    iq = synth_iq(0, nch, 0, bs)
+    d_in = sr.DeviceBuffer(iq.nbytes)
+    d_in.upload(iq)
+    outs = [sr.DeviceBuffer(nch * (bs // s.decim) * 4) for s in specs]
+    pkt = (np.arange(nch * 96, dtype=np.int64).reshape(nch, 96) * 131 % 65536 - 32768).astype(np.int16)
+    d_pkt = sr.DeviceBuffer(pkt.nbytes)
+    d_pkt.upload(pkt)
+    for rep in range(3):                                   # three rounds, nothing synchronised inside a round
+        for g, d_o in zip(inst, outs):
+            g.process_device(d_in.ptr, d_o.ptr, bs)
+        sr.lib().selenite_ring_in_write_device(ring.h, d_pkt.ptr, 96)
+        for g in inst:
+            g.sync(); g.check()
+        oring.in_write(pkt)
+    for g, s, d_o in zip(inst, specs, outs):
+        o = CpuChain(s, "orc")
+        want = None
+        for rep in range(3):
+            want = o.process(iq)
+        assert bits_equal(d_o.download((nch, bs // s.decim), np.float32), want), g.kernel_name()
+    ring.L.selenite_ring_sync(ring.h)
+    sg, so = ring.state(), oring.state()
+    assert all(np.array_equal(sg[k], so[k]) for k in so)
