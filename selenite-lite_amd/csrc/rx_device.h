@@ -168,6 +168,39 @@ __device__ __forceinline__ float wave_max(float v)
     return v;
 }
 
+// DPP row rotate inside each row of 16 lanes: lane l receives lane (l & ~15) | ((l + n) & 15)
+template <int N>
+__device__ __forceinline__ uint32_t row_ror(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x120 + N, 0xf, 0xf, false);
+}
+// maximum over each row of 16 lanes, left in every lane of the row (4 v_max_*_dpp, no LDS round trip)
+__device__ __forceinline__ uint32_t row16_umax(uint32_t v)
+{
+    v = max(v, row_ror<8>(v));
+    v = max(v, row_ror<4>(v));
+    v = max(v, row_ror<2>(v));
+    v = max(v, row_ror<1>(v));
+    return v;
+}
+__device__ __forceinline__ float row16_fmax(float v)
+{
+    v = fmaxf(v, __uint_as_float(row_ror<8>(__float_as_uint(v))));
+    v = fmaxf(v, __uint_as_float(row_ror<4>(__float_as_uint(v))));
+    v = fmaxf(v, __uint_as_float(row_ror<2>(__float_as_uint(v))));
+    v = fmaxf(v, __uint_as_float(row_ror<1>(__float_as_uint(v))));
+    return v;
+}
+// wave-uniform maximum of non-negative floats through their bit patterns (monotone for x >= 0): the
+// cross-row step runs on the scalar ALU
+__device__ __forceinline__ uint32_t wave_umax_bits(float nonneg)
+{
+    const uint32_t v = row16_umax(__float_as_uint(nonneg));
+    const uint32_t a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16);
+    const uint32_t c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
+    return max(max(a, b), max(c, d));
+}
+
 // sample loaders: f32 slot or q15 slot (int16 interleaved I/Q, dsp_if.c:286-289)
 __device__ __forceinline__ float2 load_iq(const float *p, size_t i)
 {

@@ -1,0 +1,250 @@
+// rx_fused_common.h -- geometry, argument block and device helpers shared by the fused SSB kernels
+// (rx_fused.hip: k_ssb_fused / k_ssb_mfma; rx_split16.hip: the SELENITE_ARITH_SPLIT16 kernels).
+#pragma once
+#include "rx_internal.h"
+
+#pragma clang fp contract(off)
+
+namespace srx {
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+template <int ND, int M, int NH>
+struct Geo {
+    static constexpr int P = 256;                                   // decimated outputs per pass
+    static constexpr int T = P * M;                                 // complex inputs per pass
+    static constexpr int HQ = ND ? (ND - 1 + M - 1) / M : 0;        // decimator history, phase-samples
+    static constexpr int HQ4 = (HQ + 3) & ~3;
+    static constexpr int F = ND ? (HQ4 * M + 1 - ND) : 0;           // leading zero-pad taps
+    static constexpr int NCQ = HQ4 * M + 1;                         // padded taps cq[0 .. HQ4*M]
+    static constexpr int NCR = (NCQ + 63) / 64;                     // coefficient VGPRs per lane
+    static constexpr int PLEN = HQ4 + P;                            // complex elements per phase
+    // Polyphase image: per phase p an array of (I,Q) float2 elements; each group of 4 elements
+    // (the 4 outputs one lane owns) occupies THREE 16-byte slots (48 B, last slot unused), so the
+    // ds_read_b128 of lane l at compile-time offset o is at 48*l + imm: lane stride 3 slots is
+    // conflict-free for every b128 lane group and needs no per-read address arithmetic.
+    static constexpr int PSF = 12 * (PLEN / 4);                     // floats per phase array
+    static constexpr int HH = NH ? NH - 1 : 0;                      // Hilbert history
+    static constexpr int HH4 = (HH + 3) & ~3;
+    static constexpr int FH = HH4 - HH;                             // leading pad of the FIR window
+    static constexpr int DLEN = HH4 + P + 4;
+    static constexpr int oTab = 0;
+    static constexpr int oS = 516;                                  // [M][PSF]          (ND > 0)
+    static constexpr int oD = oS + (ND ? M * PSF : 0);              // [2 rails][DLEN]
+    static constexpr int total = oD + 2 * DLEN;
+    __host__ __device__ static constexpr int elem(int idx) { return 12 * (idx >> 2) + 2 * (idx & 3); }
+};
+
+struct FusedArgs {
+    const float *cq;        // padded decimator taps: cq[k'] = dec[k' - F] (k' >= F), else 0; 64*NCR floats
+    uint32_t delay_idx;     // index of the unit tap in delay_coeffs
+    uint32_t upper;         // 1: audio = I' - Q'   0: audio = I' + Q'
+    uint32_t am;            // 1: audio = |I + jQ| (arm_cmplx_mag_f32); the Hilbert pair and its state are untouched
+    uint32_t group;         // lanes per DSP block = (block / M) / 4
+    uint32_t grp_shift;     // k_ssb_mfma: phase group of a wave = (wave >> grp_shift) & 1
+    const void *btab16;     // k_ssb_split16: Toeplitz operand, f16 hi/lo fragments
+    float split_post;       // k_hilb_split16: exact power-of-two rescale of the MFMA result
+    int split_sc;           // k_ssb_split16: the taps were scaled by 2^split_sc before their f16 hi/lo split
+    unsigned long long *dbg; // diagnostics (SELENITE_RX_DEBUG_TIMING): s_memtime stamps of workgroup 0, else NULL
+};
+
+// Workgroups of these kernels are ONE wavefront: LDS instructions of a wave execute in issue order,
+// so a store is visible to any lane's later load without s_barrier.  What is needed is only that
+// the compiler keeps the program order of LDS accesses: a wavefront-scope fence (emits nothing)
+// plus the wave_barrier scheduling fence.  __syncthreads() would add "s_waitcnt vmcnt(0)", which
+// drains the next pass's HBM prefetch and stalls the wave for a full memory latency per pass.
+__device__ __forceinline__ void wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Prologue fill of N LDS words from HBM state.  `index(i)` is the element of `base` that slot i takes,
+// negative for slots in front of the state (they are zero).  Loads are unconditional from a clamped
+// index and masked afterwards: a conditional load becomes an exec-masked branch with its own
+// s_waitcnt vmcnt(0), and the N/64 round trips of a wavefront then queue behind one another
+// (measured: 8 serialized trips = 25 % of a workgroup's lifetime).  All loads are issued before the
+// first store.
+template <int N, typename IndexFn, typename StoreFn>
+__device__ __forceinline__ void batched_fill(int lane, const float *__restrict__ base, IndexFn index, StoreFn store)
+{
+    constexpr int NI = (N + 63) / 64;
+    float v[NI];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        const int i = (N % 64 == 0) ? j * 64 + lane : min(j * 64 + lane, N - 1);
+        const int e = index(i);
+        const float x = base[e < 0 ? 0 : e];
+        v[j] = e < 0 ? 0.0f : x;
+    }
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        const int i = j * 64 + lane;
+        if (N % 64 == 0 || i < N) store(i, v[j]);
+    }
+}
+
+__device__ __forceinline__ float f4get(const float4 &v, int e)
+{
+    return e == 0 ? v.x : (e == 1 ? v.y : (e == 2 ? v.z : v.w));
+}
+
+// (I,Q) += (I,Q) * c  -- one v_pk_fma_f32, or v_pk_mul_f32 + v_pk_add_f32 in the CMSIS arithmetic
+template <int ARITH>
+__device__ __forceinline__ v2f mac2(v2f acc, v2f w, float c)
+{
+    const v2f c2 = { c, c };
+    if constexpr (ARITH == 1) {
+        return __builtin_elementwise_fma(w, c2, acc);
+    } else {
+        const v2f p = w * c2;
+        return acc + p;
+    }
+}
+
+// arm_cmplx_mult_cmplx_f32 on one (re, im) register pair: (a*c - b*d, a*d + b*c) with the four
+// products and the two sums rounded separately (ComplexMathFunctions/arm_cmplx_mult_cmplx_f32.c:186-187).
+// Three packed instructions: v_pk_mul_f32 x2 (operand halves picked by op_sel) + v_pk_add_f32.
+__device__ __forceinline__ v2f cmul_pk(v2f A, v2f L)
+{
+    // The compiler does not fold the half swaps into op_sel (it emits v_mov/v_xor pairs), hence asm:
+    //   t1 = (a*c, a*d)   t2 = (b*d, b*c)   r = (t1.lo - t2.lo, t1.hi + t2.hi)
+    // s_nop: packed-f32 results need one wait state before a non-packed consumer on gfx950 (the
+    // compiler inserts the same s_nop in its own code; it cannot see into the asm block).
+    v2f t1, t2, r;
+    asm("v_pk_mul_f32 %0, %3, %4 op_sel_hi:[0,1]\n\t"
+        "v_pk_mul_f32 %1, %3, %4 op_sel:[1,1] op_sel_hi:[1,0]\n\t"
+        "s_nop 0\n\t"
+        "v_pk_add_f32 %2, %0, %1 neg_lo:[0,1]\n\t"
+        "s_nop 0"
+        : "=&v"(t1), "=&v"(t2), "=v"(r)
+        : "v"(A), "v"(L));
+    return r;
+}
+
+// two complex multiplies in one block: the dependent v_pk_add_f32 of each sits three instructions behind
+// its v_pk_mul_f32 pair, so only the block's last result needs the wait state before a non-packed consumer
+__device__ __forceinline__ void cmul_pk2(v2f A, v2f B, v2f LA, v2f LB, v2f &ra, v2f &rb)
+{
+    v2f t1, t2, t3, t4;
+    asm("v_pk_mul_f32 %0, %6, %8 op_sel_hi:[0,1]\n\t"
+        "v_pk_mul_f32 %1, %6, %8 op_sel:[1,1] op_sel_hi:[1,0]\n\t"
+        "v_pk_mul_f32 %2, %7, %9 op_sel_hi:[0,1]\n\t"
+        "v_pk_mul_f32 %3, %7, %9 op_sel:[1,1] op_sel_hi:[1,0]\n\t"
+        "v_pk_add_f32 %4, %0, %1 neg_lo:[0,1]\n\t"
+        "v_pk_add_f32 %5, %2, %3 neg_lo:[0,1]\n\t"
+        "s_nop 0"
+        : "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4), "=&v"(ra), "=&v"(rb)
+        : "v"(A), "v"(B), "v"(LA), "v"(LB));
+}
+
+// raw global loads: two complex samples per lane per instruction
+template <typename TIn> struct Raw;
+template <> struct Raw<float> {
+    typedef float4 type;
+    static __device__ __forceinline__ type load(const float *src, size_t cplx_index)
+    {
+        // streamed once: non-temporal, so the shared LO / coefficient tables keep their cache lines
+        typedef float f4v __attribute__((ext_vector_type(4)));
+        const f4v v = __builtin_nontemporal_load(reinterpret_cast<const f4v *>(src + 2 * cplx_index));
+        return make_float4(v.x, v.y, v.z, v.w);
+    }
+    static __device__ __forceinline__ void unpack(const type &r, float2 &a, float2 &b)
+    {
+        a = make_float2(r.x, r.y); b = make_float2(r.z, r.w);
+    }
+};
+template <> struct Raw<int16_t> {
+    typedef short4 type;
+    static __device__ __forceinline__ type load(const int16_t *src, size_t cplx_index)
+    {
+        return *reinterpret_cast<const short4 *>(src + 2 * cplx_index);
+    }
+    static __device__ __forceinline__ void unpack(const type &r, float2 &a, float2 &b)
+    {
+        a = make_float2(q15_to_float(r.x), q15_to_float(r.y));
+        b = make_float2(q15_to_float(r.z), q15_to_float(r.w));
+    }
+};
+
+// arm_fir_f32 with type-III Hilbert taps for 4 adjacent outputs n = 4*lane + r.
+// dq: decimated Q rail, new samples start at HH4.  y[n] = sum_k h[k] * dq[n + k + FH].
+// The taps live lane-distributed in hreg (lane k of hreg[k>>6] = h[k]), loaded ONCE per kernel and
+// fetched by v_readlane: reading them from memory inside the pass loop costs an L2 round trip per
+// pass (the compiler cannot hoist the loads above the audio stores it must assume may alias).
+// one read-and-accumulate step t of the Hilbert FIR; tap(k) yields h[k] as a wave-uniform value
+template <int ARITH, int ND, int M, int NH, typename TapFn>
+__device__ __forceinline__ void hilbert_tstep(int t, const float *dq, int lane, TapFn tap, float (&acc)[4])
+{
+    using G = Geo<ND, M, NH>;
+    constexpr int C = (NH - 1) / 2;
+    const float4 W = *reinterpret_cast<const float4 *>(dq + 4 * lane + 4 * t);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float w = f4get(W, e);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int k = 4 * t + e - r - G::FH;
+            if (k < 0 || k >= NH || (((k - C) & 1) == 0)) continue;   // structural zeros
+            acc[r] = mac<ARITH>(acc[r], w, tap(k));
+        }
+    }
+}
+template <int ND, int M, int NH>
+struct HilbertSteps { static constexpr int N = (Geo<ND, M, NH>::HH4 + 3) / 4 + 1; };   // t = 0 .. N-1
+
+template <int ARITH, int ND, int M, int NH>
+__device__ __forceinline__ void hilbert_quad(const float *dq, int lane, const float (&hreg)[(NH + 63) / 64 ? (NH + 63) / 64 : 1],
+                                             float (&acc)[4])
+{
+#pragma unroll
+    for (int t = 0; t < HilbertSteps<ND, M, NH>::N; ++t)
+        hilbert_tstep<ARITH, ND, M, NH>(t, dq, lane, [&](int k) {
+            return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(hreg[k >> 6]), k & 63)); }, acc);
+}
+
+
+// ---- SELENITE_ARITH_SPLIT16 geometry (rx_split16.hip; the host-side table builder in rx_fused.hip
+// needs KS and the fragment order) ----
+template <int NCO, int ND, int M, int NH>
+struct GeoS {
+    using G = Geo<ND, M, NH>;
+    static constexpr int HS = G::HQ4 * M;                 // history samples in front
+    static constexpr int XN = HS + G::T;
+    static constexpr int XROWS = XN / 64;
+    static constexpr int IMG = 80 * XROWS;                // halfs per image
+    static constexpr int KTOT = ND + 4 * 15 + 1;
+    static constexpr int KS = (KTOT + 31) / 32;           // MFMA k-steps of 32
+    static constexpr int oTab = 0;                        // floats; the sine table only when the LO is computed in the kernel
+    static constexpr int oX = NCO == 1 ? 516 : 0;         // 4 images of IMG halfs = 2*IMG floats
+    static constexpr int oHf = oX + 2 * IMG;              // f32 copy of the HS history samples, (I, Q) pairs
+    static constexpr int oD = oHf + 2 * HS;
+    static constexpr int total = oD + 2 * G::DLEN;
+    __host__ __device__ static constexpr int phys(int f) { return 80 * (f >> 6) + (f & 63); }
+};
+template <int NH>
+struct GeoH {
+    static constexpr int HH = NH - 1;                              // history samples (even)
+    static constexpr int KS = (NH + 15 + 31) / 32;                 // MFMA k-steps of 32
+    static constexpr int XN = 240 + 32 * KS;                       // highest image index read + 1
+    __host__ __device__ static constexpr int phys(int u) { return u + 8 * (u >> 7); }   // 16 B pad per 128 samples
+    static constexpr int IMG = ((XN + 8 * (XN >> 7) + 8) + 7) & ~7;  // halfs per image
+    static constexpr int DIL = HH + 256;                           // f32 I rail: [history | new]
+    static constexpr int oTab = 0, oX = 516, oDI = oX + IMG /* 2 images of IMG halfs */, oDQ = oDI + DIL + 2, oO = oDQ + DIL + 2, total = oO + 256;
+    static_assert(HH % 2 == 0 && HH <= 256, "Hilbert history");
+};
+
+// instantiated shapes of the two kernel families (ND, M, NH) / (NH)
+#define SRX_SPLIT16_SHAPES(X) X(256, 4, 63) X(128, 4, 63) X(256, 4, 127)
+#define SRX_HILB16_SHAPES(X) X(63) X(127)
+hipError_t launch_ssb_split16(int nd, int m, int nh, const RxParams &p, const FusedArgs &fa, const void *src, bool q15,
+                              void *dst, hipStream_t st);
+hipError_t launch_hilb_split16(int nh, const RxParams &p, const FusedArgs &fa, const void *src, bool q15, void *dst,
+                               hipStream_t st);
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+
+}  // namespace srx

@@ -68,7 +68,8 @@ struct FusedPlan {
     float *d_cq = nullptr;        // zero-padded decimator taps in the fused kernel's indexing
     float *d_btab = nullptr;      // banded-Toeplitz B operand of the MFMA decimator
     void *d_btab16 = nullptr;     // same operand split into f16 hi / lo parts (SELENITE_ARITH_SPLIT16)
-    float split_post = 1.0f;      // 2^-(sample scale + tap scale) applied to the split-precision result
+    float split_post = 1.0f;      // 2^-(sample scale + tap scale) applied to the split-precision result (k_hilb_split16)
+    int split_sc = 0;             // tap scale exponent of the split-precision decimator (k_ssb_split16)
     bool use_mfma = false;        // FMA arithmetic: decimator on the matrix cores
     bool tables_built = false;
 };

@@ -1,0 +1,881 @@
+// rx_split16.hip -- SELENITE_ARITH_SPLIT16: the many-tap FIRs of the receive chain as split-precision
+// matrix products on the 16-bit matrix cores of gfx950 (v_mfma_f32_16x16x32_f16).
+//
+//   k_ssb_split16<NCO, ND, 4, NH, TIn, TOut, AM, GROUP>   decimating shapes (BASELINE cfg3)
+//   k_hilb_split16<NCO, NH, TIn, TOut, AM>                no-decimator shapes (cfg1 / cfg2 / cfg5)
+//
+// f32 MFMA executes on the FP32 vector ALUs (it ADDS to the VALU time, measured: DESIGN.md 5.1), so the
+// only extra arithmetic throughput on the chip is the separate 16-bit matrix pipe.  The FIR
+// (arm_fir_decimate_f32.c:193-284) is the banded-Toeplitz product
+//     D[i][n] = sum_k A[i][k] B[k][n],   A[i][k] = x[64 i + k],   B[k][n] = cq[k - 4 n]
+// (rows i = 16 blocks of 16 consecutive outputs of one rail); samples and taps are split EXACTLY into
+// f16 hi + lo parts,  x*2^s = xh + xl + O(2^-22),  c*2^SC = ch + cl + O(2^-22),  and the product is
+// xh*ch + (xh*cl + xl*ch) with f32 accumulation inside the MFMA (f16 x f16 is exact in f32); the
+// dropped xl*cl term is 2^-22 relative.  NOT bit-reproducible by a CPU loop: parity for this mode is
+// tolerance-based by construction (north star: 1e-5 relative per DSP block).
+//
+// Block floating point.  The sample scale 2^s is chosen per channel and per pass from the data: the
+// largest |component| of the samples the pass's LDS image holds (the 1024 new mixed samples and the
+// ND-1 history samples) lands in [2^14, 2^15), just under the f16 range, so hi AND lo parts stay
+// normal f16 numbers for every sample within 100 dB of the pass maximum, for any input amplitude a
+// float can hold.  s depends only on those samples, so a stream cut into calls at different pass
+// boundaries gives identical bits.  When s changes between passes the history part of the image is
+// re-split from an f32 copy kept in LDS (which is also what goes back to HBM as the CMSIS pState at
+// the end of the call: the streaming state stays exact f32 in every mode).
+#include "rx_fused_common.h"
+
+#pragma clang fp contract(off)
+
+// tuning knobs of k_ssb_split16 (tools/build_variants.sh builds A/B libraries from them)
+#ifndef SRX_SPLIT16_VPM
+#define SRX_SPLIT16_VPM 0        // vector instructions scheduled under each MFMA of the matrix stage (0: compiler's choice; 3 measured 2 % slower)
+#endif
+#ifndef SRX_MIXSPLIT
+#define SRX_MIXSPLIT 0           // f16 hi/lo split by v_fma_mixlo/hi_f16 (1; 8 instead of 12 instructions per sample pair, measured 1 % slower) or convert / subtract / convert (0)
+#endif
+#ifndef SRX_ACC4
+#define SRX_ACC4 0               // separate accumulators for the big and the small terms (1) or one per rail (0)
+#endif
+#ifndef SRX_HS_SGPR
+#define SRX_HS_SGPR 0            // Hilbert taps resident in SGPRs (1; 32 fewer v_readlane per pass, 29 SGPR spills, measured 5 % slower) or v_readlane per use (0)
+#endif
+
+namespace srx {
+
+typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+typedef unsigned int u2v __attribute__((ext_vector_type(2)));
+
+// Raw buffer resource over a wave-uniform byte range (cdna_hip_programming.md T8): loads beyond the
+// range return 0 WITHOUT memory traffic and stores beyond it are dropped, so "prefetch the next pass"
+// needs no branch in the last pass -- the scalar offset is simply pushed out of range.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *base, uint32_t bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)bytes, 0x00020000);
+}
+
+// two complex samples per lane per load (sample n = 128 i + 2 lane of a pass)
+template <typename T> struct BRaw;
+template <> struct BRaw<float> {
+    typedef u4v type;
+    static constexpr int kBytes = 16;
+    static __device__ __forceinline__ type load(__amdgpu_buffer_rsrc_t r, int voff, int soff)
+    {
+        return __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 2);      // nt: streamed once
+    }
+    static __device__ __forceinline__ void unpack(const type &r, v2f &a, v2f &b)
+    {
+        a = v2f{ __uint_as_float(r.x), __uint_as_float(r.y) };
+        b = v2f{ __uint_as_float(r.z), __uint_as_float(r.w) };
+    }
+};
+template <> struct BRaw<int16_t> {
+    typedef u2v type;
+    static constexpr int kBytes = 8;
+    static __device__ __forceinline__ type load(__amdgpu_buffer_rsrc_t r, int voff, int soff)
+    {
+        return __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 2);
+    }
+    static __device__ __forceinline__ void unpack(const type &r, v2f &a, v2f &b)
+    {
+        a = v2f{ q15_to_float((int16_t)(r.x & 0xffffu)), q15_to_float((int16_t)(r.x >> 16)) };
+        b = v2f{ q15_to_float((int16_t)(r.y & 0xffffu)), q15_to_float((int16_t)(r.y >> 16)) };
+    }
+};
+
+// four audio samples per lane per store
+template <typename T> struct BOut;
+template <> struct BOut<float> {
+    static constexpr int kBytes = 16;
+    static __device__ __forceinline__ void store(__amdgpu_buffer_rsrc_t r, int voff, int soff, const float (&au)[4])
+    {
+        const u4v v = { __float_as_uint(au[0]), __float_as_uint(au[1]), __float_as_uint(au[2]), __float_as_uint(au[3]) };
+        __builtin_amdgcn_raw_buffer_store_b128(v, r, voff, soff, 0);
+    }
+};
+template <> struct BOut<int16_t> {
+    static constexpr int kBytes = 8;
+    static __device__ __forceinline__ void store(__amdgpu_buffer_rsrc_t r, int voff, int soff, const float (&au)[4])
+    {
+        const uint32_t a = (uint16_t)float_to_q15(au[0]), b = (uint16_t)float_to_q15(au[1]);
+        const uint32_t c = (uint16_t)float_to_q15(au[2]), d = (uint16_t)float_to_q15(au[3]);
+        const u2v v = { a | (b << 16), c | (d << 16) };
+        __builtin_amdgcn_raw_buffer_store_b64(v, r, voff, soff, 0);
+    }
+};
+
+__device__ __forceinline__ float amax2(v2f x, float m) { return fmaxf(fmaxf(fabsf(x.x), fabsf(x.y)), m); }
+
+// memory-order point for the single-wave workgroups of this file: LDS operations of a wave execute in
+// issue order, so all that is needed is that the compiler keeps the program order of the memory
+// operations on either side.  Unlike wave_lds_sync() this is NOT a scheduling barrier for ALU and
+// matrix instructions: the phases on either side may overlap.
+__device__ __forceinline__ void lds_order()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// AGC of one pass (256 audio samples, 4 per lane): arm_abs + arm_max per DSP block of GROUP lanes,
+// gain law, arm_scale with the updated gain.  GROUP = 16 / 64: lane reductions by DPP, the block
+// envelopes broadcast by v_readlane; GROUP = 0: any power-of-two `group` (run time).
+template <int GROUP>
+__device__ __forceinline__ void agc_pass(const AgcParams &ap, uint32_t agc_on, int lane, int group, float (&au)[4], float &gain)
+{
+    float m = fmaxf(fmaxf(fabsf(au[0]), fabsf(au[1])), fmaxf(fabsf(au[2]), fabsf(au[3])));
+    float g = gain, mine = gain;
+    if constexpr (GROUP == 16) {
+        m = row16_fmax(m);
+        const float d = agc_desired(ap, m);          // one division sequence serves the four blocks
+        float ds[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) ds[b] = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(d), 16 * b));
+        const int myblk = lane >> 4;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            g = agc_step(ap, g, ds[b]);
+            mine = (b == myblk) ? g : mine;
+        }
+    } else if constexpr (GROUP == 64) {
+        m = __uint_as_float(wave_umax_bits(m));
+        g = agc_step(ap, g, agc_desired(ap, m));
+        mine = g;
+    } else {
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1)
+            if (off < group) m = fmaxf(m, __shfl_xor(m, off, 64));
+        const int nblk = 64 / group, myblk = lane / group;
+        for (int b = 0; b < nblk; ++b) {
+            const float env = __shfl(m, b * group, 64);
+            g = agc_update<0>(ap, g, env);
+            if (b == myblk) mine = g;
+        }
+    }
+    gain = agc_on ? g : gain;
+    mine = agc_on ? mine : 1.0f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) au[r] = au[r] * mine;
+}
+
+// ------------------------------------------------------------------------------------------
+// k_ssb_split16
+//
+// One wavefront per channel, passes of 1024 complex inputs -> 256 audio samples, software-pipelined:
+//
+//   mix(p):    buffer-loaded I/Q (prefetched a pass ahead) x LO (shared table, prefetched) by packed
+//              complex multiplies; wave maximum -> block exponent; x 2^s; f16 hi/lo split straight
+//              into the four LDS images (I/Q x hi/lo, 64-sample rows padded to 80 halfs: the A-fragment
+//              ds_read_b128 of lane l sits at 160 (l&15) + 16 (l>>4) + imm, conflict free); the last
+//              ND-1 mixed samples also as f32 (history copy).
+//   mfma(p):   KS k-steps x 6 MFMAs (big: hi*hi; small: hi*lo + lo*hi; both rails), B fragments resident
+//              in 8*KS VGPRs, A fragments read one k-step ahead.
+//   demod(p-1) runs in the SAME basic block as mfma(p): Hilbert FIR on Q (structural zeros skipped), unit
+//              delay on I, sideband combine, AGC (DPP / readlane), audio store.  Nothing but true data
+//              dependencies orders the two, so the VALU work of one pass fills the issue slots under
+//              the matrix work of the next.
+//   The pass loop body is branch-free apart from the (rare) history re-split: no exec-masked copy
+//   loops, no conditional prefetch (buffer range check instead), state written after the loop.
+// ------------------------------------------------------------------------------------------
+template <int NCO, int ND, int M, int NH, typename TIn, typename TOut, int AM, int GROUP>
+__global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa, const TIn *__restrict__ src,
+                                                       TOut *__restrict__ dst)
+{
+    using G = Geo<ND, M, NH>;
+    using GS = GeoS<NCO, ND, M, NH>;
+    using R = BRaw<TIn>;
+    using W = BOut<TOut>;
+    static_assert(ND > 0 && M == 4 && NH > 0 && G::T % 64 == 0 && GS::HS % 64 == 0, "split16 decimator: /4 + Hilbert");
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x;
+    const uint32_t c = blockIdx.x;
+#ifdef SRX_STAMP       // diagnostics build (make STAMP=1): s_memtime stamps of one wave in 1024 (tools/stamp_split16.py)
+    unsigned long long *stamp_p = (fa.dbg && (c & 1023u) == 511u) ? fa.dbg + (c >> 10) * 64 : nullptr;
+    int stamp_i = 0;
+#define STAMP(drain)                                                                   \
+    do {                                                                               \
+        if (drain) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    \
+        if (stamp_p && stamp_i < 64) stamp_p[stamp_i] = __builtin_amdgcn_s_memtime();  \
+        ++stamp_i;                                                                     \
+    } while (0)
+#else
+#define STAMP(drain) do { } while (0)
+#endif
+    STAMP(0);
+    float *tab = lds + GS::oTab;
+    _Float16 *X = reinterpret_cast<_Float16 *>(lds + GS::oX);     // [rail][hi/lo][IMG]
+    v2f *Hf = reinterpret_cast<v2f *>(lds + GS::oHf);             // f32 (I, Q) history, HS samples
+    float *D = lds + GS::oD;
+    float *dI = D, *dQ = D + G::DLEN;
+    constexpr int NLD = G::T / 128;                               // loads per lane per pass
+    constexpr int NTL = GS::HS / 128;                             // ... of which the last NTL hold the next history
+    static_assert(GS::HS % 128 == 0 && NTL >= 1 && NTL <= NLD, "history is a whole number of wave loads");
+
+    const uint32_t npass = p.nout / G::P;
+    const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(src + (size_t)c * p.in_stride * 2, p.block_size * (R::kBytes / 2));
+    const __amdgpu_buffer_rsrc_t rs_out = make_rsrc(dst + (size_t)c * p.out_stride, p.nout * (W::kBytes / 4));
+    const __amdgpu_buffer_rsrc_t rs_lo = make_rsrc(p.lo, NCO == 2 ? p.block_size * 8u : 0u);
+    constexpr int kInPass = G::T * (R::kBytes / 2);               // input bytes of one pass
+    const int in_end = (int)(p.block_size * (R::kBytes / 2));     // scalar offsets at / past this are out of range
+
+    typename R::type raw[NLD];
+    // shared LO (NCO == 2): an L2-resident table, so only LOD wave loads are kept in flight: the first LOD of a
+    // pass are issued with the pass's input prefetch, the others by the mix stage as it frees the slots
+    constexpr int LOD = 3;
+    u4v lo4[LOD];
+    auto lo_load = [&](int slot, int i, int sl) {
+        lo4[slot] = __builtin_amdgcn_raw_buffer_load_b128(rs_lo, lane * 16 + i * 1024, sl, 0);
+    };
+    auto lo_base = [&](uint32_t pass) { return pass < npass ? (int)pass * G::T * 8 : (int)p.block_size * 8; };
+    auto prefetch = [&](uint32_t pass) {                          // pass == npass: every load out of range -> zeros, no traffic
+        const int so = pass < npass ? (int)pass * kInPass : in_end;
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) raw[i] = R::load(rs_in, lane * R::kBytes + i * 64 * R::kBytes, so);
+        if constexpr (NCO == 2) {
+#pragma unroll
+            for (int i = 0; i < LOD; ++i) lo_load(i, i, lo_base(pass));
+        }
+    };
+    prefetch(0);
+
+    // Toeplitz B fragments (8 halfs per lane): [kk][hi/lo]
+    h8 Bh[GS::KS], Bl[GS::KS];
+    {
+        const h8 *bt = static_cast<const h8 *>(fa.btab16);
+#pragma unroll
+        for (int kk = 0; kk < GS::KS; ++kk) {
+            Bh[kk] = bt[(2 * kk + 0) * 64 + lane];
+            Bl[kk] = bt[(2 * kk + 1) * 64 + lane];
+        }
+    }
+    // Hilbert taps: wave-uniform values held in scalar registers for the whole kernel (only the structurally
+    // non-zero ones are ever referenced: (NH + 1) / 2 SGPRs), so a tap costs no v_readlane per pass
+    float hreg[(NH + 63) / 64];
+#pragma unroll
+    for (int v = 0; v < (NH + 63) / 64; ++v) hreg[v] = (64 * v + lane < NH) ? p.hilb_c[64 * v + lane] : 0.0f;
+#if SRX_HS_SGPR
+    float hs[NH];
+#pragma unroll
+    for (int k = 0; k < NH; ++k) hs[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(hreg[k >> 6]), k & 63));
+    auto htap = [&](int k) { return hs[k]; };
+#else
+    auto htap = [&](int k) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(hreg[k >> 6]), k & 63)); };
+#endif
+    if constexpr (NCO == 1)
+        for (int i = lane; i < 513; i += kWave) tab[i] = p.sintab[i];
+
+    // ---- prologue: streaming state.  Flat history sample f in [0, HS) is CMSIS state sample s = f - F
+    // (older slots meet zero taps only).  All loads are unconditional from a clamped index and issued
+    // before the first use (one memory round trip for the lot).
+    uint32_t e_hist;                                              // biased exponent of the largest |history component|
+    {
+        constexpr int NHI = GS::HS / kWave, NFI = 2 * G::HH4 / kWave;
+        static_assert(GS::HS % kWave == 0 && (2 * G::HH4) % kWave == 0, "prologue fills are whole wave loads");
+        const float *stI = p.dec_state + (size_t)c * 2 * (ND - 1), *stQ = stI + (ND - 1);
+        const float *stF = p.fir_state + (size_t)c * 2 * G::HH;
+        v2f hv[NHI];
+        float fv[NFI];
+#pragma unroll
+        for (int j = 0; j < NHI; ++j) {
+            const int s = j * kWave + lane - G::F, sc = s < 0 ? 0 : s;
+            const float xi = stI[sc], xq = stQ[sc];
+            hv[j] = s < 0 ? v2f{ 0.0f, 0.0f } : v2f{ xi, xq };
+        }
+#pragma unroll
+        for (int j = 0; j < NFI; ++j) {
+            const int i = j * kWave + lane;
+            const int rail = i / G::HH4, sidx = i % G::HH4 - G::FH;
+            const float x = stF[rail * G::HH + (sidx < 0 ? 0 : sidx)];
+            fv[j] = sidx < 0 ? 0.0f : x;
+        }
+        float mh = 0.0f;
+#pragma unroll
+        for (int j = 0; j < NHI; ++j) {
+            Hf[j * kWave + lane] = hv[j];
+            mh = amax2(hv[j], mh);
+        }
+#pragma unroll
+        for (int j = 0; j < NFI; ++j) {
+            const int i = j * kWave + lane;
+            D[(i / G::HH4) * G::DLEN + i % G::HH4] = fv[j];
+        }
+        e_hist = wave_umax_bits(mh) >> 23;
+    }
+    const uint32_t ph0 = NCO ? p.phase[c] : 0u;
+    const uint32_t step = NCO ? p.step[c] : 0u;
+    float gain = p.gain[c];
+    const int group = (int)fa.group;
+    const int abase = 80 * (lane & 15) + 8 * (lane >> 4);             // A-fragment lane base (halfs)
+    int s_cur = 0x7fff;                                               // sample scale exponent of the images (none yet)
+
+    // two (I, Q) samples f (even), f + 1, times the block scale `pre` -> one word in each of the four images:
+    //   hi = f16(x * pre), lo = f16(x * pre - hi), one v_fma_mixlo/hi_f16 each (the product with the power of
+    // two and the difference are exact inside the fused operation, so this IS convert / subtract / convert,
+    // bit for bit: tools/mix_split_check.hip) -- 8 plain vector instructions per sample pair instead of 12
+    // (4 of them packed) for scale, convert, convert back, subtract, convert.
+    auto put_iq = [&](int f, v2f a, v2f b, float pre) {
+        uint32_t hI, hQ, lI, lQ;
+#if SRX_MIXSPLIT
+        asm("v_fma_mixlo_f16 %0, %2, %6, 0\n\t"
+            "v_fma_mixlo_f16 %1, %3, %6, 0\n\t"
+            "v_fma_mixhi_f16 %0, %4, %6, 0\n\t"
+            "v_fma_mixhi_f16 %1, %5, %6, 0"
+            : "=&v"(hI), "=&v"(hQ) : "v"(a.x), "v"(a.y), "v"(b.x), "v"(b.y), "s"(pre));
+        asm("v_fma_mixlo_f16 %0, %2, %6, -%7 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n\t"
+            "v_fma_mixlo_f16 %1, %3, %6, -%8 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n\t"
+            "v_fma_mixhi_f16 %0, %4, %6, -%7 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+            "v_fma_mixhi_f16 %1, %5, %6, -%8 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+            : "=&v"(lI), "=&v"(lQ) : "v"(a.x), "v"(a.y), "v"(b.x), "v"(b.y), "s"(pre), "v"(hI), "v"(hQ));
+#else
+        const v2f pre2 = { pre, pre };
+        const v2f sa = a * pre2, sb = b * pre2;
+        const h2 hhI = __builtin_convertvector(v2f{ sa.x, sb.x }, h2), hhQ = __builtin_convertvector(v2f{ sa.y, sb.y }, h2);
+        const v2f ra = sa - v2f{ (float)hhI.x, (float)hhQ.x }, rb = sb - v2f{ (float)hhI.y, (float)hhQ.y };
+        const h2 llI = __builtin_convertvector(v2f{ ra.x, rb.x }, h2), llQ = __builtin_convertvector(v2f{ ra.y, rb.y }, h2);
+        hI = __builtin_bit_cast(uint32_t, hhI); hQ = __builtin_bit_cast(uint32_t, hhQ);
+        lI = __builtin_bit_cast(uint32_t, llI); lQ = __builtin_bit_cast(uint32_t, llQ);
+#endif
+        const int ph = GS::phys(f);
+        *reinterpret_cast<uint32_t *>(X + 0 * GS::IMG + ph) = hI;
+        *reinterpret_cast<uint32_t *>(X + 1 * GS::IMG + ph) = lI;
+        *reinterpret_cast<uint32_t *>(X + 2 * GS::IMG + ph) = hQ;
+        *reinterpret_cast<uint32_t *>(X + 3 * GS::IMG + ph) = lQ;
+    };
+
+    // ---- mix(p): NCO mix, block exponent, f16 split into the images, f32 history copy ----
+    auto mix = [&](uint32_t pass) {
+        const uint32_t n0 = pass * G::T;
+        v2f m[2 * NLD];
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            v2f a, b;
+            R::unpack(raw[i], a, b);
+            if constexpr (NCO == 2) {
+                const u4v l = lo4[i % LOD];
+                cmul_pk2(a, b, v2f{ __uint_as_float(l.x), __uint_as_float(l.y) }, v2f{ __uint_as_float(l.z), __uint_as_float(l.w) },
+                         m[2 * i], m[2 * i + 1]);
+                if (i + LOD < NLD) lo_load(i % LOD, i + LOD, lo_base(pass));
+            } else if constexpr (NCO == 1) {
+                const uint32_t n = 128u * i + 2u * lane;
+                const float2 la = nco_lo<0>(tab, ph0 + (n0 + n) * step), lb = nco_lo<0>(tab, ph0 + (n0 + n + 1) * step);
+                cmul_pk2(a, b, v2f{ la.x, la.y }, v2f{ lb.x, lb.y }, m[2 * i], m[2 * i + 1]);
+            } else {
+                m[2 * i] = a;
+                m[2 * i + 1] = b;
+            }
+        }
+        float mt = 0.0f, mh = 0.0f;                                   // |.| maxima: tail (next history), head
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            float &mm = (i >= NLD - NTL) ? mt : mh;
+            mm = amax2(m[2 * i], mm);
+            mm = amax2(m[2 * i + 1], mm);
+        }
+        const uint32_t e_tail = wave_umax_bits(mt) >> 23;
+        const uint32_t e_new = max(wave_umax_bits(mh) >> 23, e_tail);
+        const uint32_t e_need = max(e_new, e_hist);
+        // largest |component| * 2^s in [2^14, 2^15):  s = 14 - (E - 127); 2^s must itself be a normal float
+        int s_new = 141 - (int)e_need;
+        s_new = s_new > 127 ? 127 : (s_new < -126 ? -126 : s_new);
+        if (s_new != s_cur) {                                         // wave-uniform; always taken in the first pass
+            const float pre = __uint_as_float((uint32_t)(s_new + 127) << 23);
+#pragma unroll
+            for (int j = 0; j < GS::HS / 128; ++j) {
+                const int f = 2 * (j * kWave + lane);
+                const float4 hq = *reinterpret_cast<const float4 *>(Hf + f);
+                put_iq(f, v2f{ hq.x, hq.y }, v2f{ hq.z, hq.w }, pre);
+            }
+            s_cur = s_new;
+        }
+        e_hist = e_tail;
+        lds_order();                                                  // history reads above, history writes below
+        const float pre = __uint_as_float((uint32_t)(s_cur + 127) << 23);
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int n = 128 * i + 2 * lane;
+            put_iq(GS::HS + n, m[2 * i], m[2 * i + 1], pre);
+            if (i >= NLD - NTL)
+                *reinterpret_cast<float4 *>(Hf + (n - (G::T - GS::HS))) = make_float4(m[2 * i].x, m[2 * i].y, m[2 * i + 1].x, m[2 * i + 1].y);
+        }
+    };
+
+    // ---- mfma(p): the decimator, 3 f16 MFMAs per k-step and rail (hi*hi | hi*lo + lo*hi) ----
+    // one f32 accumulator per rail takes the big (hi*hi) and the two small (hi*lo, lo*hi) terms: the small terms are
+    // rounded at the accumulator's ulp as they arrive (~20 extra roundings of 2^-24 relative, against a 1e-5 bar)
+    // and the sum never has to be formed on the vector ALU
+    v4f accI, accQ;
+#if SRX_ACC4
+    v4f smlI, smlQ;
+#endif
+    constexpr int VPM = SRX_SPLIT16_VPM;                              // vector instructions issued under each MFMA (0: scheduler's choice)
+    auto mfma_phase = [&](auto &&side, int PIN) {
+        accI = accQ = v4f{ 0.0f, 0.0f, 0.0f, 0.0f };
+#if SRX_ACC4
+        smlI = smlQ = accI;
+#endif
+        const _Float16 *xIh = X + 0 * GS::IMG + abase, *xIl = X + 1 * GS::IMG + abase;
+        const _Float16 *xQh = X + 2 * GS::IMG + abase, *xQl = X + 3 * GS::IMG + abase;
+        auto offA = [](int kk) { return 80 * (kk >> 1) + 32 * (kk & 1); };   // phys(32*kk): rows never straddle
+        h8 aIh = *reinterpret_cast<const h8 *>(xIh + offA(0)), aIl = *reinterpret_cast<const h8 *>(xIl + offA(0));
+        h8 aQh = *reinterpret_cast<const h8 *>(xQh + offA(0)), aQl = *reinterpret_cast<const h8 *>(xQl + offA(0));
+#pragma unroll
+        for (int kk = 0; kk < GS::KS; ++kk) {
+            h8 nIh = aIh, nIl = aIl, nQh = aQh, nQl = aQl;
+            if (kk + 1 < GS::KS) {
+                const int off = offA(kk + 1);
+                nIh = *reinterpret_cast<const h8 *>(xIh + off); nIl = *reinterpret_cast<const h8 *>(xIl + off);
+                nQh = *reinterpret_cast<const h8 *>(xQh + off); nQl = *reinterpret_cast<const h8 *>(xQl + off);
+            }
+#if SRX_ACC4
+            accI = __builtin_amdgcn_mfma_f32_16x16x32_f16(aIh, Bh[kk], accI, 0, 0, 0);
+            accQ = __builtin_amdgcn_mfma_f32_16x16x32_f16(aQh, Bh[kk], accQ, 0, 0, 0);
+            smlI = __builtin_amdgcn_mfma_f32_16x16x32_f16(aIh, Bl[kk], smlI, 0, 0, 0);
+            smlQ = __builtin_amdgcn_mfma_f32_16x16x32_f16(aQh, Bl[kk], smlQ, 0, 0, 0);
+            smlI = __builtin_amdgcn_mfma_f32_16x16x32_f16(aIl, Bh[kk], smlI, 0, 0, 0);
+            smlQ = __builtin_amdgcn_mfma_f32_16x16x32_f16(aQl, Bh[kk], smlQ, 0, 0, 0);
+#else
+            accI = __builtin_amdgcn_mfma_f32_16x16x32_f16(aIh, Bl[kk], accI, 0, 0, 0);     // small terms first
+            accQ = __builtin_amdgcn_mfma_f32_16x16x32_f16(aQh, Bl[kk], accQ, 0, 0, 0);
+            accI = __builtin_amdgcn_mfma_f32_16x16x32_f16(aIl, Bh[kk], accI, 0, 0, 0);
+            accQ = __builtin_amdgcn_mfma_f32_16x16x32_f16(aQl, Bh[kk], accQ, 0, 0, 0);
+            accI = __builtin_amdgcn_mfma_f32_16x16x32_f16(aIh, Bh[kk], accI, 0, 0, 0);
+            accQ = __builtin_amdgcn_mfma_f32_16x16x32_f16(aQh, Bh[kk], accQ, 0, 0, 0);
+#endif
+            aIh = nIh; aIl = nIl; aQh = nQh; aQl = nQl;
+            side(kk);                                                 // vector work that runs under this k-step's MFMAs
+            if constexpr (VPM > 0) {
+                // issue pattern of the k-step: the A fragments of the next k-step (and two LDS reads of whatever
+                // else the block holds: the demodulator of the previous pass), then every MFMA followed by VPM
+                // vector instructions of the demodulator -- a 16x16x32 MFMA occupies the matrix pipe for 16
+                // cycles, the wave's issue port for 4
+                if (kk + 1 < GS::KS) __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+                else __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+#pragma unroll
+                for (int j = 0; j < 6; ++j) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);
+                }
+                if (kk < PIN) __builtin_amdgcn_sched_barrier(0);      // the k-steps that carry Hilbert pieces do not mix
+            }
+        }
+    };
+    // decimated rails of the pass into D behind the Hilbert history (exact power-of-two rescale)
+    auto dwrite = [&]() {
+        const int o0 = G::HH4 + 64 * (lane >> 4) + (lane & 15);
+        const int ex = -(s_cur + fa.split_sc);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#if SRX_ACC4
+            dI[o0 + 16 * r] = __builtin_ldexpf(accI[r] + smlI[r], ex);
+            dQ[o0 + 16 * r] = __builtin_ldexpf(accQ[r] + smlQ[r], ex);
+#else
+            dI[o0 + 16 * r] = __builtin_ldexpf(accI[r], ex);
+            dQ[o0 + 16 * r] = __builtin_ldexpf(accQ[r], ex);
+#endif
+        }
+    };
+    // history of the four images: last HS samples of the pass back to the front, 16 bytes per move
+    constexpr int NCB = 4 * (GS::HS / 64) * 8 / kWave;                // moves per lane
+    static_assert((4 * (GS::HS / 64) * 8) % kWave == 0, "image history is a whole number of wave moves");
+    auto cb_addr = [&](int k) {                                       // halfs; chunk i -> (image, row, 8-half column group)
+        const int i = k * kWave + lane, img = i / (8 * (GS::HS / 64)), rem = i % (8 * (GS::HS / 64));
+        return img * GS::IMG + 80 * (rem >> 3) + 8 * (rem & 7);
+    };
+    auto cb_read = [&](u4v (&cb)[NCB]) {
+#pragma unroll
+        for (int k = 0; k < NCB; ++k) cb[k] = *reinterpret_cast<const u4v *>(X + cb_addr(k) + 80 * (G::T / 64));
+    };
+    auto cb_write = [&](const u4v (&cb)[NCB]) {
+#pragma unroll
+        for (int k = 0; k < NCB; ++k) *reinterpret_cast<u4v *>(X + cb_addr(k)) = cb[k];
+    };
+    // Hilbert-pair history: last HH4 decimated samples of both rails to the front of D (every lane moves
+    // one float4; the upper half of the wave repeats the lower half's moves when 2*HH4/4 = 32)
+    constexpr int NDV = 2 * (G::HH4 / 4);
+    static_assert(NDV == 32 || NDV == 64, "Hilbert history move is one float4 per lane");
+    const int dt_off = ((lane % NDV) / (G::HH4 / 4)) * G::DLEN + 4 * (lane % (G::HH4 / 4));
+
+    // ---- demod: Hilbert pair + sideband (or AM envelope), AGC of the pass whose decimated rails are in D.
+    // Cut into KS pieces that sit, in program order, behind the MFMAs of the k-steps of the NEXT pass's matrix
+    // stage: TPK Hilbert read-and-accumulate steps per k-step, the rest (sideband, AGC) in the last pieces.
+    constexpr int NTS = HilbertSteps<ND, M, NH>::N;
+    constexpr int KH = GS::KS > 4 ? GS::KS - 3 : 1;                   // k-steps that carry Hilbert steps
+    constexpr int TPK = (NTS + KH - 1) / KH;
+    float q2[4];
+    auto demod_piece = [&](int kk, float (&au)[4]) {
+        if constexpr (AM != 0) {
+            if (kk == 0) {
+                const float4 vi = *reinterpret_cast<const float4 *>(dI + G::HH4 + 4 * lane);
+                const float4 vq = *reinterpret_cast<const float4 *>(dQ + G::HH4 + 4 * lane);
+                au[0] = cmag<0>(vi.x, vq.x); au[1] = cmag<0>(vi.y, vq.y);
+                au[2] = cmag<0>(vi.z, vq.z); au[3] = cmag<0>(vi.w, vq.w);
+                agc_pass<GROUP>(p.agcp, p.agc, lane, group, au, gain);
+            }
+        } else {
+            if (kk == 0) q2[0] = q2[1] = q2[2] = q2[3] = 0.0f;
+#pragma unroll
+            for (int j = 0; j < TPK; ++j)
+                if (kk * TPK + j < NTS) hilbert_tstep<1, ND, M, NH>(kk * TPK + j, dQ, lane, htap, q2);
+            if (kk == (NTS + TPK - 1) / TPK - 1 || (kk == GS::KS - 1 && (NTS + TPK - 1) / TPK > GS::KS)) {
+                const float *di = dI + G::FH + fa.delay_idx + 4 * lane;   // unit-impulse delay FIR
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float i2 = di[r] + 0.0f;                    // 0.0f + 1.0f*x of the dense loop
+                    au[r] = fa.upper ? (i2 - q2[r]) : (i2 + q2[r]);   // arm_sub_f32 / arm_add_f32
+                }
+                agc_pass<GROUP>(p.agcp, p.agc, lane, group, au, gain);
+            }
+        }
+    };
+    static_assert(TPK * GS::KS >= NTS, "every Hilbert step has a k-step");
+    auto demod = [&](float (&au)[4]) {                                // the whole demodulator in one piece (last pass)
+#pragma unroll
+        for (int kk = 0; kk < GS::KS; ++kk) demod_piece(kk, au);
+    };
+    auto store_audio = [&](uint32_t q, const float (&au)[4]) {
+        W::store(rs_out, lane * W::kBytes, (int)q * (G::P * (W::kBytes / 4)), au);
+    };
+
+    // ---- the pipeline ----
+    // Audio of pass q is computed under the matrix stage of pass q+1 and stored right behind the mix stage of
+    // pass q+2 -- in FRONT of that pass's prefetch loads: loads and stores share one in-order counter (vmcnt),
+    // so a store issued shortly before loaded data is consumed makes the wave wait for the write acknowledge.
+    float au[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+    lds_order();
+    STAMP(0);                                                         // [1] prologue issued
+    STAMP(1);                                                         // [2] ... and its loads landed
+    mix(0);
+    STAMP(0);
+    prefetch(1);
+    lds_order();
+    {
+        u4v cb[NCB];
+        mfma_phase([](int) {}, 0);
+        cb_read(cb);
+        lds_order();
+        cb_write(cb);
+        dwrite();
+    }
+    lds_order();
+    STAMP(0);
+    for (uint32_t pass = 1; pass < npass; ++pass) {
+        STAMP(1);                                                     // wait for the prefetched pass
+        mix(pass);
+        STAMP(0);
+        store_audio(pass - 2, au);                                    // pass 1: offset -1 pass = out of range, dropped
+        prefetch(pass + 1);
+        lds_order();
+        u4v cb[NCB];
+        v4f dt = { 0.0f, 0.0f, 0.0f, 0.0f };
+        if constexpr (AM == 0) dt = *reinterpret_cast<const v4f *>(D + dt_off + G::P);
+        mfma_phase([&](int kk) { demod_piece(kk, au); }, (NTS + TPK - 1) / TPK - 1);   // matrix pipe over the vector work of the pass before
+        cb_read(cb);
+        lds_order();
+        cb_write(cb);
+        if constexpr (AM == 0) *reinterpret_cast<v4f *>(D + dt_off) = dt;
+        dwrite();
+        lds_order();
+        STAMP(0);
+    }
+    store_audio(npass - 2, au);
+    demod(au);
+    store_audio(npass - 1, au);
+    STAMP(0);
+
+    // ---- epilogue: streaming state back to HBM (exact f32) ----
+    lds_order();
+    {
+        float *stI = p.dec_state + (size_t)c * 2 * (ND - 1), *stQ = stI + (ND - 1);
+#pragma unroll
+        for (int j = 0; j < GS::HS / kWave; ++j) {
+            const int s = j * kWave + lane - G::F;
+            const v2f h = Hf[j * kWave + lane];
+            if (s >= 0) { stI[s] = h.x; stQ[s] = h.y; }
+        }
+    }
+    if constexpr (AM == 0) {                                          // AM never ran the Hilbert pair: its state stays
+        for (int i = lane; i < 2 * G::HH4; i += kWave) {
+            const int rail = i / G::HH4, mi = i % G::HH4, s = mi - G::FH;
+            if (s >= 0) p.fir_state[((size_t)c * 2 + rail) * G::HH + s] = D[rail * G::DLEN + G::P + mi];
+        }
+    }
+    if (lane == 0) {
+        if constexpr (NCO != 0) p.phase[c] = ph0 + p.block_size * step;
+        if (p.agc) p.gain[c] = gain;
+    }
+    STAMP(1);
+#undef STAMP
+}
+
+// ------------------------------------------------------------------------------------------
+// k_hilb_split16<NCO, NH, TIn, TOut, AM> -- SELENITE_ARITH_SPLIT16 for the no-decimator shapes
+// (BASELINE cfg1 / cfg2 / cfg5: M = 1, DSP block 256): the Hilbert FIR (arm_fir_f32.c:640-936) on the
+// 16-bit matrix pipe.  Those shapes are VALU-bound by the Hilbert tap loop (64 non-zero taps of 127 per
+// output); as a banded-Toeplitz product
+//     D[i][m] = sum_k A[i][k] B[k][m],   A[i][k] = st[16 i + k],   B[k][m] = h[k - m]
+// (st = [NH-1 history | 256 new samples] of the Q rail, 16 rows of 16 outputs, K = NH + 15) it is 3 MFMAs
+// per k-step of 32 with the f16 hi/lo split and the block floating point of k_ssb_split16: the scale 2^s
+// of a pass puts the largest |Q| of [history | new] into [2^14, 2^15); the Q history is kept in f32 beside
+// the images and re-split when s changes.  15 v_mfma_f32_16x16x32_f16 per pass instead of 128 v_pk_fma +
+// 64 v_readlane.  The I rail is a pure delay (unit-impulse FIR) and stays f32; the streaming state leaves
+// from the f32 rails, bit-exact.  The MFMA result layout (lane holds outputs 64(l>>4) + 16 r + (l&15)) goes
+// through a 1 KB LDS transpose so the audio leaves as one coalesced 16-byte store per lane.
+// ------------------------------------------------------------------------------------------
+template <int NCO, int NH, typename TIn, typename TOut, int AM = 0>
+__global__ __launch_bounds__(64, 2) void k_hilb_split16(RxParams p, FusedArgs fa, const TIn *__restrict__ src,
+                                                        TOut *__restrict__ dst)
+{
+    using GH = GeoH<NH>;
+    using R = BRaw<TIn>;
+    using W = BOut<TOut>;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x;
+    const uint32_t c = blockIdx.x;
+    float *tab = lds + GH::oTab;
+    _Float16 *Xh = reinterpret_cast<_Float16 *>(lds + GH::oX), *Xl = Xh + GH::IMG;
+    float *dI = lds + GH::oDI, *dQ = lds + GH::oDQ, *O = lds + GH::oO;      // f32 rails [HH history | 256 new]
+    const uint32_t npass = p.nout / 256;
+    const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(src + (size_t)c * p.in_stride * 2, p.block_size * (R::kBytes / 2));
+    const __amdgpu_buffer_rsrc_t rs_out = make_rsrc(dst + (size_t)c * p.out_stride, p.nout * (W::kBytes / 4));
+    const __amdgpu_buffer_rsrc_t rs_lo = make_rsrc(p.lo, NCO == 2 ? p.block_size * 8u : 0u);
+    constexpr int kInPass = 256 * (R::kBytes / 2);
+    typename R::type raw[2];
+    u4v lo4[2];
+    auto prefetch = [&](uint32_t pass) {                              // pass == npass: out of range, zeros, no traffic
+        const int so = pass < npass ? (int)pass * kInPass : (int)(p.block_size * (R::kBytes / 2));
+#pragma unroll
+        for (int i = 0; i < 2; ++i) raw[i] = R::load(rs_in, lane * R::kBytes + i * 64 * R::kBytes, so);
+        if constexpr (NCO == 2) {
+            const int sl = pass < npass ? (int)pass * 256 * 8 : (int)p.block_size * 8;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) lo4[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_lo, lane * 16 + i * 1024, sl, 0);
+        }
+    };
+    prefetch(0);
+
+    h8 Bh[GH::KS], Bl[GH::KS];
+    {
+        const h8 *bt = static_cast<const h8 *>(fa.btab16);
+#pragma unroll
+        for (int kk = 0; kk < GH::KS; ++kk) {
+            Bh[kk] = bt[(2 * kk + 0) * 64 + lane];
+            Bl[kk] = bt[(2 * kk + 1) * 64 + lane];
+        }
+    }
+    if constexpr (NCO == 1)
+        for (int i = lane; i < 513; i += kWave) tab[i] = p.sintab[i];
+    // image slots u (even), u + 1 of the Q rail <- two samples times the block scale
+    auto put = [&](int u, float x0, float x1, float pre) {
+        const v2f s = v2f{ x0, x1 } * v2f{ pre, pre };
+        const h2 h = __builtin_convertvector(s, h2);
+        const h2 l = __builtin_convertvector(s - __builtin_convertvector(h, v2f), h2);
+        const int ph = GH::phys(u);
+        *reinterpret_cast<h2 *>(Xh + ph) = h;
+        *reinterpret_cast<h2 *>(Xl + ph) = l;
+    };
+    // the read-only slack behind the samples meets zero taps only, but must hold finite numbers
+    for (int u = GH::HH + 256 + 2 * lane; u < GH::XN; u += 2 * kWave) put(u, 0.0f, 0.0f, 1.0f);
+    // state: both rails' histories in f32 (branch-free: lanes beyond the history repeat its last pair)
+    const int hv = 2 * lane < GH::HH ? 2 * lane : GH::HH - 2;       // this lane's history pair
+    uint32_t e_hist;
+    {
+        const float *stI = p.fir_state + (size_t)c * 2 * GH::HH, *stQ = stI + GH::HH;
+        const float i0 = stI[hv], i1 = stI[hv + 1], q0 = stQ[hv], q1 = stQ[hv + 1];
+        *reinterpret_cast<float2 *>(dI + hv) = make_float2(i0, i1);
+        *reinterpret_cast<float2 *>(dQ + hv) = make_float2(q0, q1);
+        e_hist = wave_umax_bits(fmaxf(fabsf(q0), fabsf(q1))) >> 23;
+    }
+    const uint32_t ph0 = NCO ? p.phase[c] : 0u, step = NCO ? p.step[c] : 0u;
+    float gain = p.gain[c];
+    const int mcol = lane & 15, rg = lane >> 4;
+    int s_cur = 0x7fff;
+    lds_order();
+
+    for (uint32_t pass = 0; pass < npass; ++pass) {
+        const uint32_t n0 = pass * 256u;
+        // ---- 1. NCO mix; both rails f32 into LDS; Q rail split into the f16 images at the block scale ----
+        v2f ma[2], mb[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            v2f a, b;
+            R::unpack(raw[i], a, b);
+            if constexpr (NCO == 2) {
+                cmul_pk2(a, b, v2f{ __uint_as_float(lo4[i].x), __uint_as_float(lo4[i].y) },
+                         v2f{ __uint_as_float(lo4[i].z), __uint_as_float(lo4[i].w) }, ma[i], mb[i]);
+            } else if constexpr (NCO == 1) {
+                const uint32_t n = 128u * i + 2u * lane;
+                const float2 la = nco_lo<0>(tab, ph0 + (n0 + n) * step), lb = nco_lo<0>(tab, ph0 + (n0 + n + 1) * step);
+                cmul_pk2(a, b, v2f{ la.x, la.y }, v2f{ lb.x, lb.y }, ma[i], mb[i]);
+            } else {
+                ma[i] = a;
+                mb[i] = b;
+            }
+        }
+        prefetch(pass + 1);
+        float au[4];
+        if constexpr (AM != 0) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                *reinterpret_cast<float2 *>(O + 128 * i + 2 * lane) = make_float2(cmag<0>(ma[i].x, ma[i].y), cmag<0>(mb[i].x, mb[i].y));
+            lds_order();
+        } else {
+            // block exponent: the largest |Q| of the new samples and of the history; the new samples that will be
+            // the NEXT pass's history (the last HH of the pass) are tracked on the side
+            float mq = 0.0f, mt = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int n = 128 * i + 2 * lane;
+                const float m2 = fmaxf(fabsf(ma[i].y), fabsf(mb[i].y));
+                mq = fmaxf(mq, m2);
+                mt = fmaxf(mt, n >= 256 - GH::HH ? m2 : 0.0f);          // HH is even: a pair is inside or outside as a whole
+            }
+            const uint32_t e_tail = wave_umax_bits(mt) >> 23;
+            const uint32_t e_need = max(max(wave_umax_bits(mq) >> 23, e_tail), e_hist);
+            int s_new = 141 - (int)e_need;
+            s_new = s_new > 127 ? 127 : (s_new < -126 ? -126 : s_new);
+            if (s_new != s_cur) {                                     // wave-uniform; always in the first pass
+                const float2 hq = *reinterpret_cast<const float2 *>(dQ + hv);
+                put(hv, hq.x, hq.y, __uint_as_float((uint32_t)(s_new + 127) << 23));
+                s_cur = s_new;
+            }
+            e_hist = e_tail;
+            const float pre = __uint_as_float((uint32_t)(s_cur + 127) << 23);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int n = 128 * i + 2 * lane;
+                *reinterpret_cast<float2 *>(dI + GH::HH + n) = make_float2(ma[i].x, mb[i].x);
+                *reinterpret_cast<float2 *>(dQ + GH::HH + n) = make_float2(ma[i].y, mb[i].y);
+                put(GH::HH + n, ma[i].y, mb[i].y, pre);
+            }
+            lds_order();
+            // ---- 2. Hilbert FIR of the Q rail: 3 f16 MFMAs per k-step (small terms first, one accumulator) ----
+            v4f acc = { 0.0f, 0.0f, 0.0f, 0.0f };
+#pragma unroll
+            for (int kk = 0; kk < GH::KS; ++kk) {
+                const int u = 16 * mcol + 8 * rg + 32 * kk;                // A[i = l&15][k = 32kk + 8(l>>4) ..+7] = st[16 i + k]
+                const int ph = u + 8 * (u >> 7);
+                const h8 ah = *reinterpret_cast<const h8 *>(Xh + ph), al = *reinterpret_cast<const h8 *>(Xl + ph);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, Bl[kk], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, Bh[kk], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, Bh[kk], acc, 0, 0, 0);
+            }
+            // ---- 3. delay on I, sideband combine; transpose through LDS ----
+            const int ex = -(s_cur + fa.split_sc);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = 64 * rg + 16 * r + mcol;                     // D[row 4 rg + r][col mcol]
+                const float q2 = __builtin_ldexpf(acc[r], ex);
+                const float i2 = dI[n + fa.delay_idx] + 0.0f;
+                O[n] = fa.upper ? (i2 - q2) : (i2 + q2);
+            }
+            lds_order();
+        }
+        // ---- 4.-5. AGC on the DSP block (= the pass), coalesced store ----
+        {
+            const float4 o4 = *reinterpret_cast<const float4 *>(O + 4 * lane);
+            au[0] = o4.x; au[1] = o4.y; au[2] = o4.z; au[3] = o4.w;
+        }
+        agc_pass<64>(p.agcp, p.agc, lane, 64, au, gain);
+        W::store(rs_out, lane * W::kBytes, (int)pass * (256 * (W::kBytes / 4)), au);
+        // ---- 6. history: last NH-1 samples of both f32 rails and of both images to the front ----
+        if constexpr (AM == 0) {
+            const float2 ti = *reinterpret_cast<const float2 *>(dI + 256 + hv);
+            const float2 tq = *reinterpret_cast<const float2 *>(dQ + 256 + hv);
+            const uint32_t th = *reinterpret_cast<const uint32_t *>(Xh + GH::phys(256 + hv));
+            const uint32_t tl = *reinterpret_cast<const uint32_t *>(Xl + GH::phys(256 + hv));
+            lds_order();
+            *reinterpret_cast<float2 *>(dI + hv) = ti;
+            *reinterpret_cast<float2 *>(dQ + hv) = tq;
+            *reinterpret_cast<uint32_t *>(Xh + GH::phys(hv)) = th;
+            *reinterpret_cast<uint32_t *>(Xl + GH::phys(hv)) = tl;
+        }
+        lds_order();
+    }
+    // ---- epilogue: arm_fir_f32 pState tails (the last NH-1 samples of each rail), exact f32 ----
+    if constexpr (AM == 0) {
+        if (2 * lane < GH::HH) {
+            float *stI = p.fir_state + (size_t)c * 2 * GH::HH, *stQ = stI + GH::HH;
+            const float2 ti = *reinterpret_cast<const float2 *>(dI + hv), tq = *reinterpret_cast<const float2 *>(dQ + hv);
+            stI[hv] = ti.x; stI[hv + 1] = ti.y;
+            stQ[hv] = tq.x; stQ[hv + 1] = tq.y;
+        }
+    }
+    if (lane == 0) {
+        if constexpr (NCO != 0) p.phase[c] = ph0 + p.block_size * step;
+        if (p.agc) p.gain[c] = gain;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// host side: dispatch over the instantiated shapes
+// ------------------------------------------------------------------------------------------
+template <int NCO, int ND, int M, int NH, typename TIn, typename TOut, int AM, int GROUP>
+static hipError_t launch_k(const RxParams &p, const FusedArgs &fa, const void *src, void *dst, hipStream_t st)
+{
+    using GS = GeoS<NCO, ND, M, NH>;
+    constexpr size_t lds = (size_t)GS::total * sizeof(float);
+    static_assert(lds <= 48 * 1024, "k_ssb_split16 LDS image");
+    hipLaunchKernelGGL((k_ssb_split16<NCO, ND, M, NH, TIn, TOut, AM, GROUP>), dim3(p.channels), dim3(64), lds, st, p, fa,
+                       static_cast<const TIn *>(src), static_cast<TOut *>(dst));
+    return hipGetLastError();
+}
+
+// DSP-block geometry: 16 / 64 lanes per block (block = 256 / 1024 inputs) get the DPP reductions, any
+// other power of two the run-time variant; AM and the NCO-less chain (rare) only the run-time variant
+template <int NCO, int ND, int M, int NH, typename TIn, typename TOut>
+static hipError_t launch_io(const RxParams &p, const FusedArgs &fa, const void *src, void *dst, hipStream_t st)
+{
+    if (fa.am) return launch_k<NCO, ND, M, NH, TIn, TOut, 1, 0>(p, fa, src, dst, st);
+    if constexpr (NCO != 0) {
+        if (fa.group == 16) return launch_k<NCO, ND, M, NH, TIn, TOut, 0, 16>(p, fa, src, dst, st);
+        if (fa.group == 64) return launch_k<NCO, ND, M, NH, TIn, TOut, 0, 64>(p, fa, src, dst, st);
+    }
+    return launch_k<NCO, ND, M, NH, TIn, TOut, 0, 0>(p, fa, src, dst, st);
+}
+
+template <int ND, int M, int NH>
+static hipError_t launch_nco(const RxParams &p, const FusedArgs &fa, const void *src, bool q15, void *dst, hipStream_t st)
+{
+    if (p.nco == 2) return q15 ? launch_io<2, ND, M, NH, int16_t, int16_t>(p, fa, src, dst, st) : launch_io<2, ND, M, NH, float, float>(p, fa, src, dst, st);
+    if (p.nco == 1) return q15 ? launch_io<1, ND, M, NH, int16_t, int16_t>(p, fa, src, dst, st) : launch_io<1, ND, M, NH, float, float>(p, fa, src, dst, st);
+    return q15 ? launch_io<0, ND, M, NH, int16_t, int16_t>(p, fa, src, dst, st) : launch_io<0, ND, M, NH, float, float>(p, fa, src, dst, st);
+}
+
+hipError_t launch_ssb_split16(int nd, int m, int nh, const RxParams &p, const FusedArgs &fa, const void *src, bool q15,
+                              void *dst, hipStream_t st)
+{
+#ifdef SRX_SPLIT16_BENCH_ONLY     // A/B builds: only the bench.py default kernel
+    if (nd == 256 && m == 4 && nh == 63 && p.nco == 2 && !q15 && !fa.am && fa.group == 16)
+        return launch_k<2, 256, 4, 63, float, float, 0, 16>(p, fa, src, dst, st);
+    return hipErrorNotSupported;
+#else
+#define X(ND_, M_, NH_) if (nd == ND_ && m == M_ && nh == NH_) return launch_nco<ND_, M_, NH_>(p, fa, src, q15, dst, st);
+    SRX_SPLIT16_SHAPES(X)
+#undef X
+    return hipErrorNotSupported;
+#endif
+}
+
+template <int NH, typename TIn, typename TOut>
+static hipError_t launch_hilb16(const RxParams &p, const FusedArgs &fa, const void *src, void *dst, hipStream_t st)
+{
+    using GH = GeoH<NH>;
+    constexpr size_t lds = (size_t)GH::total * sizeof(float);
+    static_assert(lds <= 48 * 1024, "k_hilb_split16 LDS image");
+    auto k = fa.am ? (p.nco == 2 ? k_hilb_split16<2, NH, TIn, TOut, 1>
+                                 : (p.nco == 1 ? k_hilb_split16<1, NH, TIn, TOut, 1> : k_hilb_split16<0, NH, TIn, TOut, 1>))
+                   : (p.nco == 2 ? k_hilb_split16<2, NH, TIn, TOut, 0>
+                                 : (p.nco == 1 ? k_hilb_split16<1, NH, TIn, TOut, 0> : k_hilb_split16<0, NH, TIn, TOut, 0>));
+    hipLaunchKernelGGL(k, dim3(p.channels), dim3(64), lds, st, p, fa, static_cast<const TIn *>(src),
+                       static_cast<TOut *>(dst));
+    return hipGetLastError();
+}
+
+hipError_t launch_hilb_split16(int nh, const RxParams &p, const FusedArgs &fa, const void *src, bool q15, void *dst,
+                               hipStream_t st)
+{
+#define X(NH_) if (nh == NH_) return q15 ? launch_hilb16<NH_, int16_t, int16_t>(p, fa, src, dst, st) : launch_hilb16<NH_, float, float>(p, fa, src, dst, st);
+    SRX_HILB16_SHAPES(X)
+#undef X
+    return hipErrorNotSupported;
+}
+
+}  // namespace srx

@@ -31,7 +31,7 @@ struct selenite_tx_instance {
     float2 *d_lo = nullptr;
     size_t lo_bytes = 0;
     void *d_ttab16 = nullptr;     // k_tx_split16: Toeplitz fragments of the interpolator phases
-    float tpost = 1.0f;
+    int tpost = 0;                // tap scale exponent of that table
     hipStream_t stream = nullptr, own_stream = nullptr;
     int status = 0;
     std::string err;

@@ -280,11 +280,12 @@ constexpr int kKS = 3;                                             // k-steps of
 constexpr int kZN = 240 + 32 * kKS;                                // highest image index read + 1
 __host__ __device__ constexpr int zphys(int u) { return u + 8 * (u >> 7); }      // 16 B pad per 128 samples
 constexpr int kZIMG = ((kZN + 8 * (kZN >> 7) + 8) + 7) & ~7;       // halfs per image
-constexpr int oZ16 = oHQ + kHLen, kTotal16 = oZ16 + 2 * kZIMG;     // 4 images of kZIMG halfs = 2 kZIMG floats
+constexpr int oZ16 = oHQ + kHLen, oZF = oZ16 + 2 * kZIMG;          // 4 images of kZIMG halfs = 2 kZIMG floats
+constexpr int kTotal16 = oZF + 2 * kPass;                          // + the pass's interpolator input in f32, both rails
 
 template <int NCO, typename TIn, typename TOut>
 __global__ __launch_bounds__(64, 2) void k_tx_split16(TxParams p, uint32_t delay_idx, const float2 *__restrict__ lo,
-                                                      const void *__restrict__ ttab16, float post,
+                                                      const void *__restrict__ ttab16, int tap_sc,
                                                       const TIn *__restrict__ src, TOut *__restrict__ dst)
 {
     using IO = AudioIO<TIn>;
@@ -293,6 +294,7 @@ __global__ __launch_bounds__(64, 2) void k_tx_split16(TxParams p, uint32_t delay
     const uint32_t c = blockIdx.x;
     float *tab = lds + oTab, *HI = lds + oHI, *HQ = lds + oHQ;
     _Float16 *ZI = reinterpret_cast<_Float16 *>(lds + oZ16);       // [I hi | I lo | Q hi | Q lo]
+    float *ZF = lds + oZF;                                         // [rail][256] f32: the last 64 are the next pass's history slots
     const size_t in_base = (size_t)c * p.block_size, out_base = (size_t)c * p.block_size * kL;
     const uint32_t npass = p.block_size / kPass;
     typename IO::raw raw = IO::load(src, in_base + 4u * lane);
@@ -311,9 +313,10 @@ __global__ __launch_bounds__(64, 2) void k_tx_split16(TxParams p, uint32_t delay
     const float hreg = (lane < kNH) ? p.hc[lane] : 0.0f;
     if constexpr (NCO == 1)
         for (int i = lane; i < 513; i += kWave) tab[i] = p.sintab[i];
-    const float xs = 256.0f;
-    auto putz = [&](int u, float i0, float q0, float i1, float q1) {     // image slots u (even), u + 1, both rails
-        const float a[4] = { i0 * xs, i1 * xs, q0 * xs, q1 * xs };
+    // block floating point (rx_split16.hip): the scale 2^s of a pass puts the largest |component| of the image
+    // ([64 history slots | 256 new samples]) into [2^14, 2^15); `pre` = 2^s
+    auto putz = [&](int u, float i0, float q0, float i1, float q1, float pre) {     // image slots u (even), u + 1, both rails
+        const float a[4] = { i0 * pre, i1 * pre, q0 * pre, q1 * pre };
         _Float16 h[4], l[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) { h[j] = (_Float16)a[j]; l[j] = (_Float16)(a[j] - (float)h[j]); }
@@ -323,8 +326,9 @@ __global__ __launch_bounds__(64, 2) void k_tx_split16(TxParams p, uint32_t delay
         *reinterpret_cast<h2 *>(ZI + 2 * kZIMG + ph) = h2{ h[2], h[3] };
         *reinterpret_cast<h2 *>(ZI + 3 * kZIMG + ph) = h2{ l[2], l[3] };
     };
-    for (int u = kZS + kPass + 2 * lane; u < kZN; u += 2 * kWave) putz(u, 0.0f, 0.0f, 0.0f, 0.0f);   // finite slack under zero taps
-    {   // state, branch-free: Hilbert-pair histories (f32) and the interpolator history (split)
+    for (int u = kZS + kPass + 2 * lane; u < kZN; u += 2 * kWave) putz(u, 0.0f, 0.0f, 0.0f, 0.0f, 1.0f);   // finite slack under zero taps
+    uint32_t e_hist;
+    {   // state, branch-free: Hilbert-pair histories and the interpolator history, all f32
         const float *stF = p.fir_state + (size_t)c * 2 * kHH, *stZ = p.int_state + (size_t)c * 2 * (kP - 1);
         float f[2];
 #pragma unroll
@@ -334,13 +338,15 @@ __global__ __launch_bounds__(64, 2) void k_tx_split16(TxParams p, uint32_t delay
             f[j] = sidx < 0 ? 0.0f : x;
         }
         HI[lane] = f[0]; HQ[lane] = f[1];
-        // image slot u = 1 + state index; lane < 32 owns slots 2 lane, 2 lane + 1 (slot 0 = the extra zero)
-        const int u = 2 * (lane & 31);
-        const int s0 = u - 1, s1 = u;                              // state indices, s0 = -1 for slot 0
-        const float zi0 = stZ[s0 < 0 ? 0 : s0], zi1 = stZ[s1 > kP - 2 ? kP - 2 : s1];
-        const float zq0 = stZ[(kP - 1) + (s0 < 0 ? 0 : s0)], zq1 = stZ[(kP - 1) + (s1 > kP - 2 ? kP - 2 : s1)];
-        if (lane < 32) putz(u, s0 < 0 ? 0.0f : zi0, s0 < 0 ? 0.0f : zq0, zi1, zq1);
+        // history slot u = 1 + state index (slot 0 = the extra zero); lane owns slot `lane` of both rails
+        const int s0 = lane - 1;
+        const float zi = stZ[s0 < 0 ? 0 : s0], zq = stZ[(kP - 1) + (s0 < 0 ? 0 : s0)];
+        const float hi = s0 < 0 ? 0.0f : zi, hq = s0 < 0 ? 0.0f : zq;
+        ZF[kPass - kZS + lane] = hi;
+        ZF[kPass + kPass - kZS + lane] = hq;
+        e_hist = wave_umax_bits(fmaxf(fabsf(hi), fabsf(hq))) >> 23;
     }
+    int s_cur = 0x7fff;
     float gain = p.alc ? p.gain[c] : 1.0f;
     const uint32_t ph0 = NCO ? p.phase[c] : 0u, step = NCO ? p.step[c] : 0u;
     const bool am = p.mode == SELENITE_MODE_AM, up = mode_is_upper(p.mode);
@@ -348,7 +354,6 @@ __global__ __launch_bounds__(64, 2) void k_tx_split16(TxParams p, uint32_t delay
     wave_lds_sync();
 
     for (uint32_t pass = 0; pass < npass; ++pass) {
-        const bool last = (pass + 1 == npass);
         // ---- 1. ALC ----
         float a[4];
         IO::unpack(raw, a);
@@ -397,16 +402,30 @@ __global__ __launch_bounds__(64, 2) void k_tx_split16(TxParams p, uint32_t delay
                 else if (!up) rq = -rq;
                 zi[r] = ri; zq[r] = rq;
             }
-            putz(kZS + 4 * lane, zi[0], zq[0], zi[1], zq[1]);
-            putz(kZS + 4 * lane + 2, zi[2], zq[2], zi[3], zq[3]);
-            if (last) {                                            // arm_fir_interpolate_f32 pState tails, exact f32
-                float *stI = p.int_state + (size_t)c * 2 * (kP - 1), *stQ = stI + (kP - 1);
+            // block exponent over the new samples and the history; the samples that become the next history
+            // (the last 64 of the pass) on the side
+            float mq = 0.0f, mt = 0.0f;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int sidx = 4 * lane + r - (kPass - (kP - 1));
-                    if (sidx >= 0) { stI[sidx] = zi[r]; stQ[sidx] = zq[r]; }
-                }
+            for (int r = 0; r < 4; ++r) mq = fmaxf(mq, fmaxf(fabsf(zi[r]), fabsf(zq[r])));
+            mt = 4 * lane >= kPass - kZS ? mq : 0.0f;
+            const uint32_t e_tail = wave_umax_bits(mt) >> 23;
+            const uint32_t e_need = max(max(wave_umax_bits(mq) >> 23, e_tail), e_hist);
+            int s_new = 141 - (int)e_need;
+            s_new = s_new > 127 ? 127 : (s_new < -126 ? -126 : s_new);
+            if (s_new != s_cur) {                                  // wave-uniform; always in the first pass
+                const int u = 2 * (lane & 31);                     // both half-waves write the same words
+                const float2 hi = *reinterpret_cast<const float2 *>(ZF + kPass - kZS + u);
+                const float2 hq = *reinterpret_cast<const float2 *>(ZF + kPass + kPass - kZS + u);
+                putz(u, hi.x, hq.x, hi.y, hq.y, __uint_as_float((uint32_t)(s_new + 127) << 23));
+                s_cur = s_new;
             }
+            e_hist = e_tail;
+            wave_lds_sync();                                       // history reads above, f32 rail writes below
+            const float pre = __uint_as_float((uint32_t)(s_cur + 127) << 23);
+            putz(kZS + 4 * lane, zi[0], zq[0], zi[1], zq[1], pre);
+            putz(kZS + 4 * lane + 2, zi[2], zq[2], zi[3], zq[3], pre);
+            *reinterpret_cast<float4 *>(ZF + 4 * lane) = make_float4(zi[0], zi[1], zi[2], zi[3]);
+            *reinterpret_cast<float4 *>(ZF + kPass + 4 * lane) = make_float4(zq[0], zq[1], zq[2], zq[3]);
         }
         wave_lds_sync();
         {   // Hilbert-pair history
@@ -438,11 +457,12 @@ __global__ __launch_bounds__(64, 2) void k_tx_split16(TxParams p, uint32_t delay
         //         NCO up-mix and store with every wave instruction covering 1 KB of contiguous output ----
         {
             float *T = lds + kTotal16;                                  // [1024][2] un-mixed output tile of the pass
+            const int pex = -(s_cur + tap_sc);                          // exact power-of-two rescale
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float4 *tp = reinterpret_cast<float4 *>(T + 2 * kL * (64 * rg + 16 * r + mcol));
-                tp[0] = make_float4(aI[0][r] * post, aQ[0][r] * post, aI[1][r] * post, aQ[1][r] * post);
-                tp[1] = make_float4(aI[2][r] * post, aQ[2][r] * post, aI[3][r] * post, aQ[3][r] * post);
+                tp[0] = make_float4(__builtin_ldexpf(aI[0][r], pex), __builtin_ldexpf(aQ[0][r], pex), __builtin_ldexpf(aI[1][r], pex), __builtin_ldexpf(aQ[1][r], pex));
+                tp[1] = make_float4(__builtin_ldexpf(aI[2][r], pex), __builtin_ldexpf(aQ[2][r], pex), __builtin_ldexpf(aI[3][r], pex), __builtin_ldexpf(aQ[3][r], pex));
             }
             wave_lds_sync();
 #pragma unroll
@@ -491,6 +511,11 @@ __global__ __launch_bounds__(64, 2) void k_tx_split16(TxParams p, uint32_t delay
         p.fir_state[(size_t)c * 2 * kHH + (lane - kFH)] = HI[lane];
         p.fir_state[(size_t)c * 2 * kHH + kHH + (lane - kFH)] = HQ[lane];
     }
+    if (lane >= 1) {                                               // arm_fir_interpolate_f32 pState tails, exact f32
+        float *stI = p.int_state + (size_t)c * 2 * (kP - 1), *stQ = stI + (kP - 1);
+        stI[lane - 1] = ZF[kPass - kZS + lane];
+        stQ[lane - 1] = ZF[kPass + kPass - kZS + lane];
+    }
     if (lane == 0) {
         if (p.alc) p.gain[c] = gain;
         if constexpr (NCO != 0) p.phase[c] = ph0 + p.block_size * kL * step;
@@ -498,16 +523,16 @@ __global__ __launch_bounds__(64, 2) void k_tx_split16(TxParams p, uint32_t delay
 }
 
 template <typename TIn, typename TOut>
-hipError_t launch_s16(const TxParams &p, uint32_t delay_idx, const float2 *lo, const void *ttab16, float post, const void *src,
+hipError_t launch_s16(const TxParams &p, uint32_t delay_idx, const float2 *lo, const void *ttab16, int tap_sc, const void *src,
                       void *dst, hipStream_t st)
 {
     constexpr size_t lds = (size_t)(kTotal16 + 2 * kPass * kL) * sizeof(float);      // + the 8 KB output tile
     const dim3 grid(p.channels), blk(64);
     const TIn *s = static_cast<const TIn *>(src);
     TOut *d = static_cast<TOut *>(dst);
-    if (!p.nco) hipLaunchKernelGGL((k_tx_split16<0, TIn, TOut>), grid, blk, lds, st, p, delay_idx, lo, ttab16, post, s, d);
-    else if (lo) hipLaunchKernelGGL((k_tx_split16<2, TIn, TOut>), grid, blk, lds, st, p, delay_idx, lo, ttab16, post, s, d);
-    else hipLaunchKernelGGL((k_tx_split16<1, TIn, TOut>), grid, blk, lds, st, p, delay_idx, lo, ttab16, post, s, d);
+    if (!p.nco) hipLaunchKernelGGL((k_tx_split16<0, TIn, TOut>), grid, blk, lds, st, p, delay_idx, lo, ttab16, tap_sc, s, d);
+    else if (lo) hipLaunchKernelGGL((k_tx_split16<2, TIn, TOut>), grid, blk, lds, st, p, delay_idx, lo, ttab16, tap_sc, s, d);
+    else hipLaunchKernelGGL((k_tx_split16<1, TIn, TOut>), grid, blk, lds, st, p, delay_idx, lo, ttab16, tap_sc, s, d);
     return hipGetLastError();
 }
 
@@ -533,14 +558,14 @@ bool tx_fused_ok(const selenite_tx_config &g, bool delay_is_impulse, bool hilb_o
 }
 
 // Toeplitz fragments of the four interpolator phases for k_tx_split16 (f16 hi / lo, taps x 2^SC);
-// *post = 2^-(8 + SC).  Layout: [phase][k-step][hi, lo][lane][8 halfs].
-hipError_t build_tx_split16_table(const float *interp_coeffs, void **d_table, float *post)
+// *tap_sc = SC.  Layout: [phase][k-step][hi, lo][lane][8 halfs].
+hipError_t build_tx_split16_table(const float *interp_coeffs, void **d_table, int *tap_sc)
 {
     float cmax = 0.0f;
     for (int k = 0; k < kNI; ++k) cmax = std::fmax(cmax, std::fabs(interp_coeffs[k]));
     int ex = 0;
     if (cmax > 0.0f) std::frexp(cmax, &ex);
-    const int SC = 10 - ex;
+    const int SC = 15 - ex;                                        // largest |tap| * 2^SC in [2^14, 2^15)
     std::vector<_Float16> b16((size_t)kL * kKS * 2 * 64 * 8, (_Float16)0.0f);
     for (int ph = 0; ph < kL; ++ph)
         for (int kk = 0; kk < kKS; ++kk)
@@ -557,15 +582,15 @@ hipError_t build_tx_split16_table(const float *interp_coeffs, void **d_table, fl
     hipError_t e = hipMalloc(d_table, b16.size() * sizeof(_Float16));
     if (e != hipSuccess) return e;
     e = hipMemcpy(*d_table, b16.data(), b16.size() * sizeof(_Float16), hipMemcpyHostToDevice);
-    *post = std::ldexp(1.0f, -(8 + SC));
+    *tap_sc = SC;
     return e;
 }
 
-hipError_t launch_tx_split16(const TxParams &p, uint32_t delay_idx, const float2 *lo, const void *ttab16, float post,
+hipError_t launch_tx_split16(const TxParams &p, uint32_t delay_idx, const float2 *lo, const void *ttab16, int tap_sc,
                              const void *src, bool q15, void *dst, hipStream_t st)
 {
-    return q15 ? launch_s16<int16_t, int16_t>(p, delay_idx, lo, ttab16, post, src, dst, st)
-               : launch_s16<float, float>(p, delay_idx, lo, ttab16, post, src, dst, st);
+    return q15 ? launch_s16<int16_t, int16_t>(p, delay_idx, lo, ttab16, tap_sc, src, dst, st)
+               : launch_s16<float, float>(p, delay_idx, lo, ttab16, tap_sc, src, dst, st);
 }
 
 hipError_t launch_tx_fused(const TxParams &p, int arith, uint32_t delay_idx, const float2 *lo, const void *src, bool q15,

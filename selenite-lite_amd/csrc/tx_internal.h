@@ -28,8 +28,8 @@ hipError_t launch_tx_fused(const TxParams &p, int arith, uint32_t delay_idx, con
                            void *dst, hipStream_t st);
 
 // SELENITE_ARITH_SPLIT16: the interpolator on the 16-bit matrix pipe (k_tx_split16), same shape as the fused kernel
-hipError_t build_tx_split16_table(const float *interp_coeffs, void **d_table, float *post);
-hipError_t launch_tx_split16(const TxParams &p, uint32_t delay_idx, const float2 *lo, const void *ttab16, float post,
+hipError_t build_tx_split16_table(const float *interp_coeffs, void **d_table, int *tap_sc);
+hipError_t launch_tx_split16(const TxParams &p, uint32_t delay_idx, const float2 *lo, const void *ttab16, int tap_sc,
                              const void *src, bool q15, void *dst, hipStream_t st);
 
 }  // namespace srx

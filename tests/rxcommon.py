@@ -313,16 +313,17 @@ def rel_err(got, ref):
 
 # named BASELINE.json configurations (scaled by the caller through `channels` / block_size)
 def baseline_spec(name, channels, arith=ARITH_CMSIS, **kw):
+    kw.setdefault("agc", True)
     if name == "cfg1":   # single 256-sample block, USB, 63-tap Hilbert + AGC
-        return ChainSpec(channels, 256, 1, 0, 63, 0, MODE_USB, arith, agc=True, **kw)
+        return ChainSpec(channels, 256, 1, 0, 63, 0, MODE_USB, arith, **kw)
     if name == "cfg2":   # 127-tap Hilbert SSB + AGC @48k
-        return ChainSpec(channels, 256, 1, 0, 127, 0, MODE_USB, arith, agc=True, **kw)
+        return ChainSpec(channels, 256, 1, 0, 127, 0, MODE_USB, arith, **kw)
     if name == "cfg3":   # NCO + 256-tap /4 + 63-tap SSB + AGC  (the headline config)
         return ChainSpec(channels, 256, 4, 256, 63, 0, MODE_USB, arith, nco=True,
-                         nco_step_all=0x01000000, agc=True, **kw)
+                         nco_step_all=0x01000000, **kw)
     if name == "cfg4":   # CW narrow: NCO (BFO) + 4-stage biquad @500 Hz + AGC
         return ChainSpec(channels, 256, 1, 0, 0, 4, MODE_CW, arith, nco=True,
-                         nco_step_all=0x00800000, agc=True, **kw)
+                         nco_step_all=0x00800000, **kw)
     raise KeyError(name)
 
 
