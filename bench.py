@@ -5,19 +5,22 @@ One "step" = one selenite_rx_process_f32_device() call over the whole resident b
 (channels x block_size complex samples per GPU).  Inputs are generated on the device by the
 library's synthetic generator and are resident in HBM before the timed region starts.
 
-    python bench.py --gpus 1 --steps K --warmup W            # single GPU
-    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py --gpus N --steps K --warmup W
+
+N = 1 runs in this process.  N > 1: when a launcher started this process (torch.distributed.run sets
+WORLD_SIZE / RANK / LOCAL_RANK) it is one rank of N; otherwise it starts the N ranks itself
+(`python -m torch.distributed.run --nproc-per-node N ... bench.py <same args>`) before touching the
+GPU and relays rank 0's JSON line.  A world size that differs from --gpus is an error, never a number.
 
 Multi-GPU: channels shard across ranks with NO data-path collective (independent channels,
 SURVEY.md 8e) -> weak scaling, channels per GPU fixed.  The only exchange the chain can have is the
 optional global-gain AGC (--global-gain): 4 bytes per DSP block all-reduced with MAX over RCCL.
 
 Rank 0 prints ONE JSON line (see the driver contract in the task statement) carrying `roofline`
-and, at N=1, `cpu_baseline` (the oracle -- a bit-exact CPU restatement of the CMSIS-DSP chain --
-timed on this box's host cores on a bounded sample of the same workload).
+and, at N=1, `cpu_baseline` (the CMSIS-DSP chain timed on this box's host cores, single core and all
+cores, on a bounded sample of the same workload).
 """
 import argparse
-import ctypes as C
 import json
 import os
 import sys
@@ -25,71 +28,73 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "selenite-lite_amd"))
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 F32_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: f32 vector (= f32 MFMA) peak
-SEED = 0x5E1E917E
+TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r2", "traffic.json")
 
-WORKLOADS = {
-    # name: (baseline config, channels per GPU, block_size per call)
-    "cfg3": ("cfg3", 65536, 4096),     # headline: NCO + 256-tap /4 + 63-tap SSB + AGC
-    "cfg2": ("cfg2", 4096, 48000 - 48000 % 256),
-    "cfg4": ("cfg4", 65536, 4096),
-    "cfg5": ("cfg2", 131072, 1024),    # weak-scaling shape of BASELINE cfg5 (cfg2 chain)
-}
+WORKLOAD_TEXT = {"cfg3": "NCO + 256-tap arm_fir_decimate/4 + 63-tap Hilbert SSB (USB) + AGC",
+                 "cfg2": "127-tap Hilbert SSB (USB) + AGC",
+                 "cfg4": "CW: NCO + 4-stage DF1 biquad @500 Hz + AGC",
+                 "cfg5": "127-tap Hilbert SSB (USB) + AGC, cfg5 weak-scaling shape"}
 
 
-def flops_per_sample(spec):
-    """SURVEY.md 8d algorithmic flops per complex input sample."""
-    f = 0.0
-    if spec.nd_taps:
-        f += 2.0 * 2.0 * spec.nd_taps / spec.decim
-    if spec.nh_taps:
-        f += 2.0 * spec.nh_taps / spec.decim
-    if spec.nco:
-        f += 20.0
-    if spec.n_biquad:
-        f += 9.0 * spec.n_biquad / spec.decim
-    return f
-
-
-def pmc_traffic(workload, arith_name, kernel, channels, bs):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r1/traffic.json:
-    2*FETCH_SIZE*1024 + WRITE_SIZE*1024, separate --pmc passes, calibration in profiles/r1/README.md).
-    Only returned when the run is the profiled shape and kernel."""
+def pmc_traffic(workload, arith_name, kernel, channels, bs, workloads):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes of this round (profiles/r2/traffic.json:
+    2*FETCH_SIZE*1024 + WRITE_SIZE*1024, separate --pmc passes, calibration in profiles/r1/README.md).  NOT measured
+    in this run (the counters need rocprofv3 around the process): returned only for the profiled shape and kernel,
+    and labelled as such in the JSON."""
     try:
-        t = json.load(open(os.path.join(ROOT, "profiles", "r1", "traffic.json")))
+        t = json.load(open(TRAFFIC_JSON))
     except (OSError, ValueError):
         return None
     e = t.get(workload + "_" + arith_name) or t.get(workload)
-    if not e or (channels, bs) != WORKLOADS[workload][1:]:
+    if not e or (channels, bs) != workloads[workload][1:]:
         return None
     if kernel.split("<")[0] not in e["kernel"]:
         return None
     return int(e["hbm_bytes"])
 
 
-def cpu_baseline(name, arith, budget_s=12.0):
-    """Oracle (kind 'port') on the host cores, bounded sample of the same workload."""
-    import numpy as np
+def cpu_baseline(name, workloads, budget_s=10.0):
+    """The CMSIS-DSP chain on the host cores, bounded sample of the same workload: single core, then every core
+    the box has (one persistent worker thread per core, each with its own chain instance over its own channels;
+    ctypes releases the GIL for the duration of a call).
+
+    kind "reference": oracle/_ref/libcmsis_ref.so -- the reference's own CMSIS-DSP 1.5.3 sources compiled with
+    `gcc -O2 -ffp-contract=off -DARM_MATH_CM4` (oracle/Makefile) behind the composition harness oracle/ref_chain.c.
+    kind "port": oracle/rx_oracle.c, the plain-loop restatement (bit-exact against the former), when _ref is absent.
+    Either way this is test infrastructure used as a yardstick here and nowhere in the product path."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from concurrent.futures import ThreadPoolExecutor
     import rxcommon as rc
-    cores = min(os.cpu_count() or 1, 64)
-    cfg_name, _, bs = WORKLOADS[name]
+    kind, which = ("reference", "ref") if rc.ref_available() else ("port", "orc")
+    cores = os.cpu_count() or 1
+    cfg_name, _, bs = workloads[name]
     bs = min(bs, 4096)
-    channels = 32 * cores
-    spec = rc.baseline_spec(cfg_name, channels, arith)
-    iq = rc.synth_iq(0, channels, 0, bs, SEED)
-    chain = rc.CpuChain(spec, "orc")
-    chain.process(iq, nthreads=cores)          # warm-up (page in, threads)
-    calls, t0 = 0, time.perf_counter()
-    while True:
-        chain.process(iq, nthreads=cores)
-        calls += 1
-        el = time.perf_counter() - t0
-        if el >= budget_s or calls >= 1000:
-            break
-    value = channels * bs * calls / el / 1e6
+    per = 16                                           # channels per worker and call
+    spec = rc.baseline_spec(cfg_name, per, rc.ARITH_CMSIS)
+
+    def measure(nworkers, budget):
+        chains = [rc.CpuChain(spec, which) for _ in range(nworkers)]
+        iqs = [rc.synth_iq(w * per, per, 0, bs, rc.SEED) for w in range(nworkers)]
+        pool = ThreadPoolExecutor(nworkers)
+        run = lambda w: chains[w].process(iqs[w])
+        list(pool.map(run, range(nworkers)))           # warm-up: page in, spin the threads up
+        calls, t0 = 0, time.perf_counter()
+        while True:
+            list(pool.map(run, range(nworkers)))
+            calls += 1
+            el = time.perf_counter() - t0
+            if el >= budget or calls >= 2000:
+                break
+        pool.shutdown()
+        for c in chains:
+            c.close()
+        return nworkers * per * bs * calls / el / 1e6, calls, el
+
+    v1, c1, e1 = measure(1, budget_s * 0.3)
+    vn, cn, en = measure(cores, budget_s * 0.7)
     model = ""
     try:
         for line in open("/proc/cpuinfo"):
@@ -98,11 +103,25 @@ def cpu_baseline(name, arith, budget_s=12.0):
                 break
     except OSError:
         pass
-    return {"value": round(value, 3), "unit": "Msamples/s", "cores": cores, "kind": "port",
-            "sample": "%d channels x %d samples x %d calls, %s chain, oracle/rx_oracle.c "
-                      "(bit-exact vs CMSIS-DSP 1.5.3), gcc -O2 -ffp-contract=off, %d pthreads; cpu=%s"
-                      % (channels, bs, calls, cfg_name, cores, model),
-            "seconds": round(el, 2)}
+    what = ("CMSIS-DSP 1.5.3 sources of the reference behind oracle/ref_chain.c" if kind == "reference"
+            else "oracle/rx_oracle.c (un-tuned plain-loop restatement, bit-exact vs CMSIS-DSP 1.5.3)")
+    return {"value": round(vn, 3), "unit": "Msamples/s", "cores": cores, "kind": kind,
+            "sample": "%s chain, %d channels x %d samples per worker and call, %d workers x %d calls in %.1f s; %s; "
+                      "gcc -O2 -ffp-contract=off; cpu=%s" % (cfg_name, per, bs, cores, cn, en, what, model),
+            "single_core": {"value": round(v1, 3), "unit": "Msamples/s", "cores": 1, "calls": c1, "seconds": round(e1, 2)},
+            "seconds": round(e1 + en, 2)}
+
+
+def selftest_launch(env, args):
+    """--selftest-launch: the launcher / rendezvous / collective plumbing of the N > 1 path without a GPU
+    (CPU tests): no library call, gloo only."""
+    env.init_process_group("gloo", use_gpu=False)
+    env.barrier()
+    worst = env.max_over_ranks(0.001 * (env.rank + 1))
+    if env.rank == 0:
+        print(json.dumps({"selftest": "launch", "n_gpus": args.gpus, "world": env.world, "max_over_ranks_s": worst,
+                          "config": {"parallelism": "channels sharded x%d, no data-path collective" % env.world}}), flush=True)
+    env.close()
 
 
 def main():
@@ -114,57 +133,59 @@ def main():
                     help="untimed device spin-up before the W warmup steps: an idle MI355X sits at ~150 MHz and needs "
                          "~60-100 ms of load to reach its sustained clocks (tools/clock_ramp.py); a streaming DSP "
                          "service runs in that steady state.  0 disables it.")
-    ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOAD_TEXT))
     ap.add_argument("--channels", type=int, default=0, help="channels per GPU (default: workload's)")
     ap.add_argument("--block-size", type=int, default=0)
     ap.add_argument("--arith", default=os.environ.get("SELENITE_BENCH_ARITH", "split16"), choices=["cmsis", "fma", "split16"],
-                    help="split16 (default): decimator as f16 hi/lo split-precision MFMA product, <=1e-5 rel vs CMSIS "
-                         "(north-star tolerance; measured 1.6e-6); fma: FIR tap loops fused, bit-exact vs the fmaf "
-                         "oracle; cmsis: bit-exact CMSIS-DSP arithmetic")
+                    help="split16 (default): many-tap FIR as f16 hi/lo split-precision MFMA product with a per-pass block "
+                         "exponent, <=1e-5 rel vs CMSIS at any input level (north-star tolerance); fma: FIR tap loops "
+                         "fused, bit-exact vs the fmaf oracle; cmsis: bit-exact CMSIS-DSP arithmetic")
     ap.add_argument("--global-gain", action="store_true")
     ap.add_argument("--io", default="f32", choices=["f32", "q15"],
                     help="f32: the canonical float I/Q in / float audio out signature (headline); q15: the firmware's "
                          "int16 slot format either side (dsp_if.c:286-289, arm_q15_to_float / arm_float_to_q15 fused in)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--main-only", action="store_true", help="profiling runs: skip the cpu_baseline and other-arithmetic legs")
+    ap.add_argument("--main-only", action="store_true", help="profiling runs: skip the cpu_baseline and other-mode legs")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"])
+    ap.add_argument("--selftest-launch", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if os.environ.get("SELENITE_BENCH_SHARE_GPU") == "1":      # test rig: several ranks on one device (gloo only)
-        local_rank = 0
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    n_gpus = args.gpus
-    dist = None
-    torch = None
-    if world > 1 or os.environ.get("SELENITE_BENCH_FORCE_DIST") == "1":   # (the env var lets a 1-GPU box exercise this path)
-        # torch FIRST: its bundled libamdhip64 (same soname) then serves libselenite_rx.so too, so
-        # the process holds exactly one HIP runtime.
-        import torch
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend=args.dist_backend, rank=rank, world_size=world)
+    from selenite_rx import shard                         # pure Python: nothing below touches the GPU yet
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # not under a launcher: start the N ranks ourselves, as child processes, before any GPU call
+        sys.exit(shard.launch_ranks(args.gpus, os.path.abspath(__file__), sys.argv[1:]))
+    env = shard.RankEnv()
+    if env.world != args.gpus:
+        sys.stderr.write("bench.py: --gpus %d but the launcher started %d rank(s); refusing to report a number\n"
+                         % (args.gpus, env.world))
+        sys.exit(2)
+    if args.selftest_launch:
+        return selftest_launch(env, args)
+    rank, world = env.rank, env.world
+    local_rank = 0 if os.environ.get("SELENITE_BENCH_SHARE_GPU") == "1" else env.local_rank   # test rig: ranks share device 0 (gloo)
+    if world > 1 or os.environ.get("SELENITE_BENCH_FORCE_DIST") == "1":      # (the env var lets a 1-GPU box exercise this path)
+        env.local_rank = local_rank
+        env.init_process_group(args.dist_backend)
     elif args.global_gain:
         import torch
+        env.torch = torch
 
     import numpy as np
-    import rxcommon as rc
     import selenite_rx as sr
+    from selenite_rx import chain as ch
 
-    arith = {"fma": rc.ARITH_FMA, "cmsis": rc.ARITH_CMSIS, "split16": rc.ARITH_SPLIT16}[args.arith]
-    cfg_name, channels, bs = WORKLOADS[args.workload]
+    arith = {"fma": sr.ARITH_FMA, "cmsis": sr.ARITH_CMSIS, "split16": sr.ARITH_SPLIT16}[args.arith]
+    cfg_name, channels, bs = ch.WORKLOADS[args.workload]
     channels = args.channels or channels
     bs = args.block_size or bs
     sr.lib().selenite_rx_set_device(local_rank)
-    spec = rc.baseline_spec(cfg_name, channels, arith, agc_global=args.global_gain)
+    spec = ch.baseline_spec(cfg_name, channels, arith, agc_global=args.global_gain)
     rx = sr.Rx(spec.config())
     nout = bs // spec.decim
 
     d_in = sr.DeviceBuffer(channels * bs * 8)
     d_out = sr.DeviceBuffer(channels * nout * 4)
-    rx.synth_device(d_in.ptr, rank * channels, channels, 0, bs, SEED)
+    rx.synth_device(d_in.ptr, rank * channels, channels, 0, bs, ch.SEED)
     rx.sync()
     q15 = args.io == "q15"
     if q15:
@@ -183,43 +204,32 @@ def main():
         d_in.free()
         d_in = d_in16
 
-    def barrier():
-        rx.sync()
-        if dist is not None:
-            if args.dist_backend == "nccl":
-                torch.cuda.synchronize()
-            dist.barrier()
+    gg = shard.GlobalGainStepper(rx, env, bs // spec.block, local_rank) if args.global_gain else None
 
-    env_t = None
-    if args.global_gain:
-        env_t = torch.zeros(bs // spec.block, dtype=torch.float32, device="cuda:%d" % local_rank)
-        # kernels go on torch's current stream, so phase1 -> all-reduce -> phase2 are ordered on
-        # the device and a step needs no host synchronisation
-        rx.set_stream(torch.cuda.current_stream().cuda_stream)
+    def sync_all():
+        rx.sync()
+        if gg is not None:
+            gg.synchronize()
+        env.barrier()
 
     def step():
-        if args.global_gain:
-            rx.global_phase1(d_in.ptr, d_out.ptr, env_t.data_ptr(), bs)
-            if dist is not None:
-                dist.all_reduce(env_t, op=dist.ReduceOp.MAX)     # RCCL over xGMI: 4 B per DSP block
-            rx.global_phase2(d_out.ptr, env_t.data_ptr(), bs)
+        if gg is not None:
+            gg.step(d_in.ptr, d_out.ptr, bs)
         elif q15:
             rx.process_q15_device(d_in.ptr, d_out.ptr, bs)
         else:
             rx.process_device(d_in.ptr, d_out.ptr, bs)
 
     spin_t0 = time.perf_counter()
-    spin_calls = 0
     while (time.perf_counter() - spin_t0) * 1e3 < args.spinup_ms:      # clock ramp, untimed (see --spinup-ms)
         for _ in range(16):
             step()
         rx.sync()
-        spin_calls += 16
     for _ in range(args.warmup):
         step()
-    barrier()
+    sync_all()
     t0 = time.perf_counter()
-    if args.global_gain:
+    if gg is not None:
         for _ in range(args.steps):
             step()
         ev_ms = None
@@ -227,15 +237,10 @@ def main():
         # the K timed steps are issued by the library between two HIP events recorded on the
         # stream the kernels run on; the wall clock brackets the same region
         ev_ms = (rx.time_process_q15 if q15 else rx.time_process)(d_in.ptr, d_out.ptr, bs, args.steps)
-    barrier()
+    sync_all()
     t1 = time.perf_counter()
     rx.check()
-    elapsed = t1 - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64,
-                         device=("cuda:%d" % local_rank) if args.dist_backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = env.max_over_ranks(t1 - t0)
 
     if rank == 0:
         ms_per_step = elapsed * 1e3 / args.steps
@@ -247,42 +252,47 @@ def main():
             rd_bytes -= channels * 4 * bs
         k_ms = ev_ms if ev_ms is not None else ms_per_step
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9
-        fl = flops_per_sample(spec) * channels * bs
+        # flops the timed kernel executes: with one LO shared by all channels (the default shape) the NCO costs the
+        # complex multiply only (6 flops per sample); the per-sample table-lerp sin/cos is the "per_channel" leg below
+        shared_lo = bool(spec.nco and spec.nco_steps is None and os.environ.get("SELENITE_RX_NO_SHARED_LO") != "1")
+        fps = ch.flops_per_sample(spec, 6.0 if shared_lo else 20.0)
+        fl = fps * channels * bs
+        traffic = None if q15 else pmc_traffic(args.workload, args.arith, rx.kernel_name(), channels, bs, ch.WORKLOADS)
         out = {
             "metric": "Msamples/s complex I/Q through full RX chain (whole job)",
-            "value": round(value, 2), "unit": "Msamples/s", "n_gpus": n_gpus, "steps": args.steps,
+            "value": round(value, 2), "unit": "Msamples/s", "n_gpus": args.gpus, "steps": args.steps,
             "warmup": args.warmup, "spinup_ms": args.spinup_ms, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic", "io": args.io,
+            "dtype": ("f32 in / out / accumulate; FIR multiplicands as exact f16 hi+lo pairs (~22 bits) on the matrix cores"
+                      if arith == sr.ARITH_SPLIT16 and "split16" in rx.kernel_name() else "f32"),
+            "data": "synthetic", "io": args.io,
             "config": {"workload": "%s: %d channels/GPU x %d complex samples/call, %s" % (
-                           args.workload, channels, bs,
-                           {"cfg3": "NCO + 256-tap arm_fir_decimate/4 + 63-tap Hilbert SSB (USB) + AGC",
-                            "cfg2": "127-tap Hilbert SSB (USB) + AGC",
-                            "cfg4": "CW: NCO + 4-stage DF1 biquad @500 Hz + AGC",
-                            "cfg5": "127-tap Hilbert SSB (USB) + AGC, cfg5 weak-scaling shape"}[args.workload]),
-                       "arith": {rc.ARITH_CMSIS: "cmsis-exact (mul,add)", rc.ARITH_FMA: "fma (<=1e-5 rel vs CMSIS)",
-                                 rc.ARITH_SPLIT16: "split16 (f16 hi/lo x3 MFMA decimator, <=1e-5 rel vs CMSIS)"}[arith],
+                           args.workload, channels, bs, WORKLOAD_TEXT[args.workload]),
+                       "arith": {sr.ARITH_CMSIS: "cmsis-exact (mul,add)", sr.ARITH_FMA: "fma (<=1e-5 rel vs CMSIS)",
+                                 sr.ARITH_SPLIT16: "split16 (f16 hi/lo x3 MFMA FIR, block floating point, <=1e-5 rel vs CMSIS)"}[arith],
                        "kernel": rx.kernel_name(), "agc": "global" if args.global_gain else "per-channel",
+                       "nco": ("shared LO table per call" if shared_lo else "per-channel arm_sin/cos_f32") if spec.nco else "off",
                        "parallelism": "channels sharded x%d, no data-path collective" % world},
             "per_gpu_msamples_s": round(value / world, 2),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": None if q15 else pmc_traffic(args.workload, args.arith, rx.kernel_name(), channels, bs),
+                         "traffic": traffic,
+                         "traffic_source": None if traffic is None else "profiles/r2/traffic.json (committed rocprofv3 --pmc passes of this kernel and shape; not measured in this run)",
                          "algorithmic_bytes_per_launch": alg_bytes, "read_bytes_per_launch": rd_bytes,
                          "read_frac": round(rd_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                          "launch_ms_hip_events": round(k_ms, 4)},
             "fma_roof": {"achieved": round(fl / (k_ms * 1e-3) / 1e12, 2), "peak": F32_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(fl / (k_ms * 1e-3) / 1e12 / F32_PEAK_TFLOPS, 4),
-                         "flops_per_sample": flops_per_sample(spec)},
+                         "flops_per_sample": fps},
         }
         if world == 1 and not args.global_gain and not args.main_only and not q15:
-            # the same workload in the other arithmetic contracts, outside the timed region, for the record
+            # the same workload in the other arithmetic contracts and with the general (per-channel) NCO, outside the
+            # timed region, for the record
             others = {}
-            for nm, ar in (("fma", rc.ARITH_FMA), ("cmsis", rc.ARITH_CMSIS)):
+            for nm, ar in (("fma", sr.ARITH_FMA), ("cmsis", sr.ARITH_CMSIS)):
                 if ar == arith:
                     continue
-                spec_x = rc.baseline_spec(cfg_name, channels, ar)
-                rx_x = sr.Rx(spec_x.config())
+                rx_x = sr.Rx(ch.baseline_spec(cfg_name, channels, ar).config())
                 rx_x.time_process(d_in.ptr, d_out.ptr, bs, max(2, args.warmup))
                 ms_x = rx_x.time_process(d_in.ptr, d_out.ptr, bs, max(3, args.steps // 2))
                 others[nm] = {"value": round(channels * bs / (ms_x * 1e-3) / 1e6, 2), "unit": "Msamples/s",
@@ -291,16 +301,26 @@ def main():
             others["note"] = ("fma: bit-exact vs the oracle's fmaf restatement; cmsis: bit-exact (0 ULP) vs CMSIS-DSP 1.5.3 "
                               "arithmetic; split16: tolerance-based, <=1e-5 relative per DSP block")
             out["other_arith_modes"] = others
+            if spec.nco:
+                # every channel with its own NCO step: arm_sin_f32 / arm_cos_f32 per sample inside the kernel
+                # (arm_sin_f32.c:72-119), no shared LO table
+                steps_pc = (np.arange(channels, dtype=np.uint64) * 0x9E3779B1 % (1 << 26) + 0x00800000).astype(np.uint32)
+                rx_p = sr.Rx(ch.baseline_spec(cfg_name, channels, arith, nco_steps=steps_pc).config())
+                rx_p.time_process(d_in.ptr, d_out.ptr, bs, max(2, args.warmup))
+                ms_p = rx_p.time_process(d_in.ptr, d_out.ptr, bs, max(3, args.steps // 2))
+                out["other_nco_modes"] = {"per_channel": {
+                    "value": round(channels * bs / (ms_p * 1e-3) / 1e6, 2), "unit": "Msamples/s", "ms_per_step": round(ms_p, 4),
+                    "kernel": rx_p.kernel_name(), "roofline_frac": round(alg_bytes / (ms_p * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                    "note": "every channel its own NCO step; table-lerp sin/cos per sample in the kernel"}}
+                rx_p.close()
         if world == 1 and not args.no_cpu_baseline and not args.main_only:
-            out["cpu_baseline"] = cpu_baseline(args.workload, rc.ARITH_CMSIS)
+            out["cpu_baseline"] = cpu_baseline(args.workload, ch.WORKLOADS)
         print(json.dumps(out), flush=True)
 
     rx.close()
     d_in.free()
     d_out.free()
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    env.close()
 
 
 if __name__ == "__main__":

@@ -3,7 +3,7 @@
  * The reference keeps two instances of one ring type either side of the DSP slot:
  *     DSP_Buff_TypeDef dsp_in_buff, dsp_out_buff        (Core/Src/dsp_if.c:33-34,
  *                                                        Core/Inc/dsp_if.h:87-94)
- * each DSP_BUFF_SIZE = 384 I/Q frames of int16 in separate i[] / q[] arrays, a read and a write
+ * each DSP_BUFF_SIZE = 768 I/Q frames (the firmware build: USBD_AUDIO_FREQ 96000; `frames` is a parameter here) of int16 in separate i[] / q[] arrays, a read and a write
  * pointer and a "primed" flag.  Writers nudge the write pointer by one frame when the gap to the
  * reader leaves the middle half of the ring (slip / repeat drift compensation between the USB and
  * the codec clocks, dsp_if.c:116-180 and :250-301); the first reader / writer of the opposite side
@@ -28,10 +28,11 @@
  * size is a non-zero multiple of one frame (the reference reads pbuf[size-2]); frames <= 32767
  * (the reference's uint16_t gap arithmetic, dsp_if.c:252-264, must not wrap).
  *
- * Parity: dsp_if.c cannot be compiled in the build image (dsp_if.h:31 includes usbd_audio.h ->
- * usbd_ioreq.h of ST's USB device library, which the reference tree does not vendor), and the
- * reference has no tests: parity for this row is UNPINNED; the oracle (oracle/ring_oracle.c) is a
- * line-by-line restatement checked by hand-derived traces in tests/test_ring_oracle.py.
+ * Parity: pinned against the reference's own code.  Core/Src/dsp_if.c compiles in the build image from the
+ * reference tree alone (oracle/Makefile -> oracle/_ref/libdsp_if_ref.so; firmware defines STM32F411xE,
+ * USE_HAL_DRIVER); the test oracle (oracle/ring_oracle.c) equals it word for word on the fixture trace and on
+ * random traffic (tests/test_ring_oracle_vs_ref.py), tests/golden/ring_trace.npz is generated from it, and the
+ * HIP kernels are bit-exact against both (tests/test_gpu_ring.py).
  */
 #ifndef SELENITE_RING_H_
 #define SELENITE_RING_H_
@@ -44,7 +45,7 @@ extern "C" {
 
 typedef struct selenite_ring selenite_ring;
 
-#define SELENITE_RING_FRAMES_DEFAULT 384u   /* DSP_BUFF_SIZE, dsp_if.h:81-84 (48 kHz, 8 packets) */
+#define SELENITE_RING_FRAMES_DEFAULT 768u   /* DSP_BUFF_SIZE of the firmware build: dsp_if.h:81-84 with USBD_AUDIO_FREQ 96000 (usbd_audio.h:46), 8 packets */
 
 /* Host-side view of every ring's state (arrays owned by the caller). */
 typedef struct {

@@ -1,4 +1,4 @@
-/* ring_oracle.c -- TEST ORACLE ONLY.  See ring_oracle.h (PARITY UNPINNED).
+/* ring_oracle.c -- TEST ORACLE ONLY.  See ring_oracle.h (pinned against the reference's dsp_if.c).
  *
  * One `ring` below is one DSP_Buff_TypeDef of the reference (dsp_if.h:87-94); every function walks
  * the batch and applies the reference's per-call logic to each ring on its own.  All pointer

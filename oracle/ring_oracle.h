@@ -1,9 +1,11 @@
 /* ring_oracle.h -- TEST ORACLE ONLY (never linked into the product): CPU restatement of the
  * reference's DSP ring buffer, Core/Src/dsp_if.c:83-340 + Core/Inc/dsp_if.h:81-94, for a batch of
- * independent rings.  PARITY UNPINNED: dsp_if.c does not compile in this image (dsp_if.h:31 ->
- * usbd_audio.h -> usbd_ioreq.h, ST USB device library not vendored in the reference tree) and the
- * reference has no tests; tests/test_ring_oracle.py checks this file against traces derived by
- * hand from the reference source. */
+ * independent rings.  PINNED against the reference's own code: oracle/Makefile compiles Core/Src/dsp_if.c
+ * (+ Core/Src/main.c) from /root/reference into oracle/_ref/libdsp_if_ref.so behind the harness
+ * oracle/ref_ring.c; tests/test_ring_oracle_vs_ref.py compares every returned word and the whole ring
+ * state on the fixture trace and on random traffic, and tests/golden/ring_trace.npz is generated from the
+ * reference (tests/golden/make_ring_golden.py).  tests/test_ring_oracle.py additionally holds traces derived
+ * by hand from the source. */
 #ifndef RING_ORACLE_H_
 #define RING_ORACLE_H_
 #include <stdint.h>

@@ -342,7 +342,11 @@ extern "C" int selenite_ring_time_device(selenite_ring *R, const int16_t *dSrc, 
 {
     if (!R || !ms_per_pair || iters == 0) return SELENITE_RX_ARGUMENT_ERROR;
     if (!size_ok(R, size_words, "selenite_ring_time_device")) return R->status;
-    hipEvent_t e0, e1;
+    struct EventPair {                                      // destroyed on every exit path
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        ~EventPair() { if (e0) (void)hipEventDestroy(e0); if (e1) (void)hipEventDestroy(e1); }
+    } ev;
+    hipEvent_t &e0 = ev.e0, &e1 = ev.e1;
     RCHK(R, hipEventCreate(&e0));
     RCHK(R, hipEventCreate(&e1));
     RCHK(R, hipEventRecord(e0, R->stream));
@@ -354,8 +358,6 @@ extern "C" int selenite_ring_time_device(selenite_ring *R, const int16_t *dSrc, 
     RCHK(R, hipEventSynchronize(e1));
     float ms = 0.0f;
     RCHK(R, hipEventElapsedTime(&ms, e0, e1));
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
     *ms_per_pair = ms / (float)iters;
     return 0;
 }

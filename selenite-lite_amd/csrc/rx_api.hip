@@ -277,7 +277,14 @@ extern "C" const char *selenite_rx_kernel_name(const selenite_rx_instance *S)
 extern "C" int selenite_rx_set_stream(selenite_rx_instance *S, void *hip_stream)
 {
     if (!S) return SELENITE_RX_ARGUMENT_ERROR;
-    S->stream = hip_stream ? (hipStream_t)hip_stream : S->own_stream;
+    hipStream_t next = hip_stream ? (hipStream_t)hip_stream : S->own_stream;
+    if (next != S->stream) {
+        // calls already queued on the old stream and calls on the new one share the streaming state (filter
+        // histories, gains, phases, the LO table, scratch): drain the old stream before switching
+        HIPCHK(S, hipSetDevice(S->device));
+        HIPCHK(S, hipStreamSynchronize(S->stream));
+        S->stream = next;
+    }
     return SELENITE_RX_SUCCESS;
 }
 
@@ -355,8 +362,10 @@ static int run_part(selenite_rx_instance *S, const void *src, bool src_q15, void
     hipStream_t st = S->stream;
 
     // host copy of the common NCO phase (valid while every channel shares step and phase)
+    // (advanced by commit_phase() once the kernels of the call are enqueued: a call that fails before that leaves
+    // the host copy in step with d_phase)
     const uint32_t phase_now = S->phase_host;
-    if (phase != kPhase2 && g.nco_enable) S->phase_host += block_size * S->h_step[0];
+    auto commit_phase = [&]() { if (phase != kPhase2 && g.nco_enable) S->phase_host = phase_now + block_size * S->h_step[0]; };
 
     // Fused kernels serve the global-gain variant too: they run with their own AGC off (un-scaled
     // audio out), then the envelope reduction and the gain pass below finish the call.
@@ -387,12 +396,14 @@ static int run_part(selenite_rx_instance *S, const void *src, bool src_q15, void
         if (global) { pf.agc = 0; fdst = audio; fq15 = false; }
         if (ssb_fused) HIPCHK(S, launch_fused(S->plan, pf, arith, src, src_q15, fdst, fq15, S->delay_index, st));
         else HIPCHK(S, launch_cw_fused(pf, src, src_q15, fdst, fq15, st));
+        commit_phase();
         if (!global) return SELENITE_RX_SUCCESS;
     }
 
     // generic path: front -> [biquad] -> AGC / convert
     if (phase != kPhase2 && !(ssb_fused || cw_fused)) {
         HIPCHK(S, launch_front_generic(p, arith, src, src_q15, audio, st));
+        commit_phase();
         if (cw) HIPCHK(S, launch_biquad_generic(p, arith, audio, st));
     }
     if (global) {
@@ -591,20 +602,21 @@ static int time_process(selenite_rx_instance *S, const void *src, void *dst, boo
     if (!S || !ms_per_call || iters == 0) return SELENITE_RX_ARGUMENT_ERROR;
     if (!block_size_ok(S, blockSize, who)) return S->status;
     HIPCHK(S, hipSetDevice(S->device));
-    hipEvent_t e0, e1;
-    HIPCHK(S, hipEventCreate(&e0));
-    HIPCHK(S, hipEventCreate(&e1));
-    HIPCHK(S, hipEventRecord(e0, S->stream));
+    struct EventPair {                                     // destroyed on every exit path
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        ~EventPair() { if (e0) (void)hipEventDestroy(e0); if (e1) (void)hipEventDestroy(e1); }
+    } ev;
+    HIPCHK(S, hipEventCreate(&ev.e0));
+    HIPCHK(S, hipEventCreate(&ev.e1));
+    HIPCHK(S, hipEventRecord(ev.e0, S->stream));
     for (uint32_t i = 0; i < iters; ++i) {
         int rc = run_chain(S, src, q15, dst, q15, blockSize, kAll, nullptr);
-        if (rc) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return rc; }
+        if (rc) return rc;
     }
-    HIPCHK(S, hipEventRecord(e1, S->stream));
-    HIPCHK(S, hipEventSynchronize(e1));
+    HIPCHK(S, hipEventRecord(ev.e1, S->stream));
+    HIPCHK(S, hipEventSynchronize(ev.e1));
     float ms = 0.0f;
-    HIPCHK(S, hipEventElapsedTime(&ms, e0, e1));
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
+    HIPCHK(S, hipEventElapsedTime(&ms, ev.e0, ev.e1));
     *ms_per_call = ms / (float)iters;
     return SELENITE_RX_SUCCESS;
 }

@@ -702,14 +702,10 @@ static hipError_t launch_one(const RxParams &p, const FusedArgs &fa, const void 
                          : (p.nco == 1 ? k_ssb_fused<ARITH, 1, ND, M, NH, TIn, TOut, 1> : k_ssb_fused<ARITH, 0, ND, M, NH, TIn, TOut, 1>))
                    : (p.nco == 2 ? k_ssb_fused<ARITH, 2, ND, M, NH, TIn, TOut, 0>
                          : (p.nco == 1 ? k_ssb_fused<ARITH, 1, ND, M, NH, TIn, TOut, 0> : k_ssb_fused<ARITH, 0, ND, M, NH, TIn, TOut, 0>));
-    if constexpr (lds > 48 * 1024) {
-        static bool once = false;
-        if (!once) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) return e;
-            once = true;
-        }
+    if constexpr (lds > 48 * 1024) {                      // per device and per kernel: set on every launch (cheap)
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(k, dim3(p.channels), dim3(64), lds, st, p, fa, static_cast<const TIn *>(src),
                        static_cast<TOut *>(dst));
@@ -751,7 +747,8 @@ static hipError_t launch_shape(const RxParams &p, const FusedArgs &fa, const Fus
         }
     }
     if constexpr (ND > 0 && M == 4) {
-        if (arith != SELENITE_ARITH_CMSIS && plan.use_mfma && p.channels % kMfmaWaves == 0) {
+        static_assert(kMfmaWaves == 1, "one channel per workgroup: any channel count launches (plan.name says k_ssb_mfma)");
+        if (arith != SELENITE_ARITH_CMSIS && plan.use_mfma) {
             if (src_q15) return launch_mfma<ND, M, NH, int16_t, int16_t>(p, fa, plan.d_btab, src, dst, st);
             return launch_mfma<ND, M, NH, float, float>(p, fa, plan.d_btab, src, dst, st);
         }

@@ -463,7 +463,11 @@ extern "C" void selenite_tx_process_q15_device(selenite_tx_instance *S, const in
 extern "C" int selenite_tx_set_stream(selenite_tx_instance *S, void *hip_stream)
 {
     if (!S) return SELENITE_RX_ARGUMENT_ERROR;
-    S->stream = hip_stream ? (hipStream_t)hip_stream : S->own_stream;
+    hipStream_t next = hip_stream ? (hipStream_t)hip_stream : S->own_stream;
+    if (next != S->stream) {                                // the streaming state is shared: drain the old stream first
+        TCHK(S, hipStreamSynchronize(S->stream));
+        S->stream = next;
+    }
     return SELENITE_RX_SUCCESS;
 }
 
@@ -517,18 +521,19 @@ extern "C" int selenite_tx_time_process_device(selenite_tx_instance *S, const fl
 {
     if (!S || !ms_per_call || iters == 0) return SELENITE_RX_ARGUMENT_ERROR;
     if (!block_size_ok(S, bs, "selenite_tx_time_process_device")) return S->status;
-    hipEvent_t e0, e1;
-    TCHK(S, hipEventCreate(&e0));
-    TCHK(S, hipEventCreate(&e1));
-    TCHK(S, hipEventRecord(e0, S->stream));
+    struct EventPair {                                      // destroyed on every exit path
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        ~EventPair() { if (e0) (void)hipEventDestroy(e0); if (e1) (void)hipEventDestroy(e1); }
+    } ev;
+    TCHK(S, hipEventCreate(&ev.e0));
+    TCHK(S, hipEventCreate(&ev.e1));
+    TCHK(S, hipEventRecord(ev.e0, S->stream));
     for (uint32_t i = 0; i < iters; ++i)
         if (run(S, src, dst, false, bs)) return S->status;
-    TCHK(S, hipEventRecord(e1, S->stream));
-    TCHK(S, hipEventSynchronize(e1));
+    TCHK(S, hipEventRecord(ev.e1, S->stream));
+    TCHK(S, hipEventSynchronize(ev.e1));
     float ms = 0.0f;
-    TCHK(S, hipEventElapsedTime(&ms, e0, e1));
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
+    TCHK(S, hipEventElapsedTime(&ms, ev.e0, ev.e1));
     *ms_per_call = ms / (float)iters;
     return 0;
 }

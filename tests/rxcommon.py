@@ -28,109 +28,8 @@ i16p = C.POINTER(C.c_int16)
 
 
 from selenite_rx import Config, StateView, TxConfig, TxStateView  # noqa: E402  (ctypes structs of include/selenite_rx.h)
-
-
-def fptr(a):
-    return a.ctypes.data_as(f32p) if a is not None else None
-
-
-def as_f32(a):
-    return np.ascontiguousarray(a, dtype=np.float32)
-
-
-# ---------------------------------------------------------------------------------------------
-# coefficient design used by the tests (numpy, float64 -> float32).  The product ships the same
-# designs in C (selenite_rx_design_*); tests/test_design.py checks they agree.  Parity never
-# depends on this: the chain only sees the arrays.
-# ---------------------------------------------------------------------------------------------
-def design_lowpass(num_taps, cutoff):
-    n = np.arange(num_taps, dtype=np.float64)
-    m = n - (num_taps - 1) / 2.0
-    h = 2.0 * cutoff * np.sinc(2.0 * cutoff * m)
-    w = 0.54 - 0.46 * np.cos(2.0 * np.pi * n / max(num_taps - 1, 1)) if num_taps > 1 else np.ones(1)
-    h = h * w
-    h = h / h.sum()
-    return as_f32(h[::-1])          # CMSIS order {b[N-1]..b[0]}
-
-
-def design_hilbert(num_taps):
-    assert num_taps % 2 == 1
-    c = (num_taps - 1) // 2
-    n = np.arange(num_taps, dtype=np.float64)
-    m = n - c
-    h = np.zeros(num_taps, dtype=np.float64)
-    odd = (m.astype(np.int64) % 2) != 0
-    h[odd] = 2.0 / (np.pi * m[odd])
-    w = 0.54 - 0.46 * np.cos(2.0 * np.pi * n / max(num_taps - 1, 1)) if num_taps > 1 else np.ones(1)
-    h = h * w
-    d = np.zeros(num_taps, dtype=np.float64)
-    d[c] = 1.0
-    return as_f32(h[::-1]), as_f32(d[::-1])
-
-
-def design_bandpass(n_stages, f0, q):
-    w0 = 2.0 * np.pi * f0
-    alpha = np.sin(w0) / (2.0 * q)
-    a0 = 1.0 + alpha
-    b = np.array([alpha, 0.0, -alpha]) / a0
-    a1, a2 = -2.0 * np.cos(w0) / a0, (1.0 - alpha) / a0
-    one = np.array([b[0], b[1], b[2], -a1, -a2], dtype=np.float64)   # CMSIS adds the feedback
-    return as_f32(np.tile(one, n_stages))
-
-
-class ChainSpec:
-    """Python-side description of one instance; keeps the numpy arrays alive for ctypes."""
-
-    def __init__(self, channels, block, decim=1, nd_taps=0, nh_taps=0, n_biquad=0, mode=MODE_USB,
-                 arith=ARITH_CMSIS, nco=False, nco_step_all=0, nco_steps=None, agc=True,
-                 agc_global=False, dec_cutoff=None, bp_f0=500.0 / 48000.0, bp_q=4.0,
-                 agc_params=None):
-        self.channels, self.block, self.decim = channels, block, decim
-        self.nd_taps, self.nh_taps, self.n_biquad = nd_taps, nh_taps, n_biquad
-        self.mode, self.arith = mode, arith
-        self.nco, self.nco_step_all = nco, nco_step_all
-        self.nco_steps = None if nco_steps is None else np.ascontiguousarray(nco_steps, dtype=np.uint32)
-        self.agc, self.agc_global = agc, agc_global
-        if dec_cutoff is None:
-            dec_cutoff = 0.4 / decim
-        self.dec = design_lowpass(nd_taps, dec_cutoff) if nd_taps else None
-        self.hilb, self.delay = design_hilbert(nh_taps) if nh_taps else (None, None)
-        self.biq = design_bandpass(n_biquad, bp_f0, bp_q) if n_biquad else None
-        self.agc_params = dict(target=0.5, attack=0.5, decay=0.05, gain_min=1e-3, gain_max=1e4,
-                               env_floor=1e-6, gain_init=1.0)
-        if agc_params:
-            self.agc_params.update(agc_params)
-
-    def config(self):
-        g = Config()
-        g.struct_size = C.sizeof(Config)
-        g.channels, g.block, g.decim = self.channels, self.block, self.decim
-        g.nd_taps, g.nh_taps, g.n_biquad, g.arith = self.nd_taps, self.nh_taps, self.n_biquad, self.arith
-        g.mode, g.nco_enable = self.mode, int(self.nco)
-        g.agc_enable, g.agc_global = int(self.agc), int(self.agc_global)
-        g.nco_step_all = self.nco_step_all
-        g.dec_coeffs, g.hilb_coeffs = fptr(self.dec), fptr(self.hilb)
-        g.delay_coeffs, g.biquad_coeffs = fptr(self.delay), fptr(self.biq)
-        g.nco_step = self.nco_steps.ctypes.data_as(u32p) if self.nco_steps is not None else None
-        p = self.agc_params
-        g.agc_target, g.agc_attack, g.agc_decay = p["target"], p["attack"], p["decay"]
-        g.agc_gain_min, g.agc_gain_max = p["gain_min"], p["gain_max"]
-        g.agc_env_floor, g.agc_gain_init = p["env_floor"], p["gain_init"]
-        g._keepalive = self          # the struct only holds raw pointers into this spec's arrays
-        return g
-
-    def state_arrays(self):
-        c = self.channels
-        return dict(
-            dec_state=np.zeros((c, 2, max(self.nd_taps - 1, 0)), np.float32),
-            fir_state=np.zeros((c, 2, max(self.nh_taps - 1, 0)), np.float32),
-            biq_state=np.zeros((c, self.n_biquad, 4), np.float32),
-            agc_gain=np.zeros((c,), np.float32),
-            nco_phase=np.zeros((c,), np.uint32),
-        )
-
-    def out_len(self, block_size):
-        return block_size // self.decim
+from selenite_rx.chain import (ChainSpec, as_f32, baseline_spec, design_bandpass, design_hilbert,  # noqa: E402,F401
+                               design_lowpass, fptr)
 
 
 def state_view(arrs):
@@ -311,23 +210,7 @@ def rel_err(got, ref):
     return float(np.max(np.abs(got - ref)) / max(float(np.max(np.abs(ref))), 1e-30))
 
 
-# named BASELINE.json configurations (scaled by the caller through `channels` / block_size)
-def baseline_spec(name, channels, arith=ARITH_CMSIS, **kw):
-    kw.setdefault("agc", True)
-    if name == "cfg1":   # single 256-sample block, USB, 63-tap Hilbert + AGC
-        return ChainSpec(channels, 256, 1, 0, 63, 0, MODE_USB, arith, **kw)
-    if name == "cfg2":   # 127-tap Hilbert SSB + AGC @48k
-        return ChainSpec(channels, 256, 1, 0, 127, 0, MODE_USB, arith, **kw)
-    if name == "cfg3":   # NCO + 256-tap /4 + 63-tap SSB + AGC  (the headline config)
-        return ChainSpec(channels, 256, 4, 256, 63, 0, MODE_USB, arith, nco=True,
-                         nco_step_all=0x01000000, **kw)
-    if name == "cfg4":   # CW narrow: NCO (BFO) + 4-stage biquad @500 Hz + AGC
-        return ChainSpec(channels, 256, 1, 0, 0, 4, MODE_CW, arith, nco=True,
-                         nco_step_all=0x00800000, **kw)
-    raise KeyError(name)
-
-
-# ---- DSP ring buffer oracle (oracle/ring_oracle.c; parity unpinned, see its header) ----
+# ---- DSP ring buffer oracle (oracle/ring_oracle.c, pinned against the reference's own dsp_if.c: RefRing) ----
 _ring_lib = None
 
 
@@ -351,6 +234,75 @@ def ring_oracle_lib():
             getattr(L, "orc_ring_" + n).argtypes = [C.c_void_p]
         _ring_lib = L
     return _ring_lib
+
+
+def ring_ref_available():
+    return os.path.exists(os.path.join(ORACLE_DIR, "_ref", "libdsp_if_ref.so"))
+
+
+class RefRing:
+    """The reference's OWN ring-buffer code (Core/Src/dsp_if.c:116-340 compiled from /root/reference into
+    oracle/_ref/libdsp_if_ref.so by oracle/Makefile) behind the Python face of selenite_rx.Ring.  The firmware has
+    one global IN ring and one OUT ring; a batch of independent rings is run one ring at a time by moving its state
+    into the global the called function uses (oracle/ref_ring.c).  DSP_BUFF_SIZE is the firmware's: 768 frames."""
+
+    def __init__(self, channels, frames=None):
+        # RTLD_LAZY: dsp_if.c / main.c also hold functions that call the HAL; the harness never reaches them
+        self.L = C.CDLL(os.path.join(ORACLE_DIR, "_ref", "libdsp_if_ref.so"), mode=os.RTLD_LAZY)
+        vp, L = C.c_void_p, self.L
+        L.ref_ring_set.argtypes = [C.c_int, vp, vp, C.c_uint8, C.c_uint16, C.c_uint16]
+        L.ref_ring_get.argtypes = [C.c_int, vp, vp, C.POINTER(C.c_uint8), C.POINTER(C.c_uint16), C.POINTER(C.c_uint16)]
+        L.ref_ring_in_write.argtypes = [vp, C.c_uint16]
+        L.ref_ring_in_read.argtypes = [vp, C.c_uint32]
+        L.ref_ring_out_write.argtypes = [vp, C.c_uint32]
+        L.ref_ring_out_read.argtypes = [vp, C.c_uint16]
+        for fn in ("ref_ring_set", "ref_ring_get", "ref_ring_in_write", "ref_ring_in_read", "ref_ring_out_write",
+                   "ref_ring_out_read", "ref_ring_out_mute"):
+            getattr(L, fn).restype = None
+        self.frames = int(self.L.ref_ring_frames())
+        assert frames in (None, self.frames), "the firmware's DSP_BUFF_SIZE is %d" % self.frames
+        self.channels = channels
+        self.s = {"i": np.zeros((channels, self.frames), np.int16), "q": np.zeros((channels, self.frames), np.int16),
+                  "buff_enable": np.zeros(channels, np.uint8), "rd_ptr": np.zeros(channels, np.uint16),
+                  "wr_ptr": np.zeros(channels, np.uint16)}
+
+    def _each(self, out, fn):
+        s = self.s
+        en, rd, wr = C.c_uint8(), C.c_uint16(), C.c_uint16()
+        for c in range(self.channels):
+            self.L.ref_ring_set(out, s["i"][c].ctypes.data, s["q"][c].ctypes.data, int(s["buff_enable"][c]),
+                                int(s["rd_ptr"][c]), int(s["wr_ptr"][c]))
+            fn(c)
+            self.L.ref_ring_get(out, s["i"][c].ctypes.data, s["q"][c].ctypes.data, C.byref(en), C.byref(rd), C.byref(wr))
+            s["buff_enable"][c], s["rd_ptr"][c], s["wr_ptr"][c] = en.value, rd.value, wr.value
+
+    def in_write(self, pkt):
+        pkt = np.ascontiguousarray(pkt, np.int16)
+        self._each(0, lambda c: self.L.ref_ring_in_write(pkt[c].ctypes.data, pkt.shape[1]))
+
+    def out_write(self, pkt):
+        pkt = np.ascontiguousarray(pkt, np.int16)
+        self._each(1, lambda c: self.L.ref_ring_out_write(pkt[c].ctypes.data, 2 * pkt.shape[1]))
+
+    def in_read(self, size_bytes):
+        out = np.zeros((self.channels, size_bytes // 2), np.int16)
+        self._each(0, lambda c: self.L.ref_ring_in_read(out[c].ctypes.data, size_bytes))
+        return out
+
+    def out_read(self, size_words):
+        out = np.zeros((self.channels, size_words), np.int16)
+        self._each(1, lambda c: self.L.ref_ring_out_read(out[c].ctypes.data, size_words))
+        return out
+
+    def mute(self):
+        self._each(1, lambda c: self.L.ref_ring_out_mute())
+
+    def state(self):
+        return {k: v.copy() for k, v in self.s.items()}
+
+    def set_state(self, a):
+        for k in self.s:
+            self.s[k][...] = a[k]
 
 
 class OracleRing:

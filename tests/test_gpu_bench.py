@@ -28,7 +28,8 @@ def test_bench_json_contract_default_shape():
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
     assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak"
-    assert d["vs_baseline"] is None and d["higher_is_better"] is True and d["dtype"] == "f32"
+    assert d["vs_baseline"] is None and d["higher_is_better"] is True and d["dtype"].startswith("f32")
+    assert "f16 hi+lo" in d["dtype"]                                   # the default arithmetic says what its multiplicands are
     assert "workload" in d["config"] and "cfg3" in d["config"]["workload"] and "model" not in d["config"]
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
@@ -37,7 +38,10 @@ def test_bench_json_contract_default_shape():
     derived = r["algorithmic_bytes_per_launch"] / (r["launch_ms_hip_events"] * 1e-3) / 1e9
     assert abs(r["achieved"] - derived) <= 0.02 * derived             # (launch_ms is rounded to 0.1 us in the JSON)
     c = d["cpu_baseline"]
-    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
+    assert c["kind"] in ("reference", "port") and c["cores"] == os.cpu_count() and c["value"] > 0 and "sample" in c
+    assert c["single_core"]["cores"] == 1 and 0 < c["single_core"]["value"] <= c["value"]
+    assert d["other_nco_modes"]["per_channel"]["value"] > 0 and d["config"]["nco"].startswith("shared LO")
+    assert d["fma_roof"]["flops_per_sample"] == 293.5                  # shared LO: 6 NCO flops per sample, not 20
     assert d["value"] > 0 and d["ms_per_step"] > 0
 
 
@@ -59,3 +63,33 @@ def test_pure_c_host_benchmark_agrees_with_the_python_driven_one():
     assert d["host"] == "C" and d["kernel"] == "k_ssb_split16<256,4,63>" and d["channels"] == 4096
     derived = 4096 * 41952 / d["ms_per_call"] / 1e6
     assert d["msamples_per_s"] > 0 and abs(d["algorithmic_GBps"] - derived) <= 0.02 * derived
+
+
+def test_bench_launches_its_own_ranks_and_shards_the_channels():
+    """`python bench.py --gpus 2` with no launcher: bench.py starts the two ranks itself (here over gloo, both on the
+    one GPU of the test box) and reports the aggregate of both."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env["SELENITE_BENCH_SHARE_GPU"] = "1"
+    out = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--dist-backend", "gloo", "--steps", "3", "--warmup", "1",
+                          "--spinup-ms", "0", "--channels", "1024", "--main-only"], capture_output=True, text=True,
+                         timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["parallelism"].startswith("channels sharded x2")
+    assert abs(d["per_gpu_msamples_s"] * 2 - d["value"]) <= 0.01 * d["value"]
+    g = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--dist-backend", "gloo", "--steps", "3", "--warmup", "1",
+                        "--spinup-ms", "0", "--channels", "1024", "--main-only", "--global-gain"], capture_output=True,
+                       text=True, timeout=900, env=env)
+    assert g.returncode == 0, g.stderr[-2000:]
+    assert json.loads([l for l in g.stdout.splitlines() if l.startswith("{")][0])["config"]["agc"] == "global"
+
+
+def test_global_gain_ranks_on_one_stream_match_the_unsharded_oracle():
+    """Two gloo ranks on the one GPU run bench.py's GlobalGainStepper (phase 1 -> all-reduce -> phase 2 without host
+    synchronisation) and compare with the unsharded oracle: tests/dist_global_gain_worker.py."""
+    from selenite_rx import shard
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    rcode = shard.launch_ranks(2, os.path.join(rc.ROOT, "tests", "dist_global_gain_worker.py"), [], env)
+    assert rcode == 0

@@ -1,8 +1,8 @@
 """CPU: the DSP ring-buffer oracle (oracle/ring_oracle.c) against traces derived by hand from the
-reference source (Core/Src/dsp_if.c:83-340, DSP_BUFF_SIZE = 384 from dsp_if.h:81-84), against an
-independent frame-at-a-time Python model written from the same source, and against the committed
-fixture.  The reference file itself cannot be compiled here (see include/selenite_ring.h), so parity
-for this row is unpinned; these tests pin the restatement to the reading of the source."""
+reference source (Core/Src/dsp_if.c:83-340; ring of 384 frames = the 48 kHz fallback of dsp_if.h:55-57,81-84 -- the
+firmware build itself has 768), against an independent frame-at-a-time Python model written from the same source,
+and against the committed fixture, which is the output of the reference's own dsp_if.c
+(tests/golden/make_ring_golden.py; live comparison: tests/test_ring_oracle_vs_ref.py)."""
 import os
 
 import numpy as np
