@@ -24,6 +24,9 @@
 // the end of the call: the streaming state stays exact f32 in every mode).
 #include "rx_fused_common.h"
 
+#include <cstdlib>
+#include <type_traits>
+
 #pragma clang fp contract(off)
 
 // tuning knobs of k_ssb_split16 (tools/build_variants.sh builds A/B libraries from them)
@@ -35,6 +38,9 @@
 #endif
 #ifndef SRX_ACC4
 #define SRX_ACC4 0               // separate accumulators for the big and the small terms (1) or one per rail (0)
+#endif
+#ifndef SRX_SPLIT16_W2
+#define SRX_SPLIT16_W2 0         // 1: also build k_ssb_split16w2 (two waves per channel); measured equal to the one-wave kernel -- both sit at the package power cap
 #endif
 #ifndef SRX_HS_SGPR
 #define SRX_HS_SGPR 0            // Hilbert taps resident in SGPRs (1; 32 fewer v_readlane per pass, 29 SGPR spills, measured 5 % slower) or v_readlane per use (0)
@@ -186,7 +192,7 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
     static_assert(ND > 0 && M == 4 && NH > 0 && G::T % 64 == 0 && GS::HS % 64 == 0, "split16 decimator: /4 + Hilbert");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x;
-    const uint32_t c = blockIdx.x;
+    uint32_t c = blockIdx.x;                                      // persistent: this workgroup runs channels c, c + gridDim.x, ...
 #ifdef SRX_STAMP       // diagnostics build (make STAMP=1): s_memtime stamps of one wave in 1024 (tools/stamp_split16.py)
     unsigned long long *stamp_p = (fa.dbg && (c & 1023u) == 511u) ? fa.dbg + (c >> 10) * 64 : nullptr;
     int stamp_i = 0;
@@ -210,11 +216,13 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
     static_assert(GS::HS % 128 == 0 && NTL >= 1 && NTL <= NLD, "history is a whole number of wave loads");
 
     const uint32_t npass = p.nout / G::P;
-    const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(src + (size_t)c * p.in_stride * 2, p.block_size * (R::kBytes / 2));
-    const __amdgpu_buffer_rsrc_t rs_out = make_rsrc(dst + (size_t)c * p.out_stride, p.nout * (W::kBytes / 4));
+    auto in_rsrc = [&](uint32_t ch) {                             // a channel past the last one: empty range, loads return zeros
+        return make_rsrc(src + (size_t)ch * p.in_stride * 2, ch < p.channels ? p.block_size * (R::kBytes / 2) : 0u);
+    };
+    __amdgpu_buffer_rsrc_t rs_in = in_rsrc(c), rs_in_next = in_rsrc(c + gridDim.x);
+    __amdgpu_buffer_rsrc_t rs_out = make_rsrc(dst + (size_t)c * p.out_stride, p.nout * (W::kBytes / 4));
     const __amdgpu_buffer_rsrc_t rs_lo = make_rsrc(p.lo, NCO == 2 ? p.block_size * 8u : 0u);
     constexpr int kInPass = G::T * (R::kBytes / 2);               // input bytes of one pass
-    const int in_end = (int)(p.block_size * (R::kBytes / 2));     // scalar offsets at / past this are out of range
 
     typename R::type raw[NLD];
     // shared LO (NCO == 2): an L2-resident table, so only LOD wave loads are kept in flight: the first LOD of a
@@ -224,11 +232,12 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
     auto lo_load = [&](int slot, int i, int sl) {
         lo4[slot] = __builtin_amdgcn_raw_buffer_load_b128(rs_lo, lane * 16 + i * 1024, sl, 0);
     };
-    auto lo_base = [&](uint32_t pass) { return pass < npass ? (int)pass * G::T * 8 : (int)p.block_size * 8; };
-    auto prefetch = [&](uint32_t pass) {                          // pass == npass: every load out of range -> zeros, no traffic
-        const int so = pass < npass ? (int)pass * kInPass : in_end;
+    auto lo_base = [&](uint32_t pass) { return pass < npass ? (int)pass * G::T * 8 : 0; };   // pass == npass: the next channel's pass 0
+    auto prefetch = [&](uint32_t pass) {                          // pass == npass: pass 0 of this workgroup's next channel
+        const int so = pass < npass ? (int)pass * kInPass : 0;
+        const __amdgpu_buffer_rsrc_t rs = pass < npass ? rs_in : rs_in_next;
 #pragma unroll
-        for (int i = 0; i < NLD; ++i) raw[i] = R::load(rs_in, lane * R::kBytes + i * 64 * R::kBytes, so);
+        for (int i = 0; i < NLD; ++i) raw[i] = R::load(rs, lane * R::kBytes + i * 64 * R::kBytes, so);
         if constexpr (NCO == 2) {
 #pragma unroll
             for (int i = 0; i < LOD; ++i) lo_load(i, i, lo_base(pass));
@@ -262,49 +271,58 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
     if constexpr (NCO == 1)
         for (int i = lane; i < 513; i += kWave) tab[i] = p.sintab[i];
 
-    // ---- prologue: streaming state.  Flat history sample f in [0, HS) is CMSIS state sample s = f - F
-    // (older slots meet zero taps only).  All loads are unconditional from a clamped index and issued
-    // before the first use (one memory round trip for the lot).
-    uint32_t e_hist;                                              // biased exponent of the largest |history component|
-    {
-        constexpr int NHI = GS::HS / kWave, NFI = 2 * G::HH4 / kWave;
-        static_assert(GS::HS % kWave == 0 && (2 * G::HH4) % kWave == 0, "prologue fills are whole wave loads");
-        const float *stI = p.dec_state + (size_t)c * 2 * (ND - 1), *stQ = stI + (ND - 1);
-        const float *stF = p.fir_state + (size_t)c * 2 * G::HH;
-        v2f hv[NHI];
-        float fv[NFI];
+    // ---- streaming state of a channel: loaded into registers (for the next channel of this workgroup while
+    // the current one is still in its last pass), installed into LDS when the channel starts.  Flat history
+    // sample f in [0, HS) is CMSIS state sample s = f - F (older slots meet zero taps only); all loads are
+    // unconditional from a clamped index (one memory round trip for the lot).
+    constexpr int NHI = GS::HS / kWave, NFI = 2 * G::HH4 / kWave;
+    static_assert(GS::HS % kWave == 0 && (2 * G::HH4) % kWave == 0, "state fills are whole wave loads");
+    v2f st_hv[NHI];
+    float st_fv[NFI], st_gain;
+    uint32_t st_ph0, st_step;
+    auto load_state = [&](uint32_t ch) {
+        ch = ch < p.channels ? ch : p.channels - 1;               // past the last channel: harmless reload, never installed
+        const float *stI = p.dec_state + (size_t)ch * 2 * (ND - 1), *stQ = stI + (ND - 1);
+        const float *stF = p.fir_state + (size_t)ch * 2 * G::HH;
 #pragma unroll
         for (int j = 0; j < NHI; ++j) {
             const int s = j * kWave + lane - G::F, sc = s < 0 ? 0 : s;
             const float xi = stI[sc], xq = stQ[sc];
-            hv[j] = s < 0 ? v2f{ 0.0f, 0.0f } : v2f{ xi, xq };
+            st_hv[j] = s < 0 ? v2f{ 0.0f, 0.0f } : v2f{ xi, xq };
         }
 #pragma unroll
         for (int j = 0; j < NFI; ++j) {
             const int i = j * kWave + lane;
             const int rail = i / G::HH4, sidx = i % G::HH4 - G::FH;
             const float x = stF[rail * G::HH + (sidx < 0 ? 0 : sidx)];
-            fv[j] = sidx < 0 ? 0.0f : x;
+            st_fv[j] = sidx < 0 ? 0.0f : x;
         }
+        st_ph0 = NCO ? p.phase[ch] : 0u;
+        st_step = NCO ? p.step[ch] : 0u;
+        st_gain = p.gain[ch];
+    };
+    uint32_t e_hist = 0, ph0 = 0, step = 0;                       // e_hist: biased exponent of the largest |history component|
+    float gain = 1.0f;
+    int s_cur = 0x7fff;                                               // sample scale exponent of the images (none yet)
+    auto install_state = [&]() {
         float mh = 0.0f;
 #pragma unroll
         for (int j = 0; j < NHI; ++j) {
-            Hf[j * kWave + lane] = hv[j];
-            mh = amax2(hv[j], mh);
+            Hf[j * kWave + lane] = st_hv[j];
+            mh = amax2(st_hv[j], mh);
         }
 #pragma unroll
         for (int j = 0; j < NFI; ++j) {
             const int i = j * kWave + lane;
-            D[(i / G::HH4) * G::DLEN + i % G::HH4] = fv[j];
+            D[(i / G::HH4) * G::DLEN + i % G::HH4] = st_fv[j];
         }
         e_hist = wave_umax_bits(mh) >> 23;
-    }
-    const uint32_t ph0 = NCO ? p.phase[c] : 0u;
-    const uint32_t step = NCO ? p.step[c] : 0u;
-    float gain = p.gain[c];
+        ph0 = st_ph0; step = st_step; gain = st_gain;
+        s_cur = 0x7fff;
+    };
+    load_state(c);
     const int group = (int)fa.group;
     const int abase = 80 * (lane & 15) + 8 * (lane >> 4);             // A-fragment lane base (halfs)
-    int s_cur = 0x7fff;                                               // sample scale exponent of the images (none yet)
 
     // two (I, Q) samples f (even), f + 1, times the block scale `pre` -> one word in each of the four images:
     //   hi = f16(x * pre), lo = f16(x * pre - hi), one v_fma_mixlo/hi_f16 each (the product with the power of
@@ -534,75 +552,421 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
         W::store(rs_out, lane * W::kBytes, (int)q * (G::P * (W::kBytes / 4)), au);
     };
 
-    // ---- the pipeline ----
+    // ---- the pipeline, once per channel of this workgroup ----
     // Audio of pass q is computed under the matrix stage of pass q+1 and stored right behind the mix stage of
     // pass q+2 -- in FRONT of that pass's prefetch loads: loads and stores share one in-order counter (vmcnt),
     // so a store issued shortly before loaded data is consumed makes the wave wait for the write acknowledge.
-    float au[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
-    lds_order();
-    STAMP(0);                                                         // [1] prologue issued
-    STAMP(1);                                                         // [2] ... and its loads landed
-    mix(0);
-    STAMP(0);
-    prefetch(1);
-    lds_order();
-    {
-        u4v cb[NCB];
-        mfma_phase([](int) {}, 0);
-        cb_read(cb);
-        lds_order();
-        cb_write(cb);
-        dwrite();
-    }
-    lds_order();
-    STAMP(0);
-    for (uint32_t pass = 1; pass < npass; ++pass) {
-        STAMP(1);                                                     // wait for the prefetched pass
-        mix(pass);
-        STAMP(0);
-        store_audio(pass - 2, au);                                    // pass 1: offset -1 pass = out of range, dropped
-        prefetch(pass + 1);
-        lds_order();
-        u4v cb[NCB];
-        v4f dt = { 0.0f, 0.0f, 0.0f, 0.0f };
-        if constexpr (AM == 0) dt = *reinterpret_cast<const v4f *>(D + dt_off + G::P);
-        mfma_phase([&](int kk) { demod_piece(kk, au); }, (NTS + TPK - 1) / TPK - 1);   // matrix pipe over the vector work of the pass before
-        cb_read(cb);
-        lds_order();
-        cb_write(cb);
-        if constexpr (AM == 0) *reinterpret_cast<v4f *>(D + dt_off) = dt;
-        dwrite();
+    // The last pass of a channel prefetches the first pass and the state of the workgroup's next channel, so a
+    // channel switch costs no cold memory round trip and the Toeplitz fragments are loaded once per workgroup.
+    for (;;) {
+        install_state();
+        float au[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
         lds_order();
         STAMP(0);
-    }
-    store_audio(npass - 2, au);
-    demod(au);
-    store_audio(npass - 1, au);
-    STAMP(0);
+        mix(0);
+        STAMP(0);
+        prefetch(1);
+        lds_order();
+        {
+            u4v cb[NCB];
+            mfma_phase([](int) {}, 0);
+            cb_read(cb);
+            lds_order();
+            cb_write(cb);
+            dwrite();
+        }
+        lds_order();
+        STAMP(0);
+        for (uint32_t pass = 1; pass < npass; ++pass) {
+            STAMP(1);                                                 // wait for the prefetched pass
+            mix(pass);
+            STAMP(0);
+            store_audio(pass - 2, au);                                // pass 1: offset -1 pass = out of range, dropped
+            prefetch(pass + 1);
+            lds_order();
+            u4v cb[NCB];
+            v4f dt = { 0.0f, 0.0f, 0.0f, 0.0f };
+            if constexpr (AM == 0) dt = *reinterpret_cast<const v4f *>(D + dt_off + G::P);
+            mfma_phase([&](int kk) { demod_piece(kk, au); }, (NTS + TPK - 1) / TPK - 1);   // matrix pipe over the vector work of the pass before
+            cb_read(cb);
+            lds_order();
+            cb_write(cb);
+            if constexpr (AM == 0) *reinterpret_cast<v4f *>(D + dt_off) = dt;
+            dwrite();
+            lds_order();
+            STAMP(0);
+        }
+        store_audio(npass - 2, au);
+        load_state(c + gridDim.x);                                    // the next channel's state, under this channel's last demodulator pass
+        demod(au);
+        store_audio(npass - 1, au);
+        STAMP(0);
 
-    // ---- epilogue: streaming state back to HBM (exact f32) ----
-    lds_order();
-    {
-        float *stI = p.dec_state + (size_t)c * 2 * (ND - 1), *stQ = stI + (ND - 1);
+        // ---- streaming state of the channel back to HBM (exact f32) ----
+        lds_order();
+        {
+            float *stI = p.dec_state + (size_t)c * 2 * (ND - 1), *stQ = stI + (ND - 1);
 #pragma unroll
-        for (int j = 0; j < GS::HS / kWave; ++j) {
-            const int s = j * kWave + lane - G::F;
-            const v2f h = Hf[j * kWave + lane];
-            if (s >= 0) { stI[s] = h.x; stQ[s] = h.y; }
+            for (int j = 0; j < GS::HS / kWave; ++j) {
+                const int s = j * kWave + lane - G::F;
+                const v2f h = Hf[j * kWave + lane];
+                if (s >= 0) { stI[s] = h.x; stQ[s] = h.y; }
+            }
         }
-    }
-    if constexpr (AM == 0) {                                          // AM never ran the Hilbert pair: its state stays
-        for (int i = lane; i < 2 * G::HH4; i += kWave) {
-            const int rail = i / G::HH4, mi = i % G::HH4, s = mi - G::FH;
-            if (s >= 0) p.fir_state[((size_t)c * 2 + rail) * G::HH + s] = D[rail * G::DLEN + G::P + mi];
+        if constexpr (AM == 0) {                                      // AM never ran the Hilbert pair: its state stays
+            for (int i = lane; i < 2 * G::HH4; i += kWave) {
+                const int rail = i / G::HH4, mi = i % G::HH4, s = mi - G::FH;
+                if (s >= 0) p.fir_state[((size_t)c * 2 + rail) * G::HH + s] = D[rail * G::DLEN + G::P + mi];
+            }
         }
-    }
-    if (lane == 0) {
-        if constexpr (NCO != 0) p.phase[c] = ph0 + p.block_size * step;
-        if (p.agc) p.gain[c] = gain;
+        if (lane == 0) {
+            if constexpr (NCO != 0) p.phase[c] = ph0 + p.block_size * step;
+            if (p.agc) p.gain[c] = gain;
+        }
+        c += gridDim.x;
+        if (c >= p.channels) break;
+        lds_order();                                                  // the state reads above before the next channel's installs
+        rs_in = rs_in_next;
+        rs_in_next = in_rsrc(c + gridDim.x);
+        rs_out = make_rsrc(dst + (size_t)c * p.out_stride, p.nout * (W::kBytes / 4));
     }
     STAMP(1);
 #undef STAMP
+}
+
+// ------------------------------------------------------------------------------------------
+// k_ssb_split16w2 -- the same chain with TWO wavefronts per channel (128-thread workgroups).
+//
+// Counters of the one-wave kernel (profiles/r2): every unit under 55 % busy, the waves 34 % of their time in
+// s_waitcnt and 29 % stalled at issue -- two long dependent chains per SIMD cannot cover each other, and
+// 80 VGPRs of Toeplitz fragments pin the kernel at two waves per SIMD.  Here the matrix stage is split in K
+// between the two waves of a channel (half the fragments each, partial sums meet in LDS) and the vector work is
+// split by role: the FRONT wave streams the input (prefetch, NCO mix, block exponent, f16 split into the LDS
+// images), the BACK wave turns the decimated rails into audio (combine, Hilbert pair, AGC, store).  Two
+// s_barrier per pass; while the front wave mixes pass p+1 the back wave demodulates pass p.  Under 168 VGPRs:
+// three waves per SIMD, six channels in flight per CU, each with half the serial work per wave.
+// The block exponent of a pass comes from a BOUND on the mixed samples, |x * LO| <= 2 max(|I|, |Q|), taken on
+// the raw samples, so the complex multiplies do not wait for the wave reduction; the history part uses the
+// exact maximum of the mixed samples (what a call's prologue can recompute from the state: partition-invariant).
+// ------------------------------------------------------------------------------------------
+template <int NCO, int ND, int M, int NH, typename TIn, typename TOut, int AM, int GROUP>
+__global__ __launch_bounds__(128, 3) void k_ssb_split16w2(RxParams p, FusedArgs fa, const TIn *__restrict__ src,
+                                                          TOut *__restrict__ dst)
+{
+    using G = Geo<ND, M, NH>;
+    using GS = GeoS<NCO, ND, M, NH>;
+    using R = BRaw<TIn>;
+    using W = BOut<TOut>;
+    static_assert(ND > 0 && M == 4 && NH > 0 && G::T % 64 == 0 && GS::HS % 128 == 0 && GS::KS % 2 == 0, "split16 decimator: /4 + Hilbert");
+    constexpr int KH = GS::KS / 2;                                  // k-steps per wave
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t c = blockIdx.x;
+    float *tab = lds + GS::oTab;
+    _Float16 *X = reinterpret_cast<_Float16 *>(lds + GS::oX);     // [rail][hi/lo][IMG]
+    v2f *Hf = reinterpret_cast<v2f *>(lds + GS::oHf);             // f32 (I, Q) history, HS samples
+    float *D = lds + GS::oD;
+    float *dI = D, *dQ = D + G::DLEN;
+    float *P = lds + GS::total;                                   // front wave's partial sums [rail][lane][4]
+    int *SX = reinterpret_cast<int *>(P + 512);                   // block exponent of pass p at SX[p & 1]
+    constexpr int NLD = G::T / 128, NTL = GS::HS / 128;
+    const uint32_t npass = p.nout / G::P;
+    const int abase = 80 * (lane & 15) + 8 * (lane >> 4);         // A-fragment lane base (halfs)
+
+    // workgroup barrier that leaves the prefetch loads in flight: LDS traffic only is drained
+    auto wg_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+
+    // this wave's half of the Toeplitz B fragments
+    h8 Bh[KH], Bl[KH];
+    {
+        const h8 *bt = static_cast<const h8 *>(fa.btab16) + (size_t)wave * KH * 2 * 64;
+#pragma unroll
+        for (int kk = 0; kk < KH; ++kk) {
+            Bh[kk] = bt[(2 * kk + 0) * 64 + lane];
+            Bl[kk] = bt[(2 * kk + 1) * 64 + lane];
+        }
+    }
+    v4f accI, accQ;
+    auto mfma_half = [&](auto k0c) {                              // k-steps [K0, K0 + KH)
+        constexpr int K0 = decltype(k0c)::value;
+        accI = accQ = v4f{ 0.0f, 0.0f, 0.0f, 0.0f };
+        const _Float16 *xIh = X + 0 * GS::IMG + abase, *xIl = X + 1 * GS::IMG + abase;
+        const _Float16 *xQh = X + 2 * GS::IMG + abase, *xQl = X + 3 * GS::IMG + abase;
+        auto offA = [](int kk) { return 80 * (kk >> 1) + 32 * (kk & 1); };
+        h8 aIh = *reinterpret_cast<const h8 *>(xIh + offA(K0)), aIl = *reinterpret_cast<const h8 *>(xIl + offA(K0));
+        h8 aQh = *reinterpret_cast<const h8 *>(xQh + offA(K0)), aQl = *reinterpret_cast<const h8 *>(xQl + offA(K0));
+#pragma unroll
+        for (int j = 0; j < KH; ++j) {
+            h8 nIh = aIh, nIl = aIl, nQh = aQh, nQl = aQl;
+#ifdef SRX_X_NOAREAD
+            if (false) {
+#else
+            if (j + 1 < KH) {
+#endif
+                const int off = offA(K0 + j + 1);
+                nIh = *reinterpret_cast<const h8 *>(xIh + off); nIl = *reinterpret_cast<const h8 *>(xIl + off);
+                nQh = *reinterpret_cast<const h8 *>(xQh + off); nQl = *reinterpret_cast<const h8 *>(xQl + off);
+            }
+#ifdef SRX_X_NOMFMA
+            asm volatile("" :: "v"(aIh), "v"(aIl), "v"(aQh), "v"(aQl));
+#else
+            accI = __builtin_amdgcn_mfma_f32_16x16x32_f16(aIh, Bl[j], accI, 0, 0, 0);      // small terms first
+            accQ = __builtin_amdgcn_mfma_f32_16x16x32_f16(aQh, Bl[j], accQ, 0, 0, 0);
+            accI = __builtin_amdgcn_mfma_f32_16x16x32_f16(aIl, Bh[j], accI, 0, 0, 0);
+            accQ = __builtin_amdgcn_mfma_f32_16x16x32_f16(aQl, Bh[j], accQ, 0, 0, 0);
+            accI = __builtin_amdgcn_mfma_f32_16x16x32_f16(aIh, Bh[j], accI, 0, 0, 0);
+            accQ = __builtin_amdgcn_mfma_f32_16x16x32_f16(aQh, Bh[j], accQ, 0, 0, 0);
+#endif
+#ifndef SRX_X_NOAREAD
+            aIh = nIh; aIl = nIl; aQh = nQh; aQl = nQl;
+#endif
+        }
+    };
+
+    if (wave == 0) {
+        // =============================== FRONT wave: input side ===============================
+        const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(src + (size_t)c * p.in_stride * 2, p.block_size * (R::kBytes / 2));
+        const __amdgpu_buffer_rsrc_t rs_lo = make_rsrc(p.lo, NCO == 2 ? p.block_size * 8u : 0u);
+        constexpr int kInPass = G::T * (R::kBytes / 2);
+        const int in_end = (int)(p.block_size * (R::kBytes / 2));
+        typename R::type raw[NLD];
+        constexpr int LOD = 3;
+        u4v lo4[LOD];
+        auto lo_load = [&](int slot, int i, int sl) { lo4[slot] = __builtin_amdgcn_raw_buffer_load_b128(rs_lo, lane * 16 + i * 1024, sl, 0); };
+        auto lo_base = [&](uint32_t pass) { return pass < npass ? (int)pass * G::T * 8 : (int)p.block_size * 8; };
+        auto prefetch = [&](uint32_t pass) {
+            const int so = pass < npass ? (int)pass * kInPass : in_end;
+#pragma unroll
+            for (int i = 0; i < NLD; ++i) raw[i] = R::load(rs_in, lane * R::kBytes + i * 64 * R::kBytes, so);
+#ifndef SRX_X_NOLO
+            if constexpr (NCO == 2) {
+#pragma unroll
+                for (int i = 0; i < LOD; ++i) lo_load(i, i, lo_base(pass));
+            }
+#endif
+        };
+        prefetch(0);
+        if constexpr (NCO == 1)
+            for (int i = lane; i < 513; i += kWave) tab[i] = p.sintab[i];
+        uint32_t e_hist;
+        {   // CMSIS pState of the decimator -> f32 history; flat sample f is state sample f - F (older slots: zero)
+            constexpr int NHI = GS::HS / kWave;
+            const float *stI = p.dec_state + (size_t)c * 2 * (ND - 1), *stQ = stI + (ND - 1);
+            v2f hv[NHI];
+#pragma unroll
+            for (int j = 0; j < NHI; ++j) {
+                const int s = j * kWave + lane - G::F, sc = s < 0 ? 0 : s;
+                const float xi = stI[sc], xq = stQ[sc];
+                hv[j] = s < 0 ? v2f{ 0.0f, 0.0f } : v2f{ xi, xq };
+            }
+            float mh = 0.0f;
+#pragma unroll
+            for (int j = 0; j < NHI; ++j) {
+                Hf[j * kWave + lane] = hv[j];
+                mh = amax2(hv[j], mh);
+            }
+            e_hist = wave_umax_bits(mh) >> 23;
+        }
+        const uint32_t ph0 = NCO ? p.phase[c] : 0u;
+        const uint32_t step = NCO ? p.step[c] : 0u;
+        int s_cur = 0x7fff;
+        auto put_iq = [&](int f, v2f a, v2f b, float pre) {
+            const v2f pre2 = { pre, pre };
+            const v2f sa = a * pre2, sb = b * pre2;
+            const h2 hhI = __builtin_convertvector(v2f{ sa.x, sb.x }, h2), hhQ = __builtin_convertvector(v2f{ sa.y, sb.y }, h2);
+            const v2f ra = sa - v2f{ (float)hhI.x, (float)hhQ.x }, rb = sb - v2f{ (float)hhI.y, (float)hhQ.y };
+            const h2 llI = __builtin_convertvector(v2f{ ra.x, rb.x }, h2), llQ = __builtin_convertvector(v2f{ ra.y, rb.y }, h2);
+            const int ph = GS::phys(f);
+            *reinterpret_cast<h2 *>(X + 0 * GS::IMG + ph) = hhI;
+            *reinterpret_cast<h2 *>(X + 1 * GS::IMG + ph) = llI;
+            *reinterpret_cast<h2 *>(X + 2 * GS::IMG + ph) = hhQ;
+            *reinterpret_cast<h2 *>(X + 3 * GS::IMG + ph) = llQ;
+        };
+        auto mix = [&](uint32_t pass) {
+            const uint32_t n0 = pass * G::T;
+            // bound on the mixed samples from the raw ones: the complex multiplies below do not wait for it
+            float mr = 0.0f;
+#pragma unroll
+            for (int i = 0; i < NLD; ++i) {
+                v2f a, b;
+                R::unpack(raw[i], a, b);
+                mr = amax2(a, mr);
+                mr = amax2(b, mr);
+            }
+            const uint32_t e_raw = (wave_umax_bits(mr) >> 23) + (NCO != 0 ? 1u : 0u);
+            const uint32_t e_need = max(e_raw, e_hist);
+            int s_new = 141 - (int)e_need;
+            s_new = s_new > 127 ? 127 : (s_new < -126 ? -126 : s_new);
+            if (s_new != s_cur) {                                     // wave-uniform; always in the first pass
+                const float pre = __uint_as_float((uint32_t)(s_new + 127) << 23);
+#pragma unroll
+                for (int j = 0; j < GS::HS / 128; ++j) {
+                    const int f = 2 * (j * kWave + lane);
+                    const float4 hq = *reinterpret_cast<const float4 *>(Hf + f);
+                    put_iq(f, v2f{ hq.x, hq.y }, v2f{ hq.z, hq.w }, pre);
+                }
+                s_cur = s_new;
+            }
+            if (lane == 0) SX[pass & 1] = s_cur;
+            lds_order();                                              // history reads above, history writes below
+            const float pre = __uint_as_float((uint32_t)(s_cur + 127) << 23);
+            float mt = 0.0f;
+#pragma unroll
+            for (int i = 0; i < NLD; ++i) {
+                v2f a, b, ma, mb;
+                R::unpack(raw[i], a, b);
+#ifdef SRX_X_NOLO
+                if constexpr (NCO == 2) { ma = a; mb = b; } else if
+#else
+                if constexpr (NCO == 2) {
+                    const u4v l = lo4[i % LOD];
+                    cmul_pk2(a, b, v2f{ __uint_as_float(l.x), __uint_as_float(l.y) }, v2f{ __uint_as_float(l.z), __uint_as_float(l.w) }, ma, mb);
+                    if (i + LOD < NLD) lo_load(i % LOD, i + LOD, lo_base(pass));
+                } else if
+#endif
+                constexpr (NCO == 1) {
+                    const uint32_t n = 128u * i + 2u * lane;
+                    const float2 la = nco_lo<0>(tab, ph0 + (n0 + n) * step), lb = nco_lo<0>(tab, ph0 + (n0 + n + 1) * step);
+                    cmul_pk2(a, b, v2f{ la.x, la.y }, v2f{ lb.x, lb.y }, ma, mb);
+                } else {
+                    ma = a; mb = b;
+                }
+                const int n = 128 * i + 2 * lane;
+#ifdef SRX_X_NOSPLIT
+                asm volatile("" :: "v"(ma), "v"(mb));
+#else
+                put_iq(GS::HS + n, ma, mb, pre);
+#endif
+                if (i >= NLD - NTL) {                                 // the next pass's history: exact f32 copy and exact maximum
+                    *reinterpret_cast<float4 *>(Hf + (n - (G::T - GS::HS))) = make_float4(ma.x, ma.y, mb.x, mb.y);
+                    mt = amax2(ma, mt);
+                    mt = amax2(mb, mt);
+                }
+            }
+            e_hist = wave_umax_bits(mt) >> 23;
+        };
+        constexpr int NCB = 4 * (GS::HS / 64) * 8 / kWave;
+        auto cb_addr = [&](int k) {
+            const int i = k * kWave + lane, img = i / (8 * (GS::HS / 64)), rem = i % (8 * (GS::HS / 64));
+            return img * GS::IMG + 80 * (rem >> 3) + 8 * (rem & 7);
+        };
+
+        lds_order();
+        mix(0);
+        prefetch(1);
+        wg_barrier();                                                 // X: images of pass 0 complete
+        for (uint32_t pass = 0; pass < npass; ++pass) {
+            mfma_half(std::integral_constant<int, 0>{});
+            u4v cb[NCB];
+#pragma unroll
+            for (int k = 0; k < NCB; ++k) cb[k] = *reinterpret_cast<const u4v *>(X + cb_addr(k) + 80 * (G::T / 64));
+            *reinterpret_cast<v4f *>(P + 4 * lane) = accI;
+            *reinterpret_cast<v4f *>(P + 256 + 4 * lane) = accQ;
+            wg_barrier();                                             // Y: partial sums out, every A read of the pass issued
+#pragma unroll
+            for (int k = 0; k < NCB; ++k) *reinterpret_cast<u4v *>(X + cb_addr(k)) = cb[k];
+            lds_order();
+            if (pass + 1 < npass) {
+                mix(pass + 1);
+                prefetch(pass + 2);
+            }
+            wg_barrier();                                             // X: images of the next pass complete
+        }
+        // ---- epilogue: decimator state back to HBM (exact f32) ----
+        {
+            float *stI = p.dec_state + (size_t)c * 2 * (ND - 1), *stQ = stI + (ND - 1);
+#pragma unroll
+            for (int j = 0; j < GS::HS / kWave; ++j) {
+                const int s = j * kWave + lane - G::F;
+                const v2f h = Hf[j * kWave + lane];
+                if (s >= 0) { stI[s] = h.x; stQ[s] = h.y; }
+            }
+        }
+        if (lane == 0) {
+            if constexpr (NCO != 0) p.phase[c] = ph0 + p.block_size * step;
+        }
+    } else {
+        // =============================== BACK wave: audio side ===============================
+        const __amdgpu_buffer_rsrc_t rs_out = make_rsrc(dst + (size_t)c * p.out_stride, p.nout * (W::kBytes / 4));
+        float hreg[(NH + 63) / 64];
+#pragma unroll
+        for (int v = 0; v < (NH + 63) / 64; ++v) hreg[v] = (64 * v + lane < NH) ? p.hilb_c[64 * v + lane] : 0.0f;
+        {
+            constexpr int NFI = 2 * G::HH4 / kWave;
+            static_assert((2 * G::HH4) % kWave == 0, "prologue fills are whole wave loads");
+            const float *stF = p.fir_state + (size_t)c * 2 * G::HH;
+            float fv[NFI];
+#pragma unroll
+            for (int j = 0; j < NFI; ++j) {
+                const int i = j * kWave + lane;
+                const int rail = i / G::HH4, sidx = i % G::HH4 - G::FH;
+                const float x = stF[rail * G::HH + (sidx < 0 ? 0 : sidx)];
+                fv[j] = sidx < 0 ? 0.0f : x;
+            }
+#pragma unroll
+            for (int j = 0; j < NFI; ++j) {
+                const int i = j * kWave + lane;
+                D[(i / G::HH4) * G::DLEN + i % G::HH4] = fv[j];
+            }
+        }
+        float gain = p.gain[c];
+        const int group = (int)fa.group;
+        constexpr int NDV = 2 * (G::HH4 / 4);
+        static_assert(NDV == 32 || NDV == 64, "Hilbert history move is one float4 per lane");
+        const int dt_off = ((lane % NDV) / (G::HH4 / 4)) * G::DLEN + 4 * (lane % (G::HH4 / 4));
+        auto htap = [&](int k) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(hreg[k >> 6]), k & 63)); };
+
+        wg_barrier();                                                 // X
+        for (uint32_t pass = 0; pass < npass; ++pass) {
+            mfma_half(std::integral_constant<int, KH>{});
+            wg_barrier();                                             // Y
+            // combine the two K halves, exact power-of-two rescale, decimated rails into D behind the Hilbert history
+            {
+                const v4f pI = *reinterpret_cast<const v4f *>(P + 4 * lane), pQ = *reinterpret_cast<const v4f *>(P + 256 + 4 * lane);
+                const int ex = -(SX[pass & 1] + fa.split_sc);
+                const int o0 = G::HH4 + 64 * (lane >> 4) + (lane & 15);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    dI[o0 + 16 * r] = __builtin_ldexpf(accI[r] + pI[r], ex);
+                    dQ[o0 + 16 * r] = __builtin_ldexpf(accQ[r] + pQ[r], ex);
+                }
+            }
+            lds_order();
+            float au[4];
+            if constexpr (AM != 0) {
+                const float4 vi = *reinterpret_cast<const float4 *>(dI + G::HH4 + 4 * lane);
+                const float4 vq = *reinterpret_cast<const float4 *>(dQ + G::HH4 + 4 * lane);
+                au[0] = cmag<0>(vi.x, vq.x); au[1] = cmag<0>(vi.y, vq.y);
+                au[2] = cmag<0>(vi.z, vq.z); au[3] = cmag<0>(vi.w, vq.w);
+            } else {
+                float q2[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+#pragma unroll
+#ifndef SRX_X_NOHILB
+                for (int t = 0; t < HilbertSteps<ND, M, NH>::N; ++t) hilbert_tstep<1, ND, M, NH>(t, dQ, lane, htap, q2);
+#endif
+                const float *di = dI + G::FH + fa.delay_idx + 4 * lane;   // unit-impulse delay FIR
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float i2 = di[r] + 0.0f;
+                    au[r] = fa.upper ? (i2 - q2[r]) : (i2 + q2[r]);
+                }
+                const v4f dt = *reinterpret_cast<const v4f *>(D + dt_off + G::P);   // Hilbert-pair history for the next pass
+                lds_order();
+                *reinterpret_cast<v4f *>(D + dt_off) = dt;
+            }
+            agc_pass<GROUP>(p.agcp, p.agc, lane, group, au, gain);
+            W::store(rs_out, lane * W::kBytes, (int)pass * (G::P * (W::kBytes / 4)), au);
+            wg_barrier();                                             // X
+        }
+        if constexpr (AM == 0) {                                      // AM never ran the Hilbert pair: its state stays
+            for (int i = lane; i < 2 * G::HH4; i += kWave) {
+                const int rail = i / G::HH4, mi = i % G::HH4, s = mi - G::FH;
+                if (s >= 0) p.fir_state[((size_t)c * 2 + rail) * G::HH + s] = D[rail * G::DLEN + mi];
+            }
+        }
+        if (lane == 0 && p.agc) p.gain[c] = gain;
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -813,7 +1177,32 @@ static hipError_t launch_k(const RxParams &p, const FusedArgs &fa, const void *s
     using GS = GeoS<NCO, ND, M, NH>;
     constexpr size_t lds = (size_t)GS::total * sizeof(float);
     static_assert(lds <= 48 * 1024, "k_ssb_split16 LDS image");
-    hipLaunchKernelGGL((k_ssb_split16<NCO, ND, M, NH, TIn, TOut, AM, GROUP>), dim3(p.channels), dim3(64), lds, st, p, fa,
+#if SRX_SPLIT16_W2
+    if constexpr (GS::KS % 2 == 0) {
+        static const bool one_wave = std::getenv("SELENITE_RX_SPLIT16_W1") != nullptr;      // A/B: the one-wave kernel
+        if (!one_wave) {
+            constexpr size_t lds2 = lds + (512 + 4) * sizeof(float);                         // + partial sums + exponents
+            hipLaunchKernelGGL((k_ssb_split16w2<NCO, ND, M, NH, TIn, TOut, AM, GROUP>), dim3(p.channels), dim3(128), lds2, st, p, fa,
+                               static_cast<const TIn *>(src), static_cast<TOut *>(dst));
+            return hipGetLastError();
+        }
+    }
+#endif
+    // persistent grid: as many single-wave workgroups as the device keeps resident, each running channels
+    // b, b + grid, b + 2 grid, ...  (SELENITE_RX_SPLIT16_GRID=0: one workgroup per channel, the round-1 launch shape)
+    static int resident = 0;
+    if (resident == 0) {
+        int per_cu = 0, dev = 0;
+        hipDeviceProp_t prop;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_ssb_split16<NCO, ND, M, NH, TIn, TOut, AM, GROUP>, 64, lds) != hipSuccess ||
+            hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess || per_cu <= 0)
+            resident = -1;
+        else
+            resident = per_cu * prop.multiProcessorCount;
+        if (const char *e = std::getenv("SELENITE_RX_SPLIT16_GRID")) resident = std::atoi(e) > 0 ? std::atoi(e) : -1;
+    }
+    const uint32_t grid = resident > 0 && (uint32_t)resident < p.channels ? (uint32_t)resident : p.channels;
+    hipLaunchKernelGGL((k_ssb_split16<NCO, ND, M, NH, TIn, TOut, AM, GROUP>), dim3(grid), dim3(64), lds, st, p, fa,
                        static_cast<const TIn *>(src), static_cast<TOut *>(dst));
     return hipGetLastError();
 }
