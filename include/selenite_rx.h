@@ -144,11 +144,22 @@ const char *selenite_rx_error_string(const selenite_rx_instance *S);
 
 /* ---- the per-block process call ------------------------------------------------------- */
 
-/* Host buffers, synchronous (copies in, runs the HIP path, copies out).  blockSize = complex
- * input samples per channel in this call; it must be a non-zero multiple of cfg.block (several
- * DSP blocks are processed back to back exactly as successive CMSIS calls would). */
+/* Host buffers, synchronous: the literal "float* I/Q in, float* audio out, blockSize" call of the slot.
+ * blockSize = complex input samples per channel in this call; it must be a non-zero multiple of cfg.block
+ * (several DSP blocks are processed back to back exactly as successive CMSIS calls would).  The call is cut into
+ * channel chunks and pipelined over PCIe (H2D of chunk k+1 || kernels of chunk k || D2H of chunk k-1, two
+ * device buffers each way, no allocation per call).  Page-locked caller memory (selenite_rx_host_alloc,
+ * selenite_rx_host_register) is the DMA source / target itself; pageable memory is staged through the
+ * library's pinned buffers by a few host threads.  Same bits as the _device call on the same data. */
 void selenite_rx_process_f32(selenite_rx_instance *S, const float *pSrcIQ,
                              float *pDstAudio, uint32_t blockSize);
+
+/* Page-locked host memory for the buffers of the host-pointer calls: allocate it, or register memory the caller
+ * already owns (the firmware-side analogue is a DMA-capable buffer).  Optional: unregistered memory works, slower. */
+void *selenite_rx_host_alloc(size_t bytes);
+void  selenite_rx_host_free(void *hptr);
+int   selenite_rx_host_register(void *hptr, size_t bytes);
+int   selenite_rx_host_unregister(void *hptr);
 
 /* Device buffers (HBM-resident), asynchronous on the instance's stream. */
 void selenite_rx_process_f32_device(selenite_rx_instance *S, const float *dSrcIQ,

@@ -10,7 +10,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <mutex>
+#include <thread>
 
 using namespace srx;
 
@@ -109,9 +111,18 @@ static void free_device(selenite_rx_instance *S)
 {
     void *ptrs[] = { S->d_dec_c, S->d_hilb_c, S->d_delay_c, S->d_biq_c, S->d_sintab, S->d_step, S->d_phase,
                      S->d_dec_state, S->d_fir_state, S->d_biq_state, S->d_gain, S->d_scratch, S->d_env, S->d_env_part,
-                     S->d_io_in, S->d_io_out, S->d_lo };
+                     S->d_io_in, S->d_io_out, S->d_lo, S->pipe.d_in[0], S->pipe.d_in[1], S->pipe.d_out[0], S->pipe.d_out[1] };
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
+    for (int i = 0; i < 2; ++i) {
+        if (S->pipe.h_in[i]) (void)hipHostFree(S->pipe.h_in[i]);
+        if (S->pipe.h_out[i]) (void)hipHostFree(S->pipe.h_out[i]);
+        if (S->pipe.ev_in[i]) (void)hipEventDestroy(S->pipe.ev_in[i]);
+        if (S->pipe.ev_done[i]) (void)hipEventDestroy(S->pipe.ev_done[i]);
+        if (S->pipe.ev_out[i]) (void)hipEventDestroy(S->pipe.ev_out[i]);
+    }
+    if (S->pipe.h2d) (void)hipStreamDestroy(S->pipe.h2d);
+    if (S->pipe.d2h) (void)hipStreamDestroy(S->pipe.d2h);
     free_fused(S->plan);
     if (S->own_stream) (void)hipStreamDestroy(S->own_stream);
 }
@@ -315,6 +326,14 @@ static RxParams make_params(selenite_rx_instance *S, uint32_t block_size)
     p.sintab = S->d_sintab; p.step = S->d_step; p.phase = S->d_phase;
     p.dec_state = S->d_dec_state; p.fir_state = S->d_fir_state; p.biq_state = S->d_biq_state;
     p.gain = S->d_gain;
+    if (S->sub_count) {                                     // a contiguous channel range of the instance: every per-channel array moves with it
+        const size_t c0 = S->sub_first;
+        p.channels = S->sub_count;
+        p.step += c0; p.phase += c0; p.gain += c0;
+        if (p.dec_state) p.dec_state += c0 * 2 * (g.nd_taps - 1);
+        if (p.fir_state) p.fir_state += c0 * 2 * (g.nh_taps - 1);
+        if (p.biq_state) p.biq_state += c0 * 4 * g.n_biquad;
+    }
     p.agcp = AgcParams{ g.agc_target, g.agc_attack, g.agc_decay, g.agc_gain_min, g.agc_gain_max, g.agc_env_floor };
     // generic front kernel: largest pass (<= 256 outputs) whose LDS image fits 64 KiB
     uint32_t P = 256;
@@ -488,25 +507,164 @@ extern "C" void selenite_rx_global_phase2_device(selenite_rx_instance *S, float 
     run_chain(S, nullptr, false, dDstAudio, false, blockSize, kPhase2, const_cast<float *>(dEnv));
 }
 
+// ---- host-pointer entry points: the literal drop-in signature (float* / int16_t* I/Q in, audio out) ----
+//
+// Channels are independent, so a call over host buffers is cut into channel chunks and pipelined: chunk k+1 crosses
+// PCIe (H2D stream) while chunk k computes (the instance's stream) and chunk k-1 returns (D2H stream), two device
+// buffers each way, ordered by events only.  Caller memory that is page-locked (selenite_rx_host_alloc /
+// selenite_rx_host_register, or any hipHostMalloc / hipHostRegister memory) is the DMA source and target itself;
+// pageable caller memory goes through the library's own pinned staging buffers, filled and drained by a few host
+// threads (a pageable hipMemcpy is bounced by the driver at ~10 GB/s on this stack).  No allocation per call once
+// the buffers have grown to the call's chunk size.  The global-gain variant needs every channel's envelope before
+// any gain and stays one chunk.
+static bool host_ptr_is_pinned(const void *p)
+{
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }   // plain malloc memory: "invalid value"
+    return a.type == hipMemoryTypeHost;
+}
+
+static void parallel_memcpy(void *dst, const void *src, size_t bytes)
+{
+    const unsigned hw = std::thread::hardware_concurrency();
+    const size_t nt = bytes < (8u << 20) ? 1 : std::min<size_t>(8, hw ? hw : 1);
+    if (nt <= 1) { std::memcpy(dst, src, bytes); return; }
+    std::vector<std::thread> th;
+    const size_t per = ((bytes + nt - 1) / nt + 4095) & ~(size_t)4095;
+    for (size_t i = 0; i < nt; ++i) {
+        const size_t off = i * per;
+        if (off >= bytes) break;
+        const size_t n = std::min(per, bytes - off);
+        th.emplace_back([=] { std::memcpy(static_cast<char *>(dst) + off, static_cast<const char *>(src) + off, n); });
+    }
+    for (auto &t : th) t.join();
+}
+
+static int pipe_setup(selenite_rx_instance *S, size_t in_bytes, size_t out_bytes, bool stage_in, bool stage_out)
+{
+    auto &P = S->pipe;
+    if (!P.h2d) {
+        HIPCHK(S, hipStreamCreateWithFlags(&P.h2d, hipStreamNonBlocking));
+        HIPCHK(S, hipStreamCreateWithFlags(&P.d2h, hipStreamNonBlocking));
+        for (int i = 0; i < 2; ++i) {
+            HIPCHK(S, hipEventCreateWithFlags(&P.ev_in[i], hipEventDisableTiming));
+            HIPCHK(S, hipEventCreateWithFlags(&P.ev_done[i], hipEventDisableTiming));
+            HIPCHK(S, hipEventCreateWithFlags(&P.ev_out[i], hipEventDisableTiming));
+        }
+    }
+    auto grow_dev = [&](void *(&b)[2], size_t &cap, size_t need) -> int {
+        if (cap >= need) return 0;
+        HIPCHK(S, hipDeviceSynchronize());
+        for (int i = 0; i < 2; ++i) { if (b[i]) HIPCHK(S, hipFree(b[i])); b[i] = nullptr; HIPCHK(S, hipMalloc(&b[i], need)); }
+        cap = need;
+        return 0;
+    };
+    auto grow_host = [&](void *(&b)[2], size_t &cap, size_t need) -> int {
+        if (cap >= need) return 0;
+        HIPCHK(S, hipDeviceSynchronize());
+        for (int i = 0; i < 2; ++i) { if (b[i]) HIPCHK(S, hipHostFree(b[i])); b[i] = nullptr; HIPCHK(S, hipHostMalloc(&b[i], need, hipHostMallocDefault)); }
+        cap = need;
+        return 0;
+    };
+    if (grow_dev(P.d_in, P.d_in_bytes, in_bytes) || grow_dev(P.d_out, P.d_out_bytes, out_bytes)) return S->status;
+    if (stage_in && grow_host(P.h_in, P.h_in_bytes, in_bytes)) return S->status;
+    if (stage_out && grow_host(P.h_out, P.h_out_bytes, out_bytes)) return S->status;
+    return SELENITE_RX_SUCCESS;
+}
+
 static void process_host(selenite_rx_instance *S, const void *src, void *dst, uint32_t block_size, bool q15,
                          const char *who)
 {
     if (!S || !block_size_ok(S, block_size, who)) return;
     const selenite_rx_config &g = S->cfg;
     const size_t esz = q15 ? sizeof(int16_t) : sizeof(float);
-    const size_t nin = (size_t)g.channels * block_size * 2 * esz;
-    const size_t nout = (size_t)g.channels * (block_size / g.decim) * esz;
+    const size_t in_ch = (size_t)block_size * 2 * esz, out_ch = (size_t)(block_size / g.decim) * esz;   // bytes per channel
     if (hipSetDevice(S->device) != hipSuccess) { fail(S, SELENITE_RX_DEVICE_ERROR, "hipSetDevice"); return; }
-    if (ensure(S, &S->d_io_in, &S->io_in_bytes, nin)) return;
-    if (ensure(S, &S->d_io_out, &S->io_out_bytes, nout)) return;
-    if (hipMemcpyAsync(S->d_io_in, src, nin, hipMemcpyHostToDevice, S->stream) != hipSuccess) {
-        fail(S, SELENITE_RX_DEVICE_ERROR, "H2D copy failed"); return;
+
+    if (g.agc_enable && g.agc_global) {                     // one chunk: every envelope before any gain
+        const size_t nin = g.channels * in_ch, nout = g.channels * out_ch;
+        if (ensure(S, &S->d_io_in, &S->io_in_bytes, nin)) return;
+        if (ensure(S, &S->d_io_out, &S->io_out_bytes, nout)) return;
+        if (hipMemcpyAsync(S->d_io_in, src, nin, hipMemcpyHostToDevice, S->stream) != hipSuccess) { fail(S, SELENITE_RX_DEVICE_ERROR, "H2D copy failed"); return; }
+        if (run_chain(S, S->d_io_in, q15, S->d_io_out, q15, block_size, kAll, nullptr)) return;
+        if (hipMemcpyAsync(dst, S->d_io_out, nout, hipMemcpyDeviceToHost, S->stream) != hipSuccess) { fail(S, SELENITE_RX_DEVICE_ERROR, "D2H copy failed"); return; }
+        if (hipStreamSynchronize(S->stream) != hipSuccess) fail(S, SELENITE_RX_DEVICE_ERROR, "stream sync failed");
+        return;
     }
-    if (run_chain(S, S->d_io_in, q15, S->d_io_out, q15, block_size, kAll, nullptr)) return;
-    if (hipMemcpyAsync(dst, S->d_io_out, nout, hipMemcpyDeviceToHost, S->stream) != hipSuccess) {
-        fail(S, SELENITE_RX_DEVICE_ERROR, "D2H copy failed"); return;
+
+    // chunk: about 16 MiB of input, at least 64 channels (a few waves per CU would starve the kernels), at most all
+    static const size_t chunk_bytes = [] { const char *e = std::getenv("SELENITE_RX_HOST_CHUNK_MB"); return (size_t)(e && std::atoi(e) > 0 ? std::atoi(e) : 16) << 20; }();
+    uint32_t cch = (uint32_t)std::max<size_t>(64, chunk_bytes / in_ch);
+    cch = std::min<uint32_t>(cch, g.channels);
+    const uint32_t nchunk = (g.channels + cch - 1) / cch;
+    const bool stage_in = !host_ptr_is_pinned(src), stage_out = !host_ptr_is_pinned(dst);
+    if (pipe_setup(S, cch * in_ch, cch * out_ch, stage_in, stage_out)) return;
+    auto &P = S->pipe;
+    const uint32_t phase0 = S->phase_host;                  // the shared LO of a call is one table: every chunk starts from the same phase
+    uint32_t phase_end = phase0;
+    const char *hs = static_cast<const char *>(src);
+    char *hd = static_cast<char *>(dst);
+    bool ok = true;
+    auto chk = [&](hipError_t e, const char *what) { if (ok && e != hipSuccess) { fail(S, SELENITE_RX_DEVICE_ERROR, std::string(who) + ": " + what + ": " + hipGetErrorString(e)); ok = false; } };
+    auto drain_out = [&](uint32_t k) {                      // pageable destination: chunk k from pinned staging to the caller
+        const uint32_t c0 = k * cch, n = std::min(cch, g.channels - c0);
+        chk(hipEventSynchronize(P.ev_out[k & 1]), "D2H wait");
+        if (ok) parallel_memcpy(hd + (size_t)c0 * out_ch, P.h_out[k & 1], (size_t)n * out_ch);
+    };
+    for (uint32_t k = 0; k < nchunk && ok; ++k) {
+        const int s = (int)(k & 1);
+        const uint32_t c0 = k * cch, n = std::min(cch, g.channels - c0);
+        const void *from = hs + (size_t)c0 * in_ch;
+        if (stage_in) {
+            if (k >= 2) chk(hipEventSynchronize(P.ev_in[s]), "staging wait");             // H2D of chunk k-2 left this staging buffer
+            if (ok) parallel_memcpy(P.h_in[s], from, (size_t)n * in_ch);
+            from = P.h_in[s];
+        }
+        if (k >= 2) chk(hipStreamWaitEvent(P.h2d, P.ev_done[s], 0), "H2D order");            // kernels of chunk k-2 have read d_in[s]
+        chk(hipMemcpyAsync(P.d_in[s], from, (size_t)n * in_ch, hipMemcpyHostToDevice, P.h2d), "H2D copy");
+        chk(hipEventRecord(P.ev_in[s], P.h2d), "event");
+        chk(hipStreamWaitEvent(S->stream, P.ev_in[s], 0), "compute order");
+        if (k >= 2) chk(hipStreamWaitEvent(S->stream, P.ev_out[s], 0), "compute order");     // D2H of chunk k-2 has read d_out[s]
+        if (!ok) break;
+        S->sub_first = c0; S->sub_count = n;
+        S->phase_host = phase0;
+        const int rc = run_chain(S, P.d_in[s], q15, P.d_out[s], q15, block_size, kAll, nullptr);
+        phase_end = S->phase_host;
+        S->sub_first = 0; S->sub_count = 0;
+        if (rc) { ok = false; break; }
+        chk(hipEventRecord(P.ev_done[s], S->stream), "event");
+        chk(hipStreamWaitEvent(P.d2h, P.ev_done[s], 0), "D2H order");
+        if (stage_out && k >= 2) drain_out(k - 2);                                           // frees h_out[s] before it is the D2H target again
+        chk(hipMemcpyAsync(stage_out ? P.h_out[s] : (void *)(hd + (size_t)c0 * out_ch), P.d_out[s], (size_t)n * out_ch,
+                           hipMemcpyDeviceToHost, P.d2h), "D2H copy");
+        chk(hipEventRecord(P.ev_out[s], P.d2h), "event");
     }
-    if (hipStreamSynchronize(S->stream) != hipSuccess) fail(S, SELENITE_RX_DEVICE_ERROR, "stream sync failed");
+    S->phase_host = ok ? phase_end : phase0;
+    if (stage_out && ok) {
+        if (nchunk >= 2) drain_out(nchunk - 2);
+        drain_out(nchunk - 1);
+    }
+    chk(hipStreamSynchronize(P.h2d), "sync");
+    chk(hipStreamSynchronize(S->stream), "sync");
+    chk(hipStreamSynchronize(P.d2h), "sync");
+}
+
+extern "C" void *selenite_rx_host_alloc(size_t bytes)
+{
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) { g_last_error = "hipHostMalloc failed"; return nullptr; }
+    return p;
+}
+extern "C" void selenite_rx_host_free(void *hptr) { if (hptr) (void)hipHostFree(hptr); }
+extern "C" int selenite_rx_host_register(void *hptr, size_t bytes)
+{
+    HIPCHK(nullptr, hipHostRegister(hptr, bytes, hipHostRegisterDefault));
+    return SELENITE_RX_SUCCESS;
+}
+extern "C" int selenite_rx_host_unregister(void *hptr)
+{
+    HIPCHK(nullptr, hipHostUnregister(hptr));
+    return SELENITE_RX_SUCCESS;
 }
 
 extern "C" void selenite_rx_process_f32(selenite_rx_instance *S, const float *pSrcIQ, float *pDstAudio,

@@ -205,6 +205,9 @@ __device__ __forceinline__ void hilbert_quad(const float *dq, int lane, const fl
 }
 
 
+#ifndef SRX_IMG_ALIGN
+#define SRX_IMG_ALIGN 128      // halfs
+#endif
 // ---- SELENITE_ARITH_SPLIT16 geometry (rx_split16.hip; the host-side table builder in rx_fused.hip
 // needs KS and the fragment order) ----
 template <int NCO, int ND, int M, int NH>
@@ -213,7 +216,7 @@ struct GeoS {
     static constexpr int HS = G::HQ4 * M;                 // history samples in front
     static constexpr int XN = HS + G::T;
     static constexpr int XROWS = XN / 64;
-    static constexpr int IMG = 80 * XROWS;                // halfs per image
+    static constexpr int IMG = (80 * XROWS + SRX_IMG_ALIGN - 1) / SRX_IMG_ALIGN * SRX_IMG_ALIGN;   // halfs per image (stride a multiple of 256 B: two images' words leave in one ds_write2st64_b32)
     static constexpr int KTOT = ND + 4 * 15 + 1;
     static constexpr int KS = (KTOT + 31) / 32;           // MFMA k-steps of 32
     static constexpr int oTab = 0;                        // floats; the sine table only when the LO is computed in the kernel

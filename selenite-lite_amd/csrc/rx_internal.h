@@ -111,8 +111,17 @@ struct selenite_rx_instance {
     float *d_scratch = nullptr;  size_t scratch_bytes = 0;   // intermediate f32 audio
     float *d_env = nullptr;      size_t env_cap = 0;
     float *d_env_part = nullptr; size_t env_part_cap = 0;   // per-wavefront envelope maxima
-    void *d_io_in = nullptr;     size_t io_in_bytes = 0;     // staging for the host-pointer entry points
+    void *d_io_in = nullptr;     size_t io_in_bytes = 0;     // staging for the host-pointer entry points (global-gain calls)
     void *d_io_out = nullptr;    size_t io_out_bytes = 0;
+    // chunked, double-buffered pipeline of the host-pointer entry points (rx_api.hip: process_host)
+    struct HostPipe {
+        hipStream_t h2d = nullptr, d2h = nullptr;
+        hipEvent_t ev_in[2] = { nullptr, nullptr }, ev_done[2] = { nullptr, nullptr }, ev_out[2] = { nullptr, nullptr };
+        void *d_in[2] = { nullptr, nullptr }, *d_out[2] = { nullptr, nullptr };     // device chunk buffers
+        void *h_in[2] = { nullptr, nullptr }, *h_out[2] = { nullptr, nullptr };     // pinned staging (pageable callers only)
+        size_t d_in_bytes = 0, d_out_bytes = 0, h_in_bytes = 0, h_out_bytes = 0;
+    } pipe;
+    uint32_t sub_first = 0, sub_count = 0;                   // channel sub-range of the current launch (0 = all channels)
     float2 *d_lo = nullptr;      size_t lo_bytes = 0;        // shared LO table of the current call
     bool steps_uniform = false;        // every channel has the same NCO step
     bool phase_uniform = true;         // ... and the same phase (true after init/reset)

@@ -39,6 +39,12 @@
 #ifndef SRX_ACC4
 #define SRX_ACC4 0               // separate accumulators for the big and the small terms (1) or one per rail (0)
 #endif
+#ifndef SRX_IN_AUX
+#define SRX_IN_AUX 2             // cache policy of the streamed input loads (2 = nt)
+#endif
+#ifndef SRX_LO_AUX
+#define SRX_LO_AUX 0             // cache policy of the shared-LO loads
+#endif
 #ifndef SRX_SPLIT16_W2
 #define SRX_SPLIT16_W2 0         // 1: also build k_ssb_split16w2 (two waves per channel); measured equal to the one-wave kernel -- both sit at the package power cap
 #endif
@@ -66,7 +72,7 @@ template <> struct BRaw<float> {
     static constexpr int kBytes = 16;
     static __device__ __forceinline__ type load(__amdgpu_buffer_rsrc_t r, int voff, int soff)
     {
-        return __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 2);      // nt: streamed once
+        return __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, SRX_IN_AUX);      // nt: streamed once
     }
     static __device__ __forceinline__ void unpack(const type &r, v2f &a, v2f &b)
     {
@@ -79,7 +85,7 @@ template <> struct BRaw<int16_t> {
     static constexpr int kBytes = 8;
     static __device__ __forceinline__ type load(__amdgpu_buffer_rsrc_t r, int voff, int soff)
     {
-        return __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 2);
+        return __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, SRX_IN_AUX);
     }
     static __device__ __forceinline__ void unpack(const type &r, v2f &a, v2f &b)
     {
@@ -230,14 +236,14 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
     constexpr int LOD = 3;
     u4v lo4[LOD];
     auto lo_load = [&](int slot, int i, int sl) {
-        lo4[slot] = __builtin_amdgcn_raw_buffer_load_b128(rs_lo, lane * 16 + i * 1024, sl, 0);
+        lo4[slot] = __builtin_amdgcn_raw_buffer_load_b128(rs_lo, lane * 16 + i * 1024, sl, SRX_LO_AUX);
     };
     auto lo_base = [&](uint32_t pass) { return pass < npass ? (int)pass * G::T * 8 : 0; };   // pass == npass: the next channel's pass 0
     auto prefetch = [&](uint32_t pass) {                          // pass == npass: pass 0 of this workgroup's next channel
         const int so = pass < npass ? (int)pass * kInPass : 0;
         const __amdgpu_buffer_rsrc_t rs = pass < npass ? rs_in : rs_in_next;
 #pragma unroll
-        for (int i = 0; i < NLD; ++i) raw[i] = R::load(rs, lane * R::kBytes + i * 64 * R::kBytes, so);
+        for (int i = 0; i < NLD; ++i) raw[i] = R::load(rs, lane * R::kBytes + i * 64 * R::kBytes, so);      // (BRaw: aux = SRX_IN_AUX)
         if constexpr (NCO == 2) {
 #pragma unroll
             for (int i = 0; i < LOD; ++i) lo_load(i, i, lo_base(pass));

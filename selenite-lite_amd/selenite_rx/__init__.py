@@ -60,6 +60,7 @@ ABI_SYMBOLS = [
     "selenite_rx_time_process_device", "selenite_rx_time_process_q15_device", "selenite_rx_kernel_name", "selenite_rx_algorithmic_bytes",
     "selenite_rx_design_lowpass", "selenite_rx_design_hilbert", "selenite_rx_design_bandpass",
     "selenite_rx_abi_version",
+    "selenite_rx_host_alloc", "selenite_rx_host_free", "selenite_rx_host_register", "selenite_rx_host_unregister",
 ]
 
 class TxConfig(C.Structure):
@@ -139,6 +140,12 @@ def lib():
         L.selenite_rx_device_alloc.argtypes = [C.c_size_t]
         L.selenite_rx_device_alloc.restype = vp
         L.selenite_rx_device_free.argtypes = [vp]
+        L.selenite_rx_host_alloc.argtypes = [C.c_size_t]
+        L.selenite_rx_host_alloc.restype = vp
+        L.selenite_rx_host_free.argtypes = [vp]
+        L.selenite_rx_host_free.restype = None
+        L.selenite_rx_host_register.argtypes = [vp, C.c_size_t]
+        L.selenite_rx_host_unregister.argtypes = [vp]
         L.selenite_rx_memcpy_h2d.argtypes = [vp, vp, C.c_size_t]
         L.selenite_rx_memcpy_d2h.argtypes = [vp, vp, C.c_size_t]
         L.selenite_rx_set_device.argtypes = [C.c_int]
@@ -188,6 +195,30 @@ def synth_iq_host(first_channel, nch, first_sample, nsamp, seed):
     iq = np.empty((nch, nsamp, 2), np.float32)
     lib().selenite_rx_synth_iq_host(_fp(iq), first_channel, nch, first_sample, nsamp, seed)
     return iq
+
+
+class _PinnedOwner:
+    def __init__(self, nbytes):
+        self.ptr = lib().selenite_rx_host_alloc(nbytes)
+        if not self.ptr:
+            raise MemoryError("selenite_rx_host_alloc(%d) failed" % nbytes)
+
+    def __del__(self):
+        try:
+            lib().selenite_rx_host_free(self.ptr)
+        except Exception:
+            pass
+
+
+def pinned_array(shape, dtype):
+    """numpy array over page-locked host memory (selenite_rx_host_alloc): the host-pointer process calls DMA
+    straight from / into it."""
+    dtype = np.dtype(dtype)
+    n = int(np.prod(shape)) * dtype.itemsize
+    owner = _PinnedOwner(max(n, 1))
+    buf = (C.c_char * max(n, 1)).from_address(owner.ptr)
+    buf._owner = owner                       # the array keeps `buf` alive (arr.base), `buf` keeps the allocation
+    return np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
 
 
 class DeviceBuffer:
@@ -248,18 +279,21 @@ class Rx:
     def out_len(self, block_size):
         return block_size // self.cfg.decim
 
-    def process(self, iq):
+    def process(self, iq, out=None):
+        """selenite_rx_process_f32 on host arrays (pageable numpy memory, or page-locked `pinned_array`s)."""
         iq = np.ascontiguousarray(iq, np.float32)
         c, bs = iq.shape[0], iq.shape[1]
-        out = np.empty((c, self.out_len(bs)), np.float32)
+        if out is None:
+            out = np.empty((c, self.out_len(bs)), np.float32)
         self.L.selenite_rx_process_f32(self.h, _fp(iq), _fp(out), bs)
         self.check()
         return out
 
-    def process_q15(self, iq):
+    def process_q15(self, iq, out=None):
         iq = np.ascontiguousarray(iq, np.int16)
         c, bs = iq.shape[0], iq.shape[1]
-        out = np.empty((c, self.out_len(bs)), np.int16)
+        if out is None:
+            out = np.empty((c, self.out_len(bs)), np.int16)
         self.L.selenite_rx_process_q15(self.h, iq.ctypes.data_as(i16p), out.ctypes.data_as(i16p), bs)
         self.check()
         return out

@@ -647,3 +647,42 @@ def test_instances_run_concurrently_on_their_own_streams():
     ring.L.selenite_ring_sync(ring.h)
     sg, so = ring.state(), oring.state()
     assert all(np.array_equal(sg[k], so[k]) for k in so)
+
+
+@pytest.mark.parametrize("arith", [ARITH_CMSIS, rc.ARITH_SPLIT16])
+def test_host_pointer_calls_are_pipelined_in_channel_chunks_and_bit_identical(arith):
+    """selenite_rx_process_f32 / _q15 on host buffers (the literal drop-in signature): chunked H2D || kernels || D2H
+    pipeline.  With a 1 MiB chunk the 300 channels below take five chunks (the last one ragged); the result and the
+    streaming state must equal the un-chunked device call bit for bit, for pageable and for page-locked caller memory,
+    over several streamed calls (the shared LO must advance once per call, not once per chunk)."""
+    import subprocess, sys, textwrap
+    code = textwrap.dedent("""
+        import os, sys, numpy as np
+        sys.path.insert(0, %r); sys.path.insert(0, %r)
+        import rxcommon as rc, selenite_rx as sr
+        nch, bs, arith = 300, 2048, %d
+        spec = rc.baseline_spec("cfg3", nch, arith)
+        a, b, c = sr.Rx(spec.config()), sr.Rx(spec.config()), sr.Rx(spec.config())
+        d_in, d_out = sr.DeviceBuffer(nch * bs * 8), sr.DeviceBuffer(nch * (bs // 4) * 4)
+        for call in range(3):
+            iq = rc.synth_iq(0, nch, call * bs, bs)
+            d_in.upload(iq); a.process_device(d_in.ptr, d_out.ptr, bs); a.sync()
+            want = d_out.download((nch, bs // 4), np.float32)
+            got_pageable = b.process(iq)
+            pin = sr.pinned_array(iq.shape, np.float32); pin[...] = iq
+            out = sr.pinned_array((nch, bs // 4), np.float32)
+            got_pinned = c.process(pin, out)
+            assert rc.bits_equal(got_pageable, want) and rc.bits_equal(got_pinned, want), call
+        sa, sb, sc = a.state(), b.state(), c.state()
+        for k in sa:
+            assert np.array_equal(sa[k].view(np.uint32), sb[k].view(np.uint32)) and np.array_equal(sa[k].view(np.uint32), sc[k].view(np.uint32)), k
+        q = np.clip(np.trunc(rc.synth_iq(0, nch, 0, bs) * 32768.0), -32768, 32767).astype(np.int16)
+        x, y = sr.Rx(spec.config()), sr.Rx(spec.config())
+        d16i, d16o = sr.DeviceBuffer(q.nbytes), sr.DeviceBuffer(nch * (bs // 4) * 2)
+        d16i.upload(q); x.process_q15_device(d16i.ptr, d16o.ptr, bs); x.sync()
+        assert np.array_equal(y.process_q15(q), d16o.download((nch, bs // 4), np.int16))
+        print("OK")
+    """ % (os.path.join(rc.ROOT, "tests"), rc.PKG_DIR, arith))
+    env = dict(os.environ, SELENITE_RX_HOST_CHUNK_MB="1")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0 and out.stdout.strip().endswith("OK"), out.stderr[-3000:]
