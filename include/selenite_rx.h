@@ -184,6 +184,12 @@ void selenite_rx_global_phase1_device(selenite_rx_instance *S, const float *dSrc
 void selenite_rx_global_phase2_device(selenite_rx_instance *S, float *dDstAudio,
                                       const float *dEnv, uint32_t blockSize);
 
+/* The same in one call for a plain C host: phase 1, ncclAllReduce(ncclMax) of the blockSize / cfg.block envelopes
+ * over `rccl_comm` (an ncclComm_t whose rank runs on this instance's device; NULL = single rank), phase 2, all
+ * enqueued on the instance's stream.  RCCL is resolved at run time (no link dependency).  Returns the status. */
+int selenite_rx_global_process_f32_device(selenite_rx_instance *S, const float *dSrcIQ, float *dDstAudio,
+                                          uint32_t blockSize, void *rccl_comm);
+
 /* ---- streams, state, memory ----------------------------------------------------------- */
 
 /* hipStream_t passed as void*; NULL = the library-owned stream created at init. */

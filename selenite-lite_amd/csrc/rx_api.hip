@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
+#include <dlfcn.h>
 #include <mutex>
 #include <thread>
 
@@ -507,6 +508,46 @@ extern "C" void selenite_rx_global_phase2_device(selenite_rx_instance *S, float 
     run_chain(S, nullptr, false, dDstAudio, false, blockSize, kPhase2, const_cast<float *>(dEnv));
 }
 
+// ---- global-gain call with the exchange done HERE, for a plain C host: phase 1, ncclAllReduce(MAX) of the
+// per-block envelopes over RCCL / xGMI, phase 2 -- all on the instance's stream.  RCCL is bound at run time
+// (the process's already loaded librccl -- e.g. the one torch ships -- or librccl.so.1), so the library carries no
+// link-time dependency on it and a host that never uses global gain never loads it.
+typedef int (*nccl_allreduce_fn)(const void *, void *, size_t, int, int, void *, hipStream_t);
+static nccl_allreduce_fn rccl_allreduce()
+{
+    static nccl_allreduce_fn fn = [] {
+        void *sym = dlsym(RTLD_DEFAULT, "ncclAllReduce");
+        if (!sym) {
+            void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+            if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+            if (h) sym = dlsym(h, "ncclAllReduce");
+        }
+        return reinterpret_cast<nccl_allreduce_fn>(sym);
+    }();
+    return fn;
+}
+
+extern "C" int selenite_rx_global_process_f32_device(selenite_rx_instance *S, const float *dSrcIQ, float *dDstAudio,
+                                                     uint32_t blockSize, void *rccl_comm)
+{
+    if (!S || !block_size_ok(S, blockSize, "selenite_rx_global_process_f32_device")) return S ? S->status : SELENITE_RX_ARGUMENT_ERROR;
+    if (!(S->cfg.agc_enable && S->cfg.agc_global))
+        return fail(S, SELENITE_RX_ARGUMENT_ERROR, "selenite_rx_global_process_f32_device: instance is not agc_global");
+    const size_t nblk = blockSize / S->cfg.block;
+    int rc = ensure(S, (void **)&S->d_env, &S->env_cap, sizeof(float) * nblk);
+    if (rc) return rc;
+    rc = run_chain(S, dSrcIQ, false, dDstAudio, false, blockSize, kPhase1, S->d_env);
+    if (rc) return rc;
+    if (rccl_comm) {                                        // NULL: single rank, nothing to exchange
+        nccl_allreduce_fn ar = rccl_allreduce();
+        if (!ar) return fail(S, SELENITE_RX_DEVICE_ERROR, "selenite_rx_global_process_f32_device: RCCL (ncclAllReduce) is not available");
+        const int nccl_float = 7, nccl_max = 2;             // ncclFloat32, ncclMax (rccl.h)
+        const int e = ar(S->d_env, S->d_env, nblk, nccl_float, nccl_max, rccl_comm, S->stream);
+        if (e != 0) return fail(S, SELENITE_RX_DEVICE_ERROR, "selenite_rx_global_process_f32_device: ncclAllReduce failed (" + std::to_string(e) + ")");
+    }
+    return run_chain(S, nullptr, false, dDstAudio, false, blockSize, kPhase2, S->d_env);
+}
+
 // ---- host-pointer entry points: the literal drop-in signature (float* / int16_t* I/Q in, audio out) ----
 //
 // Channels are independent, so a call over host buffers is cut into channel chunks and pipelined: chunk k+1 crosses
@@ -592,8 +633,8 @@ static void process_host(selenite_rx_instance *S, const void *src, void *dst, ui
         return;
     }
 
-    // chunk: about 16 MiB of input, at least 64 channels (a few waves per CU would starve the kernels), at most all
-    static const size_t chunk_bytes = [] { const char *e = std::getenv("SELENITE_RX_HOST_CHUNK_MB"); return (size_t)(e && std::atoi(e) > 0 ? std::atoi(e) : 16) << 20; }();
+    // chunk: about 32 MiB of input (16 MiB measured slower with pageable callers: the staging copies are threads spawned per chunk), at least 64 channels (a few waves per CU would starve the kernels), at most all
+    static const size_t chunk_bytes = [] { const char *e = std::getenv("SELENITE_RX_HOST_CHUNK_MB"); return (size_t)(e && std::atoi(e) > 0 ? std::atoi(e) : 32) << 20; }();
     uint32_t cch = (uint32_t)std::max<size_t>(64, chunk_bytes / in_ch);
     cch = std::min<uint32_t>(cch, g.channels);
     const uint32_t nchunk = (g.channels + cch - 1) / cch;

@@ -60,6 +60,7 @@ ABI_SYMBOLS = [
     "selenite_rx_time_process_device", "selenite_rx_time_process_q15_device", "selenite_rx_kernel_name", "selenite_rx_algorithmic_bytes",
     "selenite_rx_design_lowpass", "selenite_rx_design_hilbert", "selenite_rx_design_bandpass",
     "selenite_rx_abi_version",
+    "selenite_rx_global_process_f32_device",
     "selenite_rx_host_alloc", "selenite_rx_host_free", "selenite_rx_host_register", "selenite_rx_host_unregister",
 ]
 

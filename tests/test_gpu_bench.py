@@ -93,3 +93,14 @@ def test_global_gain_ranks_on_one_stream_match_the_unsharded_oracle():
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
     rcode = shard.launch_ranks(2, os.path.join(rc.ROOT, "tests", "dist_global_gain_worker.py"), [], env)
     assert rcode == 0
+
+
+def test_plain_c_host_runs_the_global_gain_path_over_rccl():
+    """selenite-lite_amd/host/global_gain_rccl.c: one C process, every GPU of the box a rank, channels sharded,
+    phase 1 -> ncclAllReduce(ncclMax) -> phase 2 without host synchronisation; sharded == unsharded bit for bit.
+    (One GPU on the test box: the communicator has one rank; the driver's 8-GPU node runs the same binary.)"""
+    exe = os.path.join(rc.PKG_DIR, "host", "global_gain_rccl")
+    out = subprocess.run([exe, "0", "192", "2048", "3"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads(out.stdout.strip().splitlines()[-1])
+    assert d["host"] == "C" and d["ranks"] >= 1 and d["sharded_equals_unsharded"] is True

@@ -686,3 +686,41 @@ def test_host_pointer_calls_are_pipelined_in_channel_chunks_and_bit_identical(ar
     env = dict(os.environ, SELENITE_RX_HOST_CHUNK_MB="1")
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
     assert out.returncode == 0 and out.stdout.strip().endswith("OK"), out.stderr[-3000:]
+
+
+@pytest.mark.parametrize("arith", [ARITH_CMSIS, ARITH_FMA, rc.ARITH_SPLIT16])
+@pytest.mark.parametrize("case", ["dense_hilbert", "delay_not_impulse", "negative_zero_taps", "dense_both"])
+def test_dense_and_negative_zero_fir_pair_taps_take_the_generic_kernels_bit_exact(case, arith):
+    """The fused kernels assume what selenite_rx_design_hilbert makes: a unit-impulse delay FIR and a type-III
+    Hilbert FIR (exact +0.0f taps at even distance from the centre, which they skip).  Anything else -- dense random
+    taps, a delay FIR that is not an impulse, taps that are -0.0f (x + (-0.0 * y) is not x for x = -0) -- must fall
+    back to the generic kernels and still match the CMSIS-order oracle bit for bit (arm_fir_f32.c:640-936)."""
+    rng = np.random.default_rng(hash(case) % 1000)
+    nch = 6
+    spec = baseline_spec("cfg3", nch, arith)
+    nh = spec.nh_taps
+    if case in ("dense_hilbert", "dense_both"):
+        spec.hilb = (rng.standard_normal(nh) * 0.2).astype(np.float32)
+    if case in ("delay_not_impulse", "dense_both"):
+        d = np.zeros(nh, np.float32)
+        d[nh // 2] = 0.75
+        d[nh // 2 + 3] = 0.25
+        spec.delay = d if case == "delay_not_impulse" else (rng.standard_normal(nh) * 0.2).astype(np.float32)
+    if case == "negative_zero_taps":
+        h = spec.hilb.copy()
+        h[h == 0.0] = np.float32(-0.0)
+        spec.hilb = h
+        d = spec.delay.copy()
+        d[d == 0.0] = np.float32(-0.0)
+        spec.delay = d
+    ref_arith = ARITH_FMA if arith == rc.ARITH_SPLIT16 else arith      # outside the fused decimator split16 runs as FMA
+    spec_o = baseline_spec("cfg3", nch, ref_arith)
+    spec_o.hilb, spec_o.delay = spec.hilb, spec.delay
+    g, o = gpu_rx(spec), CpuChain(spec_o, "orc")
+    assert g.kernel_name() == "generic", g.kernel_name()
+    for call in range(2):
+        iq = synth_iq(0, nch, call * 1024, 1024)
+        iq[:, ::7, :] *= -1.0
+        yg, yo = g.process(iq), o.process(iq)
+        assert bits_equal(yg, yo), "%s arith=%d rel_err=%g" % (case, arith, rel_err(yg, yo))
+    assert_state_equal(g, o)
