@@ -761,9 +761,9 @@ static hipError_t launch_shape(const RxParams &p, const FusedArgs &fa, const Fus
     return launch_one<0, ND, M, NH, float, float>(p, fa, src, dst, st);
 }
 
-// the instantiated shapes: BASELINE.json cfg1 / cfg2 / cfg3 (+ cfg5 = cfg2 chain), and two neighbours of
-// cfg3 (half the decimator taps; the long Hilbert) to show the kernels are not tied to one tap count
-#define SRX_SHAPES(X) X(256, 4, 63, 1) X(0, 1, 63, 2) X(0, 1, 127, 3) X(128, 4, 63, 4) X(256, 4, 127, 5)
+// the instantiated shapes: BASELINE.json cfg1 / cfg2 / cfg3 (+ cfg5 = cfg2 chain) and their neighbours in both
+// tap counts -- decimator 128 / 256 taps by 4, Hilbert pair 31 / 63 / 127 taps, with or without the decimator
+#define SRX_SHAPES(X) X(256, 4, 63, 1) X(0, 1, 63, 2) X(0, 1, 127, 3) X(128, 4, 63, 4) X(256, 4, 127, 5) X(128, 4, 127, 6) X(256, 4, 31, 7) X(0, 1, 31, 8)
 
 static bool fused_mode_ok(const selenite_rx_config &g)
 {

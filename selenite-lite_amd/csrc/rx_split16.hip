@@ -514,7 +514,7 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
     // Hilbert-pair history: last HH4 decimated samples of both rails to the front of D (every lane moves
     // one float4; the upper half of the wave repeats the lower half's moves when 2*HH4/4 = 32)
     constexpr int NDV = 2 * (G::HH4 / 4);
-    static_assert(NDV == 32 || NDV == 64, "Hilbert history move is one float4 per lane");
+    static_assert(NDV == 16 || NDV == 32 || NDV == 64, "Hilbert history move is one float4 per lane (lanes beyond NDV repeat the first ones)");
     const int dt_off = ((lane % NDV) / (G::HH4 / 4)) * G::DLEN + 4 * (lane % (G::HH4 / 4));
 
     // ---- demod: Hilbert pair + sideband (or AM envelope), AGC of the pass whose decimated rails are in D.
@@ -919,7 +919,7 @@ __global__ __launch_bounds__(128, 3) void k_ssb_split16w2(RxParams p, FusedArgs 
         float gain = p.gain[c];
         const int group = (int)fa.group;
         constexpr int NDV = 2 * (G::HH4 / 4);
-        static_assert(NDV == 32 || NDV == 64, "Hilbert history move is one float4 per lane");
+        static_assert(NDV == 16 || NDV == 32 || NDV == 64, "Hilbert history move is one float4 per lane (lanes beyond NDV repeat the first ones)");
         const int dt_off = ((lane % NDV) / (G::HH4 / 4)) * G::DLEN + 4 * (lane % (G::HH4 / 4));
         auto htap = [&](int k) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(hreg[k >> 6]), k & 63)); };
 

@@ -575,11 +575,11 @@ def test_call_lengths_that_are_not_whole_passes_split_into_fused_plus_generic(ar
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("nd,nh", [(128, 63), (256, 127)])
+@pytest.mark.parametrize("nd,nh", [(128, 63), (256, 127), (128, 127), (256, 31)])
 @pytest.mark.parametrize("arith", [ARITH_CMSIS, ARITH_FMA, rc.ARITH_SPLIT16])
 def test_neighbour_shapes_of_cfg3_run_the_fused_kernels(nd, nh, arith):
     """The decimating kernels are templates: besides the BASELINE shape the library instantiates a
-    128-tap decimator and a 127-tap Hilbert variant.  Same parity contract per arithmetic mode."""
+    128-tap decimator and 31- / 127-tap Hilbert variants.  Same parity contract per arithmetic mode."""
     nch = 48
     kw = dict(nco=True, nco_step_all=0x01000000, agc=True)
     g = gpu_rx(rc.ChainSpec(nch, 256, 4, nd, nh, 0, rc.MODE_LSB, arith, **kw))
@@ -724,3 +724,23 @@ def test_dense_and_negative_zero_fir_pair_taps_take_the_generic_kernels_bit_exac
         yg, yo = g.process(iq), o.process(iq)
         assert bits_equal(yg, yo), "%s arith=%d rel_err=%g" % (case, arith, rel_err(yg, yo))
     assert_state_equal(g, o)
+
+
+@pytest.mark.parametrize("arith,kernel", [(ARITH_CMSIS, "k_ssb_fused<0,1,31>"), (ARITH_FMA, "k_ssb_fused<0,1,31>"),
+                                          (rc.ARITH_SPLIT16, "k_hilb_split16<31>")])
+def test_short_hilbert_pair_without_decimator(arith, kernel):
+    """31-tap Hilbert pair, no decimator: the shortest instantiated shape of the no-decimator kernels."""
+    nch = 20
+    g = gpu_rx(rc.ChainSpec(nch, 256, 1, 0, 31, 0, rc.MODE_USB, arith, agc=True))
+    ref_arith = ARITH_CMSIS if arith == rc.ARITH_SPLIT16 else arith
+    o = CpuChain(rc.ChainSpec(nch, 256, 1, 0, 31, 0, rc.MODE_USB, ref_arith, agc=True), "orc")
+    assert g.kernel_name() == kernel
+    for call in range(3):
+        iq = synth_iq(0, nch, 768 * call, 768)
+        yg, yo = g.process(iq), o.process(iq)
+        if arith == rc.ARITH_SPLIT16:
+            for b in range(3):
+                assert rel_err(yg[:, 256 * b:256 * b + 256], yo[:, 256 * b:256 * b + 256]) <= TOL
+        else:
+            assert bits_equal(yg, yo)
+    assert bits_equal(g.state()["fir_state"], o.state()["fir_state"])
