@@ -826,8 +826,15 @@ void free_fused(FusedPlan &plan)
 
 bool fused_block_size_ok(const FusedPlan &plan, const selenite_rx_config &g, uint32_t block_size)
 {
-    (void)plan;
-    return (block_size / g.decim) % 256 == 0;       // whole passes only; otherwise the generic path runs
+    const uint32_t nout = block_size / g.decim;
+    if (nout % 256 == 0) return true;                // whole passes
+    // k_ssb_split16 also takes a partial last pass when it holds a whole decimator history (rx_split16.hip); the
+    // other fused kernels get the whole passes and the generic kernels the rest (run_chain)
+    if (g.arith == SELENITE_ARITH_SPLIT16 && g.nd_taps && plan.d_btab16 && g.decim == 4) {
+        const uint32_t tail_in = block_size % (256u * g.decim), hs = (((g.nd_taps - 1 + 3) / 4 + 3) & ~3u) * 4;
+        return tail_in >= hs;
+    }
+    return false;
 }
 
 hipError_t launch_fused(const FusedPlan &plan, const RxParams &p, int arith, const void *src, bool src_q15,

@@ -131,7 +131,8 @@ __device__ __forceinline__ void lds_order()
 // gain law, arm_scale with the updated gain.  GROUP = 16 / 64: lane reductions by DPP, the block
 // envelopes broadcast by v_readlane; GROUP = 0: any power-of-two `group` (run time).
 template <int GROUP>
-__device__ __forceinline__ void agc_pass(const AgcParams &ap, uint32_t agc_on, int lane, int group, float (&au)[4], float &gain)
+__device__ __forceinline__ void agc_pass(const AgcParams &ap, uint32_t agc_on, int lane, int group, float (&au)[4], float &gain,
+                                         int nvb = 64)       // nvb: DSP blocks of the pass that exist (a call's last pass may be partial)
 {
     float m = fmaxf(fmaxf(fabsf(au[0]), fabsf(au[1])), fmaxf(fabsf(au[2]), fabsf(au[3])));
     float g = gain, mine = gain;
@@ -144,7 +145,8 @@ __device__ __forceinline__ void agc_pass(const AgcParams &ap, uint32_t agc_on, i
         const int myblk = lane >> 4;
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
-            g = agc_step(ap, g, ds[b]);
+            const float gn = agc_step(ap, g, ds[b]);
+            g = b < nvb ? gn : g;                    // blocks past the end of the call leave the gain alone
             mine = (b == myblk) ? g : mine;
         }
     } else if constexpr (GROUP == 64) {
@@ -155,7 +157,7 @@ __device__ __forceinline__ void agc_pass(const AgcParams &ap, uint32_t agc_on, i
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1)
             if (off < group) m = fmaxf(m, __shfl_xor(m, off, 64));
-        const int nblk = 64 / group, myblk = lane / group;
+        const int nblk = min(64 / group, nvb), myblk = lane / group;
         for (int b = 0; b < nblk; ++b) {
             const float env = __shfl(m, b * group, 64);
             g = agc_update<0>(ap, g, env);
@@ -221,7 +223,12 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
     constexpr int NTL = GS::HS / 128;                             // ... of which the last NTL hold the next history
     static_assert(GS::HS % 128 == 0 && NTL >= 1 && NTL <= NLD, "history is a whole number of wave loads");
 
-    const uint32_t npass = p.nout / G::P;
+    // passes of the call; the last one may be partial (a call is a whole number of DSP blocks, not of passes): its
+    // missing input reads as zeros and its surplus audio is dropped by the buffer range checks, the streaming state
+    // and the AGC are taken from the part that exists (the host side sends such calls here only when that part holds
+    // a whole decimator history: tail_in >= HS)
+    const uint32_t npass = (p.nout + G::P - 1) / G::P;
+    const uint32_t tail_out = p.nout - (npass - 1) * G::P;       // audio samples of the last pass: P when the call is whole passes
     auto in_rsrc = [&](uint32_t ch) {                             // a channel past the last one: empty range, loads return zeros
         return make_rsrc(src + (size_t)ch * p.in_stride * 2, ch < p.channels ? p.block_size * (R::kBytes / 2) : 0u);
     };
@@ -365,7 +372,8 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
     };
 
     // ---- mix(p): NCO mix, block exponent, f16 split into the images, f32 history copy ----
-    auto mix = [&](uint32_t pass) {
+    auto mix = [&](uint32_t pass, auto partial_c) {
+        constexpr bool PARTIAL = decltype(partial_c)::value;     // the call's last pass, with fewer than T input samples
         const uint32_t n0 = pass * G::T;
         v2f m[2 * NLD];
 #pragma unroll
@@ -416,8 +424,13 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
         for (int i = 0; i < NLD; ++i) {
             const int n = 128 * i + 2 * lane;
             put_iq(GS::HS + n, m[2 * i], m[2 * i + 1], pre);
-            if (i >= NLD - NTL)
+            if constexpr (PARTIAL) {                                  // the history is the last HS samples that exist
+                const int hidx = n - ((int)tail_out * M - GS::HS);
+                if (hidx >= 0 && hidx < GS::HS)
+                    *reinterpret_cast<float4 *>(Hf + hidx) = make_float4(m[2 * i].x, m[2 * i].y, m[2 * i + 1].x, m[2 * i + 1].y);
+            } else if (i >= NLD - NTL) {
                 *reinterpret_cast<float4 *>(Hf + (n - (G::T - GS::HS))) = make_float4(m[2 * i].x, m[2 * i].y, m[2 * i + 1].x, m[2 * i + 1].y);
+            }
         }
     };
 
@@ -524,14 +537,14 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
     constexpr int KH = GS::KS > 4 ? GS::KS - 3 : 1;                   // k-steps that carry Hilbert steps
     constexpr int TPK = (NTS + KH - 1) / KH;
     float q2[4];
-    auto demod_piece = [&](int kk, float (&au)[4]) {
+    auto demod_piece = [&](int kk, float (&au)[4], int nvb = 64) {
         if constexpr (AM != 0) {
             if (kk == 0) {
                 const float4 vi = *reinterpret_cast<const float4 *>(dI + G::HH4 + 4 * lane);
                 const float4 vq = *reinterpret_cast<const float4 *>(dQ + G::HH4 + 4 * lane);
                 au[0] = cmag<0>(vi.x, vq.x); au[1] = cmag<0>(vi.y, vq.y);
                 au[2] = cmag<0>(vi.z, vq.z); au[3] = cmag<0>(vi.w, vq.w);
-                agc_pass<GROUP>(p.agcp, p.agc, lane, group, au, gain);
+                agc_pass<GROUP>(p.agcp, p.agc, lane, group, au, gain, nvb);
             }
         } else {
             if (kk == 0) q2[0] = q2[1] = q2[2] = q2[3] = 0.0f;
@@ -545,14 +558,14 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
                     const float i2 = di[r] + 0.0f;                    // 0.0f + 1.0f*x of the dense loop
                     au[r] = fa.upper ? (i2 - q2[r]) : (i2 + q2[r]);   // arm_sub_f32 / arm_add_f32
                 }
-                agc_pass<GROUP>(p.agcp, p.agc, lane, group, au, gain);
+                agc_pass<GROUP>(p.agcp, p.agc, lane, group, au, gain, nvb);
             }
         }
     };
     static_assert(TPK * GS::KS >= NTS, "every Hilbert step has a k-step");
-    auto demod = [&](float (&au)[4]) {                                // the whole demodulator in one piece (last pass)
+    auto demod = [&](float (&au)[4], int nvb) {                       // the whole demodulator in one piece (last pass)
 #pragma unroll
-        for (int kk = 0; kk < GS::KS; ++kk) demod_piece(kk, au);
+        for (int kk = 0; kk < GS::KS; ++kk) demod_piece(kk, au, nvb);
     };
     auto store_audio = [&](uint32_t q, const float (&au)[4]) {
         W::store(rs_out, lane * W::kBytes, (int)q * (G::P * (W::kBytes / 4)), au);
@@ -569,7 +582,8 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
         float au[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
         lds_order();
         STAMP(0);
-        mix(0);
+        if (npass == 1 && tail_out != G::P) mix(0, std::true_type{});
+        else mix(0, std::false_type{});
         STAMP(0);
         prefetch(1);
         lds_order();
@@ -585,7 +599,8 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
         STAMP(0);
         for (uint32_t pass = 1; pass < npass; ++pass) {
             STAMP(1);                                                 // wait for the prefetched pass
-            mix(pass);
+            if (pass + 1 == npass && tail_out != G::P) mix(pass, std::true_type{});
+            else mix(pass, std::false_type{});
             STAMP(0);
             store_audio(pass - 2, au);                                // pass 1: offset -1 pass = out of range, dropped
             prefetch(pass + 1);
@@ -604,7 +619,7 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
         }
         store_audio(npass - 2, au);
         load_state(c + gridDim.x);                                    // the next channel's state, under this channel's last demodulator pass
-        demod(au);
+        demod(au, (int)(tail_out / (4u * (uint32_t)group)));          // DSP blocks of the last pass that exist
         store_audio(npass - 1, au);
         STAMP(0);
 
@@ -622,7 +637,7 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
         if constexpr (AM == 0) {                                      // AM never ran the Hilbert pair: its state stays
             for (int i = lane; i < 2 * G::HH4; i += kWave) {
                 const int rail = i / G::HH4, mi = i % G::HH4, s = mi - G::FH;
-                if (s >= 0) p.fir_state[((size_t)c * 2 + rail) * G::HH + s] = D[rail * G::DLEN + G::P + mi];
+                if (s >= 0) p.fir_state[((size_t)c * 2 + rail) * G::HH + s] = D[rail * G::DLEN + tail_out + mi];
             }
         }
         if (lane == 0) {
@@ -1186,7 +1201,7 @@ static hipError_t launch_k(const RxParams &p, const FusedArgs &fa, const void *s
 #if SRX_SPLIT16_W2
     if constexpr (GS::KS % 2 == 0) {
         static const bool one_wave = std::getenv("SELENITE_RX_SPLIT16_W1") != nullptr;      // A/B: the one-wave kernel
-        if (!one_wave) {
+        if (!one_wave && p.nout % 256 == 0) {
             constexpr size_t lds2 = lds + (512 + 4) * sizeof(float);                         // + partial sums + exponents
             hipLaunchKernelGGL((k_ssb_split16w2<NCO, ND, M, NH, TIn, TOut, AM, GROUP>), dim3(p.channels), dim3(128), lds2, st, p, fa,
                                static_cast<const TIn *>(src), static_cast<TOut *>(dst));
