@@ -4,10 +4,10 @@
 // The DF1 recurrence (arm_biquad_cascade_df1_f32.c:220) has no time parallelism without changing
 // the rounding, so parallelism is channels x stages.  A wavefront is a SYSTOLIC array:
 //
-//      lane = 4*channel + stage        (16 channels x 4 stages; NS = 4)
+//      lane = NS*channel + stage       (NS = 2, 4 or 8 stages: 32, 16 or 8 channels per wavefront)
 //
 // at step k stage s works on sample k-s; a stage's output reaches the next stage's lane with one
-// DPP row_shr:1 (lanes of a channel are adjacent and never straddle a 16-lane row).  Value for
+// DPP row_shr:1 (lanes of a channel are adjacent and never straddle a 16-lane row: NS divides 16).  Value for
 // value this is the reference's stage-outer loop: each stage consumes exactly the previous stage's
 // output sequence, left-to-right sums, feedback added, no fusion (both arithmetic modes -- the
 // recurrence keeps the reference rounding).
@@ -15,8 +15,8 @@
 // Per DSP block (BLK samples) and workgroup (one wavefront, 16 channels):
 //   1. coalesced dwordx4 loads (2 complex samples per lane), NCO mix real part, into ONE LDS tile
 //      x[16][BLK+4] (f32).  Shared LO: all 8 loads of a chunk use the same LO float4.
-//   2. BLK+3 systolic steps (3 masked fill + 3 masked drain steps so a block's envelope is complete
-//      before it is scaled); stage 3 writes y[n] over x[n] in place (x[n] was consumed 3 steps ago)
+//   2. BLK+NS-1 systolic steps (NS-1 masked fill + NS-1 masked drain steps so a block's envelope is complete
+//      before it is scaled); the last stage writes y[n] over x[n] in place (x[n] was consumed NS-1 steps ago)
 //      and tracks max|y|.
 //   3. AGC gain law per channel; the tile goes out as 16 rows of 1 KiB: ds_read_b128, scale by the
 //      channel's gain (v_readlane), one global dwordx4 store per lane per row.
@@ -57,20 +57,39 @@ template <> struct CwRaw<int16_t> {
     }
 };
 
-constexpr int kCwCh = 16;      // channels per wavefront
-constexpr int kCwNs = 4;       // biquad stages (lanes per channel)
+// Geometry of the systolic array for NS stages per channel (NS = 2, 4, 8: lanes of a channel are adjacent and never
+// straddle a 16-lane DPP row): CH = 64 / NS channels per wavefront, input chunks of CS = 1024 / CH samples (eight
+// dwordx4 loads of two complex samples per lane and chunk), D = NS - 1 fill / drain steps per DSP block.  Stage NS-1
+// emits y[k - D] at step k; trips are four steps, so an aligned float4 of outputs is NCAR values carried from the
+// trip before plus the first 4 - NCAR of this one (NCAR = 4 - D mod 4), PRO = D / 4 + 1 trips behind the input.
+template <int NS>
+struct CwGeo {
+    static_assert(NS == 2 || NS == 4 || NS == 8, "systolic CW kernel: 2, 4 or 8 biquad stages");
+    static constexpr int CH = 64 / NS;
+    static constexpr int CS = 1024 / CH;
+    static constexpr int LPC = CS / 2;              // lanes per channel row of a load
+    static constexpr int CPL = 64 / LPC;            // channels per load
+    static constexpr int D = NS - 1;
+    static constexpr int R = D % 4;                 // outputs of a trip that complete the pending group
+    static constexpr int NCAR = 4 - R;
+    static constexpr int PRO = D / 4 + 1;
+};
 
-template <int NCO, int BLK, typename TIn, typename TOut>
+template <int NS, int NCO, int BLK, typename TIn, typename TOut>
 __global__ __launch_bounds__(64) void k_cw_fused(RxParams p, const TIn *__restrict__ src, TOut *__restrict__ dst)
 {
+    using CG = CwGeo<NS>;
+    constexpr int CH = CG::CH, CS = CG::CS, D = CG::D, R = CG::R, NCAR = CG::NCAR, PRO = CG::PRO;
     constexpr int RS = BLK + 4;                         // tile row stride (floats); rows stay 16 B aligned
-    constexpr int NCHUNK = BLK / 64;                    // input chunks of 64 samples x 16 channels
-    __shared__ __attribute__((aligned(16))) float tile[kCwCh * RS + 4 * 64];
+    constexpr int NCHUNK = BLK / CS;                    // input chunks of CS samples x CH channels
+    constexpr int TPC = CS / 4;                         // trips per chunk
+    static_assert(BLK % CS == 0 && PRO <= TPC && 4 * PRO <= BLK, "block holds whole chunks; prologue inside the first chunk");
+    __shared__ __attribute__((aligned(16))) float tile[CH * RS + 4 * 64];
     __shared__ float tab[NCO == 1 ? 516 : 4];
     const int lane = threadIdx.x;
-    const int s = lane & 3, ch = lane >> 2;
-    const uint32_t c0 = blockIdx.x * kCwCh;
-    // the last workgroup of a channel count that is not a multiple of 16: lanes past the end work on a
+    const int s = lane & (NS - 1), ch = lane / NS;
+    const uint32_t c0 = blockIdx.x * CH;
+    // the last workgroup of a channel count that is not a multiple of CH: lanes past the end work on a
     // copy of the last channel (every load index is clamped) and none of their stores is issued
     const bool live = c0 + ch < p.channels;
     const uint32_t c = live ? c0 + ch : p.channels - 1;
@@ -80,24 +99,24 @@ __global__ __launch_bounds__(64) void k_cw_fused(RxParams p, const TIn *__restri
     // per-lane stage constants and state
     const float b0 = p.biq_c[5 * s], b1 = p.biq_c[5 * s + 1], b2 = p.biq_c[5 * s + 2];
     const float a1 = p.biq_c[5 * s + 3], a2 = p.biq_c[5 * s + 4];
-    float4 st = *reinterpret_cast<const float4 *>(p.biq_state + ((size_t)c * kCwNs + s) * 4);
+    float4 st = *reinterpret_cast<const float4 *>(p.biq_state + ((size_t)c * NS + s) * 4);
     float x1 = st.x, x2 = st.y, y1 = st.z, y2 = st.w;
     float gain = p.agc ? p.gain[c] : 1.0f;
-    // load-phase geometry: load j of a chunk covers channel 2j + (lane>>5), samples 2*(lane&31), +1
-    const int lch = lane >> 5, lsm = 2 * (lane & 31);
+    // load-phase geometry: load j of a chunk covers channel CPL*j + lane/LPC, samples 2*(lane%LPC), +1
+    const int lch = lane / CG::LPC, lsm = 2 * (lane % CG::LPC);
     const uint32_t ph_own = NCO ? p.phase[c] : 0u, st_own = NCO ? p.step[c] : 0u;
-    // stage-3 lanes write y[4i..4i+3] at tile[ch][4i]; other lanes write a private dummy float4
-    float *wbase = (s == 3) ? (tile + ch * RS) : (tile + kCwCh * RS + 4 * lane);
-    const int wstride = (s == 3) ? 1 : 0;
+    // last-stage lanes write y[4i..4i+3] at tile[ch][4i]; other lanes write a private dummy float4
+    float *wbase = (s == NS - 1) ? (tile + ch * RS) : (tile + CH * RS + 4 * lane);
+    const int wstride = (s == NS - 1) ? 1 : 0;
     const float *rbase = tile + ch * RS;
 
     typedef typename CwRaw<TIn>::type raw_t;
     raw_t raw[8];
     float4 lo4 = make_float4(1.0f, 0.0f, 1.0f, 0.0f);
-    auto issue_loads = [&](uint32_t n_first) {          // chunk of 64 samples x 16 channels starting at n_first
+    auto issue_loads = [&](uint32_t n_first) {          // chunk of CS samples x CH channels starting at n_first
 #pragma unroll
         for (int j = 0; j < 8; ++j)
-            raw[j] = CwRaw<TIn>::load(src, (size_t)min(c0 + 2 * j + lch, p.channels - 1) * p.in_stride + n_first + lsm);
+            raw[j] = CwRaw<TIn>::load(src, (size_t)min(c0 + CG::CPL * j + lch, p.channels - 1) * p.in_stride + n_first + lsm);
         if constexpr (NCO == 2) lo4 = *reinterpret_cast<const float4 *>(p.lo + n_first + lsm);
     };
     auto mix_write = [&](uint32_t n_first, int q) {      // NCO mix (real part) of the loaded chunk into the tile
@@ -113,7 +132,7 @@ __global__ __launch_bounds__(64) void k_cw_fused(RxParams p, const TIn *__restri
                 if constexpr (NCO == 2) {
                     la = make_float2(lo4.x, lo4.y); lb = make_float2(lo4.z, lo4.w);
                 } else {
-                    const uint32_t cj = min(c0 + 2 * j + lch, p.channels - 1);
+                    const uint32_t cj = min(c0 + CG::CPL * j + lch, p.channels - 1);
                     const uint32_t phj = p.phase[cj], stj = p.step[cj];
                     la = nco_lo<0>(tab, phj + (n_first + lsm) * stj);
                     lb = nco_lo<0>(tab, phj + (n_first + lsm + 1) * stj);
@@ -121,7 +140,7 @@ __global__ __launch_bounds__(64) void k_cw_fused(RxParams p, const TIn *__restri
                 xa = cmul<0>(a, la).x;                        // arm_cmplx_mult_cmplx_f32 real part: ac - bd
                 xb = cmul<0>(b, lb).x;
             }
-            *reinterpret_cast<float2 *>(tile + (2 * j + lch) * RS + 64 * q + lsm) = make_float2(xa, xb);
+            *reinterpret_cast<float2 *>(tile + (CG::CPL * j + lch) * RS + CS * q + lsm) = make_float2(xa, xb);
         }
     };
     // one DF1 step of this lane's stage; xs = stage-0 input of the step
@@ -150,54 +169,77 @@ __global__ __launch_bounds__(64) void k_cw_fused(RxParams p, const TIn *__restri
     cw_lds_sync();
     for (uint32_t blk = 0; blk < nblk; ++blk) {
         const uint32_t n0 = blk * BLK;
-        float m = 0.0f, ycarry = 0.0f;
+        float m = 0.0f;
+        float car[NCAR];                                              // outputs waiting for the rest of their float4
+#pragma unroll
+        for (int v = 0; v < NCAR; ++v) car[v] = 0.0f;
 #pragma unroll 1
         for (int q = 0; q < NCHUNK; ++q) {
             // ---- 1. this chunk's input into the tile; next chunk's HBM loads in flight meanwhile ----
-            mix_write(n0 + 64 * q, q);
+            mix_write(n0 + CS * q, q);
             {
-                const uint32_t nxt = n0 + 64 * (q + 1);               // next chunk (may be the next block's first)
+                const uint32_t nxt = n0 + CS * (q + 1);               // next chunk (may be the next block's first)
                 if (nxt < p.block_size) issue_loads(nxt);
             }
             cw_lds_sync();
-            // ---- 2. 16 trips of 4 systolic steps; stage-0 input is one aligned float4 per trip ----
-            int i = 16 * q;
+            // ---- 2. TPC trips of 4 systolic steps; stage-0 input is one aligned float4 per trip ----
+            int i = TPC * q;
             float4 xq = *reinterpret_cast<const float4 *>(rbase + 4 * i);
-            if (q == 0) {                                             // block prologue: 3 fill steps + step 3
-                float4 xn = *reinterpret_cast<const float4 *>(rbase + 4);
-                (void)step_masked(xq.x, 0);
-                (void)step_masked(xq.y, 1);
-                (void)step_masked(xq.z, 2);
-                ycarry = step(xq.w);                                  // y[0] in stage-3 lanes
-                m = fmaxf(m, fabsf(ycarry));
-                xq = xn;
-                i = 1;
+            if (q == 0) {                                             // block prologue: the D fill steps, first outputs into `car`
+#pragma unroll
+                for (int tpro = 0; tpro < PRO; ++tpro) {
+                    const float4 xn = *reinterpret_cast<const float4 *>(rbase + 4 * (tpro + 1));
+                    const float o[4] = { step_masked(xq.x, 4 * tpro), step_masked(xq.y, 4 * tpro + 1),
+                                         step_masked(xq.z, 4 * tpro + 2), step_masked(xq.w, 4 * tpro + 3) };
+                    if (tpro == PRO - 1) {
+#pragma unroll
+                        for (int j = R; j < 4; ++j) {                 // y[0 .. NCAR-1] (last-stage lanes)
+                            car[j - R] = o[j];
+                            m = fmaxf(m, fabsf(o[j]));
+                        }
+                    }
+                    xq = xn;
+                }
+                i = PRO;
             }
 #pragma unroll 1
-            for (; i < 16 * q + 16; ++i) {
+            for (; i < TPC * q + TPC; ++i) {
                 // prefetch the next trip's input (stays inside this chunk; harmless re-read at the end)
-                const int inext = (i + 1 < 16 * q + 16) ? i + 1 : i;
+                const int inext = (i + 1 < TPC * q + TPC) ? i + 1 : i;
                 const float4 xn = *reinterpret_cast<const float4 *>(rbase + 4 * inext);
-                const float ya = step(xq.x), yb = step(xq.y), yc = step(xq.z), yd = step(xq.w);
-                // outputs y[4i-3 .. 4i]: the aligned group y[4i-4 .. 4i-1] is complete after yc
-                *reinterpret_cast<float4 *>(wbase + (4 * i - 4) * wstride) = make_float4(ycarry, ya, yb, yc);
-                m = fmaxf(fmaxf(m, fabsf(ya)), fmaxf(fabsf(yb), fmaxf(fabsf(yc), fabsf(yd))));
-                ycarry = yd;
+                const float o[4] = { step(xq.x), step(xq.y), step(xq.z), step(xq.w) };
+                // the aligned group y[4(i-PRO) .. +3]: NCAR carried outputs, then the first R of this trip
+                float gq[4];
+#pragma unroll
+                for (int v = 0; v < 4; ++v) gq[v] = v < NCAR ? car[v] : o[v - NCAR];
+                *reinterpret_cast<float4 *>(wbase + 4 * (i - PRO) * wstride) = make_float4(gq[0], gq[1], gq[2], gq[3]);
+                m = fmaxf(fmaxf(m, fabsf(o[0])), fmaxf(fabsf(o[1]), fmaxf(fabsf(o[2]), fabsf(o[3]))));
+#pragma unroll
+                for (int v = 0; v < NCAR; ++v) car[v] = o[R + v];
                 xq = xn;
             }
         }
-        // ---- drain: stages 1..3 finish samples BLK-3 .. BLK-1 ----
+        // ---- drain: stages 1..NS-1 finish samples BLK-D .. BLK-1 ----
         {
-            const float ya = step_masked(0.0f, BLK), yb = step_masked(0.0f, BLK + 1), yc = step_masked(0.0f, BLK + 2);
-            *reinterpret_cast<float4 *>(wbase + (BLK - 4) * wstride) = make_float4(ycarry, ya, yb, yc);
-            m = fmaxf(fmaxf(m, fabsf(ya)), fmaxf(fabsf(yb), fabsf(yc)));
+            float seq[4 * PRO];
+#pragma unroll
+            for (int v = 0; v < NCAR; ++v) seq[v] = car[v];
+#pragma unroll
+            for (int w = 0; w < D; ++w) {
+                seq[NCAR + w] = step_masked(0.0f, BLK + w);
+                m = fmaxf(m, fabsf(seq[NCAR + w]));
+            }
+#pragma unroll
+            for (int tpro = 0; tpro < PRO; ++tpro)
+                *reinterpret_cast<float4 *>(wbase + (BLK - 4 * PRO + 4 * tpro) * wstride) =
+                    make_float4(seq[4 * tpro], seq[4 * tpro + 1], seq[4 * tpro + 2], seq[4 * tpro + 3]);
         }
         cw_lds_sync();
-        // ---- 3. AGC gain law (stage-3 lanes hold max|y| of their channel) and scaled store ----
+        // ---- 3. AGC gain law (last-stage lanes hold max|y| of their channel) and scaled store ----
         if (p.agc) gain = agc_update<0>(p.agcp, gain, m);
 #pragma unroll 4
-        for (int r = 0; r < kCwCh; ++r) {
-            const float g = __shfl(gain, 4 * r + 3, 64);
+        for (int r = 0; r < CH; ++r) {
+            const float g = __shfl(gain, NS * r + NS - 1, 64);
 #pragma unroll
             for (int h = 0; h < (BLK / 4 + 63) / 64; ++h) {
                 const int t = 4 * (lane + 64 * h);
@@ -219,8 +261,8 @@ __global__ __launch_bounds__(64) void k_cw_fused(RxParams p, const TIn *__restri
         cw_lds_sync();
     }
     if (!live) return;
-    *reinterpret_cast<float4 *>(p.biq_state + ((size_t)c * kCwNs + s) * 4) = make_float4(x1, x2, y1, y2);
-    if (s == 3) {
+    *reinterpret_cast<float4 *>(p.biq_state + ((size_t)c * NS + s) * 4) = make_float4(x1, x2, y1, y2);
+    if (s == NS - 1) {
         if (p.agc) p.gain[c] = gain;
         if constexpr (NCO != 0) p.phase[c] = ph_own + p.block_size * st_own;
     }
@@ -228,29 +270,39 @@ __global__ __launch_bounds__(64) void k_cw_fused(RxParams p, const TIn *__restri
 
 bool cw_fused_ok(const selenite_rx_config &g, uint32_t block_size)
 {
-    return mode_is_cw(g.mode) && g.nd_taps == 0 && g.decim == 1 && g.nh_taps == 0 && g.n_biquad == kCwNs &&
-           g.block == 256 && block_size % g.block == 0;
+    return mode_is_cw(g.mode) && g.nd_taps == 0 && g.decim == 1 && g.nh_taps == 0 &&
+           (g.n_biquad == 2 || g.n_biquad == 4 || g.n_biquad == 8) && g.block == 256 && block_size % g.block == 0;
 }
 
-template <int NCO, typename TIn, typename TOut>
+template <int NS, int NCO, typename TIn, typename TOut>
 static hipError_t cw_launch(const RxParams &p, const void *src, void *dst, hipStream_t st)
 {
-    hipLaunchKernelGGL((k_cw_fused<NCO, 256, TIn, TOut>), dim3((p.channels + kCwCh - 1) / kCwCh), dim3(64), 0, st, p,
+    constexpr int CH = CwGeo<NS>::CH;
+    hipLaunchKernelGGL((k_cw_fused<NS, NCO, 256, TIn, TOut>), dim3((p.channels + CH - 1) / CH), dim3(64), 0, st, p,
                        static_cast<const TIn *>(src), static_cast<TOut *>(dst));
     return hipGetLastError();
+}
+
+template <int NS>
+static hipError_t cw_launch_ns(const RxParams &p, const void *src, bool q15, void *dst, hipStream_t st)
+{
+    if (q15) {
+        if (p.nco == 2) return cw_launch<NS, 2, int16_t, int16_t>(p, src, dst, st);
+        if (p.nco == 1) return cw_launch<NS, 1, int16_t, int16_t>(p, src, dst, st);
+        return cw_launch<NS, 0, int16_t, int16_t>(p, src, dst, st);
+    }
+    if (p.nco == 2) return cw_launch<NS, 2, float, float>(p, src, dst, st);
+    if (p.nco == 1) return cw_launch<NS, 1, float, float>(p, src, dst, st);
+    return cw_launch<NS, 0, float, float>(p, src, dst, st);
 }
 
 hipError_t launch_cw_fused(const RxParams &p, const void *src, bool src_q15, void *dst, bool dst_q15, hipStream_t st)
 {
     if (src_q15 != dst_q15) return hipErrorNotSupported;
-    if (src_q15) {
-        if (p.nco == 2) return cw_launch<2, int16_t, int16_t>(p, src, dst, st);
-        if (p.nco == 1) return cw_launch<1, int16_t, int16_t>(p, src, dst, st);
-        return cw_launch<0, int16_t, int16_t>(p, src, dst, st);
-    }
-    if (p.nco == 2) return cw_launch<2, float, float>(p, src, dst, st);
-    if (p.nco == 1) return cw_launch<1, float, float>(p, src, dst, st);
-    return cw_launch<0, float, float>(p, src, dst, st);
+    if (p.nbiq == 2) return cw_launch_ns<2>(p, src, src_q15, dst, st);
+    if (p.nbiq == 4) return cw_launch_ns<4>(p, src, src_q15, dst, st);
+    if (p.nbiq == 8) return cw_launch_ns<8>(p, src, src_q15, dst, st);
+    return hipErrorNotSupported;
 }
 
 }  // namespace srx

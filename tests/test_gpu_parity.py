@@ -744,3 +744,31 @@ def test_short_hilbert_pair_without_decimator(arith, kernel):
         else:
             assert bits_equal(yg, yo)
     assert bits_equal(g.state()["fir_state"], o.state()["fir_state"])
+
+
+@pytest.mark.parametrize("stages", [2, 8])
+@pytest.mark.parametrize("variant", ["shared_lo", "per_channel_nco", "no_nco_no_agc", "q15"])
+@pytest.mark.parametrize("nch", [50, 64])
+def test_cw_fused_kernel_two_and_eight_stages(stages, variant, nch):
+    """The systolic CW kernel for 2 and 8 DF1 sections (32 / 8 channels per wavefront, 1 / 7 fill and drain steps):
+    bit-exact against the oracle like the 4-stage BASELINE shape, ragged channel counts included
+    (arm_biquad_cascade_df1_f32.c:165-407)."""
+    kw = dict(block=256, decim=1, nd_taps=0, nh_taps=0, n_biquad=stages, mode=MODE_CW, arith=ARITH_CMSIS,
+              nco=True, nco_step_all=0x00800000, agc=True, bp_q=2.0 if stages == 8 else 4.0)
+    if variant == "per_channel_nco":
+        kw["nco_steps"] = (np.arange(nch, dtype=np.uint32) * np.uint32(0x00123457) + np.uint32(0x00400000))
+    elif variant == "no_nco_no_agc":
+        kw["nco"] = False
+        kw["agc"] = False
+    spec = ChainSpec(nch, **kw)
+    g, o = gpu_rx(spec), CpuChain(spec, "orc")
+    assert g.kernel_name() == "k_cw_fused<%d,256>" % stages
+    for call in range(3):
+        iq = synth_iq(0, nch, call * 768, 768)
+        if variant == "q15":
+            q = np.clip(np.trunc(iq * 32768.0), -32768, 32767).astype(np.int16)
+            assert np.array_equal(g.process_q15(q), o.process_q15(q)), call
+        else:
+            yg, yo = g.process(iq), o.process(iq)
+            assert np.isfinite(yg).all() and bits_equal(yg, yo), "%s call %d rel_err %g" % (variant, call, rel_err(yg, yo))
+    assert_state_equal(g, o)
