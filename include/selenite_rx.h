@@ -46,6 +46,8 @@ extern "C" {
 #define SELENITE_RX_SUCCESS          0   /* ARM_MATH_SUCCESS          */
 #define SELENITE_RX_ARGUMENT_ERROR (-1)  /* ARM_MATH_ARGUMENT_ERROR   */
 #define SELENITE_RX_LENGTH_ERROR   (-2)  /* ARM_MATH_LENGTH_ERROR     */
+#define SELENITE_RX_NANINF         (-4)  /* ARM_MATH_NANINF (arm_math.h:405): a process call produced NaN / Inf audio -- latched by
+                                           * selenite_rx_sync() and the host-pointer process calls; SELENITE_ARITH_SPLIT16 kernels only */
 #define SELENITE_RX_DEVICE_ERROR   (-7)  /* outside arm_status: HIP device/runtime failure */
 
 /* Demodulator modes: the values of the firmware's Mode enum (Core/Inc/rxtx_if.h:33-43),

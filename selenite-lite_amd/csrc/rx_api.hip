@@ -110,7 +110,7 @@ static void classify_coeffs(selenite_rx_instance *S)
 
 static void free_device(selenite_rx_instance *S)
 {
-    void *ptrs[] = { S->d_dec_c, S->d_hilb_c, S->d_delay_c, S->d_biq_c, S->d_sintab, S->d_step, S->d_phase,
+    void *ptrs[] = { S->d_flags, S->d_dec_c, S->d_hilb_c, S->d_delay_c, S->d_biq_c, S->d_sintab, S->d_step, S->d_phase,
                      S->d_dec_state, S->d_fir_state, S->d_biq_state, S->d_gain, S->d_scratch, S->d_env, S->d_env_part,
                      S->d_io_in, S->d_io_out, S->d_lo, S->pipe.d_in[0], S->pipe.d_in[1], S->pipe.d_out[0], S->pipe.d_out[1] };
     for (void *p : ptrs)
@@ -136,12 +136,22 @@ static int reset_state(selenite_rx_instance *S)
     if (g.nh_taps > 1) HIPCHK(S, hipMemsetAsync(S->d_fir_state, 0, C * 2 * (g.nh_taps - 1) * sizeof(float), S->stream));
     if (g.n_biquad) HIPCHK(S, hipMemsetAsync(S->d_biq_state, 0, C * 4 * g.n_biquad * sizeof(float), S->stream));
     HIPCHK(S, hipMemsetAsync(S->d_phase, 0, C * sizeof(uint32_t), S->stream));
+    HIPCHK(S, hipMemsetAsync(S->d_flags, 0, sizeof(uint32_t), S->stream));
     std::vector<float> gi(C, g.agc_gain_init);
     HIPCHK(S, hipMemcpyAsync(S->d_gain, gi.data(), C * sizeof(float), hipMemcpyHostToDevice, S->stream));
     HIPCHK(S, hipStreamSynchronize(S->stream));
     S->phase_uniform = true;
     S->phase_host = 0;
     return SELENITE_RX_SUCCESS;
+}
+
+// the kernels' flag word (non-finite audio: ARM_MATH_NANINF), read after the stream has drained; latches the status
+static int check_device_flags(selenite_rx_instance *S)
+{
+    uint32_t f = 0;
+    HIPCHK(S, hipMemcpy(&f, S->d_flags, sizeof f, hipMemcpyDeviceToHost));
+    if (f & 1u) fail(S, SELENITE_RX_NANINF, "a process call produced NaN / Inf audio (non-finite input samples?)");
+    return S->status;
 }
 
 extern "C" int selenite_rx_abi_version(void) { return SELENITE_RX_ABI_VERSION; }
@@ -237,6 +247,7 @@ extern "C" int selenite_rx_init(selenite_rx_instance **out, const selenite_rx_co
     INITCHK(dev_alloc(&S->d_fir_state, cfg->nh_taps > 1 ? C * 2 * (cfg->nh_taps - 1) : 0));
     INITCHK(dev_alloc(&S->d_biq_state, C * 4 * cfg->n_biquad));
     INITCHK(dev_alloc(&S->d_gain, C));
+    INITCHK(dev_alloc(&S->d_flags, (size_t)1));
 #undef INITCHK
     classify_coeffs(S);
     if (plan_fused(S->cfg, S->delay_is_impulse, S->delay_index, S->hilb_odd_only, S->plan) != hipSuccess) {
@@ -305,7 +316,7 @@ extern "C" int selenite_rx_sync(selenite_rx_instance *S)
 {
     if (!S) return SELENITE_RX_ARGUMENT_ERROR;
     HIPCHK(S, hipStreamSynchronize(S->stream));
-    return S->status;
+    return check_device_flags(S);
 }
 
 extern "C" int selenite_rx_reset(selenite_rx_instance *S)
@@ -328,6 +339,7 @@ static RxParams make_params(selenite_rx_instance *S, uint32_t block_size)
     p.sintab = S->d_sintab; p.step = S->d_step; p.phase = S->d_phase;
     p.dec_state = S->d_dec_state; p.fir_state = S->d_fir_state; p.biq_state = S->d_biq_state;
     p.gain = S->d_gain;
+    p.flags = S->d_flags;
     if (S->sub_count) {                                     // a contiguous channel range of the instance: every per-channel array moves with it
         const size_t c0 = S->sub_first;
         p.channels = S->sub_count;
@@ -689,6 +701,7 @@ static void process_host(selenite_rx_instance *S, const void *src, void *dst, ui
     chk(hipStreamSynchronize(P.h2d), "sync");
     chk(hipStreamSynchronize(S->stream), "sync");
     chk(hipStreamSynchronize(P.d2h), "sync");
+    if (ok) (void)check_device_flags(S);
 }
 
 extern "C" void *selenite_rx_host_alloc(size_t bytes)

@@ -35,6 +35,7 @@ struct RxParams {
     float *fir_state;      // [C][2][nh-1]
     float *biq_state;      // [C][nbiq][4]
     float *gain;           // [C]
+    uint32_t *flags;       // [1] device flag word: bit 0 = a split16 kernel produced non-finite audio (ARM_MATH_NANINF)
     AgcParams agcp;
 };
 
@@ -108,6 +109,7 @@ struct selenite_rx_instance {
     float *d_dec_c = nullptr, *d_hilb_c = nullptr, *d_delay_c = nullptr, *d_biq_c = nullptr, *d_sintab = nullptr;
     uint32_t *d_step = nullptr, *d_phase = nullptr;
     float *d_dec_state = nullptr, *d_fir_state = nullptr, *d_biq_state = nullptr, *d_gain = nullptr;
+    uint32_t *d_flags = nullptr;
     float *d_scratch = nullptr;  size_t scratch_bytes = 0;   // intermediate f32 audio
     float *d_env = nullptr;      size_t env_cap = 0;
     float *d_env_part = nullptr; size_t env_part_cap = 0;   // per-wavefront envelope maxima

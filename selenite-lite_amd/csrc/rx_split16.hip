@@ -567,7 +567,10 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
 #pragma unroll
         for (int kk = 0; kk < GS::KS; ++kk) demod_piece(kk, au, nvb);
     };
+    bool nonfinite = false;                                           // any audio sample of this workgroup NaN / Inf (x * 0 is NaN iff x is)
     auto store_audio = [&](uint32_t q, const float (&au)[4]) {
+        const float z = __builtin_fmaf(au[3], 0.0f, __builtin_fmaf(au[2], 0.0f, __builtin_fmaf(au[1], 0.0f, au[0] * 0.0f)));
+        nonfinite = nonfinite || (z != z);
         W::store(rs_out, lane * W::kBytes, (int)q * (G::P * (W::kBytes / 4)), au);
     };
 
@@ -651,6 +654,7 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
         rs_in_next = in_rsrc(c + gridDim.x);
         rs_out = make_rsrc(dst + (size_t)c * p.out_stride, p.nout * (W::kBytes / 4));
     }
+    if (nonfinite) p.flags[0] = 1u;                                   // ARM_MATH_NANINF, read by selenite_rx_sync
     STAMP(1);
 #undef STAMP
 }
@@ -1072,6 +1076,7 @@ __global__ __launch_bounds__(64, 2) void k_hilb_split16(RxParams p, FusedArgs fa
     float gain = p.gain[c];
     const int mcol = lane & 15, rg = lane >> 4;
     int s_cur = 0x7fff;
+    bool nonfinite = false;                                           // any audio sample NaN / Inf (x * 0 is NaN iff x is)
     lds_order();
 
     for (uint32_t pass = 0; pass < npass; ++pass) {
@@ -1159,6 +1164,10 @@ __global__ __launch_bounds__(64, 2) void k_hilb_split16(RxParams p, FusedArgs fa
             au[0] = o4.x; au[1] = o4.y; au[2] = o4.z; au[3] = o4.w;
         }
         agc_pass<64>(p.agcp, p.agc, lane, 64, au, gain);
+        {
+            const float z = __builtin_fmaf(au[3], 0.0f, __builtin_fmaf(au[2], 0.0f, __builtin_fmaf(au[1], 0.0f, au[0] * 0.0f)));
+            nonfinite = nonfinite || (z != z);
+        }
         W::store(rs_out, lane * W::kBytes, (int)pass * (256 * (W::kBytes / 4)), au);
         // ---- 6. history: last NH-1 samples of both f32 rails and of both images to the front ----
         if constexpr (AM == 0) {
@@ -1183,6 +1192,7 @@ __global__ __launch_bounds__(64, 2) void k_hilb_split16(RxParams p, FusedArgs fa
             stQ[hv] = tq.x; stQ[hv + 1] = tq.y;
         }
     }
+    if (nonfinite) p.flags[0] = 1u;                                   // ARM_MATH_NANINF, read by selenite_rx_sync
     if (lane == 0) {
         if constexpr (NCO != 0) p.phase[c] = ph0 + p.block_size * step;
         if (p.agc) p.gain[c] = gain;

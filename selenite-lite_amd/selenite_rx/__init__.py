@@ -18,7 +18,7 @@ if os.environ.get("SELENITE_RX_LIB"):            # A/B experiments: another buil
 
 MODE_LSB, MODE_USB, MODE_CW, MODE_CWR, MODE_AM, MODE_FM, MODE_DIG, MODE_PKT = 0, 1, 2, 3, 4, 8, 0x0A, 0x0C
 ARITH_CMSIS, ARITH_FMA, ARITH_SPLIT16 = 0, 1, 2
-SUCCESS, ARGUMENT_ERROR, LENGTH_ERROR, DEVICE_ERROR = 0, -1, -2, -7
+SUCCESS, ARGUMENT_ERROR, LENGTH_ERROR, NANINF, DEVICE_ERROR = 0, -1, -2, -4, -7
 
 f32p = C.POINTER(C.c_float)
 u32p = C.POINTER(C.c_uint32)

@@ -19,7 +19,7 @@ if PKG_DIR not in sys.path:
 
 MODE_LSB, MODE_USB, MODE_CW, MODE_CWR, MODE_AM, MODE_FM, MODE_DIG, MODE_PKT = 0, 1, 2, 3, 4, 8, 0x0A, 0x0C
 ARITH_CMSIS, ARITH_FMA, ARITH_SPLIT16 = 0, 1, 2
-SUCCESS, ARGUMENT_ERROR, LENGTH_ERROR, DEVICE_ERROR = 0, -1, -2, -7
+SUCCESS, ARGUMENT_ERROR, LENGTH_ERROR, NANINF, DEVICE_ERROR = 0, -1, -2, -4, -7
 SEED = 0x5E1E917E
 
 f32p = C.POINTER(C.c_float)

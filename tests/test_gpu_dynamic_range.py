@@ -166,3 +166,36 @@ def test_tx_amplitude_sweep(amp, alc):
                 worst = max(worst, rel_err(yg[ch, b:b + 256], yo[ch, b:b + 256]))
     print("tx amp=%g alc=%s worst per-block rel_err %.3g" % (amp, alc, worst))
     assert worst <= TOL, (amp, alc, worst)
+
+
+@pytest.mark.parametrize("name", ["cfg3", "cfg2"])
+@pytest.mark.parametrize("poison", [np.nan, np.inf, -np.inf])
+def test_non_finite_input_raises_arm_math_naninf_and_spares_the_other_channels(name, poison):
+    """Inf / NaN input is outside the parity contract (the structural-zero skipping changes how NaN spreads), but it
+    must not pass silently: the split16 kernels flag non-finite audio and selenite_rx_sync / the host-pointer calls
+    latch ARM_MATH_NANINF (arm_math.h:405).  Channels are independent: the clean ones still match the oracle."""
+    import selenite_rx as sr
+    nch, bs = 6, 2048
+    g = gpu_rx(baseline_spec(name, nch, rc.ARITH_SPLIT16))
+    o = CpuChain(baseline_spec(name, nch, ARITH_CMSIS), "orc")
+    iq = synth_iq(0, nch, 0, bs)
+    clean = iq.copy()
+    iq[3, 700, 1] = poison
+    with pytest.raises(sr.RxError) as e:
+        g.process(iq)
+    assert e.value.code == rc.NANINF and g.status() == rc.NANINF
+    # same data, straight through the device entry point: the other channels are untouched by channel 3's poison
+    g2 = gpu_rx(baseline_spec(name, nch, rc.ARITH_SPLIT16))
+    d_in, d_out = sr.DeviceBuffer(iq.nbytes), sr.DeviceBuffer(nch * (bs // g2.cfg.decim) * 4)
+    d_in.upload(iq)
+    g2.process_device(d_in.ptr, d_out.ptr, bs)
+    with pytest.raises(sr.RxError):
+        g2.sync()
+    got = d_out.download((nch, bs // g2.cfg.decim), np.float32)
+    want = o.process(clean)
+    na = 256 // g2.cfg.decim
+    for ch in (0, 1, 2, 4, 5):
+        assert np.isfinite(got[ch]).all()
+        for b in range(want.shape[1] // na):
+            assert rel_err(got[ch, b * na:(b + 1) * na], want[ch, b * na:(b + 1) * na]) <= TOL
+    assert not np.isfinite(got[3]).all()
