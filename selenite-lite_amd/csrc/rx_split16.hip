@@ -250,11 +250,18 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
         const int so = pass < npass ? (int)pass * kInPass : 0;
         const __amdgpu_buffer_rsrc_t rs = pass < npass ? rs_in : rs_in_next;
 #pragma unroll
+#ifdef SRX_X_NOINPUT
+        for (int i = 0; i < NLD; ++i) { raw[i] = typename R::type{}; asm volatile("" : "+v"(raw[i])); }
+        (void)rs; (void)so;
+#else
         for (int i = 0; i < NLD; ++i) raw[i] = R::load(rs, lane * R::kBytes + i * 64 * R::kBytes, so);      // (BRaw: aux = SRX_IN_AUX)
+#endif
+#ifndef SRX_X_NOLO
         if constexpr (NCO == 2) {
 #pragma unroll
             for (int i = 0; i < LOD; ++i) lo_load(i, i, lo_base(pass));
         }
+#endif
     };
     prefetch(0);
 
@@ -380,12 +387,17 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
         for (int i = 0; i < NLD; ++i) {
             v2f a, b;
             R::unpack(raw[i], a, b);
+#ifdef SRX_X_NOLO
+            if constexpr (NCO == 2) { m[2 * i] = a; m[2 * i + 1] = b; } else
+#else
             if constexpr (NCO == 2) {
                 const u4v l = lo4[i % LOD];
                 cmul_pk2(a, b, v2f{ __uint_as_float(l.x), __uint_as_float(l.y) }, v2f{ __uint_as_float(l.z), __uint_as_float(l.w) },
                          m[2 * i], m[2 * i + 1]);
                 if (i + LOD < NLD) lo_load(i % LOD, i + LOD, lo_base(pass));
-            } else if constexpr (NCO == 1) {
+            } else
+#endif
+            if constexpr (NCO == 1) {
                 const uint32_t n = 128u * i + 2u * lane;
                 const float2 la = nco_lo<0>(tab, ph0 + (n0 + n) * step), lb = nco_lo<0>(tab, ph0 + (n0 + n + 1) * step);
                 cmul_pk2(a, b, v2f{ la.x, la.y }, v2f{ lb.x, lb.y }, m[2 * i], m[2 * i + 1]);
@@ -423,7 +435,11 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
             const int n = 128 * i + 2 * lane;
+#ifdef SRX_X_NOSPLIT
+            asm volatile("" :: "v"(m[2 * i]), "v"(m[2 * i + 1]));
+#else
             put_iq(GS::HS + n, m[2 * i], m[2 * i + 1], pre);
+#endif
             if constexpr (PARTIAL) {                                  // the history is the last HS samples that exist
                 const int hidx = n - ((int)tail_out * M - GS::HS);
                 if (hidx >= 0 && hidx < GS::HS)
@@ -456,12 +472,18 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
 #pragma unroll
         for (int kk = 0; kk < GS::KS; ++kk) {
             h8 nIh = aIh, nIl = aIl, nQh = aQh, nQl = aQl;
+#ifdef SRX_X_NOAREAD
+            if (false) {
+#else
             if (kk + 1 < GS::KS) {
+#endif
                 const int off = offA(kk + 1);
                 nIh = *reinterpret_cast<const h8 *>(xIh + off); nIl = *reinterpret_cast<const h8 *>(xIl + off);
                 nQh = *reinterpret_cast<const h8 *>(xQh + off); nQl = *reinterpret_cast<const h8 *>(xQl + off);
             }
-#if SRX_ACC4
+#ifdef SRX_X_NOMFMA
+            asm volatile("" :: "v"(aIh), "v"(aIl), "v"(aQh), "v"(aQl));
+#elif SRX_ACC4
             accI = __builtin_amdgcn_mfma_f32_16x16x32_f16(aIh, Bh[kk], accI, 0, 0, 0);
             accQ = __builtin_amdgcn_mfma_f32_16x16x32_f16(aQh, Bh[kk], accQ, 0, 0, 0);
             smlI = __builtin_amdgcn_mfma_f32_16x16x32_f16(aIh, Bl[kk], smlI, 0, 0, 0);
@@ -544,13 +566,17 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
                 const float4 vq = *reinterpret_cast<const float4 *>(dQ + G::HH4 + 4 * lane);
                 au[0] = cmag<0>(vi.x, vq.x); au[1] = cmag<0>(vi.y, vq.y);
                 au[2] = cmag<0>(vi.z, vq.z); au[3] = cmag<0>(vi.w, vq.w);
+#ifndef SRX_X_NOAGC
                 agc_pass<GROUP>(p.agcp, p.agc, lane, group, au, gain, nvb);
+#endif
             }
         } else {
             if (kk == 0) q2[0] = q2[1] = q2[2] = q2[3] = 0.0f;
 #pragma unroll
             for (int j = 0; j < TPK; ++j)
+#ifndef SRX_X_NOHILB
                 if (kk * TPK + j < NTS) hilbert_tstep<1, ND, M, NH>(kk * TPK + j, dQ, lane, htap, q2);
+#endif
             if (kk == (NTS + TPK - 1) / TPK - 1 || (kk == GS::KS - 1 && (NTS + TPK - 1) / TPK > GS::KS)) {
                 const float *di = dI + G::FH + fa.delay_idx + 4 * lane;   // unit-impulse delay FIR
 #pragma unroll
@@ -558,7 +584,9 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
                     const float i2 = di[r] + 0.0f;                    // 0.0f + 1.0f*x of the dense loop
                     au[r] = fa.upper ? (i2 - q2[r]) : (i2 + q2[r]);   // arm_sub_f32 / arm_add_f32
                 }
+#ifndef SRX_X_NOAGC
                 agc_pass<GROUP>(p.agcp, p.agc, lane, group, au, gain, nvb);
+#endif
             }
         }
     };
@@ -571,7 +599,11 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
     auto store_audio = [&](uint32_t q, const float (&au)[4]) {
         const float z = __builtin_fmaf(au[3], 0.0f, __builtin_fmaf(au[2], 0.0f, __builtin_fmaf(au[1], 0.0f, au[0] * 0.0f)));
         nonfinite = nonfinite || (z != z);
+#ifdef SRX_X_NOSTORE
+        asm volatile("" :: "v"(au[0]), "v"(au[1]), "v"(au[2]), "v"(au[3]));
+#else
         W::store(rs_out, lane * W::kBytes, (int)q * (G::P * (W::kBytes / 4)), au);
+#endif
     };
 
     // ---- the pipeline, once per channel of this workgroup ----
@@ -966,8 +998,8 @@ __global__ __launch_bounds__(128, 3) void k_ssb_split16w2(RxParams p, FusedArgs 
                 au[2] = cmag<0>(vi.z, vq.z); au[3] = cmag<0>(vi.w, vq.w);
             } else {
                 float q2[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
-#pragma unroll
 #ifndef SRX_X_NOHILB
+#pragma unroll
                 for (int t = 0; t < HilbertSteps<ND, M, NH>::N; ++t) hilbert_tstep<1, ND, M, NH>(t, dQ, lane, htap, q2);
 #endif
                 const float *di = dI + G::FH + fa.delay_idx + 4 * lane;   // unit-impulse delay FIR
