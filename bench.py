@@ -254,7 +254,7 @@ def main():
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9
         # flops the timed kernel executes: with one LO shared by all channels (the default shape) the NCO costs the
         # complex multiply only (6 flops per sample); the per-sample table-lerp sin/cos is the "per_channel" leg below
-        shared_lo = bool(spec.nco and spec.nco_steps is None and os.environ.get("SELENITE_RX_NO_SHARED_LO") != "1")
+        shared_lo = rx.nco_path().startswith("shared")
         fps = ch.flops_per_sample(spec, 6.0 if shared_lo else 20.0)
         fl = fps * channels * bs
         traffic = None if q15 else pmc_traffic(args.workload, args.arith, rx.kernel_name(), channels, bs, ch.WORKLOADS)
@@ -271,7 +271,7 @@ def main():
                        "arith": {sr.ARITH_CMSIS: "cmsis-exact (mul,add)", sr.ARITH_FMA: "fma (<=1e-5 rel vs CMSIS)",
                                  sr.ARITH_SPLIT16: "split16 (f16 hi/lo x3 MFMA FIR, block floating point, <=1e-5 rel vs CMSIS)"}[arith],
                        "kernel": rx.kernel_name(), "agc": "global" if args.global_gain else "per-channel",
-                       "nco": ("shared LO table per call" if shared_lo else "per-channel arm_sin/cos_f32") if spec.nco else "off",
+                       "nco": rx.nco_path(),
                        "parallelism": "channels sharded x%d, no data-path collective" % world},
             "per_gpu_msamples_s": round(value / world, 2),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -313,6 +313,19 @@ def main():
                     "kernel": rx_p.kernel_name(), "roofline_frac": round(alg_bytes / (ms_p * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                     "note": "every channel its own NCO step; table-lerp sin/cos per sample in the kernel"}}
                 rx_p.close()
+                if "registers" in rx.nco_path():
+                    # the same shared LO read as a per-call table from L2 (what a step off the fs / 256 grid gets)
+                    os.environ["SELENITE_RX_NO_PERIODIC_LO"] = "1"
+                    rx_t = sr.Rx(spec.config())
+                    del os.environ["SELENITE_RX_NO_PERIODIC_LO"]
+                    rx_t.time_process(d_in.ptr, d_out.ptr, bs, max(2, args.warmup))
+                    ms_t = rx_t.time_process(d_in.ptr, d_out.ptr, bs, max(3, args.steps // 2))
+                    out["other_nco_modes"]["shared_table"] = {
+                        "value": round(channels * bs / (ms_t * 1e-3) / 1e6, 2), "unit": "Msamples/s", "ms_per_step": round(ms_t, 4),
+                        "kernel": rx_t.kernel_name(), "nco": rx_t.nco_path(),
+                        "roofline_frac": round(alg_bytes / (ms_t * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                        "note": "one NCO step for all channels that is NOT a multiple of fs / 256: LO table computed per call, read from L2"}
+                    rx_t.close()
         if world == 1 and not args.no_cpu_baseline and not args.main_only:
             out["cpu_baseline"] = cpu_baseline(args.workload, ch.WORKLOADS)
         print(json.dumps(out), flush=True)

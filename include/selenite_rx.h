@@ -235,6 +235,11 @@ int  selenite_rx_time_process_q15_device(selenite_rx_instance *S, const int16_t 
 /* Name of the kernel variant process_f32_device dispatches to for this instance
  * (e.g. "rx_ssb_fused<256,4,63>" or "generic"); for logs and profiles. */
 const char *selenite_rx_kernel_name(const selenite_rx_instance *S);
+/* How the NCO of the next call is served: "off", "per-channel arm_sin/cos_f32 in the kernel" (steps or phases differ
+ * between channels: arm_sin_f32.c:72-119 per sample), "shared LO table per call" (one step, one phase: the table is
+ * computed once per call with the same arm_sin/cos arithmetic), or "shared LO, period 256 samples, held in registers"
+ * (same table; a step that is a multiple of 2^24 repeats it every 256 samples).  All three give identical results. */
+const char *selenite_rx_nco_path(const selenite_rx_instance *S);
 
 /* Algorithmic HBM bytes of one process call (SURVEY.md 8d formula):
  *   channels * (8*blockSize + 4*blockSize/decim + S_in + S_out).

@@ -220,6 +220,8 @@ extern "C" int selenite_rx_init(selenite_rx_instance **out, const selenite_rx_co
     S->force_generic = (fg && fg[0] == '1') ? 1 : 0;
     const char *nl = std::getenv("SELENITE_RX_NO_SHARED_LO");
     S->no_shared_lo = (nl && nl[0] == '1') ? 1 : 0;
+    const char *npl = std::getenv("SELENITE_RX_NO_PERIODIC_LO");
+    S->no_periodic_lo = (npl && npl[0] == '1') ? 1 : 0;
 
 #define INITCHK(call)                                                                        \
     do {                                                                                     \
@@ -296,6 +298,24 @@ extern "C" const char *selenite_rx_kernel_name(const selenite_rx_instance *S)
     if (cw_fused_ok(S->cfg, S->cfg.block))
         return S->cfg.n_biquad == 2 ? "k_cw_fused<2,256>" : (S->cfg.n_biquad == 8 ? "k_cw_fused<8,256>" : "k_cw_fused<4,256>");
     return "generic";
+}
+
+// the shared LO repeats every 256 samples and the kernel of this instance can keep it in registers
+static bool periodic_lo(const selenite_rx_instance *S)
+{
+    const selenite_rx_config &g = S->cfg;
+    return g.nco_enable && S->steps_uniform && (S->h_step[0] & 0x00FFFFFFu) == 0 && !S->no_periodic_lo &&
+           g.arith == SELENITE_ARITH_SPLIT16 && S->plan.d_btab16 && g.nd_taps &&
+           ssb_split16_periodic_lo((int)g.nd_taps, (int)g.decim, (int)g.nh_taps);
+}
+
+extern "C" const char *selenite_rx_nco_path(const selenite_rx_instance *S)
+{
+    if (!S) return "";
+    if (!S->cfg.nco_enable) return "off";
+    const bool fused = !S->force_generic && (S->plan.kind != 0 || cw_fused_ok(S->cfg, S->cfg.block));
+    if (!fused || !S->steps_uniform || !S->phase_uniform || S->no_shared_lo) return "per-channel arm_sin/cos_f32 in the kernel";
+    return periodic_lo(S) ? "shared LO, period 256 samples, held in registers" : "shared LO table per call";
 }
 
 extern "C" int selenite_rx_set_stream(selenite_rx_instance *S, void *hip_stream)
@@ -423,6 +443,9 @@ static int run_part(selenite_rx_instance *S, const void *src, bool src_q15, void
             HIPCHK(S, launch_lo_table(S->d_lo, S->d_sintab, phase_now, S->h_step[0], block_size, st));
             pf.nco = 2;
             pf.lo = S->d_lo;
+            // a step that is a multiple of 2^24 repeats the LO every 256 samples (channelised receivers: LO
+            // frequencies on a grid of fs / 256): k_ssb_split16 then keeps it in registers (its NCO == 3 flavour)
+            pf.lo_period = periodic_lo(S) ? 256u : 0u;
         }
         void *fdst = dst;
         bool fq15 = dst_q15;

@@ -29,6 +29,7 @@ struct RxParams {
     uint32_t pass_out;     // generic front kernel: decimated outputs per pass
     const float *dec_c, *hilb_c, *delay_c, *biq_c, *sintab;
     const float2 *lo;      // nco == 2: LO[n] = (cos, -sin) for the samples of this call (all channels share it)
+    uint32_t lo_period;    // nco == 2: 256 when LO[n + 256] == LO[n] for every n (NCO step a multiple of 2^24), else 0
     const uint32_t *step;
     uint32_t *phase;
     float *dec_state;      // [C][2][nd-1]
@@ -81,6 +82,9 @@ bool fused_block_size_ok(const FusedPlan &plan, const selenite_rx_config &cfg, u
 hipError_t launch_fused(const FusedPlan &plan, const RxParams &p, int arith, const void *src,
                         bool src_q15, void *dst, bool dst_q15, int delay_index, hipStream_t st);
 
+// true when k_ssb_split16 of this shape has the periodic-LO flavour (a pass is a whole number of 256-sample periods)
+bool ssb_split16_periodic_lo(int nd, int m, int nh);
+
 // fused CW kernel (rx_cw.hip): NCO -> real part -> 4-stage biquad cascade -> AGC
 bool cw_fused_ok(const selenite_rx_config &cfg, uint32_t block_size);
 hipError_t launch_cw_fused(const RxParams &p, const void *src, bool src_q15, void *dst, bool dst_q15, hipStream_t st);
@@ -131,6 +135,7 @@ struct selenite_rx_instance {
     bool delay_is_impulse = false; int delay_index = 0; bool hilb_odd_only = false;
     srx::FusedPlan plan;
     int no_shared_lo = 0;              // SELENITE_RX_NO_SHARED_LO=1: always compute the LO per channel
+    int no_periodic_lo = 0;            // SELENITE_RX_NO_PERIODIC_LO=1: never keep a periodic shared LO in registers
     int force_generic = 0;             // SELENITE_RX_FORCE_GENERIC=1 (tests cross-check both paths)
     int status = SELENITE_RX_SUCCESS;
     std::string err;

@@ -246,6 +246,14 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
         lo4[slot] = __builtin_amdgcn_raw_buffer_load_b128(rs_lo, lane * 16 + i * 1024, sl, SRX_LO_AUX);
     };
     auto lo_base = [&](uint32_t pass) { return pass < npass ? (int)pass * G::T * 8 : 0; };   // pass == npass: the next channel's pass 0
+    // periodic shared LO (NCO == 3: the table repeats every 256 samples and a pass is a whole number of periods): load
+    // i of any pass multiplies by LO[(128 i + 2 lane, + 1) mod 256] -- two register quads for the whole kernel
+    u4v lo_per[2];
+    if constexpr (NCO == 3) {
+        static_assert(NCO != 3 || G::T % 256 == 0, "a pass is a whole number of LO periods");
+        lo_per[0] = *reinterpret_cast<const u4v *>(p.lo + 2 * lane);
+        lo_per[1] = *reinterpret_cast<const u4v *>(p.lo + 128 + 2 * lane);
+    }
     auto prefetch = [&](uint32_t pass) {                          // pass == npass: pass 0 of this workgroup's next channel
         const int so = pass < npass ? (int)pass * kInPass : 0;
         const __amdgpu_buffer_rsrc_t rs = pass < npass ? rs_in : rs_in_next;
@@ -395,6 +403,10 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
                 cmul_pk2(a, b, v2f{ __uint_as_float(l.x), __uint_as_float(l.y) }, v2f{ __uint_as_float(l.z), __uint_as_float(l.w) },
                          m[2 * i], m[2 * i + 1]);
                 if (i + LOD < NLD) lo_load(i % LOD, i + LOD, lo_base(pass));
+            } else if constexpr (NCO == 3) {
+                const u4v l = lo_per[i & 1];
+                cmul_pk2(a, b, v2f{ __uint_as_float(l.x), __uint_as_float(l.y) }, v2f{ __uint_as_float(l.z), __uint_as_float(l.w) },
+                         m[2 * i], m[2 * i + 1]);
             } else
 #endif
             if constexpr (NCO == 1) {
@@ -1241,7 +1253,7 @@ static hipError_t launch_k(const RxParams &p, const FusedArgs &fa, const void *s
     constexpr size_t lds = (size_t)GS::total * sizeof(float);
     static_assert(lds <= 48 * 1024, "k_ssb_split16 LDS image");
 #if SRX_SPLIT16_W2
-    if constexpr (GS::KS % 2 == 0) {
+    if constexpr (GS::KS % 2 == 0 && NCO != 3) {
         static const bool one_wave = std::getenv("SELENITE_RX_SPLIT16_W1") != nullptr;      // A/B: the one-wave kernel
         if (!one_wave && p.nout % 256 == 0) {
             constexpr size_t lds2 = lds + (512 + 4) * sizeof(float);                         // + partial sums + exponents
@@ -1286,9 +1298,20 @@ static hipError_t launch_io(const RxParams &p, const FusedArgs &fa, const void *
 template <int ND, int M, int NH>
 static hipError_t launch_nco(const RxParams &p, const FusedArgs &fa, const void *src, bool q15, void *dst, hipStream_t st)
 {
+    if constexpr (Geo<ND, M, NH>::T % 256 == 0)
+        if (p.nco == 2 && p.lo_period == 256)      // LO held in registers
+            return q15 ? launch_io<3, ND, M, NH, int16_t, int16_t>(p, fa, src, dst, st) : launch_io<3, ND, M, NH, float, float>(p, fa, src, dst, st);
     if (p.nco == 2) return q15 ? launch_io<2, ND, M, NH, int16_t, int16_t>(p, fa, src, dst, st) : launch_io<2, ND, M, NH, float, float>(p, fa, src, dst, st);
     if (p.nco == 1) return q15 ? launch_io<1, ND, M, NH, int16_t, int16_t>(p, fa, src, dst, st) : launch_io<1, ND, M, NH, float, float>(p, fa, src, dst, st);
     return q15 ? launch_io<0, ND, M, NH, int16_t, int16_t>(p, fa, src, dst, st) : launch_io<0, ND, M, NH, float, float>(p, fa, src, dst, st);
+}
+
+bool ssb_split16_periodic_lo(int nd, int m, int nh)
+{
+#define X(ND_, M_, NH_) if (nd == ND_ && m == M_ && nh == NH_) return Geo<ND_, M_, NH_>::T % 256 == 0;
+    SRX_SPLIT16_SHAPES(X)
+#undef X
+    return false;
 }
 
 hipError_t launch_ssb_split16(int nd, int m, int nh, const RxParams &p, const FusedArgs &fa, const void *src, bool q15,
@@ -1296,7 +1319,8 @@ hipError_t launch_ssb_split16(int nd, int m, int nh, const RxParams &p, const Fu
 {
 #ifdef SRX_SPLIT16_BENCH_ONLY     // A/B builds: only the bench.py default kernel
     if (nd == 256 && m == 4 && nh == 63 && p.nco == 2 && !q15 && !fa.am && fa.group == 16)
-        return launch_k<2, 256, 4, 63, float, float, 0, 16>(p, fa, src, dst, st);
+        return p.lo_period == 256 ? launch_k<3, 256, 4, 63, float, float, 0, 16>(p, fa, src, dst, st)
+                                  : launch_k<2, 256, 4, 63, float, float, 0, 16>(p, fa, src, dst, st);
     return hipErrorNotSupported;
 #else
 #define X(ND_, M_, NH_) if (nd == ND_ && m == M_ && nh == NH_) return launch_nco<ND_, M_, NH_>(p, fa, src, q15, dst, st);

@@ -57,7 +57,7 @@ ABI_SYMBOLS = [
     "selenite_rx_reset", "selenite_rx_device_alloc", "selenite_rx_device_free",
     "selenite_rx_memcpy_h2d", "selenite_rx_memcpy_d2h", "selenite_rx_device_count",
     "selenite_rx_set_device", "selenite_rx_synth_iq_host", "selenite_rx_synth_iq_device",
-    "selenite_rx_time_process_device", "selenite_rx_time_process_q15_device", "selenite_rx_kernel_name", "selenite_rx_algorithmic_bytes",
+    "selenite_rx_time_process_device", "selenite_rx_time_process_q15_device", "selenite_rx_kernel_name", "selenite_rx_nco_path", "selenite_rx_algorithmic_bytes",
     "selenite_rx_design_lowpass", "selenite_rx_design_hilbert", "selenite_rx_design_bandpass",
     "selenite_rx_abi_version",
     "selenite_rx_global_process_f32_device",
@@ -155,6 +155,8 @@ def lib():
         L.selenite_rx_time_process_device.argtypes = [vp, vp, vp, C.c_uint32, C.c_uint32, f32p]
         L.selenite_rx_kernel_name.argtypes = [vp]
         L.selenite_rx_kernel_name.restype = C.c_char_p
+        L.selenite_rx_nco_path.argtypes = [vp]
+        L.selenite_rx_nco_path.restype = C.c_char_p
         L.selenite_rx_algorithmic_bytes.argtypes = [C.POINTER(Config), C.c_uint32, C.POINTER(C.c_uint64)]
         L.selenite_rx_algorithmic_bytes.restype = C.c_uint64
         L.selenite_rx_design_lowpass.argtypes = [f32p, C.c_uint32, C.c_double]
@@ -338,6 +340,9 @@ class Rx:
 
     def kernel_name(self):
         return self.L.selenite_rx_kernel_name(self.h).decode()
+
+    def nco_path(self):
+        return self.L.selenite_rx_nco_path(self.h).decode()
 
     def time_process(self, d_src, d_dst, block_size, iters):
         ms = C.c_float()

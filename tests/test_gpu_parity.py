@@ -772,3 +772,63 @@ def test_cw_fused_kernel_two_and_eight_stages(stages, variant, nch):
             yg, yo = g.process(iq), o.process(iq)
             assert np.isfinite(yg).all() and bits_equal(yg, yo), "%s call %d rel_err %g" % (variant, call, rel_err(yg, yo))
     assert_state_equal(g, o)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("q15", [False, True])
+def test_periodic_shared_lo_in_registers_equals_the_table_path_bit_for_bit(q15):
+    """A common NCO step that is a multiple of 2^24 repeats the LO every 256 samples: k_ssb_split16 then keeps it
+    in registers (selenite_rx_nco_path says so).  Same LO values, same arithmetic -> same bits as the per-call table,
+    audio and state, for whole-pass calls, calls with a partial last pass, a non-zero common phase; a step off
+    that grid must take the table path and meet the tolerance against the oracle."""
+    nch = 70
+    spec = baseline_spec("cfg3", nch, rc.ARITH_SPLIT16)           # step 0x01000000
+    reg = gpu_rx(spec)
+    os.environ["SELENITE_RX_NO_PERIODIC_LO"] = "1"
+    try:
+        tab = gpu_rx(spec)
+    finally:
+        del os.environ["SELENITE_RX_NO_PERIODIC_LO"]
+    assert "registers" in reg.nco_path() and reg.kernel_name() == "k_ssb_split16<256,4,63>"
+    assert tab.nco_path() == "shared LO table per call"
+    st = reg.state()
+    st["nco_phase"][:] = 0x3456789A
+    reg.set_state(st)
+    tab.set_state(st)
+    pos = 0
+    for bs in (4096, 4352, 1024, 8192 + 256):
+        iq = synth_iq(0, nch, pos, bs)
+        pos += bs
+        if q15:
+            iq = np.clip(np.round(iq * 20000.0), -32768, 32767).astype(np.int16)
+            ya, yb = reg.process_q15(iq), tab.process_q15(iq)
+            assert np.array_equal(ya, yb)
+        else:
+            ya, yb = reg.process(iq), tab.process(iq)
+            assert bits_equal(ya, yb)
+    sa, sb = reg.state(), tab.state()
+    for k in sa:
+        assert np.array_equal(sa[k].view(np.uint32) if sa[k].dtype == np.float32 else sa[k],
+                              sb[k].view(np.uint32) if sb[k].dtype == np.float32 else sb[k]), k
+    # phases that differ per channel: back to the per-channel NCO
+    st = reg.state()
+    st["nco_phase"] = (st["nco_phase"] + np.arange(nch, dtype=np.uint32) * np.uint32(0x01234567)).astype(np.uint32)
+    reg.set_state(st)
+    assert reg.nco_path().startswith("per-channel")
+    if q15:
+        return
+    # a step off the fs / 256 grid: table path, tolerance against the CMSIS oracle
+    spec_o = baseline_spec("cfg3", nch, rc.ARITH_SPLIT16)
+    spec_o.nco_step_all = 0x01000100
+    spec_c = baseline_spec("cfg3", nch, ARITH_CMSIS)
+    spec_c.nco_step_all = 0x01000100
+    g, o = gpu_rx(spec_o), CpuChain(spec_c, "orc")
+    assert g.nco_path() == "shared LO table per call"
+    na = spec_c.block // spec_c.decim
+    for call in range(2):
+        iq = synth_iq(0, nch, call * 4096, 4096)
+        yg, yo = g.process(iq), o.process(iq)
+        for c in range(nch):
+            for b in range(yo.shape[1] // na):
+                assert rel_err(yg[c, b * na:(b + 1) * na], yo[c, b * na:(b + 1) * na]) <= TOL
+    assert bits_equal(g.state()["dec_state"], o.state()["dec_state"])
