@@ -108,6 +108,17 @@ float orc_cos_f32(float x, int arith)
     return p0 + p1;
 }
 
+/* LO samples for an array of integer phases: lo[2n] = cos(x), lo[2n+1] = -sin(x), x = (float)(phase >> 8) * ORC_NCO_K
+ * (the NCO of the chain below, step 1, exposed for the tests of the GPU kernels' restated sin/cos sequence) */
+void orc_nco_lo(const uint32_t *phase, uint32_t n, float *lo)
+{
+    for (uint32_t k = 0; k < n; ++k) {
+        float x = (float)(phase[k] >> 8) * ORC_NCO_K;
+        lo[2 * k] = orc_cos_f32(x, SELENITE_ARITH_CMSIS);
+        lo[2 * k + 1] = -orc_sin_f32(x, SELENITE_ARITH_CMSIS);
+    }
+}
+
 /* ComplexMathFunctions/arm_cmplx_mult_cmplx_f32.c:72-192 (values per :186-187) */
 void orc_cmplx_mult_cmplx_f32(const float *A, const float *B, float *dst, uint32_t n, int arith)
 {

@@ -31,6 +31,7 @@ extern "C" {
 const float *orc_sin_table(void);                      /* 513 entries */
 float orc_sin_f32(float x, int arith);
 float orc_cos_f32(float x, int arith);
+void  orc_nco_lo(const uint32_t *phase, uint32_t n, float *lo);   /* lo[2n] = cos, lo[2n+1] = -sin of the chain's NCO */
 void  orc_cmplx_mult_cmplx_f32(const float *a, const float *b, float *dst, uint32_t n, int arith);
 void  orc_cmplx_mag_f32(const float *src, float *dst, uint32_t n, int arith);
 void  orc_fir_decimate_f32(const float *coeffs, uint32_t num_taps, uint32_t M, float *state,

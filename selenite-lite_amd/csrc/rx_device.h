@@ -80,6 +80,36 @@ __host__ __device__ __forceinline__ float2 nco_lo(const float *T, uint32_t phase
     return make_float2(c, -s);
 }
 
+// Two LO samples (integer phases pe, po) at once, the same arithmetic as nco_lo<0> restated for the vector ALU:
+//   * x >= 0 here (x comes from an unsigned phase), so the negative-argument branches of arm_sin_f32.c:77-95 and
+//     arm_cos_f32.c:86-89 never run;
+//   * for in >= 0, `in - (float)(int)in` is in - floor(in), which v_fract_f32 returns exactly (the difference is
+//     always representable and < 1); likewise findex - (float)index with index = (uint16)findex, findex in [0, 512);
+//   * every multiply / add is the reference's, in the reference's order, two at a time in v_pk_* (no contraction).
+// tests/test_nco_fast_path.py checks the restatement against the oracle for all 2^24 phase values (numpy model, CPU)
+// and the kernels that use it against the oracle's mixed samples (GPU).  T: sinTable_f32[513] in LDS.
+typedef float lo_v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void nco_lo_pair(const float *T, uint32_t pe, uint32_t po, lo_v2f &le, lo_v2f &lo)
+{
+    const lo_v2f u = { (float)(pe >> 8), (float)(po >> 8) };
+    const lo_v2f x = u * kNcoK;
+    const lo_v2f ps = x * kInv2Pi;                              // arm_sin_f32.c:88 / arm_cos_f32.c:81
+    const lo_v2f pc = ps + 0.25f;                               // arm_cos_f32.c:81
+    const lo_v2f is = { __builtin_amdgcn_fractf(ps.x), __builtin_amdgcn_fractf(ps.y) };
+    const lo_v2f ic = { __builtin_amdgcn_fractf(pc.x), __builtin_amdgcn_fractf(pc.y) };
+    const lo_v2f fs = is * 512.0f, fc = ic * 512.0f;            // findex
+    const uint32_t s0 = (uint32_t)fs.x, s1 = (uint32_t)fs.y, c0 = (uint32_t)fc.x, c1 = (uint32_t)fc.y;
+    const lo_v2f rs = { __builtin_amdgcn_fractf(fs.x), __builtin_amdgcn_fractf(fs.y) };      // fract
+    const lo_v2f rc = { __builtin_amdgcn_fractf(fc.x), __builtin_amdgcn_fractf(fc.y) };
+    const lo_v2f as = { T[s0], T[s1] }, bs = { T[s0 + 1], T[s1 + 1] };
+    const lo_v2f ac = { T[c0], T[c1] }, bc = { T[c0 + 1], T[c1 + 1] };
+    const lo_v2f ws = 1.0f - rs, wc = 1.0f - rc;
+    const lo_v2f s = ws * as + rs * bs;                         // (1 - fract) * a + fract * b
+    const lo_v2f c = wc * ac + rc * bc;
+    le = lo_v2f{ c.x, -s.x };
+    lo = lo_v2f{ c.y, -s.y };
+}
+
 // ComplexMathFunctions/arm_cmplx_mult_cmplx_f32.c:186-187
 template <int ARITH>
 __device__ __forceinline__ float2 cmul(float2 A, float2 B)

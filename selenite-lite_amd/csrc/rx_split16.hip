@@ -390,6 +390,7 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
     auto mix = [&](uint32_t pass, auto partial_c) {
         constexpr bool PARTIAL = decltype(partial_c)::value;     // the call's last pass, with fewer than T input samples
         const uint32_t n0 = pass * G::T;
+        const uint32_t ph_lane = ph0 + 2u * lane * step;
         v2f m[2 * NLD];
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
@@ -410,9 +411,11 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
             } else
 #endif
             if constexpr (NCO == 1) {
-                const uint32_t n = 128u * i + 2u * lane;
-                const float2 la = nco_lo<0>(tab, ph0 + (n0 + n) * step), lb = nco_lo<0>(tab, ph0 + (n0 + n + 1) * step);
-                cmul_pk2(a, b, v2f{ la.x, la.y }, v2f{ lb.x, lb.y }, m[2 * i], m[2 * i + 1]);
+                // phase of sample n0 + 128 i + 2 lane: a per-channel lane term plus a wave-uniform term
+                const uint32_t pe = ph_lane + (n0 + 128u * i) * step;
+                v2f la, lb;
+                nco_lo_pair(tab, pe, pe + step, la, lb);
+                cmul_pk2(a, b, la, lb, m[2 * i], m[2 * i + 1]);
             } else {
                 m[2 * i] = a;
                 m[2 * i + 1] = b;
@@ -895,9 +898,10 @@ __global__ __launch_bounds__(128, 3) void k_ssb_split16w2(RxParams p, FusedArgs 
                 } else if
 #endif
                 constexpr (NCO == 1) {
-                    const uint32_t n = 128u * i + 2u * lane;
-                    const float2 la = nco_lo<0>(tab, ph0 + (n0 + n) * step), lb = nco_lo<0>(tab, ph0 + (n0 + n + 1) * step);
-                    cmul_pk2(a, b, v2f{ la.x, la.y }, v2f{ lb.x, lb.y }, ma, mb);
+                    const uint32_t pe = ph0 + 2u * lane * step + (n0 + 128u * i) * step;
+                    v2f la, lb;
+                    nco_lo_pair(tab, pe, pe + step, la, lb);
+                    cmul_pk2(a, b, la, lb, ma, mb);
                 } else {
                     ma = a; mb = b;
                 }
@@ -1135,9 +1139,10 @@ __global__ __launch_bounds__(64, 2) void k_hilb_split16(RxParams p, FusedArgs fa
                 cmul_pk2(a, b, v2f{ __uint_as_float(lo4[i].x), __uint_as_float(lo4[i].y) },
                          v2f{ __uint_as_float(lo4[i].z), __uint_as_float(lo4[i].w) }, ma[i], mb[i]);
             } else if constexpr (NCO == 1) {
-                const uint32_t n = 128u * i + 2u * lane;
-                const float2 la = nco_lo<0>(tab, ph0 + (n0 + n) * step), lb = nco_lo<0>(tab, ph0 + (n0 + n + 1) * step);
-                cmul_pk2(a, b, v2f{ la.x, la.y }, v2f{ lb.x, lb.y }, ma[i], mb[i]);
+                const uint32_t pe = ph0 + 2u * lane * step + (n0 + 128u * i) * step;
+                v2f la, lb;
+                nco_lo_pair(tab, pe, pe + step, la, lb);
+                cmul_pk2(a, b, la, lb, ma[i], mb[i]);
             } else {
                 ma[i] = a;
                 mb[i] = b;

@@ -1,0 +1,90 @@
+"""How close is each arithmetic mode to EXACT arithmetic?  The cfg3 chain (AGC off) is evaluated in f64 on the very f32
+samples the chain mixes (the oracle's NCO and complex multiply, bit-exact with every GPU mode: decimator state), and the
+GPU modes and the CMSIS oracle are measured against that.  The point: on channels whose energy sits in the decimator's
+stop band the audio is 20-45 dB below the input, and there two correct f32-class implementations differ from each other
+by more than 1e-5 of the (small) block maximum -- both carry rounding noise of about 1e-7 of the INPUT level.  The split16
+kernels are held to: no further from exact arithmetic than twice the reference's own distance (plus 2^-23 of the input)."""
+import numpy as np
+import pytest
+
+import rxcommon as rc
+from rxcommon import CpuChain
+
+pytestmark = pytest.mark.gpu
+NCH, BS = 48, 8192
+
+
+def make_input(seed):
+    rng = np.random.default_rng(seed)
+    n = np.arange(BS)
+    iq = np.zeros((NCH, BS, 2), np.float32)
+    for c in range(NCH):
+        f = rng.uniform(0.15, 0.5, 3) if c % 2 == 0 else np.r_[rng.uniform(0.0, 0.08), rng.uniform(0.15, 0.5, 2)]
+        z = sum(a * np.exp(2j * np.pi * ff * n + 1j * rng.uniform(0, 6)) for a, ff in zip((0.4, 0.2, 0.1), f))
+        z = z + rng.uniform(-0.05, 0.05, BS) + 1j * rng.uniform(-0.05, 0.05, BS)
+        iq[c, :, 0], iq[c, :, 1] = z.real, z.imag
+    return iq, rng
+
+
+def exact_chain(spec, mixed):
+    h, hb, dl = (np.asarray(v, np.float64) for v in (spec.dec, spec.hilb, spec.delay))
+
+    def dec(x):      # arm_fir_decimate_f32.c: output j = sum_k coeff[k] * state[k] over the OLDEST numTaps of the state
+        xp = np.concatenate([np.zeros((NCH, len(h) - 1)), x.astype(np.float64)], axis=1)
+        return np.lib.stride_tricks.sliding_window_view(xp, len(h), axis=1)[:, 0::spec.decim] @ h
+
+    def fir(c, d):   # arm_fir_f32.c: same convention
+        dp = np.concatenate([np.zeros((NCH, len(c) - 1)), d], axis=1)
+        return np.lib.stride_tricks.sliding_window_view(dp, len(c), axis=1) @ c
+
+    return fir(dl, dec(mixed[:, :, 0])) - fir(hb, dec(mixed[:, :, 1]))      # USB
+
+
+@pytest.mark.parametrize("nco", ["off", "per_channel", "table", "periodic"])
+def test_split16_is_as_close_to_exact_arithmetic_as_the_reference_is(nco):
+    import selenite_rx as sr
+    iq, rng = make_input(11)
+    kw = dict(nco=False)
+    mixed = iq
+    if nco != "off":
+        steps = rng.integers(0, 1 << 32, NCH, dtype=np.uint64).astype(np.uint32)
+        if nco != "per_channel":
+            steps[:] = 0x01000100 if nco == "table" else 0x01000000
+        kw = dict(nco=True, nco_steps=steps) if nco == "per_channel" else dict(nco=True, nco_step_all=int(steps[0]))
+        L = rc.oracle_lib()
+        L.orc_nco_lo.argtypes = [rc.C.c_void_p, rc.C.c_uint32, rc.C.c_void_p]
+        L.orc_nco_lo.restype = None
+        mixed = np.empty_like(iq)
+        for c in range(NCH):
+            ph = (np.arange(BS, dtype=np.uint64) * int(steps[c])).astype(np.uint32)
+            lo = np.empty((BS, 2), np.float32)
+            L.orc_nco_lo(ph.ctypes.data, BS, lo.ctypes.data)
+            a, b, lc, ls = iq[c, :, 0], iq[c, :, 1], lo[:, 0], lo[:, 1]
+            mixed[c, :, 0] = a * lc - b * ls                      # arm_cmplx_mult_cmplx_f32.c:186-187, f32 operations
+            mixed[c, :, 1] = a * ls + b * lc
+    mk = lambda ar: rc.ChainSpec(NCH, 256, 4, 256, 63, 0, rc.MODE_USB, ar, agc=False, **kw)
+    spec = mk(rc.ARITH_CMSIS)
+    o = CpuChain(spec, "orc")
+    yo = o.process(iq).astype(np.float64)
+    assert np.array_equal(o.state()["dec_state"][:, 0], mixed[:, -255:, 0])          # the model mixes as the chain does
+    exact = exact_chain(spec, mixed)
+    g = sr.Rx(mk(rc.ARITH_SPLIT16).config())
+    assert g.kernel_name() == "k_ssb_split16<256,4,63>"
+    yg = g.process(iq).astype(np.float64)
+    assert rc.bits_equal(g.state()["dec_state"], o.state()["dec_state"])
+    im = np.abs(iq).reshape(NCH, -1).max(axis=1)
+    e_ref = np.abs(yo - exact).max(axis=1) / im          # the reference's own distance from exact arithmetic
+    e_gpu = np.abs(yg - exact).max(axis=1) / im
+    out_in = np.abs(exact).max(axis=1) / im
+    print("nco=%s: out/in %.3f..%.3f; input-referred error vs exact: reference %.2e..%.2e, split16 %.2e..%.2e" % (
+        nco, out_in.min(), out_in.max(), e_ref.min(), e_ref.max(), e_gpu.min(), e_gpu.max()))
+    assert (e_gpu <= 2.0 * e_ref + 2.0 ** -23).all(), (e_gpu / e_ref).max()
+    assert e_gpu.max() <= 1.5e-6
+    # and the north-star figure against the reference wherever the audio is not buried: blocks within 12 dB of the input
+    na = 64
+    d = np.abs(yg - yo).reshape(NCH, -1, na).max(axis=2)
+    m = np.abs(yo).reshape(NCH, -1, na).max(axis=2)
+    loud = m >= 0.25 * im[:, None]
+    assert (d[loud] <= 1e-5 * m[loud]).all()
+    # everywhere: 1e-5 of the block maximum plus the f32 noise floor of the input level
+    assert (d <= 1e-5 * m + 4e-7 * im[:, None]).all()
