@@ -115,3 +115,32 @@ def test_full_size_determinism_and_block_partition_invariance(name, arith):
     y2 = np.concatenate(parts, axis=1)
     assert checksum(y2) == c1, "streaming in %d-sample calls changed the result" % step
     assert bits_equal(y1, y2)
+
+
+def test_every_channel_of_the_bench_workload_split16_within_the_north_star_tolerance():
+    """The bench.py default (cfg3, 65 536 channels x 4096 samples, split16, one NCO step for all channels): EVERY DSP
+    block of EVERY channel against the oracle (all host cores), two streamed calls -- 8.4 M blocks -- plus the
+    end-of-call state of every channel."""
+    import os
+    run = FullRun("cfg3", rc.ARITH_SPLIT16)
+    assert run.rx.kernel_name() == "k_ssb_split16<256,4,63>" and "registers" in run.rx.nco_path()
+    o = CpuChain(baseline_spec("cfg3", run.nch, ARITH_CMSIS), "orc")
+    na = run.spec.block // run.spec.decim
+    worst = 0.0
+    for k in range(2):
+        y = run.call(k)
+        iq = run.d_in.download((run.nch, run.bs, 2), np.float32)     # device generator == oracle generator (test_device_synth_matches_host)
+        yo = o.process(iq, nthreads=os.cpu_count() or 8)
+        del iq
+        d = np.abs(y.astype(np.float64) - yo).reshape(run.nch, -1, na).max(axis=2)
+        m = np.abs(yo).reshape(run.nch, -1, na).max(axis=2)
+        assert m.min() > 0.0
+        e = d / m
+        worst = max(worst, float(e.max()))
+        assert (e <= TOL).all(), "call %d: %d blocks over, worst %.3g" % (k, int((e > TOL).sum()), e.max())
+    print("bench workload, all %d blocks: worst per-block relative error %.3g" % (2 * run.nch * run.nout // na, worst))
+    sg, so = run.rx.state(), o.state()
+    assert bits_equal(sg["dec_state"], so["dec_state"])
+    assert np.array_equal(sg["nco_phase"], so["nco_phase"])
+    assert rel_err(sg["fir_state"], so["fir_state"]) <= TOL
+    assert np.allclose(sg["agc_gain"], so["agc_gain"], rtol=1e-5, atol=0)
