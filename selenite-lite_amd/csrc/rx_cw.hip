@@ -36,9 +36,9 @@ __device__ __forceinline__ void cw_lds_sync()
 
 __device__ __forceinline__ float dpp_row_shr1(float v)
 {
-    // lane l receives lane l-1 (within its row of 16); lanes 0,16,32,48 keep `v` (they are stage 0
-    // lanes and never use the shifted value)
-    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x111, 0xf, 0xf, false));
+    // lane l receives lane l-1 (within its row of 16); lanes 0,16,32,48 read 0 (bound_ctrl: they are stage 0
+    // lanes and never use the shifted value) -- no `old` operand, so no register copy in front of the DPP move
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x111, 0xf, 0xf, true));
 }
 
 template <typename T> struct CwRaw;
@@ -155,6 +155,38 @@ __global__ __launch_bounds__(64) void k_cw_fused(RxParams p, const TIn *__restri
         x2 = x1; x1 = xin; y2 = y1; y1 = y;
         return y;
     };
+    // four steps of the steady state.  Each delay line is ONE register pair whose halves swap roles every step: on
+    // an even step (x1, x2) = (lo, hi) and the new input overwrites hi (x2 is dead by then), on an odd step
+    // (x1, x2) = (hi, lo) and the packed multiply reads its first operand's halves swapped (op_sel).  So the packed
+    // products (b1 x1, b2 x2) and (a1 y1, a2 y2) never need a register copy: 9 vector instructions per step (DPP
+    // move, select, 1 + 2 multiplies, 4 adds).  Same products, same left-to-right sum as step().
+    typedef float cw_v2f __attribute__((ext_vector_type(2)));
+    const cw_v2f b12 = { b1, b2 }, a12 = { a1, a2 };
+    auto trip4 = [&](const float4 &xq, float (&o)[4]) {
+        cw_v2f X = { x1, x2 }, Y = { y1, y2 };
+        const float xs[4] = { xq.x, xq.y, xq.z, xq.w };
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float prev = dpp_row_shr1((j & 1) ? Y.y : Y.x);
+            const float xin = (s == 0) ? xs[j] : prev;
+            cw_v2f px, py;
+            if (j & 1) {
+                asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[0,1]" : "=v"(px) : "v"(X), "v"(b12));
+                asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[0,1]" : "=v"(py) : "v"(Y), "v"(a12));
+            } else {
+                px = X * b12;
+                py = Y * a12;
+            }
+            const float p0 = b0 * xin;
+            float y = p0 + px.x;
+            y = y + px.y;
+            y = y + py.x;
+            y = y + py.y;
+            if (j & 1) { X.x = xin; Y.x = y; } else { X.y = xin; Y.y = y; }
+            o[j] = y;
+        }
+        x1 = X.x; x2 = X.y; y1 = Y.x; y2 = Y.y;
+    };
     // the same with the state update suppressed where stage s has no sample at step k (fill / drain)
     auto step_masked = [&](float xs, int k) -> float {
         const float ox1 = x1, ox2 = x2, oy1 = y1, oy2 = y2;
@@ -207,7 +239,8 @@ __global__ __launch_bounds__(64) void k_cw_fused(RxParams p, const TIn *__restri
                 // prefetch the next trip's input (stays inside this chunk; harmless re-read at the end)
                 const int inext = (i + 1 < TPC * q + TPC) ? i + 1 : i;
                 const float4 xn = *reinterpret_cast<const float4 *>(rbase + 4 * inext);
-                const float o[4] = { step(xq.x), step(xq.y), step(xq.z), step(xq.w) };
+                float o[4];
+                trip4(xq, o);
                 // the aligned group y[4(i-PRO) .. +3]: NCAR carried outputs, then the first R of this trip
                 float gq[4];
 #pragma unroll
