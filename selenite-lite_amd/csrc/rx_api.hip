@@ -438,9 +438,16 @@ static int run_part(selenite_rx_instance *S, const void *src, bool src_q15, void
         RxParams pf = p;
         if (g.nco_enable && S->steps_uniform && S->phase_uniform && !S->no_shared_lo) {
             // one LO for all channels: computed once per call, read from L2 by every wavefront
-            int rc = ensure(S, (void **)&S->d_lo, &S->lo_bytes, (size_t)block_size * sizeof(float2));
-            if (rc) return rc;
-            HIPCHK(S, launch_lo_table(S->d_lo, S->d_sintab, phase_now, S->h_step[0], block_size, st));
+            // the table is a pure function of (start phase, step, length): a call that starts where the table in d_lo
+            // starts reuses it -- every chunk of a pipelined host call, and EVERY call when the phase advance of a call
+            // is a multiple of 2^32 (an LO on the fs / 256 grid with calls of whole DSP blocks)
+            if (!(S->lo_valid && S->lo_phase == phase_now && S->lo_step == S->h_step[0] && S->lo_n >= block_size)) {
+                S->lo_valid = false;
+                int rc = ensure(S, (void **)&S->d_lo, &S->lo_bytes, (size_t)block_size * sizeof(float2));
+                if (rc) return rc;
+                HIPCHK(S, launch_lo_table(S->d_lo, S->d_sintab, phase_now, S->h_step[0], block_size, st));
+                S->lo_valid = true; S->lo_phase = phase_now; S->lo_step = S->h_step[0]; S->lo_n = block_size;
+            }
             pf.nco = 2;
             pf.lo = S->d_lo;
             // a step that is a multiple of 2^24 repeats the LO every 256 samples (channelised receivers: LO

@@ -129,6 +129,7 @@ struct selenite_rx_instance {
     } pipe;
     uint32_t sub_first = 0, sub_count = 0;                   // channel sub-range of the current launch (0 = all channels)
     float2 *d_lo = nullptr;      size_t lo_bytes = 0;        // shared LO table of the current call
+    bool lo_valid = false; uint32_t lo_phase = 0, lo_step = 0, lo_n = 0;   // what d_lo holds: LO[n], n < lo_n, from (lo_phase, lo_step)
     bool steps_uniform = false;        // every channel has the same NCO step
     bool phase_uniform = true;         // ... and the same phase (true after init/reset)
     uint32_t phase_host = 0;           // that common phase, tracked on the host
