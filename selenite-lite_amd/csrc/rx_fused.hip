@@ -154,7 +154,7 @@ __global__ __launch_bounds__(64, 2) void k_ssb_fused(RxParams p, FusedArgs fa, c
 {
     using G = Geo<ND, M, NH>;
     using R = Raw<TIn>;
-    static_assert(ND == 0 ? M == 1 : M == 4, "fused kernel: no decimator, or decimate by 4");
+    static_assert(ND == 0 ? M == 1 : (M == 2 || M == 4 || M == 8), "fused kernel: no decimator, or decimate by 2, 4 or 8");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x;
     const uint32_t c = blockIdx.x;
@@ -633,7 +633,7 @@ static hipError_t build_tables(const selenite_rx_config &g, FusedPlan &plan)
             if (e != hipSuccess) return e;
             e = hipMemcpy(plan.d_btab, bt.data(), bt.size() * sizeof(float), hipMemcpyHostToDevice);
             if (e != hipSuccess) return e;
-            if constexpr (NH > 0) {
+            if (NH > 0 && ssb_split16_has_shape(ND, M, NH)) {
                 // SELENITE_ARITH_SPLIT16: taps scaled by 2^SC (largest |tap| lands in [2^14, 2^15)), split into
                 // f16 hi + lo; fragment of lane l at k-step kk: 8 halfs B[k = 32kk + 8(l>>4) + j][n = l&15]
                 using GS = GeoS<2, ND, M, NH>;
@@ -763,7 +763,8 @@ static hipError_t launch_shape(const RxParams &p, const FusedArgs &fa, const Fus
 
 // the instantiated shapes: BASELINE.json cfg1 / cfg2 / cfg3 (+ cfg5 = cfg2 chain) and their neighbours in both
 // tap counts -- decimator 128 / 256 taps by 4, Hilbert pair 31 / 63 / 127 taps, with or without the decimator
-#define SRX_SHAPES(X) X(256, 4, 63, 1) X(0, 1, 63, 2) X(0, 1, 127, 3) X(128, 4, 63, 4) X(256, 4, 127, 5) X(128, 4, 127, 6) X(256, 4, 31, 7) X(0, 1, 31, 8)
+#define SRX_SHAPES(X) X(256, 4, 63, 1) X(0, 1, 63, 2) X(0, 1, 127, 3) X(128, 4, 63, 4) X(256, 4, 127, 5) X(128, 4, 127, 6) X(256, 4, 31, 7) X(0, 1, 31, 8) \
+                      X(256, 2, 63, 9) X(256, 8, 63, 10) X(64, 4, 63, 11) X(128, 2, 63, 12)
 
 static bool fused_mode_ok(const selenite_rx_config &g)
 {
@@ -803,7 +804,7 @@ hipError_t plan_fused(const selenite_rx_config &g, bool delay_is_impulse, int de
     const std::string shape = "<" + std::to_string(g.nd_taps) + "," + std::to_string(g.decim) + "," + std::to_string(g.nh_taps) + ">";
     plan.name_buf = "k_ssb_fused" + shape;
     (void)name;
-    if (plan.use_mfma && g.arith == SELENITE_ARITH_FMA) plan.name_buf = "k_ssb_mfma" + shape;
+    if (plan.use_mfma && g.arith != SELENITE_ARITH_CMSIS) plan.name_buf = "k_ssb_mfma" + shape;     // split16 without a matrix kernel of its own runs as fma
     if (plan.d_btab16 && g.arith == SELENITE_ARITH_SPLIT16) {
         if (g.nd_taps) plan.name_buf = "k_ssb_split16" + shape;
         else if (na == 256) plan.name_buf = "k_hilb_split16<" + std::to_string(g.nh_taps) + ">";

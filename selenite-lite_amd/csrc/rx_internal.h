@@ -84,6 +84,8 @@ hipError_t launch_fused(const FusedPlan &plan, const RxParams &p, int arith, con
 
 // true when k_ssb_split16 of this shape has the periodic-LO flavour (a pass is a whole number of 256-sample periods)
 bool ssb_split16_periodic_lo(int nd, int m, int nh);
+// true when rx_split16.hip instantiates k_ssb_split16 for this shape
+bool ssb_split16_has_shape(int nd, int m, int nh);
 
 // fused CW kernel (rx_cw.hip): NCO -> real part -> 4-stage biquad cascade -> AGC
 bool cw_fused_ok(const selenite_rx_config &cfg, uint32_t block_size);

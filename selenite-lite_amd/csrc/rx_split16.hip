@@ -1311,6 +1311,14 @@ static hipError_t launch_nco(const RxParams &p, const FusedArgs &fa, const void 
     return q15 ? launch_io<0, ND, M, NH, int16_t, int16_t>(p, fa, src, dst, st) : launch_io<0, ND, M, NH, float, float>(p, fa, src, dst, st);
 }
 
+bool ssb_split16_has_shape(int nd, int m, int nh)
+{
+#define X(ND_, M_, NH_) if (nd == ND_ && m == M_ && nh == NH_) return true;
+    SRX_SPLIT16_SHAPES(X)
+#undef X
+    return false;
+}
+
 bool ssb_split16_periodic_lo(int nd, int m, int nh)
 {
 #define X(ND_, M_, NH_) if (nd == ND_ && m == M_ && nh == NH_) return Geo<ND_, M_, NH_>::T % 256 == 0;
