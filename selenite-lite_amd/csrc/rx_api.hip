@@ -434,6 +434,7 @@ static int run_part(selenite_rx_instance *S, const void *src, bool src_q15, void
         if (rc) return rc;
         audio = S->d_scratch;
     }
+    bool env_emitted = false;      // global gain: the fused kernel wrote the per-channel block maxima
     if (ssb_fused || cw_fused) {
         RxParams pf = p;
         if (g.nco_enable && S->steps_uniform && S->phase_uniform && !S->no_shared_lo) {
@@ -456,7 +457,19 @@ static int run_part(selenite_rx_instance *S, const void *src, bool src_q15, void
         }
         void *fdst = dst;
         bool fq15 = dst_q15;
-        if (global) { pf.agc = 0; fdst = audio; fq15 = false; }
+        if (global) {
+            pf.agc = 0; fdst = audio; fq15 = false;
+            // k_ssb_split16 (16-lane DSP blocks, whole passes) leaves the block maxima of every channel behind: the
+            // envelope reduction below then folds channels x blocks floats instead of reading the audio again
+            if (ssb_fused && arith == SELENITE_ARITH_SPLIT16 && S->plan.d_btab16 && g.nd_taps && (g.block / g.decim) / 4 == 16 &&
+                (block_size / g.decim) % 256 == 0) {
+                const size_t need = sizeof(float) * env_fold_scratch_floats(p.channels, block_size / g.block);
+                int rc = ensure(S, (void **)&S->d_env_part, &S->env_part_cap, need);
+                if (rc) return rc;
+                pf.env_part = S->d_env_part;
+                env_emitted = true;
+            }
+        }
         if (ssb_fused) HIPCHK(S, launch_fused(S->plan, pf, arith, src, src_q15, fdst, fq15, S->delay_index, st));
         else HIPCHK(S, launch_cw_fused(pf, src, src_q15, fdst, fq15, st));
         commit_phase();
@@ -478,10 +491,14 @@ static int run_part(selenite_rx_instance *S, const void *src, bool src_q15, void
             env = S->d_env;
         }
         if (phase != kPhase2) {
-            const size_t need = sizeof(float) * env_global_rows(p) * (block_size / g.block);
-            int rc = ensure(S, (void **)&S->d_env_part, &S->env_part_cap, need);
-            if (rc) return rc;
-            HIPCHK(S, launch_env_global(p, audio, S->d_env_part, env, st));
+            if (env_emitted) {
+                HIPCHK(S, launch_env_fold(S->d_env_part, env, p.channels, block_size / g.block, st));
+            } else {
+                const size_t need = sizeof(float) * env_global_rows(p) * (block_size / g.block);
+                int rc = ensure(S, (void **)&S->d_env_part, &S->env_part_cap, need);
+                if (rc) return rc;
+                HIPCHK(S, launch_env_global(p, audio, S->d_env_part, env, st));
+            }
         }
         if (phase != kPhase1) HIPCHK(S, launch_agc_apply_global(p, arith, audio, env, dst, dst_q15, st));
     } else if (g.agc_enable || dst_q15) {

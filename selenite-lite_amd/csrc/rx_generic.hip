@@ -395,6 +395,37 @@ hipError_t launch_agc_generic(const RxParams &p, int arith, const float *audio, 
     return hipGetLastError();
 }
 
+// First step of a fold over MANY rows (one per channel): thread j of the launch takes the elements j, j + n, j + 2n, ...
+// of part[rows][nblk] with n = threads of the launch, a multiple of nblk, so all of them belong to block j % nblk;
+// out[j] is again a [n / nblk][nblk] array for k_env_fold.  Coalesced; exact (max is associative).
+constexpr uint32_t kEnvColsGrid = 256, kEnvColsThreads = 256;
+__global__ __launch_bounds__(kEnvColsThreads) void k_env_cols(const float *part, float *out, size_t total)
+{
+    const size_t j = (size_t)blockIdx.x * kEnvColsThreads + threadIdx.x, n = (size_t)gridDim.x * kEnvColsThreads;
+    float m = 0.0f;
+    for (size_t i = j; i < total; i += n) m = fmaxf(m, part[i]);
+    out[j] = m;
+}
+
+// `part` needs room for kEnvColsGrid * kEnvColsThreads more floats behind its rows * nblk when rows is large
+size_t env_fold_scratch_floats(uint32_t rows, uint32_t nblk)
+{
+    return (size_t)rows * nblk + (size_t)kEnvColsGrid * kEnvColsThreads;
+}
+
+hipError_t launch_env_fold(float *part, float *env, uint32_t rows, uint32_t nblk, hipStream_t st)
+{
+    const uint32_t n = kEnvColsGrid * kEnvColsThreads;
+    if (rows > 4096 && n % nblk == 0) {
+        float *cols = part + (size_t)rows * nblk;
+        hipLaunchKernelGGL(k_env_cols, dim3(kEnvColsGrid), dim3(kEnvColsThreads), 0, st, part, cols, (size_t)rows * nblk);
+        hipLaunchKernelGGL(k_env_fold, dim3(nblk), dim3(64), 0, st, cols, env, n / nblk, nblk);
+    } else {
+        hipLaunchKernelGGL(k_env_fold, dim3(nblk), dim3(64), 0, st, part, env, rows, nblk);
+    }
+    return hipGetLastError();
+}
+
 uint32_t env_global_rows(const RxParams &p)
 {
     const uint32_t grid = (p.channels + kEnvWaves - 1) / kEnvWaves;

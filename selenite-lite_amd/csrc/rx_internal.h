@@ -36,6 +36,8 @@ struct RxParams {
     float *fir_state;      // [C][2][nh-1]
     float *biq_state;      // [C][nbiq][4]
     float *gain;           // [C]
+    float *env_part;       // global gain, phase 1 (k_ssb_split16, 16-lane DSP blocks, whole passes): max |audio| of every DSP block,
+                           // [channels][block_size / block]; NULL = not wanted
     uint32_t *flags;       // [1] device flag word: bit 0 = a split16 kernel produced non-finite audio (ARM_MATH_NANINF)
     AgcParams agcp;
 };
@@ -59,6 +61,9 @@ hipError_t launch_agc_generic(const RxParams &p, int arith, const float *audio, 
 // global-gain AGC pieces: env[b] = max over channels of max|audio| in DSP block b
 uint32_t env_global_rows(const RxParams &p);
 hipError_t launch_env_global(const RxParams &p, const float *audio, float *part, float *env, hipStream_t st);
+// env[b] = max over `rows` rows of part[row][b]; part holds env_fold_scratch_floats(rows, nblk) floats (scratch behind the rows)
+size_t env_fold_scratch_floats(uint32_t rows, uint32_t nblk);
+hipError_t launch_env_fold(float *part, float *env, uint32_t rows, uint32_t nblk, hipStream_t st);
 hipError_t launch_agc_apply_global(const RxParams &p, int arith, const float *audio, const float *env,
                                    void *dst, bool dst_q15, hipStream_t st);
 

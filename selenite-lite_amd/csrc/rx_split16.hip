@@ -234,6 +234,11 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
     };
     __amdgpu_buffer_rsrc_t rs_in = in_rsrc(c), rs_in_next = in_rsrc(c + gridDim.x);
     __amdgpu_buffer_rsrc_t rs_out = make_rsrc(dst + (size_t)c * p.out_stride, p.nout * (W::kBytes / 4));
+    // global gain, phase 1: the kernel runs with its own AGC off and leaves max |audio| of every DSP block of every channel
+    // behind, so the envelope reduction does not have to read the audio again (GROUP == 16 launches with whole passes only)
+    const uint32_t env_nblk = p.env_part ? p.block_size / p.block : 0u;
+    auto env_rsrc = [&](uint32_t ch) { return make_rsrc(p.env_part + (size_t)ch * env_nblk, env_nblk * 4u); };
+    __amdgpu_buffer_rsrc_t rs_env = env_rsrc(c);
     const __amdgpu_buffer_rsrc_t rs_lo = make_rsrc(p.lo, NCO == 2 ? p.block_size * 8u : 0u);
     constexpr int kInPass = G::T * (R::kBytes / 2);               // input bytes of one pass
 
@@ -619,6 +624,14 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
 #else
         W::store(rs_out, lane * W::kBytes, (int)q * (G::P * (W::kBytes / 4)), au);
 #endif
+        if constexpr (GROUP == 16) {
+            if (env_nblk) {                                           // wave-uniform
+                const float m = row16_fmax(fmaxf(fmaxf(fabsf(au[0]), fabsf(au[1])), fmaxf(fabsf(au[2]), fabsf(au[3]))));
+                // block 4 q + (lane >> 4) from the first lane of its row; the other lanes point past the range (dropped)
+                const int voff = (lane & 15) == 0 ? (lane >> 4) * 4 : 0x40000000;
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(m), rs_env, voff, (int)q * 16, 0);
+            }
+        }
     };
 
     // ---- the pipeline, once per channel of this workgroup ----
@@ -700,6 +713,7 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
         rs_in = rs_in_next;
         rs_in_next = in_rsrc(c + gridDim.x);
         rs_out = make_rsrc(dst + (size_t)c * p.out_stride, p.nout * (W::kBytes / 4));
+        rs_env = env_rsrc(c);
     }
     if (nonfinite) p.flags[0] = 1u;                                   // ARM_MATH_NANINF, read by selenite_rx_sync
     STAMP(1);
