@@ -633,6 +633,8 @@ static hipError_t build_tables(const selenite_rx_config &g, FusedPlan &plan)
             if (e != hipSuccess) return e;
             e = hipMemcpy(plan.d_btab, bt.data(), bt.size() * sizeof(float), hipMemcpyHostToDevice);
             if (e != hipSuccess) return e;
+        }
+        if constexpr (M == 4 || M == 2) {
             if (NH > 0 && ssb_split16_has_shape(ND, M, NH)) {
                 // SELENITE_ARITH_SPLIT16: taps scaled by 2^SC (largest |tap| lands in [2^14, 2^15)), split into
                 // f16 hi + lo; fragment of lane l at k-step kk: 8 halfs B[k = 32kk + 8(l>>4) + j][n = l&15]
@@ -646,9 +648,9 @@ static hipError_t build_tables(const selenite_rx_config &g, FusedPlan &plan)
                 for (int kk = 0; kk < GS::KS; ++kk)
                     for (int l = 0; l < 64; ++l)
                         for (int j = 0; j < 8; ++j) {
-                            const int idx = 32 * kk + 8 * (l >> 4) + j - 4 * (l & 15);
+                            const int idx = 32 * kk + 8 * (l >> 4) + j - M * (l & 15);      // B[k][n] = cq[k - M n]
                             float cv = 0.0f;
-                            if (idx >= 0 && idx <= ND) cv = std::ldexp(cq[idx], SC);
+                            if (idx >= 0 && idx < G::NCQ) cv = std::ldexp(cq[idx], SC);
                             const _Float16 hi = (_Float16)cv;
                             const _Float16 lo = (_Float16)(cv - (float)hi);
                             b16[(((size_t)2 * kk + 0) * 64 + l) * 8 + j] = hi;
@@ -660,8 +662,8 @@ static hipError_t build_tables(const selenite_rx_config &g, FusedPlan &plan)
                 if (e != hipSuccess) return e;
                 plan.split_sc = SC;
             }
-            return hipSuccess;
         }
+        return hipSuccess;
     }
     if constexpr (ND == 0 && M == 1 && NH > 0) {
         // k_hilb_split16: Hilbert taps scaled by 2^SC, f16 hi + lo; fragment of lane l at k-step kk:
@@ -736,7 +738,7 @@ static hipError_t launch_shape(const RxParams &p, const FusedArgs &fa, const Fus
                                const void *src, bool src_q15, void *dst, bool dst_q15, hipStream_t st)
 {
     if (src_q15 != dst_q15) return hipErrorNotSupported;
-    if constexpr (ND > 0 && M == 4 && NH > 0) {
+    if constexpr (ND > 0 && (M == 4 || M == 2) && NH > 0) {
         if (arith == SELENITE_ARITH_SPLIT16 && plan.d_btab16) {
             return launch_ssb_split16(ND, M, NH, p, fa, src, src_q15, dst, st);      // rx_split16.hip
         }
@@ -831,8 +833,9 @@ bool fused_block_size_ok(const FusedPlan &plan, const selenite_rx_config &g, uin
     if (nout % 256 == 0) return true;                // whole passes
     // k_ssb_split16 also takes a partial last pass when it holds a whole decimator history (rx_split16.hip); the
     // other fused kernels get the whole passes and the generic kernels the rest (run_chain)
-    if (g.arith == SELENITE_ARITH_SPLIT16 && g.nd_taps && plan.d_btab16 && g.decim == 4) {
-        const uint32_t tail_in = block_size % (256u * g.decim), hs = (((g.nd_taps - 1 + 3) / 4 + 3) & ~3u) * 4;
+    if (g.arith == SELENITE_ARITH_SPLIT16 && g.nd_taps && plan.d_btab16) {
+        const uint32_t hq = (g.nd_taps - 1 + g.decim - 1) / g.decim, hs = ((hq + 3) & ~3u) * g.decim;    // Geo::HQ4 * M
+        const uint32_t tail_in = block_size % (256u * g.decim);
         return tail_in >= hs;
     }
     return false;

@@ -215,16 +215,21 @@ struct GeoS {
     using G = Geo<ND, M, NH>;
     static constexpr int HS = G::HQ4 * M;                 // history samples in front
     static constexpr int XN = HS + G::T;
-    static constexpr int XROWS = XN / 64;
-    static constexpr int IMG = (80 * XROWS + SRX_IMG_ALIGN - 1) / SRX_IMG_ALIGN * SRX_IMG_ALIGN;   // halfs per image (stride a multiple of 256 B: two images' words leave in one ds_write2st64_b32)
-    static constexpr int KTOT = ND + 4 * 15 + 1;
+    // physical image rows: the 16 M samples one row of the 16 x 16 output tile advances by (64 for /4, 32 for /2), padded by a
+    // quarter (80 / 40 halfs): the A-fragment ds_read_b128 of lane l sits at RSTR (l&15) + 8 (l>>4) + phys(32 kk), conflict free,
+    // and a fragment never straddles a row (8 (l>>4) + 32 kk mod RL + 7 < RL)
+    static constexpr int RL = 16 * M;
+    static constexpr int RSTR = RL + RL / 4;
+    static constexpr int XROWS = XN / RL;
+    static constexpr int IMG = (RSTR * XROWS + SRX_IMG_ALIGN - 1) / SRX_IMG_ALIGN * SRX_IMG_ALIGN;   // halfs per image (stride a multiple of 256 B: two images' words leave in one ds_write2st64_b32)
+    static constexpr int KTOT = G::HQ4 * M + M * 15 + 1;  // padded taps 0 .. HQ4*M  +  shift of 15 outputs
     static constexpr int KS = (KTOT + 31) / 32;           // MFMA k-steps of 32
     static constexpr int oTab = 0;                        // floats; the sine table only when the LO is computed in the kernel
     static constexpr int oX = NCO == 1 ? 516 : 0;         // 4 images of IMG halfs = 2*IMG floats
     static constexpr int oHf = oX + 2 * IMG;              // f32 copy of the HS history samples, (I, Q) pairs
     static constexpr int oD = oHf + 2 * HS;
     static constexpr int total = oD + 2 * G::DLEN;
-    __host__ __device__ static constexpr int phys(int f) { return 80 * (f >> 6) + (f & 63); }
+    __host__ __device__ static constexpr int phys(int f) { return RSTR * (f / RL) + (f % RL); }
 };
 template <int NH>
 struct GeoH {
@@ -239,7 +244,7 @@ struct GeoH {
 };
 
 // instantiated shapes of the two kernel families (ND, M, NH) / (NH)
-#define SRX_SPLIT16_SHAPES(X) X(256, 4, 63) X(128, 4, 63) X(256, 4, 127) X(128, 4, 127) X(256, 4, 31)
+#define SRX_SPLIT16_SHAPES(X) X(256, 4, 63) X(128, 4, 63) X(256, 4, 127) X(128, 4, 127) X(256, 4, 31) X(256, 2, 63) X(128, 2, 63)
 #define SRX_HILB16_SHAPES(X) X(63) X(127) X(31)
 hipError_t launch_ssb_split16(int nd, int m, int nh, const RxParams &p, const FusedArgs &fa, const void *src, bool q15,
                               void *dst, hipStream_t st);

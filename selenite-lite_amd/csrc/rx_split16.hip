@@ -197,7 +197,7 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
     using GS = GeoS<NCO, ND, M, NH>;
     using R = BRaw<TIn>;
     using W = BOut<TOut>;
-    static_assert(ND > 0 && M == 4 && NH > 0 && G::T % 64 == 0 && GS::HS % 64 == 0, "split16 decimator: /4 + Hilbert");
+    static_assert(ND > 0 && (M == 4 || M == 2) && NH > 0 && G::T % 128 == 0 && GS::HS % 128 == 0, "split16 decimator: /4 or /2, + Hilbert");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x;
     uint32_t c = blockIdx.x;                                      // persistent: this workgroup runs channels c, c + gridDim.x, ...
@@ -355,7 +355,7 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
     };
     load_state(c);
     const int group = (int)fa.group;
-    const int abase = 80 * (lane & 15) + 8 * (lane >> 4);             // A-fragment lane base (halfs)
+    const int abase = GS::RSTR * (lane & 15) + 8 * (lane >> 4);       // A-fragment lane base (halfs): row l&15 of the output tile
 
     // two (I, Q) samples f (even), f + 1, times the block scale `pre` -> one word in each of the four images:
     //   hi = f16(x * pre), lo = f16(x * pre - hi), one v_fma_mixlo/hi_f16 each (the product with the power of
@@ -486,7 +486,7 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
 #endif
         const _Float16 *xIh = X + 0 * GS::IMG + abase, *xIl = X + 1 * GS::IMG + abase;
         const _Float16 *xQh = X + 2 * GS::IMG + abase, *xQl = X + 3 * GS::IMG + abase;
-        auto offA = [](int kk) { return 80 * (kk >> 1) + 32 * (kk & 1); };   // phys(32*kk): rows never straddle
+        auto offA = [](int kk) { return GS::phys(32 * kk); };                // fragments never straddle a row (GeoS)
         h8 aIh = *reinterpret_cast<const h8 *>(xIh + offA(0)), aIl = *reinterpret_cast<const h8 *>(xIl + offA(0));
         h8 aQh = *reinterpret_cast<const h8 *>(xQh + offA(0)), aQl = *reinterpret_cast<const h8 *>(xQl + offA(0));
 #pragma unroll
@@ -552,15 +552,16 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
         }
     };
     // history of the four images: last HS samples of the pass back to the front, 16 bytes per move
-    constexpr int NCB = 4 * (GS::HS / 64) * 8 / kWave;                // moves per lane
-    static_assert((4 * (GS::HS / 64) * 8) % kWave == 0, "image history is a whole number of wave moves");
+    constexpr int CPI = GS::HS / 8, CPR = GS::RL / 8;                 // 16-byte chunks per image history / per physical row
+    constexpr int NCB = 4 * CPI / kWave;                              // moves per lane
+    static_assert((4 * CPI) % kWave == 0 && GS::HS % GS::RL == 0, "image history is a whole number of wave moves and of rows");
     auto cb_addr = [&](int k) {                                       // halfs; chunk i -> (image, row, 8-half column group)
-        const int i = k * kWave + lane, img = i / (8 * (GS::HS / 64)), rem = i % (8 * (GS::HS / 64));
-        return img * GS::IMG + 80 * (rem >> 3) + 8 * (rem & 7);
+        const int i = k * kWave + lane, img = i / CPI, rem = i % CPI;
+        return img * GS::IMG + GS::RSTR * (rem / CPR) + 8 * (rem % CPR);
     };
     auto cb_read = [&](u4v (&cb)[NCB]) {
 #pragma unroll
-        for (int k = 0; k < NCB; ++k) cb[k] = *reinterpret_cast<const u4v *>(X + cb_addr(k) + 80 * (G::T / 64));
+        for (int k = 0; k < NCB; ++k) cb[k] = *reinterpret_cast<const u4v *>(X + cb_addr(k) + GS::RSTR * (G::T / GS::RL));
     };
     auto cb_write = [&](const u4v (&cb)[NCB]) {
 #pragma unroll
@@ -1272,7 +1273,7 @@ static hipError_t launch_k(const RxParams &p, const FusedArgs &fa, const void *s
     constexpr size_t lds = (size_t)GS::total * sizeof(float);
     static_assert(lds <= 48 * 1024, "k_ssb_split16 LDS image");
 #if SRX_SPLIT16_W2
-    if constexpr (GS::KS % 2 == 0 && NCO != 3) {
+    if constexpr (GS::KS % 2 == 0 && NCO != 3 && M == 4) {
         static const bool one_wave = std::getenv("SELENITE_RX_SPLIT16_W1") != nullptr;      // A/B: the one-wave kernel
         if (!one_wave && p.nout % 256 == 0) {
             constexpr size_t lds2 = lds + (512 + 4) * sizeof(float);                         // + partial sums + exponents
