@@ -283,7 +283,11 @@ def main():
                          "launch_ms_hip_events": round(k_ms, 4)},
             "fma_roof": {"achieved": round(fl / (k_ms * 1e-3) / 1e12, 2), "peak": F32_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(fl / (k_ms * 1e-3) / 1e12 / F32_PEAK_TFLOPS, 4),
-                         "flops_per_sample": fps},
+                         "flops_per_sample": fps,
+                         "note": ("algorithmic f32 flops of the chain against the f32 vector / f32-MFMA peak (SURVEY 8d: cfg3 is "
+                                  "FMA-bound in direct-form f32)" + ("; the split16 kernel executes the FIR on the f16 matrix pipe "
+                                  "instead (three f16 MFMAs per product), so this roof does not bind it"
+                                  if arith == sr.ARITH_SPLIT16 and "split16" in rx.kernel_name() else ""))},
         }
         if world == 1 and not args.global_gain and not args.main_only and not q15:
             # the same workload in the other arithmetic contracts and with the general (per-channel) NCO, outside the
