@@ -29,6 +29,7 @@ struct selenite_tx_instance {
     bool delay_is_impulse = false, hilb_odd_only = false, phase_uniform = true, steps_same = true, force_generic = false;
     uint32_t delay_index = 0, phase_host = 0;
     float2 *d_lo = nullptr;
+    bool lo_valid = false; uint32_t lo_phase = 0, lo_step = 0, lo_n = 0;   // what d_lo holds
     size_t lo_bytes = 0;
     void *d_ttab16 = nullptr;     // k_tx_split16: Toeplitz fragments of the interpolator phases
     int tpost = 0;                // tap scale exponent of that table
@@ -279,12 +280,23 @@ int run(selenite_tx_instance *S, const void *src, void *dst, bool q15, uint32_t 
         const float2 *lo = nullptr;
         if (g.nco_enable && S->phase_uniform) {
             // every channel shares step and phase: one LO per call, read from L2 by every wavefront
-            if (ensure(S, (void **)&S->d_lo, &S->lo_bytes, (size_t)bs * g.interp * sizeof(float2))) return S->status;
-            TCHK(S, launch_lo_table(S->d_lo, S->d_sintab, phase_now, S->h_step[0], bs * g.interp, S->stream));
+            // the table is a pure function of (start phase, step, length): reused when the call starts where it starts
+            // (every call for an LO on the fs / 256 grid: the phase advance of a call is then a multiple of 2^32)
+            const uint32_t nlo = bs * g.interp;
+            if (!(S->lo_valid && S->lo_phase == phase_now && S->lo_step == S->h_step[0] && S->lo_n >= nlo)) {
+                S->lo_valid = false;
+                if (ensure(S, (void **)&S->d_lo, &S->lo_bytes, (size_t)nlo * sizeof(float2))) return S->status;
+                TCHK(S, launch_lo_table(S->d_lo, S->d_sintab, phase_now, S->h_step[0], nlo, S->stream));
+                S->lo_valid = true; S->lo_phase = phase_now; S->lo_step = S->h_step[0]; S->lo_n = nlo;
+            }
             lo = S->d_lo;
         }
-        if (g.arith == SELENITE_ARITH_SPLIT16 && S->d_ttab16)
-            TCHK(S, launch_tx_split16(p, S->delay_index, lo, S->d_ttab16, S->tpost, src, q15, dst, S->stream));
+        if (g.arith == SELENITE_ARITH_SPLIT16 && S->d_ttab16) {
+            TxParams ps = p;
+            const char *npl = std::getenv("SELENITE_RX_NO_PERIODIC_LO");
+            ps.lo_period = (lo && (S->h_step[0] & 0x00FFFFFFu) == 0 && !(npl && npl[0] == '1')) ? 256u : 0u;   // k_tx_split16 keeps it in registers
+            TCHK(S, launch_tx_split16(ps, S->delay_index, lo, S->d_ttab16, S->tpost, src, q15, dst, S->stream));
+        }
         else
             TCHK(S, launch_tx_fused(p, (int)g.arith, S->delay_index, lo, src, q15, dst, S->stream));
         return 0;

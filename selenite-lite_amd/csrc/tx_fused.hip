@@ -313,6 +313,13 @@ __global__ __launch_bounds__(64, 2) void k_tx_split16(TxParams p, uint32_t delay
     const float hreg = (lane < kNH) ? p.hc[lane] : 0.0f;
     if constexpr (NCO == 1)
         for (int i = lane; i < 513; i += kWave) tab[i] = p.sintab[i];
+    // periodic shared LO (NCO == 3): the table repeats every 256 output samples, a pass is four periods: step j of any
+    // pass multiplies by LO[(128 j + 2 lane, + 1) mod 256] -- two register quads for the whole kernel
+    float4 lo_per[2] = { make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0) };
+    if constexpr (NCO == 3) {
+        lo_per[0] = *reinterpret_cast<const float4 *>(lo + 2 * lane);
+        lo_per[1] = *reinterpret_cast<const float4 *>(lo + 128 + 2 * lane);
+    }
     // block floating point (rx_split16.hip): the scale 2^s of a pass puts the largest |component| of the image
     // ([64 history slots | 256 new samples]) into [2^14, 2^15); `pre` = 2^s
     auto putz = [&](int u, float i0, float q0, float i1, float q1, float pre) {     // image slots u (even), u + 1, both rails
@@ -474,6 +481,10 @@ __global__ __launch_bounds__(64, 2) void k_tx_split16(TxParams p, uint32_t delay
                     const float4 l = *reinterpret_cast<const float4 *>(lo + (size_t)pass * kPass * kL + o);
                     y0 = cmul<0>(y0, make_float2(l.x, -l.y));
                     y1 = cmul<0>(y1, make_float2(l.z, -l.w));
+                } else if constexpr (NCO == 3) {                          // periodic shared LO: o mod 256 = 128 (j & 1) + 2 lane
+                    const float4 l = lo_per[j & 1];
+                    y0 = cmul<0>(y0, make_float2(l.x, -l.y));
+                    y1 = cmul<0>(y1, make_float2(l.z, -l.w));
                 } else if constexpr (NCO == 1) {
                     const uint32_t phase = ph0 + (pass * kPass * kL + o) * step;
                     const float x0 = (float)(phase >> 8) * kNcoK, x1 = (float)((phase + step) >> 8) * kNcoK;
@@ -531,6 +542,7 @@ hipError_t launch_s16(const TxParams &p, uint32_t delay_idx, const float2 *lo, c
     const TIn *s = static_cast<const TIn *>(src);
     TOut *d = static_cast<TOut *>(dst);
     if (!p.nco) hipLaunchKernelGGL((k_tx_split16<0, TIn, TOut>), grid, blk, lds, st, p, delay_idx, lo, ttab16, tap_sc, s, d);
+    else if (lo && p.lo_period == 256) hipLaunchKernelGGL((k_tx_split16<3, TIn, TOut>), grid, blk, lds, st, p, delay_idx, lo, ttab16, tap_sc, s, d);
     else if (lo) hipLaunchKernelGGL((k_tx_split16<2, TIn, TOut>), grid, blk, lds, st, p, delay_idx, lo, ttab16, tap_sc, s, d);
     else hipLaunchKernelGGL((k_tx_split16<1, TIn, TOut>), grid, blk, lds, st, p, delay_idx, lo, ttab16, tap_sc, s, d);
     return hipGetLastError();

@@ -233,3 +233,33 @@ def test_tx_split16_q15_silence_and_full_scale():
     gq, oq = gpu_tx(rc.TxSpec(9, arith=rc.ARITH_SPLIT16)), rc.TxCpuChain(rc.TxSpec(9), "orc")
     aq = np.clip(np.trunc(rc.synth_audio(0, 9, 0, 512) * 32768.0), -32768, 32767).astype(np.int16)
     assert np.max(np.abs(gq.process_q15(aq).astype(np.int32) - oq.process_q15(aq).astype(np.int32))) <= 1
+
+
+@pytest.mark.parametrize("q15", [False, True])
+def test_tx_periodic_shared_lo_in_registers_equals_the_table_path_bit_for_bit(q15):
+    """k_tx_split16 keeps a shared LO of period 256 (NCO step a multiple of 2^24: the default TX spec) in registers; the
+    same LO values as the per-call table, so the same bits -- output and state, calls of several lengths, a non-zero
+    start phase."""
+    import os
+    spec = rc.TxSpec(70, arith=rc.ARITH_SPLIT16)
+    assert spec.nco_step_all & 0x00FFFFFF == 0
+    reg, tab = gpu_tx(spec), gpu_tx(spec)
+    st = reg.state()
+    st["nco_phase"][:] = 0x3456789A
+    reg.set_state(st)
+    tab.set_state(st)
+    for k, bs in enumerate((256, 1024, 512, 2048)):
+        a = rc.synth_audio(0, 70, 4096 * k, bs)
+        if q15:
+            a = np.clip(np.round(a * 20000.0), -32768, 32767).astype(np.int16)
+        ya = reg.process_q15(a) if q15 else reg.process(a)
+        os.environ["SELENITE_RX_NO_PERIODIC_LO"] = "1"
+        try:
+            yb = tab.process_q15(a) if q15 else tab.process(a)
+        finally:
+            del os.environ["SELENITE_RX_NO_PERIODIC_LO"]
+        assert np.array_equal(ya.view(np.uint32) if not q15 else ya, yb.view(np.uint32) if not q15 else yb)
+    sa, sb = reg.state(), tab.state()
+    for key in sa:
+        assert np.array_equal(sa[key].view(np.uint32) if sa[key].dtype == np.float32 else sa[key],
+                              sb[key].view(np.uint32) if sb[key].dtype == np.float32 else sb[key]), key
