@@ -1,6 +1,6 @@
 // mfma_energy.hip <variant> -- what does a matrix instruction cost at the package power cap?  2048 single-wave workgroups
 // (two per SIMD, like k_ssb_split16) issue back-to-back MFMAs on random register operands, four independent accumulators.
-// variant 0: v_mfma_f32_16x16x32_f16   1: v_mfma_i32_16x16x64_i8   2: v_mfma_f32_16x16x32_bf16
+// variant 0: v_mfma_f32_16x16x32_f16   1: v_mfma_i32_16x16x64_i8   2: v_mfma_f32_16x16x32_bf16   3: v_mfma_f32_32x32x16_f16
 // Runs ~3 s; prints time per launch and instructions per second.  Sample rocm-smi beside it (tools/mfma_energy.sh).
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -36,6 +36,17 @@ __global__ __launch_bounds__(64, 2) void k(const unsigned *__restrict__ seed, fl
 #pragma unroll
                 for (int j = 0; j < 4; ++j) c[j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[j], b[(j + u) & 3], c[j], 0, 0, 0);
         out[blockIdx.x * 64 + l] = (float)(c[0][0] + c[1][1] + c[2][2] + c[3][3]);
+    } else if constexpr (V == 3) {
+        typedef float f16v __attribute__((ext_vector_type(16)));
+        h8 a[4], b[4];
+        for (int j = 0; j < 4; ++j) for (int e = 0; e < 8; ++e) { a[j][e] = (_Float16)(((rnd() >> 8) & 1 ? 1.0f : -1.0f) * (1.0f + (float)(rnd() >> 22) / 1024.0f)); b[j][e] = (_Float16)(((rnd() >> 8) & 1 ? 1.0f : -1.0f) * (1.0f + (float)(rnd() >> 22) / 1024.0f)); }
+        f16v c[4] = {};
+        for (int it = 0; it < ITER; it += 4)
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) c[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[j], b[(j + u) & 3], c[j], 0, 0, 0);
+        out[blockIdx.x * 64 + l] = c[0][0] + c[1][1] + c[2][2] + c[3][3];
     } else {
         b8 a[4], b[4];
         for (int j = 0; j < 4; ++j) for (int e = 0; e < 8; ++e) { a[j][e] = (__bf16)(((rnd() >> 8) & 1 ? 1.0f : -1.0f) * (1.0f + (float)(rnd() >> 25) / 128.0f)); b[j][e] = (__bf16)(((rnd() >> 8) & 1 ? 1.0f : -1.0f) * (1.0f + (float)(rnd() >> 25) / 128.0f)); }
@@ -56,7 +67,7 @@ int main(int argc, char **argv)
     hipMalloc(&ds, sizeof hs); hipMalloc(&dout, 2048 * 64 * 4);
     hipMemcpy(ds, hs, sizeof hs, hipMemcpyHostToDevice);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    auto launch = [&]() { if (v == 0) k<0><<<2048, 64, 40960>>>(ds, dout); else if (v == 1) k<1><<<2048, 64, 40960>>>(ds, dout); else k<2><<<2048, 64, 40960>>>(ds, dout); };
+    auto launch = [&]() { if (v == 0) k<0><<<2048, 64, 40960>>>(ds, dout); else if (v == 1) k<1><<<2048, 64, 40960>>>(ds, dout); else if (v == 3) k<3><<<2048, 64, 40960>>>(ds, dout); else k<2><<<2048, 64, 40960>>>(ds, dout); };
     for (int w = 0; w < 200; ++w) launch();
     hipDeviceSynchronize();
     int n = 0; float total = 0;
