@@ -149,6 +149,23 @@ __device__ __forceinline__ void agc_pass(const AgcParams &ap, uint32_t agc_on, i
             g = b < nvb ? gn : g;                    // blocks past the end of the call leave the gain alone
             mine = (b == myblk) ? g : mine;
         }
+    } else if constexpr (GROUP == 32) {
+        // two DSP blocks of two 16-lane rows each (decimation by 2): row maxima by DPP, the two rows of a block joined on
+        // the scalar unit (|.| >= 0: the bit patterns order like the values), one division sequence for both blocks
+        m = row16_fmax(m);
+        const uint32_t r0 = __builtin_amdgcn_readlane(__float_as_uint(m), 0), r1 = __builtin_amdgcn_readlane(__float_as_uint(m), 16);
+        const uint32_t r2 = __builtin_amdgcn_readlane(__float_as_uint(m), 32), r3 = __builtin_amdgcn_readlane(__float_as_uint(m), 48);
+        const float e0 = __uint_as_float(r0 > r1 ? r0 : r1), e1 = __uint_as_float(r2 > r3 ? r2 : r3);
+        const float d = agc_desired(ap, lane < 32 ? e0 : e1);
+        const float ds[2] = { __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(d), 0)),
+                              __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(d), 32)) };
+        const int myblk = lane >> 5;
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const float gn = agc_step(ap, g, ds[b]);
+            g = b < nvb ? gn : g;
+            mine = (b == myblk) ? g : mine;
+        }
     } else if constexpr (GROUP == 64) {
         m = __uint_as_float(wave_umax_bits(m));
         g = agc_step(ap, g, agc_desired(ap, m));
@@ -1308,7 +1325,9 @@ template <int NCO, int ND, int M, int NH, typename TIn, typename TOut>
 static hipError_t launch_io(const RxParams &p, const FusedArgs &fa, const void *src, void *dst, hipStream_t st)
 {
     if (fa.am) return launch_k<NCO, ND, M, NH, TIn, TOut, 1, 0>(p, fa, src, dst, st);
-    if constexpr (NCO != 0) {
+    if constexpr (NCO != 0 && M == 2) {
+        if (fa.group == 32) return launch_k<NCO, ND, M, NH, TIn, TOut, 0, 32>(p, fa, src, dst, st);      // DSP block 256 inputs / 2
+    } else if constexpr (NCO != 0) {
         if (fa.group == 16) return launch_k<NCO, ND, M, NH, TIn, TOut, 0, 16>(p, fa, src, dst, st);
         if (fa.group == 64) return launch_k<NCO, ND, M, NH, TIn, TOut, 0, 64>(p, fa, src, dst, st);
     }
