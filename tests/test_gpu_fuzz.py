@@ -83,3 +83,40 @@ def test_random_configurations_of_the_fused_kernels():
     rng = np.random.default_rng(20261002)
     for idx in range(int(os.environ.get("SELENITE_FUZZ_CASES", "150"))):
         one_case(rng, idx)
+
+
+def test_random_configurations_of_the_cw_kernel():
+    """k_cw_fused: 2 / 4 / 8 biquad stages, any channel count, call lengths, slot formats, NCO flavours, CW / CW-R, both exact
+    arithmetic modes: always bit-exact, output and state."""
+    import selenite_rx as sr
+    rng = np.random.default_rng(4242)
+    for idx in range(int(os.environ.get("SELENITE_FUZZ_CASES", "150")) // 3):
+        ns = int(rng.choice([2, 4, 8]))
+        arith = int(rng.choice([ARITH_CMSIS, ARITH_FMA]))
+        nch = int(rng.choice([1, 2, 7, 8, 15, 16, 17, 31, 32, 33, 64, 65, 100]))
+        q15 = bool(rng.integers(2))
+        mode = int(rng.choice([rc.MODE_CW, rc.MODE_CWR]))
+        nco = ["off", "shared", "per_channel"][int(rng.integers(3))]
+        kw = dict(agc=bool(rng.integers(4)))
+        if nco == "shared":
+            kw.update(nco=True, nco_step_all=int(rng.integers(1, 1 << 32)))
+        elif nco == "per_channel":
+            kw.update(nco=True, nco_steps=rng.integers(0, 1 << 32, nch, dtype=np.uint64).astype(np.uint32))
+        spec = rc.ChainSpec(nch, 256, 1, 0, 0, ns, mode, arith, **kw)
+        g, o = sr.Rx(spec.config()), CpuChain(spec, "orc")
+        desc = "cw case %d: stages %d arith %d nch %d q15 %d mode %#x nco %s %s" % (idx, ns, arith, nch, q15, mode, nco, g.kernel_name())
+        assert g.kernel_name().startswith("k_cw_fused<%d" % ns), desc
+        pos = 0
+        for _ in range(int(rng.integers(1, 4))):
+            bs = 256 * int(rng.integers(1, 13))
+            iq = synth_iq(0, nch, pos, bs)
+            pos += bs
+            if q15:
+                iq16 = np.clip(np.round(iq * 20000.0), -32768, 32767).astype(np.int16)
+                assert np.array_equal(g.process_q15(iq16), o.process_q15(iq16)), desc
+            else:
+                assert bits_equal(g.process(iq), o.process(iq)), desc
+        sg, so = g.state(), o.state()
+        for key in sg:
+            assert (bits_equal(sg[key], so[key]) if sg[key].dtype == np.float32 else np.array_equal(sg[key], so[key])), desc + " " + key
+        g.close()
