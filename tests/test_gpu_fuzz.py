@@ -120,3 +120,56 @@ def test_random_configurations_of_the_cw_kernel():
         for key in sg:
             assert (bits_equal(sg[key], so[key]) if sg[key].dtype == np.float32 else np.array_equal(sg[key], so[key])), desc + " " + key
         g.close()
+
+
+def test_random_configurations_of_the_tx_chain():
+    """TX mirror (BASELINE-like shape: ALC block 64, 256-tap interpolator by 4, 63-tap Hilbert pair): channel count, call
+    lengths, slot formats, NCO flavours, ALC, modes.  Exact modes bit-exact; split16 within 1e-5 per 256 output samples
+    (ALC off: same reasoning as the RX fuzz) and its ALC / NCO / Hilbert state exact."""
+    import selenite_rx as sr
+    rng = np.random.default_rng(777)
+    for idx in range(int(os.environ.get("SELENITE_FUZZ_CASES", "150")) // 3):
+        arith = [ARITH_CMSIS, ARITH_FMA, rc.ARITH_SPLIT16][int(rng.integers(3))]
+        nch = int(rng.choice([1, 2, 15, 16, 17, 63, 64, 65, 100]))
+        q15 = bool(rng.integers(2))
+        mode = int(rng.choice([rc.MODE_USB, rc.MODE_LSB, rc.MODE_AM, rc.MODE_CW]))
+        nco = ["off", "periodic", "table", "per_channel"][int(rng.integers(4))]
+        kw = dict(alc=bool(rng.integers(4)) and arith != rc.ARITH_SPLIT16, mode=mode)
+        if nco == "off":
+            kw["nco"] = False
+        elif nco == "periodic":
+            kw["nco_step_all"] = int(rng.integers(1, 64)) << 24
+        elif nco == "table":
+            kw["nco_step_all"] = int(rng.integers(1, 1 << 32)) | 1
+        else:
+            kw["nco_steps"] = rng.integers(0, 1 << 32, nch, dtype=np.uint64).astype(np.uint32)
+        g = sr.Tx(rc.TxSpec(nch, arith=arith, **kw).config())
+        tol_mode = arith == rc.ARITH_SPLIT16 and "split16" in g.kernel_name()
+        o = rc.TxCpuChain(rc.TxSpec(nch, arith=ARITH_CMSIS if tol_mode else (ARITH_FMA if arith == rc.ARITH_SPLIT16 else arith), **kw), "orc")
+        desc = "tx case %d: arith %d nch %d q15 %d mode %#x nco %s alc %d %s" % (idx, arith, nch, q15, mode, nco, kw["alc"], g.kernel_name())
+        pos = 0
+        for _ in range(int(rng.integers(1, 4))):
+            bs = 256 * int(rng.integers(1, 9))
+            a = rc.synth_audio(0, nch, pos, bs)
+            pos += bs
+            if q15:
+                a16 = np.clip(np.round(a * 20000.0), -32768, 32767).astype(np.int16)
+                yg, yo = g.process_q15(a16), o.process_q15(a16)
+                if tol_mode:
+                    assert np.abs(yg.astype(np.int32) - yo.astype(np.int32)).max() <= 1, desc
+                else:
+                    assert np.array_equal(yg, yo), desc
+            else:
+                yg, yo = g.process(a), o.process(a)
+                if tol_mode:
+                    im = np.abs(a).max(axis=1)
+                    d = np.abs(yg.astype(np.float64) - yo).reshape(nch, -1, 512).max(axis=2)      # 256 complex outputs
+                    m = np.abs(yo).reshape(nch, -1, 512).max(axis=2)
+                    assert (d <= 1e-5 * m + 1e-6 * im[:, None]).all(), desc + " worst %.3g" % (d / np.maximum(m, 1e-30)).max()
+                else:
+                    assert bits_equal(yg, yo), desc
+        sg, so = g.state(), o.state()
+        assert np.array_equal(sg["nco_phase"], so["nco_phase"]) and bits_equal(sg["fir_state"], so["fir_state"]), desc
+        if not tol_mode:
+            assert bits_equal(sg["interp_state"], so["interp_state"]) and bits_equal(sg["alc_gain"], so["alc_gain"]), desc
+        g.close()
