@@ -16,6 +16,7 @@
 
 #include "rx_internal.h"
 #include "tx_internal.h"
+#include <cstdlib>
 
 namespace srx {
 
@@ -291,13 +292,14 @@ __global__ __launch_bounds__(64, 2) void k_tx_split16(TxParams p, uint32_t delay
     using IO = AudioIO<TIn>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x;
-    const uint32_t c = blockIdx.x;
     float *tab = lds + oTab, *HI = lds + oHI, *HQ = lds + oHQ;
     _Float16 *ZI = reinterpret_cast<_Float16 *>(lds + oZ16);       // [I hi | I lo | Q hi | Q lo]
     float *ZF = lds + oZF;                                         // [rail][256] f32: the last 64 are the next pass's history slots
-    const size_t in_base = (size_t)c * p.block_size, out_base = (size_t)c * p.block_size * kL;
     const uint32_t npass = p.block_size / kPass;
-    typename IO::raw raw = IO::load(src, in_base + 4u * lane);
+    // persistent grid (as k_ssb_split16): this workgroup runs channels blockIdx.x, + gridDim.x, ...; the 96 VGPRs of Toeplitz
+    // fragments (24 KB per workgroup), the Hilbert taps and the periodic LO are loaded once, and the first audio samples of
+    // the next channel are prefetched under the last pass of the current one
+    typename IO::raw raw = IO::load(src, (size_t)blockIdx.x * p.block_size + 4u * lane);
 
     h8 Bh[kL][kKS], Bl[kL][kKS];                                   // 96 VGPRs of Toeplitz fragments
     {
@@ -334,6 +336,11 @@ __global__ __launch_bounds__(64, 2) void k_tx_split16(TxParams p, uint32_t delay
         *reinterpret_cast<h2 *>(ZI + 3 * kZIMG + ph) = h2{ l[2], l[3] };
     };
     for (int u = kZS + kPass + 2 * lane; u < kZN; u += 2 * kWave) putz(u, 0.0f, 0.0f, 0.0f, 0.0f, 1.0f);   // finite slack under zero taps
+    const bool am = p.mode == SELENITE_MODE_AM, up = mode_is_upper(p.mode);
+    const int mcol = lane & 15, rg = lane >> 4;
+    for (uint32_t c = blockIdx.x; c < p.channels; c += gridDim.x) {
+    const size_t in_base = (size_t)c * p.block_size, out_base = (size_t)c * p.block_size * kL;
+    const uint32_t cn = c + gridDim.x < p.channels ? c + gridDim.x : c;     // next channel of this workgroup (or a harmless re-read)
     uint32_t e_hist;
     {   // state, branch-free: Hilbert-pair histories and the interpolator history, all f32
         const float *stF = p.fir_state + (size_t)c * 2 * kHH, *stZ = p.int_state + (size_t)c * 2 * (kP - 1);
@@ -356,19 +363,17 @@ __global__ __launch_bounds__(64, 2) void k_tx_split16(TxParams p, uint32_t delay
     int s_cur = 0x7fff;
     float gain = p.alc ? p.gain[c] : 1.0f;
     const uint32_t ph0 = NCO ? p.phase[c] : 0u, step = NCO ? p.step[c] : 0u;
-    const bool am = p.mode == SELENITE_MODE_AM, up = mode_is_upper(p.mode);
-    const int mcol = lane & 15, rg = lane >> 4;
     wave_lds_sync();
 
     for (uint32_t pass = 0; pass < npass; ++pass) {
         // ---- 1. ALC ----
         float a[4];
         IO::unpack(raw, a);
-        if (pass + 1 < npass) raw = IO::load(src, in_base + (size_t)(pass + 1) * kPass + 4u * lane);
+        raw = pass + 1 < npass ? IO::load(src, in_base + (size_t)(pass + 1) * kPass + 4u * lane)
+                               : IO::load(src, (size_t)cn * p.block_size + 4u * lane);
         if (p.alc) {
             float m = fmaxf(fmaxf(fabsf(a[0]), fabsf(a[1])), fmaxf(fabsf(a[2]), fabsf(a[3])));
-#pragma unroll
-            for (int off = 1; off < 16; off <<= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+            m = row16_fmax(m);                                     // ALC block = 64 audio samples = one 16-lane row (DPP)
             const float dmine = agc_desired(p.alcp, m);
             float g = gain, mine = gain;
 #pragma unroll
@@ -531,6 +536,8 @@ __global__ __launch_bounds__(64, 2) void k_tx_split16(TxParams p, uint32_t delay
         if (p.alc) p.gain[c] = gain;
         if constexpr (NCO != 0) p.phase[c] = ph0 + p.block_size * kL * step;
     }
+    wave_lds_sync();                                               // the state reads above before the next channel's installs
+    }
 }
 
 template <typename TIn, typename TOut>
@@ -538,7 +545,19 @@ hipError_t launch_s16(const TxParams &p, uint32_t delay_idx, const float2 *lo, c
                       void *dst, hipStream_t st)
 {
     constexpr size_t lds = (size_t)(kTotal16 + 2 * kPass * kL) * sizeof(float);      // + the 8 KB output tile
-    const dim3 grid(p.channels), blk(64);
+    // persistent grid: as many single-wave workgroups as the device keeps resident (SELENITE_TX_SPLIT16_GRID=0: one per channel)
+    static int resident = 0;
+    if (resident == 0) {
+        int per_cu = 0, dev = 0;
+        hipDeviceProp_t prop;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_tx_split16<2, TIn, TOut>, 64, lds) != hipSuccess ||
+            hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess || per_cu <= 0)
+            resident = -1;
+        else
+            resident = per_cu * prop.multiProcessorCount;
+        if (const char *e = std::getenv("SELENITE_TX_SPLIT16_GRID")) resident = std::atoi(e) > 0 ? std::atoi(e) : -1;
+    }
+    const dim3 grid(resident > 0 && (uint32_t)resident < p.channels ? (uint32_t)resident : p.channels), blk(64);
     const TIn *s = static_cast<const TIn *>(src);
     TOut *d = static_cast<TOut *>(dst);
     if (!p.nco) hipLaunchKernelGGL((k_tx_split16<0, TIn, TOut>), grid, blk, lds, st, p, delay_idx, lo, ttab16, tap_sc, s, d);
