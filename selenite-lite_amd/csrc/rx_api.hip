@@ -304,9 +304,11 @@ extern "C" const char *selenite_rx_kernel_name(const selenite_rx_instance *S)
 static bool periodic_lo(const selenite_rx_instance *S)
 {
     const selenite_rx_config &g = S->cfg;
-    return g.nco_enable && S->steps_uniform && (S->h_step[0] & 0x00FFFFFFu) == 0 && !S->no_periodic_lo &&
-           g.arith == SELENITE_ARITH_SPLIT16 && S->plan.d_btab16 && g.nd_taps &&
-           ssb_split16_periodic_lo((int)g.nd_taps, (int)g.decim, (int)g.nh_taps);
+    if (!(g.nco_enable && S->steps_uniform && (S->h_step[0] & 0x00FFFFFFu) == 0 && !S->no_periodic_lo)) return false;
+    if (g.arith == SELENITE_ARITH_SPLIT16 && S->plan.d_btab16 && g.nd_taps)
+        return ssb_split16_periodic_lo((int)g.nd_taps, (int)g.decim, (int)g.nh_taps);
+    // k_ssb_mfma (fma arithmetic, and split16 shapes without a matrix kernel of their own): decimation by 4, 1024-sample passes
+    return g.arith != SELENITE_ARITH_CMSIS && S->plan.use_mfma && g.nd_taps && g.decim == 4;
 }
 
 extern "C" const char *selenite_rx_nco_path(const selenite_rx_instance *S)

@@ -416,6 +416,14 @@ __global__ __launch_bounds__(64 * kMfmaWaves, 2) void k_ssb_mfma(RxParams p, Fus
     const int group = (int)fa.group;
     const int abase = 66 * (lane & 15) + (lane >> 4);                 // A-operand lane base (dwords)
 
+    // periodic shared LO (NCO == 3, as in k_ssb_split16): the table repeats every 256 samples and a pass is a whole number of
+    // periods, so load i of any pass multiplies by LO[(128 i + 2 lane, + 1) mod 256]: two register quads for the kernel
+    float4 lo_per[2] = { make_float4(0.0f, 0.0f, 0.0f, 0.0f), make_float4(0.0f, 0.0f, 0.0f, 0.0f) };
+    if constexpr (NCO == 3) {
+        static_assert(NCO != 3 || G::T % 256 == 0, "a pass is a whole number of LO periods");
+        lo_per[0] = *reinterpret_cast<const float4 *>(p.lo + 2 * lane);
+        lo_per[1] = *reinterpret_cast<const float4 *>(p.lo + 128 + 2 * lane);
+    }
     // ---- V phase, part 2: NCO mix of the prefetched pass into the X image, then prefetch the next ----
     auto stage = [&](uint32_t pass) {
         const uint32_t n0 = pass * G::T;
@@ -433,6 +441,10 @@ __global__ __launch_bounds__(64 * kMfmaWaves, 2) void k_ssb_mfma(RxParams p, Fus
             R::unpack(raw[i], a, b);
             if constexpr (NCO == 2) {
                 const float4 l2 = lo4[i];
+                a = cmul<0>(a, make_float2(l2.x, l2.y));
+                b = cmul<0>(b, make_float2(l2.z, l2.w));
+            } else if constexpr (NCO == 3) {
+                const float4 l2 = lo_per[i & 1];
                 a = cmul<0>(a, make_float2(l2.x, l2.y));
                 b = cmul<0>(b, make_float2(l2.z, l2.w));
             } else if constexpr (NCO == 1) {
@@ -721,10 +733,11 @@ static hipError_t launch_mfma(const RxParams &p, const FusedArgs &fa, const floa
     using GM = GeoM<ND, M, NH>;
     constexpr size_t lds = (size_t)kMfmaWaves * GM::total * sizeof(float);
     static_assert(lds <= 160 * 1024, "k_ssb_mfma LDS image");
-    auto k = fa.am ? (p.nco == 2 ? k_ssb_mfma<2, ND, M, NH, TIn, TOut, 1>
-                         : (p.nco == 1 ? k_ssb_mfma<1, ND, M, NH, TIn, TOut, 1> : k_ssb_mfma<0, ND, M, NH, TIn, TOut, 1>))
-                   : (p.nco == 2 ? k_ssb_mfma<2, ND, M, NH, TIn, TOut, 0>
-                         : (p.nco == 1 ? k_ssb_mfma<1, ND, M, NH, TIn, TOut, 0> : k_ssb_mfma<0, ND, M, NH, TIn, TOut, 0>));
+    const uint32_t nco = (p.nco == 2 && p.lo_period == 256 && Geo<ND, M, NH>::T % 256 == 0) ? 3u : p.nco;     // periodic LO: in registers
+    auto k = fa.am ? (nco == 3 ? k_ssb_mfma<3, ND, M, NH, TIn, TOut, 1> : nco == 2 ? k_ssb_mfma<2, ND, M, NH, TIn, TOut, 1>
+                         : (nco == 1 ? k_ssb_mfma<1, ND, M, NH, TIn, TOut, 1> : k_ssb_mfma<0, ND, M, NH, TIn, TOut, 1>))
+                   : (nco == 3 ? k_ssb_mfma<3, ND, M, NH, TIn, TOut, 0> : nco == 2 ? k_ssb_mfma<2, ND, M, NH, TIn, TOut, 0>
+                         : (nco == 1 ? k_ssb_mfma<1, ND, M, NH, TIn, TOut, 0> : k_ssb_mfma<0, ND, M, NH, TIn, TOut, 0>));
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)lds);
     if (e != hipSuccess) return e;
