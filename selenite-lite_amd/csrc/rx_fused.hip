@@ -372,18 +372,19 @@ __global__ __launch_bounds__(64 * kMfmaWaves, 2) void k_ssb_mfma(RxParams p, Fus
     const int lane = threadIdx.x & 63;
     const int grp = (wave >> fa.grp_shift) & 1;                       // 0: MFMA on even half-steps, 1: on odd
     float *lds = lds_all + wave * GM::total;
-    const uint32_t c = blockIdx.x * kMfmaWaves + wave;
+    // persistent grid (as k_ssb_split16): this wavefront runs channels c, c + gridDim.x * kMfmaWaves, ...; the Toeplitz operand,
+    // the taps and the periodic LO are loaded once; the first pass of the next channel is prefetched under the last pass
+    const uint32_t c_first = blockIdx.x * kMfmaWaves + wave, c_step = gridDim.x * kMfmaWaves;
     float *tab = lds + GM::oTab;
     float *XI = lds + GM::oX, *XQ = XI + GM::XLEN;
     float *D = lds + GM::oD;
     float *dI = D, *dQ = D + G::DLEN;
     constexpr int NLD = G::T / 128;
 
-    const size_t in_base = (size_t)c * p.in_stride, out_base = (size_t)c * p.out_stride;
     const uint32_t npass = p.nout / G::P;
     typename R::type raw[NLD];
 #pragma unroll
-    for (int i = 0; i < NLD; ++i) raw[i] = R::load(src, in_base + 128u * i + 2u * lane);
+    for (int i = 0; i < NLD; ++i) raw[i] = R::load(src, (size_t)c_first * p.in_stride + 128u * i + 2u * lane);
 
     // Toeplitz B operand: lane l holds B[k = 4*ks + (l>>4)][n = l&15] = cq[k - 4n]
     float B[GM::KS];
@@ -392,6 +393,22 @@ __global__ __launch_bounds__(64 * kMfmaWaves, 2) void k_ssb_mfma(RxParams p, Fus
 
     if constexpr (NCO == 1)
         for (int i = lane; i < 513; i += kWave) tab[i] = p.sintab[i];
+    float hreg[(NH + 63) / 64 ? (NH + 63) / 64 : 1];
+#pragma unroll
+    for (int v = 0; v < (NH + 63) / 64; ++v) hreg[v] = (64 * v + lane < NH) ? p.hilb_c[64 * v + lane] : 0.0f;
+    const int group = (int)fa.group;
+    const int abase = 66 * (lane & 15) + (lane >> 4);                 // A-operand lane base (dwords)
+    // periodic shared LO (NCO == 3, as in k_ssb_split16): the table repeats every 256 samples and a pass is a whole number of
+    // periods, so load i of any pass multiplies by LO[(128 i + 2 lane, + 1) mod 256]: two register quads for the kernel
+    float4 lo_per[2] = { make_float4(0.0f, 0.0f, 0.0f, 0.0f), make_float4(0.0f, 0.0f, 0.0f, 0.0f) };
+    if constexpr (NCO == 3) {
+        static_assert(NCO != 3 || G::T % 256 == 0, "a pass is a whole number of LO periods");
+        lo_per[0] = *reinterpret_cast<const float4 *>(p.lo + 2 * lane);
+        lo_per[1] = *reinterpret_cast<const float4 *>(p.lo + 128 + 2 * lane);
+    }
+    for (uint32_t c = c_first; c < p.channels; c += c_step) {
+    const size_t in_base = (size_t)c * p.in_stride, out_base = (size_t)c * p.out_stride;
+    const uint32_t cn = c + c_step < p.channels ? c + c_step : c;        // next channel of this wavefront (or a harmless re-read)
     // history: flat sample f in [0, HS) is CMSIS state sample s = f - F (older slots meet zero taps)
     batched_fill<2 * GM::HS>(lane, p.dec_state + (size_t)c * 2 * (ND - 1),
         [&](int i) {
@@ -407,23 +424,10 @@ __global__ __launch_bounds__(64 * kMfmaWaves, 2) void k_ssb_mfma(RxParams p, Fus
             },
             [&](int i, float v) { D[(i / G::HH4) * G::DLEN + i % G::HH4] = v; });
     }
-    float hreg[(NH + 63) / 64 ? (NH + 63) / 64 : 1];
-#pragma unroll
-    for (int v = 0; v < (NH + 63) / 64; ++v) hreg[v] = (64 * v + lane < NH) ? p.hilb_c[64 * v + lane] : 0.0f;
     const uint32_t ph0 = NCO ? p.phase[c] : 0u;
     const uint32_t step = NCO ? p.step[c] : 0u;
     float gain = p.agc ? p.gain[c] : 1.0f;
-    const int group = (int)fa.group;
-    const int abase = 66 * (lane & 15) + (lane >> 4);                 // A-operand lane base (dwords)
 
-    // periodic shared LO (NCO == 3, as in k_ssb_split16): the table repeats every 256 samples and a pass is a whole number of
-    // periods, so load i of any pass multiplies by LO[(128 i + 2 lane, + 1) mod 256]: two register quads for the kernel
-    float4 lo_per[2] = { make_float4(0.0f, 0.0f, 0.0f, 0.0f), make_float4(0.0f, 0.0f, 0.0f, 0.0f) };
-    if constexpr (NCO == 3) {
-        static_assert(NCO != 3 || G::T % 256 == 0, "a pass is a whole number of LO periods");
-        lo_per[0] = *reinterpret_cast<const float4 *>(p.lo + 2 * lane);
-        lo_per[1] = *reinterpret_cast<const float4 *>(p.lo + 128 + 2 * lane);
-    }
     // ---- V phase, part 2: NCO mix of the prefetched pass into the X image, then prefetch the next ----
     auto stage = [&](uint32_t pass) {
         const uint32_t n0 = pass * G::T;
@@ -457,9 +461,10 @@ __global__ __launch_bounds__(64 * kMfmaWaves, 2) void k_ssb_mfma(RxParams p, Fus
             *reinterpret_cast<float2 *>(XQ + ph) = make_float2(a.y, b.y);
         }
         wave_lds_sync();
-        if (pass + 1 < npass) {
+        {   // the next pass of this channel, or the first pass of the wavefront's next channel
+            const size_t nb = pass + 1 < npass ? in_base + n0 + G::T : (size_t)cn * p.in_stride;
 #pragma unroll
-            for (int i = 0; i < NLD; ++i) raw[i] = R::load(src, in_base + n0 + G::T + 128u * i + 2u * lane);
+            for (int i = 0; i < NLD; ++i) raw[i] = R::load(src, nb + 128u * i + 2u * lane);
         }
     };
     // ---- M phase: decimator on the matrix cores, 2 accumulator tiles (I, Q), KS steps each ----
@@ -590,6 +595,8 @@ __global__ __launch_bounds__(64 * kMfmaWaves, 2) void k_ssb_mfma(RxParams p, Fus
     if (lane == 0) {
         if constexpr (NCO != 0) p.phase[c] = ph0 + p.block_size * step;
         if (p.agc) p.gain[c] = gain;
+    }
+    wave_lds_sync();                                                  // the state reads above before the next channel's fills
     }
 }
 
@@ -741,7 +748,21 @@ static hipError_t launch_mfma(const RxParams &p, const FusedArgs &fa, const floa
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k, dim3(p.channels / kMfmaWaves), dim3(64 * kMfmaWaves), lds, st, p, fa, btab,
+    // persistent grid: as many workgroups as the device keeps resident (SELENITE_RX_MFMA_GRID=0: one per channel)
+    static int resident = 0;                // per shape and slot format; the NCO / AM flavours share the resource footprint closely enough
+    if (resident == 0) {
+        int per_cu = 0, dev = 0;
+        hipDeviceProp_t prop;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k, 64 * kMfmaWaves, lds) == hipSuccess && per_cu > 0 &&
+            hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+            resident = per_cu * prop.multiProcessorCount;
+        else
+            resident = -1;
+        if (const char *ge = std::getenv("SELENITE_RX_MFMA_GRID")) resident = std::atoi(ge) > 0 ? std::atoi(ge) : -1;
+    }
+    uint32_t grid = p.channels / kMfmaWaves;
+    if (resident > 0 && (uint32_t)resident < grid) grid = (uint32_t)resident;
+    hipLaunchKernelGGL(k, dim3(grid), dim3(64 * kMfmaWaves), lds, st, p, fa, btab,
                        static_cast<const TIn *>(src), static_cast<TOut *>(dst));
     return hipGetLastError();
 }
