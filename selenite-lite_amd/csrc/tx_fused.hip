@@ -338,31 +338,41 @@ __global__ __launch_bounds__(64, 2) void k_tx_split16(TxParams p, uint32_t delay
     for (int u = kZS + kPass + 2 * lane; u < kZN; u += 2 * kWave) putz(u, 0.0f, 0.0f, 0.0f, 0.0f, 1.0f);   // finite slack under zero taps
     const bool am = p.mode == SELENITE_MODE_AM, up = mode_is_upper(p.mode);
     const int mcol = lane & 15, rg = lane >> 4;
+    // streaming state of a channel, branch-free (Hilbert-pair histories, interpolator history, ALC gain, NCO phase / step): loaded
+    // into registers -- for the next channel of this workgroup right after the current one is installed, so that its memory
+    // round trip hides under the current channel's passes -- and installed into LDS when the channel starts
+    float st_f[2], st_zi, st_zq, st_gain;
+    uint32_t st_ph0, st_step;
+    auto load_state = [&](uint32_t ch) {
+        const float *stF = p.fir_state + (size_t)ch * 2 * kHH, *stZ = p.int_state + (size_t)ch * 2 * (kP - 1);
+        const int sidx = lane - kFH, s0 = lane - 1;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) st_f[j] = stF[j * kHH + (sidx < 0 ? 0 : sidx)];
+        st_zi = stZ[s0 < 0 ? 0 : s0];
+        st_zq = stZ[(kP - 1) + (s0 < 0 ? 0 : s0)];
+        st_gain = p.alc ? p.gain[ch] : 1.0f;
+        st_ph0 = NCO ? p.phase[ch] : 0u;
+        st_step = NCO ? p.step[ch] : 0u;
+    };
+    load_state(blockIdx.x);
     for (uint32_t c = blockIdx.x; c < p.channels; c += gridDim.x) {
     const size_t in_base = (size_t)c * p.block_size, out_base = (size_t)c * p.block_size * kL;
     const uint32_t cn = c + gridDim.x < p.channels ? c + gridDim.x : c;     // next channel of this workgroup (or a harmless re-read)
     uint32_t e_hist;
-    {   // state, branch-free: Hilbert-pair histories and the interpolator history, all f32
-        const float *stF = p.fir_state + (size_t)c * 2 * kHH, *stZ = p.int_state + (size_t)c * 2 * (kP - 1);
-        float f[2];
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int sidx = lane - kFH;
-            const float x = stF[j * kHH + (sidx < 0 ? 0 : sidx)];
-            f[j] = sidx < 0 ? 0.0f : x;
-        }
-        HI[lane] = f[0]; HQ[lane] = f[1];
+    {
+        const int sidx = lane - kFH, s0 = lane - 1;
+        HI[lane] = sidx < 0 ? 0.0f : st_f[0];
+        HQ[lane] = sidx < 0 ? 0.0f : st_f[1];
         // history slot u = 1 + state index (slot 0 = the extra zero); lane owns slot `lane` of both rails
-        const int s0 = lane - 1;
-        const float zi = stZ[s0 < 0 ? 0 : s0], zq = stZ[(kP - 1) + (s0 < 0 ? 0 : s0)];
-        const float hi = s0 < 0 ? 0.0f : zi, hq = s0 < 0 ? 0.0f : zq;
+        const float hi = s0 < 0 ? 0.0f : st_zi, hq = s0 < 0 ? 0.0f : st_zq;
         ZF[kPass - kZS + lane] = hi;
         ZF[kPass + kPass - kZS + lane] = hq;
         e_hist = wave_umax_bits(fmaxf(fabsf(hi), fabsf(hq))) >> 23;
     }
     int s_cur = 0x7fff;
-    float gain = p.alc ? p.gain[c] : 1.0f;
-    const uint32_t ph0 = NCO ? p.phase[c] : 0u, step = NCO ? p.step[c] : 0u;
+    float gain = st_gain;
+    const uint32_t ph0 = st_ph0, step = st_step;
+    load_state(cn);                                                 // the next channel's state: in flight during this channel's passes
     wave_lds_sync();
 
     for (uint32_t pass = 0; pass < npass; ++pass) {
