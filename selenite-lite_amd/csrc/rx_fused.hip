@@ -406,27 +406,37 @@ __global__ __launch_bounds__(64 * kMfmaWaves, 2) void k_ssb_mfma(RxParams p, Fus
         lo_per[0] = *reinterpret_cast<const float4 *>(p.lo + 2 * lane);
         lo_per[1] = *reinterpret_cast<const float4 *>(p.lo + 128 + 2 * lane);
     }
+    // streaming state of a channel: loaded into registers (for the wavefront's next channel right after the current one is
+    // installed: the memory round trip hides under the current channel's passes), installed into LDS when the channel starts.
+    // History: flat sample f in [0, HS) is CMSIS state sample s = f - F (older slots meet zero taps)
+    float st_x[(2 * GM::HS + 63) / 64], st_d[NH > 0 ? (2 * G::HH4 + 63) / 64 : 1], st_gain;
+    uint32_t st_ph0, st_step;
+    auto load_state = [&](uint32_t ch) {
+        batched_load<2 * GM::HS>(lane, p.dec_state + (size_t)ch * 2 * (ND - 1),
+            [&](int i) {
+                const int rail = i / GM::HS, sidx = i % GM::HS - G::F;
+                return sidx >= 0 ? rail * (ND - 1) + sidx : -1;
+            }, st_x);
+        if constexpr (NH > 0)
+            batched_load<2 * G::HH4>(lane, p.fir_state + (size_t)ch * 2 * G::HH,
+                [&](int i) {
+                    const int rail = i / G::HH4, sidx = i % G::HH4 - G::FH;
+                    return sidx >= 0 ? rail * G::HH + sidx : -1;
+                }, st_d);
+        st_ph0 = NCO ? p.phase[ch] : 0u;
+        st_step = NCO ? p.step[ch] : 0u;
+        st_gain = p.agc ? p.gain[ch] : 1.0f;
+    };
+    load_state(c_first < p.channels ? c_first : p.channels - 1);
     for (uint32_t c = c_first; c < p.channels; c += c_step) {
     const size_t in_base = (size_t)c * p.in_stride, out_base = (size_t)c * p.out_stride;
     const uint32_t cn = c + c_step < p.channels ? c + c_step : c;        // next channel of this wavefront (or a harmless re-read)
-    // history: flat sample f in [0, HS) is CMSIS state sample s = f - F (older slots meet zero taps)
-    batched_fill<2 * GM::HS>(lane, p.dec_state + (size_t)c * 2 * (ND - 1),
-        [&](int i) {
-            const int rail = i / GM::HS, sidx = i % GM::HS - G::F;
-            return sidx >= 0 ? rail * (ND - 1) + sidx : -1;
-        },
-        [&](int i, float v) { (i / GM::HS ? XQ : XI)[GM::phys(i % GM::HS)] = v; });
-    if constexpr (NH > 0) {
-        batched_fill<2 * G::HH4>(lane, p.fir_state + (size_t)c * 2 * G::HH,
-            [&](int i) {
-                const int rail = i / G::HH4, sidx = i % G::HH4 - G::FH;
-                return sidx >= 0 ? rail * G::HH + sidx : -1;
-            },
-            [&](int i, float v) { D[(i / G::HH4) * G::DLEN + i % G::HH4] = v; });
-    }
-    const uint32_t ph0 = NCO ? p.phase[c] : 0u;
-    const uint32_t step = NCO ? p.step[c] : 0u;
-    float gain = p.agc ? p.gain[c] : 1.0f;
+    batched_store<2 * GM::HS>(lane, st_x, [&](int i, float v) { (i / GM::HS ? XQ : XI)[GM::phys(i % GM::HS)] = v; });
+    if constexpr (NH > 0)
+        batched_store<2 * G::HH4>(lane, st_d, [&](int i, float v) { D[(i / G::HH4) * G::DLEN + i % G::HH4] = v; });
+    const uint32_t ph0 = st_ph0, step = st_step;
+    float gain = st_gain;
+    load_state(cn);
 
     // ---- V phase, part 2: NCO mix of the prefetched pass into the X image, then prefetch the next ----
     auto stage = [&](uint32_t pass) {

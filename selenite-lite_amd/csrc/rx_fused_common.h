@@ -85,6 +85,28 @@ __device__ __forceinline__ void batched_fill(int lane, const float *__restrict__
     }
 }
 
+// the two halves of batched_fill on their own: the loads of a channel's state can then be issued long before its LDS slots are free
+template <int N, typename IndexFn>
+__device__ __forceinline__ void batched_load(int lane, const float *__restrict__ base, IndexFn index, float (&v)[(N + 63) / 64])
+{
+#pragma unroll
+    for (int j = 0; j < (N + 63) / 64; ++j) {
+        const int i = (N % 64 == 0) ? j * 64 + lane : min(j * 64 + lane, N - 1);
+        const int e = index(i);
+        const float x = base[e < 0 ? 0 : e];
+        v[j] = e < 0 ? 0.0f : x;
+    }
+}
+template <int N, typename StoreFn>
+__device__ __forceinline__ void batched_store(int lane, const float (&v)[(N + 63) / 64], StoreFn store)
+{
+#pragma unroll
+    for (int j = 0; j < (N + 63) / 64; ++j) {
+        const int i = j * 64 + lane;
+        if (N % 64 == 0 || i < N) store(i, v[j]);
+    }
+}
+
 __device__ __forceinline__ float f4get(const float4 &v, int e)
 {
     return e == 0 ? v.x : (e == 1 ? v.y : (e == 2 ? v.z : v.w));
