@@ -134,8 +134,10 @@ __global__ __launch_bounds__(64) void k_cw_fused(RxParams p, const TIn *__restri
                 } else {
                     const uint32_t cj = min(c0 + CG::CPL * j + lch, p.channels - 1);
                     const uint32_t phj = p.phase[cj], stj = p.step[cj];
-                    la = nco_lo<0>(tab, phj + (n_first + lsm) * stj);
-                    lb = nco_lo<0>(tab, phj + (n_first + lsm + 1) * stj);
+                    lo_v2f va, vb;                                    // arm_sin/cos_f32 restated for the vector ALU: same bits (rx_device.h)
+                    const uint32_t pe = phj + (n_first + lsm) * stj;
+                    nco_lo_pair(tab, pe, pe + stj, va, vb);
+                    la = make_float2(va.x, va.y); lb = make_float2(vb.x, vb.y);
                 }
                 xa = cmul<0>(a, la).x;                        // arm_cmplx_mult_cmplx_f32 real part: ac - bd
                 xb = cmul<0>(b, lb).x;

@@ -226,8 +226,11 @@ __global__ __launch_bounds__(64, 2) void k_ssb_fused(RxParams p, FusedArgs fa, c
                 a = cmul<0>(a, make_float2(l2.x, l2.y));
                 b = cmul<0>(b, make_float2(l2.z, l2.w));
             } else if constexpr (NCO == 1) {
-                a = cmul<0>(a, nco_lo<0>(tab, ph0 + (n0 + n) * step));
-                b = cmul<0>(b, nco_lo<0>(tab, ph0 + (n0 + n + 1) * step));
+                lo_v2f la, lb;                                            // arm_sin/cos_f32 restated for the vector ALU: same bits (rx_device.h)
+                const uint32_t pe = ph0 + (n0 + n) * step;
+                nco_lo_pair(tab, pe, pe + step, la, lb);
+                a = cmul<0>(a, make_float2(la.x, la.y));
+                b = cmul<0>(b, make_float2(lb.x, lb.y));
             }
             if constexpr (ND > 0) {
                 const int m = G::HQ4 + (int)(n / M), pp = (int)(n % M);   // n even: pp in {0,2}
@@ -462,8 +465,11 @@ __global__ __launch_bounds__(64 * kMfmaWaves, 2) void k_ssb_mfma(RxParams p, Fus
                 a = cmul<0>(a, make_float2(l2.x, l2.y));
                 b = cmul<0>(b, make_float2(l2.z, l2.w));
             } else if constexpr (NCO == 1) {
-                a = cmul<0>(a, nco_lo<0>(tab, ph0 + (n0 + n) * step));
-                b = cmul<0>(b, nco_lo<0>(tab, ph0 + (n0 + n + 1) * step));
+                lo_v2f la, lb;                                            // arm_sin/cos_f32 restated for the vector ALU: same bits (rx_device.h)
+                const uint32_t pe = ph0 + (n0 + n) * step;
+                nco_lo_pair(tab, pe, pe + step, la, lb);
+                a = cmul<0>(a, make_float2(la.x, la.y));
+                b = cmul<0>(b, make_float2(lb.x, lb.y));
             }
             const int f = GM::HS + (int)n;                            // even: (f, f+1) share a row
             const int ph = f + 2 * (f >> 6);
