@@ -502,9 +502,10 @@ __global__ __launch_bounds__(64, 2) void k_tx_split16(TxParams p, uint32_t delay
                     y1 = cmul<0>(y1, make_float2(l.z, -l.w));
                 } else if constexpr (NCO == 1) {
                     const uint32_t phase = ph0 + (pass * kPass * kL + o) * step;
-                    const float x0 = (float)(phase >> 8) * kNcoK, x1 = (float)((phase + step) >> 8) * kNcoK;
-                    y0 = cmul<0>(y0, make_float2(cos_f32<0>(tab, x0), sin_f32<0>(tab, x0)));
-                    y1 = cmul<0>(y1, make_float2(cos_f32<0>(tab, x1), sin_f32<0>(tab, x1)));
+                    lo_v2f la, lb;                                        // (cos, -sin) pairs, arm_sin/cos_f32 restated (rx_device.h): same bits
+                    nco_lo_pair(tab, phase, phase + step, la, lb);
+                    y0 = cmul<0>(y0, make_float2(la.x, -la.y));
+                    y1 = cmul<0>(y1, make_float2(lb.x, -lb.y));
                 }
                 const size_t at = out_base + (size_t)pass * kPass * kL + o;
                 if constexpr (sizeof(TOut) == 4) {
