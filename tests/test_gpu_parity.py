@@ -835,7 +835,7 @@ def test_periodic_shared_lo_in_registers_equals_the_table_path_bit_for_bit(q15):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("nd,M,nh", [(256, 2, 63), (256, 8, 63), (64, 4, 63), (128, 2, 63)])
+@pytest.mark.parametrize("nd,M,nh", [(256, 2, 63), (256, 8, 63), (64, 4, 63), (128, 2, 63), (128, 8, 63), (64, 2, 63), (64, 8, 63)])
 @pytest.mark.parametrize("arith", [ARITH_CMSIS, ARITH_FMA, rc.ARITH_SPLIT16])
 @pytest.mark.parametrize("q15", [False, True])
 def test_other_decimation_ratios_and_a_64_tap_decimator_run_the_fused_kernels(nd, M, nh, arith, q15):
@@ -847,7 +847,7 @@ def test_other_decimation_ratios_and_a_64_tap_decimator_run_the_fused_kernels(nd
     nch = 37
     kw = dict(nco=True, nco_step_all=0x01234567, agc=True)
     g = gpu_rx(rc.ChainSpec(nch, 256, M, nd, nh, 0, rc.MODE_USB, arith, **kw))
-    split = arith == rc.ARITH_SPLIT16 and M == 2                  # /2 has a split-precision matrix kernel of its own
+    split = arith == rc.ARITH_SPLIT16 and M == 2 and nd >= 128    # 128 / 256 taps by 2 have a split-precision matrix kernel of their own
     ref_arith = ARITH_CMSIS if split else (ARITH_FMA if arith == rc.ARITH_SPLIT16 else arith)
     o = CpuChain(rc.ChainSpec(nch, 256, M, nd, nh, 0, rc.MODE_USB, ref_arith, **kw), "orc")
     want = "k_ssb_split16" if split else ("k_ssb_mfma" if (arith != ARITH_CMSIS and M == 4) else "k_ssb_fused")
