@@ -22,6 +22,7 @@
 //      channel's gain (v_readlane), one global dwordx4 store per lane per row.
 // State (4 floats per channel-stage) is one coalesced dwordx4 load/store per lane per call.
 #include "rx_internal.h"
+#include <cstdlib>
 
 #pragma clang fp contract(off)
 
@@ -313,7 +314,8 @@ template <int NS, int NCO, typename TIn, typename TOut>
 static hipError_t cw_launch(const RxParams &p, const void *src, void *dst, hipStream_t st)
 {
     constexpr int CH = CwGeo<NS>::CH;
-    hipLaunchKernelGGL((k_cw_fused<NS, NCO, 256, TIn, TOut>), dim3((p.channels + CH - 1) / CH), dim3(64), 0, st, p,
+    static const size_t pad = std::getenv("SELENITE_RX_CW_LDS_PAD") ? (size_t)std::atoi(std::getenv("SELENITE_RX_CW_LDS_PAD")) : 0;   // occupancy experiments
+    hipLaunchKernelGGL((k_cw_fused<NS, NCO, 256, TIn, TOut>), dim3((p.channels + CH - 1) / CH), dim3(64), pad, st, p,
                        static_cast<const TIn *>(src), static_cast<TOut *>(dst));
     return hipGetLastError();
 }
