@@ -17,7 +17,16 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-5
 
 AMPS = [1e-30, 1e-7, 1e-6, 1e-5, 1e-4, 1e-3, 1e-2, 0.1, 1.0, 10.0, 200.0, 255.9, 256.0, 3.0e4, 1e20]
-KERNEL = {"cfg3": "k_ssb_split16<256,4,63>", "cfg2": "k_hilb_split16<127>", "cfg1": "k_hilb_split16<63>"}
+KERNEL = {"cfg3": "k_ssb_split16<256,4,63>", "cfg2": "k_hilb_split16<127>", "cfg1": "k_hilb_split16<63>",
+          "by2": "k_ssb_split16<256,2,63>"}
+
+
+def make_spec(name, nch, arith, **kw):
+    """BASELINE configurations, plus "by2": the cfg3 chain with a decimation by 2 (the other k_ssb_split16 geometry)"""
+    if name == "by2":
+        kw.setdefault("agc", True)
+        return rc.ChainSpec(nch, 256, 2, 256, 63, 0, rc.MODE_USB, arith, nco=True, nco_step_all=0x01000000, **kw)
+    return baseline_spec(name, nch, arith, **kw)
 
 
 def gpu_rx(spec):
@@ -34,8 +43,8 @@ def worst_block_err(yg, yo, na):
 
 
 def stream(name, nch, make_iq, ncalls=2, bs=2048, **spec_kw):
-    spec_s = baseline_spec(name, nch, rc.ARITH_SPLIT16, **spec_kw)
-    spec_c = baseline_spec(name, nch, ARITH_CMSIS, **spec_kw)
+    spec_s = make_spec(name, nch, rc.ARITH_SPLIT16, **spec_kw)
+    spec_c = make_spec(name, nch, ARITH_CMSIS, **spec_kw)
     g, o = gpu_rx(spec_s), CpuChain(spec_c, "orc")
     assert g.kernel_name() == KERNEL[name]
     na = spec_c.block // spec_c.decim
@@ -48,7 +57,7 @@ def stream(name, nch, make_iq, ncalls=2, bs=2048, **spec_kw):
     return worst, g, o
 
 
-@pytest.mark.parametrize("name", ["cfg3", "cfg2", "cfg1"])
+@pytest.mark.parametrize("name", ["cfg3", "cfg2", "cfg1", "by2"])
 @pytest.mark.parametrize("amp", AMPS)
 def test_amplitude_sweep(name, amp):
     nch = 6
@@ -56,13 +65,13 @@ def test_amplitude_sweep(name, amp):
     print("%s amp=%g worst per-block rel_err %.3g" % (name, amp, worst))
     assert worst <= TOL, (name, amp, worst)
     sg, so = g.state(), o.state()
-    if name == "cfg3":
+    if name in ("cfg3", "by2"):
         assert bits_equal(sg["dec_state"], so["dec_state"])      # the mixed samples are exact f32 at every amplitude
     else:
         assert bits_equal(sg["fir_state"], so["fir_state"])
 
 
-@pytest.mark.parametrize("name", ["cfg3", "cfg2"])
+@pytest.mark.parametrize("name", ["cfg3", "cfg2", "by2"])
 @pytest.mark.parametrize("amp", [1e-6, 1.0, 1e4])
 def test_amplitude_sweep_without_agc(name, amp):
     """AGC off: the audio itself spans the input's range (no gain_max / env_floor clamps in the way)."""
@@ -90,7 +99,7 @@ def test_two_tones_100_db_apart(name):
     del spec
 
 
-@pytest.mark.parametrize("name", ["cfg3", "cfg2"])
+@pytest.mark.parametrize("name", ["cfg3", "cfg2", "by2"])
 def test_level_steps_of_60_and_120_db_inside_a_call(name):
     """The block exponent follows the signal from pass to pass: bursts that rise and fall by 60 dB and 120 dB
     at positions that are not pass boundaries (the history part of the LDS image is re-split when the
@@ -111,17 +120,18 @@ def test_level_steps_of_60_and_120_db_inside_a_call(name):
     assert worst <= TOL, worst
 
 
-def test_split16_is_invariant_under_the_call_partition():
+@pytest.mark.parametrize("name,piece", [("cfg3", 1024), ("by2", 512)])
+def test_split16_is_invariant_under_the_call_partition(name, piece):
     """The block exponent of a pass depends only on the samples its LDS image holds, so one 4096-sample call and
-    four 1024-sample calls give identical bits (the full-size variant is in test_gpu_fullsize.py)."""
+    calls of one pass each (1024 samples by 4, 512 by 2) give identical bits (the full-size variant is in test_gpu_fullsize.py)."""
     nch = 7
-    spec = baseline_spec("cfg3", nch, rc.ARITH_SPLIT16)
+    spec = make_spec(name, nch, rc.ARITH_SPLIT16)
     a, b = gpu_rx(spec), gpu_rx(spec)
     amp = np.float32(3e-5)
     iq = (synth_iq(0, nch, 0, 4096) * amp).astype(np.float32)
     iq[:, 1500:2500] *= np.float32(1e3)
     ya = a.process(iq)
-    yb = np.concatenate([b.process(np.ascontiguousarray(iq[:, k:k + 1024])) for k in range(0, 4096, 1024)], axis=1)
+    yb = np.concatenate([b.process(np.ascontiguousarray(iq[:, k:k + piece])) for k in range(0, 4096, piece)], axis=1)
     assert bits_equal(ya, yb)
     sa, sb = a.state(), b.state()
     for k in sa:
