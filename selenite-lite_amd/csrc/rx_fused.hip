@@ -816,7 +816,8 @@ static hipError_t launch_shape(const RxParams &p, const FusedArgs &fa, const Fus
 // the instantiated shapes: BASELINE.json cfg1 / cfg2 / cfg3 (+ cfg5 = cfg2 chain) and their neighbours in both
 // tap counts -- decimator 128 / 256 taps by 4, Hilbert pair 31 / 63 / 127 taps, with or without the decimator
 #define SRX_SHAPES(X) X(256, 4, 63, 1) X(0, 1, 63, 2) X(0, 1, 127, 3) X(128, 4, 63, 4) X(256, 4, 127, 5) X(128, 4, 127, 6) X(256, 4, 31, 7) X(0, 1, 31, 8) \
-                      X(256, 2, 63, 9) X(256, 8, 63, 10) X(64, 4, 63, 11) X(128, 2, 63, 12) X(128, 8, 63, 13) X(64, 2, 63, 14) X(64, 8, 63, 15)
+                      X(256, 2, 63, 9) X(256, 8, 63, 10) X(64, 4, 63, 11) X(128, 2, 63, 12) X(128, 8, 63, 13) X(64, 2, 63, 14) X(64, 8, 63, 15) \
+                      X(128, 4, 31, 16) X(256, 2, 127, 17) X(128, 2, 127, 18) X(256, 2, 31, 19) X(128, 2, 31, 20)
 
 static bool fused_mode_ok(const selenite_rx_config &g)
 {

@@ -266,7 +266,8 @@ struct GeoH {
 };
 
 // instantiated shapes of the two kernel families (ND, M, NH) / (NH)
-#define SRX_SPLIT16_SHAPES(X) X(256, 4, 63) X(128, 4, 63) X(256, 4, 127) X(128, 4, 127) X(256, 4, 31) X(256, 2, 63) X(128, 2, 63)
+#define SRX_SPLIT16_SHAPES(X) X(256, 4, 63) X(128, 4, 63) X(256, 4, 127) X(128, 4, 127) X(256, 4, 31) X(128, 4, 31) \
+                              X(256, 2, 63) X(128, 2, 63) X(256, 2, 127) X(128, 2, 127) X(256, 2, 31) X(128, 2, 31)
 #define SRX_HILB16_SHAPES(X) X(63) X(127) X(31)
 hipError_t launch_ssb_split16(int nd, int m, int nh, const RxParams &p, const FusedArgs &fa, const void *src, bool q15,
                               void *dst, hipStream_t st);

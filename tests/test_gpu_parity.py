@@ -575,7 +575,7 @@ def test_call_lengths_that_are_not_whole_passes_split_into_fused_plus_generic(ar
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("nd,nh", [(128, 63), (256, 127), (128, 127), (256, 31)])
+@pytest.mark.parametrize("nd,nh", [(128, 63), (256, 127), (128, 127), (256, 31), (128, 31)])
 @pytest.mark.parametrize("arith", [ARITH_CMSIS, ARITH_FMA, rc.ARITH_SPLIT16])
 def test_neighbour_shapes_of_cfg3_run_the_fused_kernels(nd, nh, arith):
     """The decimating kernels are templates: besides the BASELINE shape the library instantiates a
@@ -835,7 +835,8 @@ def test_periodic_shared_lo_in_registers_equals_the_table_path_bit_for_bit(q15):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("nd,M,nh", [(256, 2, 63), (256, 8, 63), (64, 4, 63), (128, 2, 63), (128, 8, 63), (64, 2, 63), (64, 8, 63)])
+@pytest.mark.parametrize("nd,M,nh", [(256, 2, 63), (256, 8, 63), (64, 4, 63), (128, 2, 63), (128, 8, 63), (64, 2, 63), (64, 8, 63),
+                                     (256, 2, 127), (128, 2, 127), (256, 2, 31), (128, 2, 31)])
 @pytest.mark.parametrize("arith", [ARITH_CMSIS, ARITH_FMA, rc.ARITH_SPLIT16])
 @pytest.mark.parametrize("q15", [False, True])
 def test_other_decimation_ratios_and_a_64_tap_decimator_run_the_fused_kernels(nd, M, nh, arith, q15):
