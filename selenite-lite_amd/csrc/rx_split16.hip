@@ -206,7 +206,7 @@ __device__ __forceinline__ void agc_pass(const AgcParams &ap, uint32_t agc_on, i
 //   The pass loop body is branch-free apart from the (rare) history re-split: no exec-masked copy
 //   loops, no conditional prefetch (buffer range check instead), state written after the loop.
 // ------------------------------------------------------------------------------------------
-template <int NCO, int ND, int M, int NH, typename TIn, typename TOut, int AM, int GROUP>
+template <int NCO, int ND, int M, int NH, typename TIn, typename TOut, int AM, int GROUP, int ENV = 0>
 __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa, const TIn *__restrict__ src,
                                                        TOut *__restrict__ dst)
 {
@@ -253,9 +253,10 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
     __amdgpu_buffer_rsrc_t rs_out = make_rsrc(dst + (size_t)c * p.out_stride, p.nout * (W::kBytes / 4));
     // global gain, phase 1: the kernel runs with its own AGC off and leaves max |audio| of every DSP block of every channel
     // behind, so the envelope reduction does not have to read the audio again (GROUP == 16 launches with whole passes only)
-    const uint32_t env_nblk = p.env_part ? p.block_size / p.block : 0u;
+    // (ENV: its own instantiation -- the extra descriptor and branch cost the plain kernel 1.3 % when they were always compiled in)
+    const uint32_t env_nblk = ENV ? p.block_size / p.block : 0u;
     auto env_rsrc = [&](uint32_t ch) { return make_rsrc(p.env_part + (size_t)ch * env_nblk, env_nblk * 4u); };
-    __amdgpu_buffer_rsrc_t rs_env = env_rsrc(c);
+    __amdgpu_buffer_rsrc_t rs_env = env_rsrc(ENV ? c : 0u);
     const __amdgpu_buffer_rsrc_t rs_lo = make_rsrc(p.lo, NCO == 2 ? p.block_size * 8u : 0u);
     constexpr int kInPass = G::T * (R::kBytes / 2);               // input bytes of one pass
 
@@ -642,8 +643,8 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
 #else
         W::store(rs_out, lane * W::kBytes, (int)q * (G::P * (W::kBytes / 4)), au);
 #endif
-        if constexpr (GROUP == 16) {
-            if (env_nblk) {                                           // wave-uniform
+        if constexpr (GROUP == 16 && ENV != 0) {
+            {
                 const float m = row16_fmax(fmaxf(fmaxf(fabsf(au[0]), fabsf(au[1])), fmaxf(fabsf(au[2]), fabsf(au[3]))));
                 // block 4 q + (lane >> 4) from the first lane of its row; the other lanes point past the range (dropped)
                 const int voff = (lane & 15) == 0 ? (lane >> 4) * 4 : 0x40000000;
@@ -731,7 +732,7 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
         rs_in = rs_in_next;
         rs_in_next = in_rsrc(c + gridDim.x);
         rs_out = make_rsrc(dst + (size_t)c * p.out_stride, p.nout * (W::kBytes / 4));
-        rs_env = env_rsrc(c);
+        if constexpr (ENV != 0) rs_env = env_rsrc(c);
     }
     if (nonfinite) p.flags[0] = 1u;                                   // ARM_MATH_NANINF, read by selenite_rx_sync
     STAMP(1);
@@ -1314,6 +1315,14 @@ static hipError_t launch_k(const RxParams &p, const FusedArgs &fa, const void *s
         if (const char *e = std::getenv("SELENITE_RX_SPLIT16_GRID")) resident = std::atoi(e) > 0 ? std::atoi(e) : -1;
     }
     const uint32_t grid = resident > 0 && (uint32_t)resident < p.channels ? (uint32_t)resident : p.channels;
+    if constexpr (GROUP == 16 && AM == 0 && sizeof(TOut) == 4) {
+        if (p.env_part) {                         // global gain, phase 1: the flavour that also leaves the block maxima behind
+            hipLaunchKernelGGL((k_ssb_split16<NCO, ND, M, NH, TIn, TOut, AM, GROUP, 1>), dim3(grid), dim3(64), lds, st, p, fa,
+                               static_cast<const TIn *>(src), static_cast<TOut *>(dst));
+            return hipGetLastError();
+        }
+    }
+    if (p.env_part) return hipErrorNotSupported;  // the host side asks for the maxima only from launches that provide them
     hipLaunchKernelGGL((k_ssb_split16<NCO, ND, M, NH, TIn, TOut, AM, GROUP>), dim3(grid), dim3(64), lds, st, p, fa,
                        static_cast<const TIn *>(src), static_cast<TOut *>(dst));
     return hipGetLastError();
