@@ -136,7 +136,7 @@ def main():
     ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOAD_TEXT))
     ap.add_argument("--channels", type=int, default=0, help="channels per GPU (default: workload's)")
     ap.add_argument("--block-size", type=int, default=0)
-    ap.add_argument("--arith", default=os.environ.get("SELENITE_BENCH_ARITH", "split16"), choices=["cmsis", "fma", "split16"],
+    ap.add_argument("--arith", default=os.environ.get("SELENITE_BENCH_ARITH", "split16"), choices=["cmsis", "fma", "split16", "auto"],
                     help="split16 (default): many-tap FIR as f16 hi/lo split-precision MFMA product with a per-pass block "
                          "exponent, <=1e-5 rel vs CMSIS at any input level (north-star tolerance); fma: FIR tap loops "
                          "fused, bit-exact vs the fmaf oracle; cmsis: bit-exact CMSIS-DSP arithmetic")
@@ -174,7 +174,7 @@ def main():
     import selenite_rx as sr
     from selenite_rx import chain as ch
 
-    arith = {"fma": sr.ARITH_FMA, "cmsis": sr.ARITH_CMSIS, "split16": sr.ARITH_SPLIT16}[args.arith]
+    arith = {"fma": sr.ARITH_FMA, "cmsis": sr.ARITH_CMSIS, "split16": sr.ARITH_SPLIT16, "auto": sr.ARITH_AUTO}[args.arith]
     cfg_name, channels, bs = ch.WORKLOADS[args.workload]
     channels = args.channels or channels
     bs = args.block_size or bs
@@ -264,12 +264,13 @@ def main():
             "warmup": args.warmup, "spinup_ms": args.spinup_ms, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
             "dtype": ("f32 in / out / accumulate; FIR multiplicands as exact f16 hi+lo pairs (~22 bits) on the matrix cores"
-                      if arith == sr.ARITH_SPLIT16 and "split16" in rx.kernel_name() else "f32"),
+                      if arith in (sr.ARITH_SPLIT16, sr.ARITH_AUTO) and "split16" in rx.kernel_name() else "f32"),
             "data": "synthetic", "io": args.io,
             "config": {"workload": "%s: %d channels/GPU x %d complex samples/call, %s" % (
                            args.workload, channels, bs, WORKLOAD_TEXT[args.workload]),
                        "arith": {sr.ARITH_CMSIS: "cmsis-exact (mul,add)", sr.ARITH_FMA: "fma (<=1e-5 rel vs CMSIS)",
-                                 sr.ARITH_SPLIT16: "split16 (f16 hi/lo x3 MFMA FIR, block floating point, <=1e-5 rel vs CMSIS)"}[arith],
+                                 sr.ARITH_SPLIT16: "split16 (f16 hi/lo x3 MFMA FIR, block floating point, <=1e-5 rel vs CMSIS)",
+                                 sr.ARITH_AUTO: "auto (split16 + bit-exact rerun of the channels under the parity guard)"}[arith],
                        "kernel": rx.kernel_name(), "agc": "global" if args.global_gain else "per-channel",
                        "nco": rx.nco_path(),
                        "parallelism": "channels sharded x%d, no data-path collective" % world},

@@ -47,7 +47,7 @@ extern "C" {
 #define SELENITE_RX_ARGUMENT_ERROR (-1)  /* ARM_MATH_ARGUMENT_ERROR   */
 #define SELENITE_RX_LENGTH_ERROR   (-2)  /* ARM_MATH_LENGTH_ERROR     */
 #define SELENITE_RX_NANINF         (-4)  /* ARM_MATH_NANINF (arm_math.h:405): a process call produced NaN / Inf audio -- latched by
-                                           * selenite_rx_sync() and the host-pointer process calls; SELENITE_ARITH_SPLIT16 kernels only */
+                                           * selenite_rx_sync() and the host-pointer process calls (every fused kernel) */
 #define SELENITE_RX_DEVICE_ERROR   (-7)  /* outside arm_status: HIP device/runtime failure */
 
 /* Demodulator modes: the values of the firmware's Mode enum (Core/Inc/rxtx_if.h:33-43),
@@ -78,7 +78,16 @@ extern "C" {
                                     level); on channels with an EMPTY pass band the small block maximum makes
                                     the figure against CMSIS up to 2.7e-5.  Everything
                                     else, and every configuration without such a kernel, runs as
-                                    SELENITE_ARITH_FMA.  Streaming filter state stays exact f32. */
+                                    SELENITE_ARITH_FMA.  Streaming filter state stays exact f32.  Every DSP block
+                                    that falls outside the guaranteed zone is COUNTED (selenite_rx_guard_stats). */
+#define SELENITE_ARITH_AUTO 3    /* SELENITE_ARITH_SPLIT16 with the conditional zone closed: a channel with a guarded DSP
+                                    block in a call (max |audio| more than 12 dB under the largest sample its matrix
+                                    product saw -- selenite_rx_set_guard_ratio) is recomputed for that call, from its
+                                    pre-call streaming state, by the bit-exact SELENITE_ARITH_CMSIS kernel, on the device,
+                                    inside the same process call.  <=1e-5 relative vs CMSIS per DSP block on EVERY
+                                    block: unguarded blocks by the split product's accuracy (~1e-6 of the input level,
+                                    so <=1e-5 of a block maximum within 12 dB of it), guarded channels with 0 ULP.
+                                    Configurations without a split-precision kernel run as SELENITE_ARITH_CMSIS. */
 
 typedef struct selenite_rx_config {
     uint32_t struct_size;     /* = sizeof(selenite_rx_config) */
@@ -195,6 +204,24 @@ void selenite_rx_global_phase2_device(selenite_rx_instance *S, float *dDstAudio,
  * enqueued on the instance's stream.  RCCL is resolved at run time (no link dependency).  Returns the status. */
 int selenite_rx_global_process_f32_device(selenite_rx_instance *S, const float *dSrcIQ, float *dDstAudio,
                                           uint32_t blockSize, void *rccl_comm);
+
+/* ---- parity guard of the split-precision arithmetic (SELENITE_ARITH_SPLIT16 / _AUTO) -------------------------- */
+
+/* A DSP block is GUARDED when max |audio| of the block (before the AGC) is below `ratio` x the largest |component| of the
+ * mixed samples its pass of the matrix product held (new samples and FIR history): there the 1e-5-of-the-block-maximum
+ * figure against CMSIS is not guaranteed for the split product.  Default ratio 0.25 (-12 dB);
+ * 0 disables the guard, +inf guards every block with non-zero input (SELENITE_ARITH_AUTO then recomputes every channel
+ * bit-exactly: a test hook).  Takes effect with the next process call. */
+int selenite_rx_set_guard_ratio(selenite_rx_instance *S, float ratio);
+/* Counters since init / the last selenite_rx_guard_clear (any pointer may be NULL); drains the instance's stream:
+ *   guard_blocks         DSP blocks guarded
+ *   guard_channel_calls  (channel, process call) pairs with at least one guarded block
+ *   rerun_channel_calls  of those, how many SELENITE_ARITH_AUTO recomputed with the bit-exact kernel (0 for _SPLIT16) */
+int selenite_rx_guard_stats(selenite_rx_instance *S, uint64_t *guard_blocks, uint64_t *guard_channel_calls,
+                            uint64_t *rerun_channel_calls);
+/* per_channel[channels]: guarded DSP blocks of every channel since init / the last clear (sticky per-channel view). */
+int selenite_rx_guard_channels(selenite_rx_instance *S, uint32_t *per_channel);
+int selenite_rx_guard_clear(selenite_rx_instance *S);
 
 /* ---- streams, state, memory ----------------------------------------------------------- */
 

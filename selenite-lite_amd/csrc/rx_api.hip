@@ -110,7 +110,7 @@ static void classify_coeffs(selenite_rx_instance *S)
 
 static void free_device(selenite_rx_instance *S)
 {
-    void *ptrs[] = { S->d_flags, S->d_dec_c, S->d_hilb_c, S->d_delay_c, S->d_biq_c, S->d_sintab, S->d_step, S->d_phase,
+    void *ptrs[] = { S->d_flags, S->d_guard_ch, S->d_rerun_list, S->d_dec_c, S->d_hilb_c, S->d_delay_c, S->d_biq_c, S->d_sintab, S->d_step, S->d_phase,
                      S->d_dec_state, S->d_fir_state, S->d_biq_state, S->d_gain, S->d_scratch, S->d_env, S->d_env_part,
                      S->d_io_in, S->d_io_out, S->d_lo, S->pipe.d_in[0], S->pipe.d_in[1], S->pipe.d_out[0], S->pipe.d_out[1] };
     for (void *p : ptrs)
@@ -136,7 +136,9 @@ static int reset_state(selenite_rx_instance *S)
     if (g.nh_taps > 1) HIPCHK(S, hipMemsetAsync(S->d_fir_state, 0, C * 2 * (g.nh_taps - 1) * sizeof(float), S->stream));
     if (g.n_biquad) HIPCHK(S, hipMemsetAsync(S->d_biq_state, 0, C * 4 * g.n_biquad * sizeof(float), S->stream));
     HIPCHK(S, hipMemsetAsync(S->d_phase, 0, C * sizeof(uint32_t), S->stream));
-    HIPCHK(S, hipMemsetAsync(S->d_flags, 0, sizeof(uint32_t), S->stream));
+    HIPCHK(S, hipMemsetAsync(S->d_flags, 0, kFlagWords * sizeof(uint32_t), S->stream));
+    HIPCHK(S, hipMemsetAsync(S->d_guard_ch, 0, C * sizeof(uint32_t), S->stream));
+    S->rerun_parity = 0;
     std::vector<float> gi(C, g.agc_gain_init);
     HIPCHK(S, hipMemcpyAsync(S->d_gain, gi.data(), C * sizeof(float), hipMemcpyHostToDevice, S->stream));
     HIPCHK(S, hipStreamSynchronize(S->stream));
@@ -179,7 +181,8 @@ extern "C" int selenite_rx_init(selenite_rx_instance **out, const selenite_rx_co
         return fail(nullptr, SELENITE_RX_ARGUMENT_ERROR, "selenite_rx_init: channels, block, decim must be non-zero");
     if (!mode_valid(cfg->mode))
         return fail(nullptr, SELENITE_RX_ARGUMENT_ERROR, "selenite_rx_init: unsupported mode (FM is not demodulated)");
-    if (cfg->arith != SELENITE_ARITH_CMSIS && cfg->arith != SELENITE_ARITH_FMA && cfg->arith != SELENITE_ARITH_SPLIT16)
+    if (cfg->arith != SELENITE_ARITH_CMSIS && cfg->arith != SELENITE_ARITH_FMA && cfg->arith != SELENITE_ARITH_SPLIT16 &&
+        cfg->arith != SELENITE_ARITH_AUTO)
         return fail(nullptr, SELENITE_RX_ARGUMENT_ERROR, "selenite_rx_init: bad arith");
     if (cfg->nd_taps == 0 && cfg->decim != 1)
         return fail(nullptr, SELENITE_RX_ARGUMENT_ERROR, "selenite_rx_init: decim > 1 needs a decimator (nd_taps)");
@@ -216,6 +219,8 @@ extern "C" int selenite_rx_init(selenite_rx_instance **out, const selenite_rx_co
     S->cfg.nco_step = S->h_step.data();
     S->steps_uniform = true;
     for (size_t c = 1; c < C; ++c) S->steps_uniform = S->steps_uniform && S->h_step[c] == S->h_step[0];
+    S->steps_grid256 = true;
+    for (size_t c = 0; c < C; ++c) S->steps_grid256 = S->steps_grid256 && (S->h_step[c] & 0x00FFFFFFu) == 0;
     const char *fg = std::getenv("SELENITE_RX_FORCE_GENERIC");
     S->force_generic = (fg && fg[0] == '1') ? 1 : 0;
     const char *nl = std::getenv("SELENITE_RX_NO_SHARED_LO");
@@ -249,7 +254,9 @@ extern "C" int selenite_rx_init(selenite_rx_instance **out, const selenite_rx_co
     INITCHK(dev_alloc(&S->d_fir_state, cfg->nh_taps > 1 ? C * 2 * (cfg->nh_taps - 1) : 0));
     INITCHK(dev_alloc(&S->d_biq_state, C * 4 * cfg->n_biquad));
     INITCHK(dev_alloc(&S->d_gain, C));
-    INITCHK(dev_alloc(&S->d_flags, (size_t)1));
+    INITCHK(dev_alloc(&S->d_flags, (size_t)kFlagWords));
+    INITCHK(dev_alloc(&S->d_guard_ch, C));
+    INITCHK(dev_alloc(&S->d_rerun_list, cfg->arith == SELENITE_ARITH_AUTO ? C : 0));
 #undef INITCHK
     classify_coeffs(S);
     if (plan_fused(S->cfg, S->delay_is_impulse, S->delay_index, S->hilb_odd_only, S->plan) != hipSuccess) {
@@ -305,10 +312,21 @@ static bool periodic_lo(const selenite_rx_instance *S)
 {
     const selenite_rx_config &g = S->cfg;
     if (!(g.nco_enable && S->steps_uniform && (S->h_step[0] & 0x00FFFFFFu) == 0 && !S->no_periodic_lo)) return false;
-    if (g.arith == SELENITE_ARITH_SPLIT16 && S->plan.d_btab16 && g.nd_taps)
+    if ((g.arith == SELENITE_ARITH_SPLIT16 || g.arith == SELENITE_ARITH_AUTO) && S->plan.d_btab16 && g.nd_taps)
         return ssb_split16_periodic_lo((int)g.nd_taps, (int)g.decim, (int)g.nh_taps);
+    if (g.arith == SELENITE_ARITH_AUTO) return false;      // (runs the bit-exact k_ssb_fused)
     // k_ssb_mfma (fma arithmetic, and split16 shapes without a matrix kernel of their own): decimation by 4, 1024-sample passes
     return g.arith != SELENITE_ARITH_CMSIS && S->plan.use_mfma && g.nd_taps && g.decim == 4;
+}
+
+// every channel has its own LO, each of them periodic in 256 samples (all steps multiples of 2^24), and the split16 kernel
+// of this instance computes it once per channel and keeps it in registers (its NCO == 4 flavour)
+static bool periodic_lo_per_channel(const selenite_rx_instance *S)
+{
+    const selenite_rx_config &g = S->cfg;
+    return g.nco_enable && S->steps_grid256 && !S->no_periodic_lo && g.nd_taps && S->plan.d_btab16 &&
+           (g.arith == SELENITE_ARITH_SPLIT16 || g.arith == SELENITE_ARITH_AUTO) &&
+           ssb_split16_periodic_lo((int)g.nd_taps, (int)g.decim, (int)g.nh_taps);
 }
 
 extern "C" const char *selenite_rx_nco_path(const selenite_rx_instance *S)
@@ -316,7 +334,11 @@ extern "C" const char *selenite_rx_nco_path(const selenite_rx_instance *S)
     if (!S) return "";
     if (!S->cfg.nco_enable) return "off";
     const bool fused = !S->force_generic && (S->plan.kind != 0 || cw_fused_ok(S->cfg, S->cfg.block));
-    if (!fused || !S->steps_uniform || !S->phase_uniform || S->no_shared_lo) return "per-channel arm_sin/cos_f32 in the kernel";
+    if (!fused || !S->steps_uniform || !S->phase_uniform || S->no_shared_lo) {
+        if (fused && S->plan.kind != 0 && periodic_lo_per_channel(S))
+            return "per-channel LO, period 256 samples (arm_sin/cos_f32 once per channel and call), held in registers";
+        return "per-channel arm_sin/cos_f32 in the kernel";
+    }
     return periodic_lo(S) ? "shared LO, period 256 samples, held in registers" : "shared LO table per call";
 }
 
@@ -341,6 +363,47 @@ extern "C" int selenite_rx_sync(selenite_rx_instance *S)
     return check_device_flags(S);
 }
 
+extern "C" int selenite_rx_set_guard_ratio(selenite_rx_instance *S, float ratio)
+{
+    if (!S || !(ratio >= 0.0f)) return SELENITE_RX_ARGUMENT_ERROR;      // (NaN rejected)
+    S->guard_ratio = ratio;
+    return SELENITE_RX_SUCCESS;
+}
+
+extern "C" int selenite_rx_guard_stats(selenite_rx_instance *S, uint64_t *guard_blocks, uint64_t *guard_channel_calls,
+                                       uint64_t *rerun_channel_calls)
+{
+    if (!S) return SELENITE_RX_ARGUMENT_ERROR;
+    HIPCHK(S, hipSetDevice(S->device));
+    HIPCHK(S, hipStreamSynchronize(S->stream));
+    uint32_t w[kFlagWords];
+    HIPCHK(S, hipMemcpy(w, S->d_flags, sizeof w, hipMemcpyDeviceToHost));
+    auto u64 = [&](int i) { return (uint64_t)w[i] | ((uint64_t)w[i + 1] << 32); };
+    if (guard_blocks) *guard_blocks = u64(kFlagGuardBlocks);
+    if (guard_channel_calls) *guard_channel_calls = u64(kFlagGuardCalls);
+    if (rerun_channel_calls) *rerun_channel_calls = u64(kFlagRerunCalls);
+    return SELENITE_RX_SUCCESS;
+}
+
+extern "C" int selenite_rx_guard_channels(selenite_rx_instance *S, uint32_t *per_channel)
+{
+    if (!S || !per_channel) return SELENITE_RX_ARGUMENT_ERROR;
+    HIPCHK(S, hipSetDevice(S->device));
+    HIPCHK(S, hipStreamSynchronize(S->stream));
+    HIPCHK(S, hipMemcpy(per_channel, S->d_guard_ch, (size_t)S->cfg.channels * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return SELENITE_RX_SUCCESS;
+}
+
+extern "C" int selenite_rx_guard_clear(selenite_rx_instance *S)
+{
+    if (!S) return SELENITE_RX_ARGUMENT_ERROR;
+    HIPCHK(S, hipSetDevice(S->device));
+    // the three 64-bit counters only: the rerun counters of the launches in flight stay
+    HIPCHK(S, hipMemsetAsync(S->d_flags + kFlagGuardBlocks, 0, 6 * sizeof(uint32_t), S->stream));
+    HIPCHK(S, hipMemsetAsync(S->d_guard_ch, 0, (size_t)S->cfg.channels * sizeof(uint32_t), S->stream));
+    return SELENITE_RX_SUCCESS;
+}
+
 extern "C" int selenite_rx_reset(selenite_rx_instance *S)
 {
     if (!S) return SELENITE_RX_ARGUMENT_ERROR;
@@ -362,10 +425,12 @@ static RxParams make_params(selenite_rx_instance *S, uint32_t block_size)
     p.dec_state = S->d_dec_state; p.fir_state = S->d_fir_state; p.biq_state = S->d_biq_state;
     p.gain = S->d_gain;
     p.flags = S->d_flags;
+    p.guard_ratio = S->guard_ratio;
+    p.guard_ch = S->d_guard_ch;
     if (S->sub_count) {                                     // a contiguous channel range of the instance: every per-channel array moves with it
         const size_t c0 = S->sub_first;
         p.channels = S->sub_count;
-        p.step += c0; p.phase += c0; p.gain += c0;
+        p.step += c0; p.phase += c0; p.gain += c0; p.guard_ch += c0;
         if (p.dec_state) p.dec_state += c0 * 2 * (g.nd_taps - 1);
         if (p.fir_state) p.fir_state += c0 * 2 * (g.nh_taps - 1);
         if (p.biq_state) p.biq_state += c0 * 4 * g.n_biquad;
@@ -412,6 +477,7 @@ static int run_part(selenite_rx_instance *S, const void *src, bool src_q15, void
     if (front_generic_lds_bytes(p) > 64 * 1024 && (S->force_generic || S->plan.kind == 0))
         return fail(S, SELENITE_RX_LENGTH_ERROR, "filter lengths exceed the LDS budget of the generic kernel");
     const int arith = (int)g.arith;
+    const int garith = arith == SELENITE_ARITH_AUTO ? SELENITE_ARITH_CMSIS : arith;      // the generic kernels: AUTO is bit-exact there
     const bool global = g.agc_enable && g.agc_global;
     const bool cw = mode_is_cw(g.mode) && g.n_biquad;
     hipStream_t st = S->stream;
@@ -444,18 +510,30 @@ static int run_part(selenite_rx_instance *S, const void *src, bool src_q15, void
             // the table is a pure function of (start phase, step, length): a call that starts where the table in d_lo
             // starts reuses it -- every chunk of a pipelined host call, and EVERY call when the phase advance of a call
             // is a multiple of 2^32 (an LO on the fs / 256 grid with calls of whole DSP blocks)
-            if (!(S->lo_valid && S->lo_phase == phase_now && S->lo_step == S->h_step[0] && S->lo_n >= block_size)) {
+            // (at least one whole period: the register-resident flavour reads LO[0 .. 255] whatever the call length)
+            const uint32_t lo_n = block_size < 256u ? 256u : block_size;
+            if (!(S->lo_valid && S->lo_phase == phase_now && S->lo_step == S->h_step[0] && S->lo_n >= lo_n)) {
                 S->lo_valid = false;
-                int rc = ensure(S, (void **)&S->d_lo, &S->lo_bytes, (size_t)block_size * sizeof(float2));
+                int rc = ensure(S, (void **)&S->d_lo, &S->lo_bytes, (size_t)lo_n * sizeof(float2));
                 if (rc) return rc;
-                HIPCHK(S, launch_lo_table(S->d_lo, S->d_sintab, phase_now, S->h_step[0], block_size, st));
-                S->lo_valid = true; S->lo_phase = phase_now; S->lo_step = S->h_step[0]; S->lo_n = block_size;
+                HIPCHK(S, launch_lo_table(S->d_lo, S->d_sintab, phase_now, S->h_step[0], lo_n, st));
+                S->lo_valid = true; S->lo_phase = phase_now; S->lo_step = S->h_step[0]; S->lo_n = lo_n;
             }
             pf.nco = 2;
             pf.lo = S->d_lo;
             // a step that is a multiple of 2^24 repeats the LO every 256 samples (channelised receivers: LO
             // frequencies on a grid of fs / 256): k_ssb_split16 then keeps it in registers (its NCO == 3 flavour)
             pf.lo_period = periodic_lo(S) ? 256u : 0u;
+        } else if (ssb_fused && periodic_lo_per_channel(S)) {
+            pf.lo_period = 256u;                          // pf.nco stays 1: every channel computes its own period once
+        }
+        if (arith == SELENITE_ARITH_AUTO && ssb_fused) {
+            // the split16 kernel appends the channels it guards to d_rerun_list (counter of this launch: d_flags[kFlagRerunCnt0 +
+            // parity]; it zeroes the OTHER counter for the next launch) and the bit-exact kernel recomputes them (launch_fused)
+            pf.rerun_list = S->d_rerun_list;
+            pf.rerun_cnt = S->d_flags + kFlagRerunCnt0 + S->rerun_parity;
+            pf.rerun_cnt_other = S->d_flags + kFlagRerunCnt0 + (S->rerun_parity ^ 1u);
+            S->rerun_parity ^= 1u;
         }
         void *fdst = dst;
         bool fq15 = dst_q15;
@@ -463,8 +541,8 @@ static int run_part(selenite_rx_instance *S, const void *src, bool src_q15, void
             pf.agc = 0; fdst = audio; fq15 = false;
             // k_ssb_split16 (16-lane DSP blocks, whole passes) leaves the block maxima of every channel behind: the
             // envelope reduction below then folds channels x blocks floats instead of reading the audio again
-            if (ssb_fused && arith == SELENITE_ARITH_SPLIT16 && S->plan.d_btab16 && g.nd_taps && (g.block / g.decim) / 4 == 16 &&
-                (block_size / g.decim) % 256 == 0 && g.nco_enable && g.mode != SELENITE_MODE_AM) {   // the launches with the DPP block reductions
+            if (ssb_fused && arith == SELENITE_ARITH_SPLIT16 && S->plan.d_btab16 && g.nd_taps && g.decim == 4 && (g.block / g.decim) / 4 == 16 &&
+                (block_size / g.decim) % 256 == 0 && g.nco_enable && g.mode != SELENITE_MODE_AM) {   // the launches with the DPP block reductions (decimation by 4, 64-sample audio blocks)
                 const size_t need = sizeof(float) * env_fold_scratch_floats(p.channels, block_size / g.block);
                 int rc = ensure(S, (void **)&S->d_env_part, &S->env_part_cap, need);
                 if (rc) return rc;
@@ -480,9 +558,9 @@ static int run_part(selenite_rx_instance *S, const void *src, bool src_q15, void
 
     // generic path: front -> [biquad] -> AGC / convert
     if (phase != kPhase2 && !(ssb_fused || cw_fused)) {
-        HIPCHK(S, launch_front_generic(p, arith, src, src_q15, audio, st));
+        HIPCHK(S, launch_front_generic(p, garith, src, src_q15, audio, st));
         commit_phase();
-        if (cw) HIPCHK(S, launch_biquad_generic(p, arith, audio, st));
+        if (cw) HIPCHK(S, launch_biquad_generic(p, garith, audio, st));
     }
     if (global) {
         float *env = ext_env;
@@ -502,9 +580,9 @@ static int run_part(selenite_rx_instance *S, const void *src, bool src_q15, void
                 HIPCHK(S, launch_env_global(p, audio, S->d_env_part, env, st));
             }
         }
-        if (phase != kPhase1) HIPCHK(S, launch_agc_apply_global(p, arith, audio, env, dst, dst_q15, st));
+        if (phase != kPhase1) HIPCHK(S, launch_agc_apply_global(p, garith, audio, env, dst, dst_q15, st));
     } else if (g.agc_enable || dst_q15) {
-        HIPCHK(S, launch_agc_generic(p, arith, audio, dst, dst_q15, st));
+        HIPCHK(S, launch_agc_generic(p, garith, audio, dst, dst_q15, st));
     }
     return SELENITE_RX_SUCCESS;
 }

@@ -219,11 +219,11 @@ __global__ __launch_bounds__(64) void k_cw_fused(RxParams p, const TIn *__restri
             cw_lds_sync();
             // ---- 2. TPC trips of 4 systolic steps; stage-0 input is one aligned float4 per trip ----
             int i = TPC * q;
-            float4 xq = *reinterpret_cast<const float4 *>(rbase + 4 * i);
+            float4 xq = lds_ld4f(rbase + 4 * i);
             if (q == 0) {                                             // block prologue: the D fill steps, first outputs into `car`
 #pragma unroll
                 for (int tpro = 0; tpro < PRO; ++tpro) {
-                    const float4 xn = *reinterpret_cast<const float4 *>(rbase + 4 * (tpro + 1));
+                    const float4 xn = lds_ld4f(rbase + 4 * (tpro + 1));
                     const float o[4] = { step_masked(xq.x, 4 * tpro), step_masked(xq.y, 4 * tpro + 1),
                                          step_masked(xq.z, 4 * tpro + 2), step_masked(xq.w, 4 * tpro + 3) };
                     if (tpro == PRO - 1) {
@@ -241,7 +241,7 @@ __global__ __launch_bounds__(64) void k_cw_fused(RxParams p, const TIn *__restri
             for (; i < TPC * q + TPC; ++i) {
                 // prefetch the next trip's input (stays inside this chunk; harmless re-read at the end)
                 const int inext = (i + 1 < TPC * q + TPC) ? i + 1 : i;
-                const float4 xn = *reinterpret_cast<const float4 *>(rbase + 4 * inext);
+                const float4 xn = lds_ld4f(rbase + 4 * inext);
                 float o[4];
                 trip4(xq, o);
                 // the aligned group y[4(i-PRO) .. +3]: NCAR carried outputs, then the first R of this trip
@@ -280,7 +280,7 @@ __global__ __launch_bounds__(64) void k_cw_fused(RxParams p, const TIn *__restri
             for (int h = 0; h < (BLK / 4 + 63) / 64; ++h) {
                 const int t = 4 * (lane + 64 * h);
                 if (t < BLK && c0 + r < p.channels) {
-                    float4 v = *reinterpret_cast<const float4 *>(tile + r * RS + t);
+                    float4 v = lds_ld4f(tile + r * RS + t);
                     v.x = v.x * g; v.y = v.y * g; v.z = v.z * g; v.w = v.w * g;
                     const size_t o = (size_t)(c0 + r) * p.out_stride + n0 + t;
                     if constexpr (sizeof(TOut) == 4) {

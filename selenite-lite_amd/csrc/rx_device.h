@@ -19,6 +19,20 @@
 namespace srx {
 
 constexpr int kWave = 64;
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+
+// 16-byte LDS access as ONE ds_read_b128 / ds_write_b128.  HIP's float4 is a struct whose loads the backend may only assume to
+// be 8-byte aligned: it then emits ds_read2_b64 -- two 8-byte accesses banked modulo 32 dwords, i.e. 2-way conflicts at a
+// 16-byte lane stride and four times the LDS cycles of a ds_read_b128 (measured: the Hilbert reads of k_ssb_split16 owned
+// 69 % of the kernel's bank-conflict cycles, profiles/r3/lds_conflicts.txt).  A native 4-vector carries the alignment.
+__device__ __forceinline__ v4f lds_ld4(const float *p) { return *reinterpret_cast<const v4f *>(__builtin_assume_aligned(p, 16)); }
+__device__ __forceinline__ void lds_st4(float *p, v4f v) { *reinterpret_cast<v4f *>(__builtin_assume_aligned(p, 16)) = v; }
+__device__ __forceinline__ float4 lds_ld4f(const float *p) { const v4f v = lds_ld4(p); return make_float4(v.x, v.y, v.z, v.w); }
+__device__ __forceinline__ void lds_st4f(float *p, float4 v) { lds_st4(p, v4f{ v.x, v.y, v.z, v.w }); }
+
 constexpr float kNcoK = 0x1.921fb6p-22f;        // 2*pi / 2^24: radians per (phase >> 8) unit
 constexpr float kInv2Pi = 0.159154943092f;      // arm_sin_f32.c:88, arm_cos_f32.c:81
 

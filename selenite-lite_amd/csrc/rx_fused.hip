@@ -48,7 +48,7 @@ __device__ __forceinline__ void decim_quad(const float *S, int lane, const float
         float4 W[M];
 #pragma unroll
         for (int p = 0; p < M; ++p)
-            W[p] = *reinterpret_cast<const float4 *>(base + p * G::PSF + 4 * (3 * (o >> 1) + (o & 1)));
+            W[p] = lds_ld4f(base + p * G::PSF + 4 * (3 * (o >> 1) + (o & 1)));
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
 #pragma unroll
@@ -77,14 +77,14 @@ template <int ARITH, int GROUP, int ND, int M, int NH, typename TOut, int AM = 0
 __device__ __forceinline__ void demod_agc_store(const RxParams &p, const FusedArgs &fa, const float *dI,
                                                 const float *dQ, int lane, int group,
                                                 const float (&hreg)[(NH + 63) / 64 ? (NH + 63) / 64 : 1], float &gain,
-                                                TOut *__restrict__ dst, size_t out_index)
+                                                TOut *__restrict__ dst, size_t out_index, bool &nonfinite)
 {
     using G = Geo<ND, M, NH>;
     float au[4];
     if constexpr (NH > 0 && AM != 0) {
         // AM: envelope of the decimated rails; new sample n of a pass sits at HH4 + n
-        const float4 vi = *reinterpret_cast<const float4 *>(dI + G::HH4 + 4 * lane);
-        const float4 vq = *reinterpret_cast<const float4 *>(dQ + G::HH4 + 4 * lane);
+        const float4 vi = lds_ld4f(dI + G::HH4 + 4 * lane);
+        const float4 vq = lds_ld4f(dQ + G::HH4 + 4 * lane);
         au[0] = cmag<0>(vi.x, vq.x); au[1] = cmag<0>(vi.y, vq.y);
         au[2] = cmag<0>(vi.z, vq.z); au[3] = cmag<0>(vi.w, vq.w);
     } else if constexpr (NH > 0) {
@@ -97,7 +97,7 @@ __device__ __forceinline__ void demod_agc_store(const RxParams &p, const FusedAr
             au[r] = fa.upper ? (i2 - q2[r]) : (i2 + q2[r]);       // arm_sub_f32 / arm_add_f32
         }
     } else {
-        const float4 v = *reinterpret_cast<const float4 *>(dI + 4 * lane);
+        const float4 v = lds_ld4f(dI + 4 * lane);
         au[0] = v.x; au[1] = v.y; au[2] = v.z; au[3] = v.w;
     }
     // AGC: arm_abs + arm_max per DSP block (group lanes), gain law, arm_scale
@@ -137,6 +137,10 @@ __device__ __forceinline__ void demod_agc_store(const RxParams &p, const FusedAr
 #pragma unroll
         for (int r = 0; r < 4; ++r) au[r] = au[r] * mine;
     }
+    {   // ARM_MATH_NANINF: x * 0 is NaN iff x is not finite
+        const float z = __builtin_fmaf(au[3], 0.0f, __builtin_fmaf(au[2], 0.0f, __builtin_fmaf(au[1], 0.0f, au[0] * 0.0f)));
+        nonfinite = nonfinite || (z != z);
+    }
     const size_t o = out_index + 4 * lane;
     if constexpr (sizeof(TOut) == 4) {
         *reinterpret_cast<float4 *>(reinterpret_cast<float *>(dst) + o) = make_float4(au[0], au[1], au[2], au[3]);
@@ -157,12 +161,20 @@ __global__ __launch_bounds__(64, 2) void k_ssb_fused(RxParams p, FusedArgs fa, c
     static_assert(ND == 0 ? M == 1 : (M == 2 || M == 4 || M == 8), "fused kernel: no decimator, or decimate by 2, 4 or 8");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x;
-    const uint32_t c = blockIdx.x;
     float *tab = lds + G::oTab;
     float *S = lds + G::oS;
     float *D = lds + G::oD;
     float *dI = D, *dQ = D + G::DLEN;
     constexpr int NLD = G::T / 128;                      // raw loads per lane per pass
+    bool nonfinite = false;                              // any audio sample of this workgroup NaN / Inf
+    // One channel per workgroup, c = blockIdx.x -- or, as the rerun pass of SELENITE_ARITH_AUTO (p.chan_list: the channels
+    // whose split-precision result fell under the parity guard, appended by the split16 kernel of the same call), the list
+    // entries blockIdx.x, blockIdx.x + gridDim.x, ...: the count is only known on the device.
+    uint32_t li = blockIdx.x;
+    const uint32_t ln = p.chan_list ? *p.chan_count : 0u;
+    if (p.chan_list && li >= ln) return;
+  for (;;) {
+    const uint32_t c = p.chan_list ? p.chan_list[li] : li;
 
     const size_t in_base = (size_t)c * p.in_stride, out_base = (size_t)c * p.out_stride;
     const uint32_t npass = p.nout / G::P;
@@ -258,11 +270,11 @@ __global__ __launch_bounds__(64, 2) void k_ssb_fused(RxParams p, FusedArgs fa, c
         }
         // ---- 3-5. Hilbert pair + sideband, AGC, store ----
         if (group == 16)
-            demod_agc_store<ARITH, 16, ND, M, NH, TOut, AM>(p, fa, dI, dQ, lane, group, hreg, gain, dst, out_base + (size_t)pass * G::P);
+            demod_agc_store<ARITH, 16, ND, M, NH, TOut, AM>(p, fa, dI, dQ, lane, group, hreg, gain, dst, out_base + (size_t)pass * G::P, nonfinite);
         else if (group == 64)
-            demod_agc_store<ARITH, 64, ND, M, NH, TOut, AM>(p, fa, dI, dQ, lane, group, hreg, gain, dst, out_base + (size_t)pass * G::P);
+            demod_agc_store<ARITH, 64, ND, M, NH, TOut, AM>(p, fa, dI, dQ, lane, group, hreg, gain, dst, out_base + (size_t)pass * G::P, nonfinite);
         else
-            demod_agc_store<ARITH, 0, ND, M, NH, TOut, AM>(p, fa, dI, dQ, lane, group, hreg, gain, dst, out_base + (size_t)pass * G::P);
+            demod_agc_store<ARITH, 0, ND, M, NH, TOut, AM>(p, fa, dI, dQ, lane, group, hreg, gain, dst, out_base + (size_t)pass * G::P, nonfinite);
         wave_lds_sync();
         // ---- 6. history copy-back (arm_fir_decimate_f32.c:396-426, arm_fir_f32.c:947-978) ----
         if constexpr (ND > 0) {
@@ -274,8 +286,8 @@ __global__ __launch_bounds__(64, 2) void k_ssb_fused(RxParams p, FusedArgs fa, c
                 const int i = k * 64 + lane;
                 if (i < NG) {
                     const float *sp = S + (i / (G::HQ4 / 4)) * G::PSF + 12 * (G::P / 4 + i % (G::HQ4 / 4));
-                    t0[k] = *reinterpret_cast<const float4 *>(sp);
-                    t1[k] = *reinterpret_cast<const float4 *>(sp + 4);
+                    t0[k] = lds_ld4f(sp);
+                    t1[k] = lds_ld4f(sp + 4);
                 }
             }
             wave_lds_sync();
@@ -294,7 +306,7 @@ __global__ __launch_bounds__(64, 2) void k_ssb_fused(RxParams p, FusedArgs fa, c
             static_assert(NV <= 64, "Hilbert history move assumes <= 64 float4");
             float4 tmp;
             const int rail = lane / (G::HH4 / 4), v = lane % (G::HH4 / 4);
-            if (lane < NV) tmp = *reinterpret_cast<const float4 *>(D + rail * G::DLEN + G::P + 4 * v);
+            if (lane < NV) tmp = lds_ld4f(D + rail * G::DLEN + G::P + 4 * v);
             wave_lds_sync();
             if (lane < NV) *reinterpret_cast<float4 *>(D + rail * G::DLEN + 4 * v) = tmp;
         }
@@ -321,6 +333,12 @@ __global__ __launch_bounds__(64, 2) void k_ssb_fused(RxParams p, FusedArgs fa, c
         if constexpr (NCO != 0) p.phase[c] = ph0 + p.block_size * step;
         if (p.agc) p.gain[c] = gain;
     }
+    if (!p.chan_list) break;
+    li += gridDim.x;
+    if (li >= ln) break;
+    wave_lds_sync();                                     // the state reads above before the next channel's prologue fills
+  }
+    if (nonfinite) p.flags[kFlagNanInf] = 1u;            // ARM_MATH_NANINF, read by selenite_rx_sync
 }
 
 // ------------------------------------------------------------------------------------------
@@ -385,6 +403,7 @@ __global__ __launch_bounds__(64 * kMfmaWaves, 2) void k_ssb_mfma(RxParams p, Fus
     constexpr int NLD = G::T / 128;
 
     const uint32_t npass = p.nout / G::P;
+    bool nonfinite = false;                                           // any audio sample of this wavefront NaN / Inf
     typename R::type raw[NLD];
 #pragma unroll
     for (int i = 0; i < NLD; ++i) raw[i] = R::load(src, (size_t)c_first * p.in_stride + 128u * i + 2u * lane);
@@ -531,9 +550,9 @@ __global__ __launch_bounds__(64 * kMfmaWaves, 2) void k_ssb_mfma(RxParams p, Fus
     // ---- V phase, part 1: Hilbert pair + sideband, AGC, store; history copy-backs ----
     auto finish = [&](uint32_t pass) {
         if (group == 16)
-            demod_agc_store<1, 16, ND, M, NH, TOut, AM>(p, fa, dI, dQ, lane, group, hreg, gain, dst, out_base + (size_t)pass * G::P);
+            demod_agc_store<1, 16, ND, M, NH, TOut, AM>(p, fa, dI, dQ, lane, group, hreg, gain, dst, out_base + (size_t)pass * G::P, nonfinite);
         else
-            demod_agc_store<1, 0, ND, M, NH, TOut, AM>(p, fa, dI, dQ, lane, group, hreg, gain, dst, out_base + (size_t)pass * G::P);
+            demod_agc_store<1, 0, ND, M, NH, TOut, AM>(p, fa, dI, dQ, lane, group, hreg, gain, dst, out_base + (size_t)pass * G::P, nonfinite);
         wave_lds_sync();
         {
             constexpr int NV = 2 * GM::HS / 2;                        // float2 moves
@@ -561,7 +580,7 @@ __global__ __launch_bounds__(64 * kMfmaWaves, 2) void k_ssb_mfma(RxParams p, Fus
             constexpr int NV = 2 * (G::HH4 / 4);
             float4 tmp;
             const int rail = lane / (G::HH4 / 4), v = lane % (G::HH4 / 4);
-            if (lane < NV) tmp = *reinterpret_cast<const float4 *>(D + rail * G::DLEN + G::P + 4 * v);
+            if (lane < NV) tmp = lds_ld4f(D + rail * G::DLEN + G::P + 4 * v);
             wave_lds_sync();
             if (lane < NV) *reinterpret_cast<float4 *>(D + rail * G::DLEN + 4 * v) = tmp;
         }
@@ -614,6 +633,7 @@ __global__ __launch_bounds__(64 * kMfmaWaves, 2) void k_ssb_mfma(RxParams p, Fus
     }
     wave_lds_sync();                                                  // the state reads above before the next channel's fills
     }
+    if (nonfinite) p.flags[kFlagNanInf] = 1u;                         // ARM_MATH_NANINF, read by selenite_rx_sync
 }
 
 // LO[n] = (cos x, -sin x), x from the integer phase phase0 + n*step: the NCO of DESIGN.md section 2,
@@ -744,7 +764,9 @@ static hipError_t launch_one(const RxParams &p, const FusedArgs &fa, const void 
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(k, dim3(p.channels), dim3(64), lds, st, p, fa, static_cast<const TIn *>(src),
+    // (rerun pass of SELENITE_ARITH_AUTO: the list length is only known on the device -- a resident-sized grid strides over it)
+    const uint32_t grid = p.chan_list ? (p.channels < 2048u ? p.channels : 2048u) : p.channels;
+    hipLaunchKernelGGL(k, dim3(grid), dim3(64), lds, st, p, fa, static_cast<const TIn *>(src),
                        static_cast<TOut *>(dst));
     return hipGetLastError();
 }
@@ -788,16 +810,32 @@ static hipError_t launch_shape(const RxParams &p, const FusedArgs &fa, const Fus
                                const void *src, bool src_q15, void *dst, bool dst_q15, hipStream_t st)
 {
     if (src_q15 != dst_q15) return hipErrorNotSupported;
+    const bool auto_ = arith == SELENITE_ARITH_AUTO;
+    const bool split = arith == SELENITE_ARITH_SPLIT16 || auto_;
+    // SELENITE_ARITH_AUTO, second launch: the bit-exact kernel over the channels the split16 kernel put on the rerun list
+    // (their streaming state is still the pre-call state; audio and state are recomputed in the CMSIS arithmetic)
+    auto rerun = [&]() -> hipError_t {
+        RxParams p2 = p;
+        p2.chan_list = p.rerun_list; p2.chan_count = p.rerun_cnt;
+        p2.rerun_list = nullptr; p2.rerun_cnt = nullptr; p2.rerun_cnt_other = nullptr; p2.guard_ch = nullptr;
+        if (src_q15) return launch_one<0, ND, M, NH, int16_t, int16_t>(p2, fa, src, dst, st);
+        return launch_one<0, ND, M, NH, float, float>(p2, fa, src, dst, st);
+    };
     if constexpr (ND > 0 && (M == 4 || M == 2) && NH > 0) {
-        if (arith == SELENITE_ARITH_SPLIT16 && plan.d_btab16) {
-            return launch_ssb_split16(ND, M, NH, p, fa, src, src_q15, dst, st);      // rx_split16.hip
+        if (split && plan.d_btab16) {
+            hipError_t e = launch_ssb_split16(ND, M, NH, p, fa, src, src_q15, dst, st);      // rx_split16.hip
+            if (e == hipSuccess && auto_ && p.rerun_list) e = rerun();
+            return e;
         }
     }
     if constexpr (ND == 0 && M == 1 && NH > 0) {
-        if (arith == SELENITE_ARITH_SPLIT16 && plan.d_btab16 && fa.group == 64) {
-            return launch_hilb_split16(NH, p, fa, src, src_q15, dst, st);            // rx_split16.hip
+        if (split && plan.d_btab16 && fa.group == 64) {
+            hipError_t e = launch_hilb_split16(NH, p, fa, src, src_q15, dst, st);            // rx_split16.hip
+            if (e == hipSuccess && auto_ && p.rerun_list) e = rerun();
+            return e;
         }
     }
+    if (auto_) arith = SELENITE_ARITH_CMSIS;      // no split-precision kernel for this launch: the bit-exact one
     if constexpr (ND > 0 && M == 4) {
         static_assert(kMfmaWaves == 1, "one channel per workgroup: any channel count launches (plan.name says k_ssb_mfma)");
         if (arith != SELENITE_ARITH_CMSIS && plan.use_mfma) {
@@ -858,9 +896,11 @@ hipError_t plan_fused(const selenite_rx_config &g, bool delay_is_impulse, int de
     plan.name_buf = "k_ssb_fused" + shape;
     (void)name;
     if (plan.use_mfma && g.arith != SELENITE_ARITH_CMSIS) plan.name_buf = "k_ssb_mfma" + shape;     // split16 without a matrix kernel of its own runs as fma
-    if (plan.d_btab16 && g.arith == SELENITE_ARITH_SPLIT16) {
-        if (g.nd_taps) plan.name_buf = "k_ssb_split16" + shape;
-        else if (na == 256) plan.name_buf = "k_hilb_split16<" + std::to_string(g.nh_taps) + ">";
+    if (g.arith == SELENITE_ARITH_AUTO) plan.name_buf = "k_ssb_fused" + shape;                      // without a matrix kernel of its own: bit-exact
+    if (plan.d_btab16 && (g.arith == SELENITE_ARITH_SPLIT16 || g.arith == SELENITE_ARITH_AUTO)) {
+        const char *tail = g.arith == SELENITE_ARITH_AUTO ? "+exact rerun of guarded channels" : "";
+        if (g.nd_taps) plan.name_buf = "k_ssb_split16" + shape + tail;
+        else if (na == 256) plan.name_buf = "k_hilb_split16<" + std::to_string(g.nh_taps) + ">" + tail;
     }
     plan.name = plan.name_buf.c_str();
     return hipSuccess;

@@ -201,10 +201,10 @@ __device__ __forceinline__ void hilbert_tstep(int t, const float *dq, int lane, 
 {
     using G = Geo<ND, M, NH>;
     constexpr int C = (NH - 1) / 2;
-    const float4 W = *reinterpret_cast<const float4 *>(dq + 4 * lane + 4 * t);
+    const v4f W = lds_ld4(dq + 4 * lane + 4 * t);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-        const float w = f4get(W, e);
+        const float w = W[e];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int k = 4 * t + e - r - G::FH;
@@ -247,7 +247,7 @@ struct GeoS {
     static constexpr int KTOT = G::HQ4 * M + M * 15 + 1;  // padded taps 0 .. HQ4*M  +  shift of 15 outputs
     static constexpr int KS = (KTOT + 31) / 32;           // MFMA k-steps of 32
     static constexpr int oTab = 0;                        // floats; the sine table only when the LO is computed in the kernel
-    static constexpr int oX = NCO == 1 ? 516 : 0;         // 4 images of IMG halfs = 2*IMG floats
+    static constexpr int oX = (NCO == 1 || NCO == 4) ? 516 : 0;   // 4 images of IMG halfs = 2*IMG floats
     static constexpr int oHf = oX + 2 * IMG;              // f32 copy of the HS history samples, (I, Q) pairs
     static constexpr int oD = oHf + 2 * HS;
     static constexpr int total = oD + 2 * G::DLEN;
@@ -273,9 +273,5 @@ hipError_t launch_ssb_split16(int nd, int m, int nh, const RxParams &p, const Fu
                               void *dst, hipStream_t st);
 hipError_t launch_hilb_split16(int nh, const RxParams &p, const FusedArgs &fa, const void *src, bool q15, void *dst,
                                hipStream_t st);
-
-typedef float v4f __attribute__((ext_vector_type(4)));
-typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 
 }  // namespace srx

@@ -29,7 +29,8 @@ struct RxParams {
     uint32_t pass_out;     // generic front kernel: decimated outputs per pass
     const float *dec_c, *hilb_c, *delay_c, *biq_c, *sintab;
     const float2 *lo;      // nco == 2: LO[n] = (cos, -sin) for the samples of this call (all channels share it)
-    uint32_t lo_period;    // nco == 2: 256 when LO[n + 256] == LO[n] for every n (NCO step a multiple of 2^24), else 0
+    uint32_t lo_period;    // nco == 2: 256 when LO[n + 256] == LO[n] for every n (NCO step a multiple of 2^24), else 0;
+                           // nco == 1: 256 when EVERY channel's step is a multiple of 2^24 (each channel's own LO has that period)
     const uint32_t *step;
     uint32_t *phase;
     float *dec_state;      // [C][2][nd-1]
@@ -38,9 +39,27 @@ struct RxParams {
     float *gain;           // [C]
     float *env_part;       // global gain, phase 1 (k_ssb_split16, 16-lane DSP blocks, whole passes): max |audio| of every DSP block,
                            // [channels][block_size / block]; NULL = not wanted
-    uint32_t *flags;       // [1] device flag word: bit 0 = a split16 kernel produced non-finite audio (ARM_MATH_NANINF)
+    uint32_t *flags;       // device flag / counter words (kFlag* below): [0] bit 0 = a kernel produced non-finite audio (ARM_MATH_NANINF)
+    // ---- parity guard of the split-precision kernels ----
+    // A DSP block is GUARDED when max |audio| (before the AGC) < guard_ratio * the largest |component| of the samples its
+    // pass's matrix product saw: the region where the split product and CMSIS, two f32-class results with independent
+    // rounding noise of ~1e-7 of the INPUT, may differ by more than 1e-5 of the (small) block maximum.
+    float guard_ratio;
+    uint32_t *guard_ch;    // [channels] sticky count of guarded DSP blocks per channel, or NULL
+    // SELENITE_ARITH_AUTO: a channel with a guarded block in this call keeps its pre-call streaming state (the split16
+    // kernel does not write it back) and is appended to rerun_list; a second launch of the bit-exact kernel (chan_list =
+    // that list) recomputes the call for those channels -- audio and state -- in the CMSIS arithmetic
+    uint32_t *rerun_list;  // [channels] or NULL (plain SPLIT16: count only)
+    uint32_t *rerun_cnt;   // entries in rerun_list (device counter of THIS launch)
+    uint32_t *rerun_cnt_other;   // the other launch parity's counter: zeroed by this launch for the next one
+    const uint32_t *chan_list;   // exact kernels: process channels chan_list[0 .. *chan_count) instead of 0 .. channels-1
+    const uint32_t *chan_count;
     AgcParams agcp;
 };
+
+// words of RxParams::flags
+enum { kFlagNanInf = 0, kFlagGuardBlocks = 2 /* u64 */, kFlagGuardCalls = 4 /* u64 */, kFlagRerunCalls = 6 /* u64 */,
+       kFlagRerunCnt0 = 8, kFlagRerunCnt1 = 9, kFlagWords = 16 };
 
 __host__ __device__ inline bool mode_is_cw(uint32_t m) { return m == SELENITE_MODE_CW || m == SELENITE_MODE_CWR; }
 __host__ __device__ inline bool mode_is_upper(uint32_t m)
@@ -120,7 +139,12 @@ struct selenite_rx_instance {
     float *d_dec_c = nullptr, *d_hilb_c = nullptr, *d_delay_c = nullptr, *d_biq_c = nullptr, *d_sintab = nullptr;
     uint32_t *d_step = nullptr, *d_phase = nullptr;
     float *d_dec_state = nullptr, *d_fir_state = nullptr, *d_biq_state = nullptr, *d_gain = nullptr;
-    uint32_t *d_flags = nullptr;
+    uint32_t *d_flags = nullptr;       // kFlagWords words
+    uint32_t *d_guard_ch = nullptr;    // [channels] guarded DSP blocks per channel (sticky)
+    uint32_t *d_rerun_list = nullptr;  // [channels] SELENITE_ARITH_AUTO: channels of the current call to recompute exactly
+    uint32_t rerun_parity = 0;
+    float guard_ratio = 0.25f;         // -12 dB
+    bool steps_grid256 = false;        // every NCO step is a multiple of 2^24: every channel's LO repeats every 256 samples
     float *d_scratch = nullptr;  size_t scratch_bytes = 0;   // intermediate f32 audio
     float *d_env = nullptr;      size_t env_cap = 0;
     float *d_env_part = nullptr; size_t env_part_cap = 0;   // per-wavefront envelope maxima

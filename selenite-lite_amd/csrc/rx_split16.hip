@@ -130,14 +130,27 @@ __device__ __forceinline__ void lds_order()
 // AGC of one pass (256 audio samples, 4 per lane): arm_abs + arm_max per DSP block of GROUP lanes,
 // gain law, arm_scale with the updated gain.  GROUP = 16 / 64: lane reductions by DPP, the block
 // envelopes broadcast by v_readlane; GROUP = 0: any power-of-two `group` (run time).
+// Parity guard: `gd.thr` = guard ratio x the largest |component| the pass's matrix product saw; every DSP block of the pass
+// whose envelope (max |audio| before the gain) is below it is counted in gd.n (gd.first: the first lane of every DSP block).
+struct GuardPass {
+    float thr;
+    uint64_t first;
+    uint32_t n;
+};
 template <int GROUP>
 __device__ __forceinline__ void agc_pass(const AgcParams &ap, uint32_t agc_on, int lane, int group, float (&au)[4], float &gain,
-                                         int nvb = 64)       // nvb: DSP blocks of the pass that exist (a call's last pass may be partial)
+                                         int nvb, GuardPass &gd)   // nvb: DSP blocks of the pass that exist (a call's last pass may be partial)
 {
     float m = fmaxf(fmaxf(fabsf(au[0]), fabsf(au[1])), fmaxf(fabsf(au[2]), fabsf(au[3])));
     float g = gain, mine = gain;
+    auto guard = [&](float env) {                    // env: the block envelope, in (at least) the first lane of every block
+        const int lanes = nvb * (GROUP ? GROUP : group);
+        const uint64_t exist = lanes >= 64 ? ~0ull : ((1ull << lanes) - 1ull);
+        gd.n += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(env < gd.thr) & gd.first & exist);
+    };
     if constexpr (GROUP == 16) {
         m = row16_fmax(m);
+        guard(m);
         const float d = agc_desired(ap, m);          // one division sequence serves the four blocks
         float ds[4];
 #pragma unroll
@@ -156,6 +169,7 @@ __device__ __forceinline__ void agc_pass(const AgcParams &ap, uint32_t agc_on, i
         const uint32_t r0 = __builtin_amdgcn_readlane(__float_as_uint(m), 0), r1 = __builtin_amdgcn_readlane(__float_as_uint(m), 16);
         const uint32_t r2 = __builtin_amdgcn_readlane(__float_as_uint(m), 32), r3 = __builtin_amdgcn_readlane(__float_as_uint(m), 48);
         const float e0 = __uint_as_float(r0 > r1 ? r0 : r1), e1 = __uint_as_float(r2 > r3 ? r2 : r3);
+        guard(lane < 32 ? e0 : e1);
         const float d = agc_desired(ap, lane < 32 ? e0 : e1);
         const float ds[2] = { __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(d), 0)),
                               __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(d), 32)) };
@@ -168,12 +182,14 @@ __device__ __forceinline__ void agc_pass(const AgcParams &ap, uint32_t agc_on, i
         }
     } else if constexpr (GROUP == 64) {
         m = __uint_as_float(wave_umax_bits(m));
+        guard(m);
         g = agc_step(ap, g, agc_desired(ap, m));
         mine = g;
     } else {
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1)
             if (off < group) m = fmaxf(m, __shfl_xor(m, off, 64));
+        guard(m);
         const int nblk = min(64 / group, nvb), myblk = lane / group;
         for (int b = 0; b < nblk; ++b) {
             const float env = __shfl(m, b * group, 64);
@@ -271,9 +287,11 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
     auto lo_base = [&](uint32_t pass) { return pass < npass ? (int)pass * G::T * 8 : 0; };   // pass == npass: the next channel's pass 0
     // periodic shared LO (NCO == 3: the table repeats every 256 samples and a pass is a whole number of periods): load
     // i of any pass multiplies by LO[(128 i + 2 lane, + 1) mod 256] -- two register quads for the whole kernel
+    // (NCO == 4: the same for a PER-CHANNEL step that is a multiple of 2^24 -- every channel on the fs / 256 grid with its own LO:
+    // the two quads are computed once per channel, in install_state, with the arithmetic of the per-sample NCO (nco_lo_pair))
     u4v lo_per[2];
+    static_assert((NCO != 3 && NCO != 4) || G::T % 256 == 0, "a pass is a whole number of LO periods");
     if constexpr (NCO == 3) {
-        static_assert(NCO != 3 || G::T % 256 == 0, "a pass is a whole number of LO periods");
         lo_per[0] = *reinterpret_cast<const u4v *>(p.lo + 2 * lane);
         lo_per[1] = *reinterpret_cast<const u4v *>(p.lo + 128 + 2 * lane);
     }
@@ -319,7 +337,7 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
 #else
     auto htap = [&](int k) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(hreg[k >> 6]), k & 63)); };
 #endif
-    if constexpr (NCO == 1)
+    if constexpr (NCO == 1 || NCO == 4)
         for (int i = lane; i < 513; i += kWave) tab[i] = p.sintab[i];
 
     // ---- streaming state of a channel: loaded into registers (for the next channel of this workgroup while
@@ -352,9 +370,21 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
         st_step = NCO ? p.step[ch] : 0u;
         st_gain = p.gain[ch];
     };
-    uint32_t e_hist = 0, ph0 = 0, step = 0;                       // e_hist: biased exponent of the largest |history component|
+    uint32_t b_hist = 0, ph0 = 0, step = 0;                       // b_hist: bit pattern of the largest |history component|
     float gain = 1.0f;
     int s_cur = 0x7fff;                                               // sample scale exponent of the images (none yet)
+    // parity guard (GuardPass): thresholds of the pass being mixed and of the pass before it (whose demodulator runs later)
+    float thr_cur = 0.0f, thr_prev = 0.0f;
+    GuardPass gd;
+    gd.thr = 0.0f; gd.n = 0u;
+    if constexpr (GROUP == 16) gd.first = 0x0001000100010001ull;
+    else if constexpr (GROUP == 32) gd.first = 0x0000000100000001ull;
+    else if constexpr (GROUP == 64) gd.first = 1ull;
+    else {
+        gd.first = 0ull;
+        for (int l = 0; l < 64; l += (int)fa.group) gd.first |= 1ull << l;
+    }
+    if (blockIdx.x == 0 && lane == 0 && p.rerun_cnt_other) *p.rerun_cnt_other = 0u;     // the next launch's rerun counter
     auto install_state = [&]() {
         float mh = 0.0f;
 #pragma unroll
@@ -367,9 +397,20 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
             const int i = j * kWave + lane;
             D[(i / G::HH4) * G::DLEN + i % G::HH4] = st_fv[j];
         }
-        e_hist = wave_umax_bits(mh) >> 23;
+        b_hist = wave_umax_bits(mh);
         ph0 = st_ph0; step = st_step; gain = st_gain;
         s_cur = 0x7fff;
+        gd.n = 0u;
+        if constexpr (NCO == 4) {
+            // LO of samples 2 lane, 2 lane + 1 and 128 + 2 lane, 129 + 2 lane of every 256-sample period: the phases the
+            // per-sample NCO (NCO == 1) would form for them in any pass, n0 * step and 256 * step being multiples of 2^32
+            const uint32_t pe = ph0 + 2u * lane * step;
+            v2f la, lb;
+            nco_lo_pair(tab, pe, pe + step, la, lb);
+            lo_per[0] = u4v{ __float_as_uint(la.x), __float_as_uint(la.y), __float_as_uint(lb.x), __float_as_uint(lb.y) };
+            nco_lo_pair(tab, pe + 128u * step, pe + 129u * step, la, lb);
+            lo_per[1] = u4v{ __float_as_uint(la.x), __float_as_uint(la.y), __float_as_uint(lb.x), __float_as_uint(lb.y) };
+        }
     };
     load_state(c);
     const int group = (int)fa.group;
@@ -427,7 +468,7 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
                 cmul_pk2(a, b, v2f{ __uint_as_float(l.x), __uint_as_float(l.y) }, v2f{ __uint_as_float(l.z), __uint_as_float(l.w) },
                          m[2 * i], m[2 * i + 1]);
                 if (i + LOD < NLD) lo_load(i % LOD, i + LOD, lo_base(pass));
-            } else if constexpr (NCO == 3) {
+            } else if constexpr (NCO == 3 || NCO == 4) {
                 const u4v l = lo_per[i & 1];
                 cmul_pk2(a, b, v2f{ __uint_as_float(l.x), __uint_as_float(l.y) }, v2f{ __uint_as_float(l.z), __uint_as_float(l.w) },
                          m[2 * i], m[2 * i + 1]);
@@ -451,9 +492,11 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
             mm = amax2(m[2 * i], mm);
             mm = amax2(m[2 * i + 1], mm);
         }
-        const uint32_t e_tail = wave_umax_bits(mt) >> 23;
-        const uint32_t e_new = max(wave_umax_bits(mh) >> 23, e_tail);
-        const uint32_t e_need = max(e_new, e_hist);
+        const uint32_t b_tail = wave_umax_bits(mt);
+        const uint32_t b_need = max(max(wave_umax_bits(mh), b_tail), b_hist);       // the largest |component| the pass's images hold
+        const uint32_t e_need = b_need >> 23;
+        thr_prev = thr_cur;
+        thr_cur = __uint_as_float(b_need) * p.guard_ratio;
         // largest |component| * 2^s in [2^14, 2^15):  s = 14 - (E - 127); 2^s must itself be a normal float
         int s_new = 141 - (int)e_need;
         s_new = s_new > 127 ? 127 : (s_new < -126 ? -126 : s_new);
@@ -462,12 +505,12 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
 #pragma unroll
             for (int j = 0; j < GS::HS / 128; ++j) {
                 const int f = 2 * (j * kWave + lane);
-                const float4 hq = *reinterpret_cast<const float4 *>(Hf + f);
+                const float4 hq = lds_ld4f(reinterpret_cast<const float *>(Hf + f));
                 put_iq(f, v2f{ hq.x, hq.y }, v2f{ hq.z, hq.w }, pre);
             }
             s_cur = s_new;
         }
-        e_hist = e_tail;
+        b_hist = b_tail;
         lds_order();                                                  // history reads above, history writes below
         const float pre = __uint_as_float((uint32_t)(s_cur + 127) << 23);
 #pragma unroll
@@ -558,6 +601,10 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
     auto dwrite = [&]() {
         const int o0 = G::HH4 + 64 * (lane >> 4) + (lane & 15);
         const int ex = -(s_cur + fa.split_sc);
+#ifdef SRX_X_NODWRITE
+        asm volatile("" :: "v"(accI), "v"(accQ), "s"(ex)); (void)o0;
+        return;
+#endif
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
 #if SRX_ACC4
@@ -578,10 +625,17 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
         return img * GS::IMG + GS::RSTR * (rem / CPR) + 8 * (rem % CPR);
     };
     auto cb_read = [&](u4v (&cb)[NCB]) {
+#ifdef SRX_X_NOCB
+        for (int k = 0; k < NCB; ++k) cb[k] = u4v{ 0u, 0u, 0u, 0u };
+        return;
+#endif
 #pragma unroll
         for (int k = 0; k < NCB; ++k) cb[k] = *reinterpret_cast<const u4v *>(X + cb_addr(k) + GS::RSTR * (G::T / GS::RL));
     };
     auto cb_write = [&](const u4v (&cb)[NCB]) {
+#ifdef SRX_X_NOCB
+        return;
+#endif
 #pragma unroll
         for (int k = 0; k < NCB; ++k) *reinterpret_cast<u4v *>(X + cb_addr(k)) = cb[k];
     };
@@ -601,12 +655,12 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
     auto demod_piece = [&](int kk, float (&au)[4], int nvb = 64) {
         if constexpr (AM != 0) {
             if (kk == 0) {
-                const float4 vi = *reinterpret_cast<const float4 *>(dI + G::HH4 + 4 * lane);
-                const float4 vq = *reinterpret_cast<const float4 *>(dQ + G::HH4 + 4 * lane);
+                const float4 vi = lds_ld4f(dI + G::HH4 + 4 * lane);
+                const float4 vq = lds_ld4f(dQ + G::HH4 + 4 * lane);
                 au[0] = cmag<0>(vi.x, vq.x); au[1] = cmag<0>(vi.y, vq.y);
                 au[2] = cmag<0>(vi.z, vq.z); au[3] = cmag<0>(vi.w, vq.w);
 #ifndef SRX_X_NOAGC
-                agc_pass<GROUP>(p.agcp, p.agc, lane, group, au, gain, nvb);
+                agc_pass<GROUP>(p.agcp, p.agc, lane, group, au, gain, nvb, gd);
 #endif
             }
         } else {
@@ -620,11 +674,15 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
                 const float *di = dI + G::FH + fa.delay_idx + 4 * lane;   // unit-impulse delay FIR
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
+#ifdef SRX_X_NODI
+                    const float i2 = q2[(r + 1) & 3] + 0.0f; (void)di;
+#else
                     const float i2 = di[r] + 0.0f;                    // 0.0f + 1.0f*x of the dense loop
+#endif
                     au[r] = fa.upper ? (i2 - q2[r]) : (i2 + q2[r]);   // arm_sub_f32 / arm_add_f32
                 }
 #ifndef SRX_X_NOAGC
-                agc_pass<GROUP>(p.agcp, p.agc, lane, group, au, gain, nvb);
+                agc_pass<GROUP>(p.agcp, p.agc, lane, group, au, gain, nvb, gd);
 #endif
             }
         }
@@ -690,6 +748,7 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
             u4v cb[NCB];
             v4f dt = { 0.0f, 0.0f, 0.0f, 0.0f };
             if constexpr (AM == 0) dt = *reinterpret_cast<const v4f *>(D + dt_off + G::P);
+            gd.thr = thr_prev;                                        // the demodulator below belongs to the pass before
             mfma_phase([&](int kk) { demod_piece(kk, au); }, (NTS + TPK - 1) / TPK - 1);   // matrix pipe over the vector work of the pass before
             cb_read(cb);
             lds_order();
@@ -701,13 +760,28 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
         }
         store_audio(npass - 2, au);
         load_state(c + gridDim.x);                                    // the next channel's state, under this channel's last demodulator pass
+        gd.thr = thr_cur;
         demod(au, (int)(tail_out / (4u * (uint32_t)group)));          // DSP blocks of the last pass that exist
         store_audio(npass - 1, au);
         STAMP(0);
 
+        // ---- parity guard: count; SELENITE_ARITH_AUTO: a guarded channel keeps its pre-call state and joins the rerun list ----
+        bool keep_state = false;
+        if (gd.n != 0u) {                                             // wave-uniform, rare
+            keep_state = p.rerun_list != nullptr;
+            if (lane == 0) {
+                atomicAdd(reinterpret_cast<unsigned long long *>(p.flags + kFlagGuardBlocks), (unsigned long long)gd.n);
+                atomicAdd(reinterpret_cast<unsigned long long *>(p.flags + kFlagGuardCalls), 1ull);
+                if (p.guard_ch) p.guard_ch[c] += gd.n;
+                if (keep_state) {
+                    atomicAdd(reinterpret_cast<unsigned long long *>(p.flags + kFlagRerunCalls), 1ull);
+                    p.rerun_list[atomicAdd(p.rerun_cnt, 1u)] = c;
+                }
+            }
+        }
         // ---- streaming state of the channel back to HBM (exact f32) ----
         lds_order();
-        {
+        if (!keep_state) {
             float *stI = p.dec_state + (size_t)c * 2 * (ND - 1), *stQ = stI + (ND - 1);
 #pragma unroll
             for (int j = 0; j < GS::HS / kWave; ++j) {
@@ -717,12 +791,13 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
             }
         }
         if constexpr (AM == 0) {                                      // AM never ran the Hilbert pair: its state stays
-            for (int i = lane; i < 2 * G::HH4; i += kWave) {
-                const int rail = i / G::HH4, mi = i % G::HH4, s = mi - G::FH;
-                if (s >= 0) p.fir_state[((size_t)c * 2 + rail) * G::HH + s] = D[rail * G::DLEN + tail_out + mi];
-            }
+            if (!keep_state)
+                for (int i = lane; i < 2 * G::HH4; i += kWave) {
+                    const int rail = i / G::HH4, mi = i % G::HH4, s = mi - G::FH;
+                    if (s >= 0) p.fir_state[((size_t)c * 2 + rail) * G::HH + s] = D[rail * G::DLEN + tail_out + mi];
+                }
         }
-        if (lane == 0) {
+        if (lane == 0 && !keep_state) {
             if constexpr (NCO != 0) p.phase[c] = ph0 + p.block_size * step;
             if (p.agc) p.gain[c] = gain;
         }
@@ -908,7 +983,7 @@ __global__ __launch_bounds__(128, 3) void k_ssb_split16w2(RxParams p, FusedArgs 
 #pragma unroll
                 for (int j = 0; j < GS::HS / 128; ++j) {
                     const int f = 2 * (j * kWave + lane);
-                    const float4 hq = *reinterpret_cast<const float4 *>(Hf + f);
+                    const float4 hq = lds_ld4f(reinterpret_cast<const float *>(Hf + f));
                     put_iq(f, v2f{ hq.x, hq.y }, v2f{ hq.z, hq.w }, pre);
                 }
                 s_cur = s_new;
@@ -1041,8 +1116,8 @@ __global__ __launch_bounds__(128, 3) void k_ssb_split16w2(RxParams p, FusedArgs 
             lds_order();
             float au[4];
             if constexpr (AM != 0) {
-                const float4 vi = *reinterpret_cast<const float4 *>(dI + G::HH4 + 4 * lane);
-                const float4 vq = *reinterpret_cast<const float4 *>(dQ + G::HH4 + 4 * lane);
+                const float4 vi = lds_ld4f(dI + G::HH4 + 4 * lane);
+                const float4 vq = lds_ld4f(dQ + G::HH4 + 4 * lane);
                 au[0] = cmag<0>(vi.x, vq.x); au[1] = cmag<0>(vi.y, vq.y);
                 au[2] = cmag<0>(vi.z, vq.z); au[3] = cmag<0>(vi.w, vq.w);
             } else {
@@ -1061,7 +1136,8 @@ __global__ __launch_bounds__(128, 3) void k_ssb_split16w2(RxParams p, FusedArgs 
                 lds_order();
                 *reinterpret_cast<v4f *>(D + dt_off) = dt;
             }
-            agc_pass<GROUP>(p.agcp, p.agc, lane, group, au, gain);
+            GuardPass gdw{ 0.0f, 0ull, 0u };                           // (experimental kernel: no parity guard)
+            agc_pass<GROUP>(p.agcp, p.agc, lane, group, au, gain, 64, gdw);
             W::store(rs_out, lane * W::kBytes, (int)pass * (G::P * (W::kBytes / 4)), au);
             wg_barrier();                                             // X
         }
@@ -1145,14 +1221,16 @@ __global__ __launch_bounds__(64, 2) void k_hilb_split16(RxParams p, FusedArgs fa
     for (int u = GH::HH + 256 + 2 * lane; u < GH::XN; u += 2 * kWave) put(u, 0.0f, 0.0f, 1.0f);
     // state: both rails' histories in f32 (branch-free: lanes beyond the history repeat its last pair)
     const int hv = 2 * lane < GH::HH ? 2 * lane : GH::HH - 2;       // this lane's history pair
-    uint32_t e_hist;
+    uint32_t b_hist;                                                  // bit pattern of the largest |Q| of the history
     {
         const float *stI = p.fir_state + (size_t)c * 2 * GH::HH, *stQ = stI + GH::HH;
         const float i0 = stI[hv], i1 = stI[hv + 1], q0 = stQ[hv], q1 = stQ[hv + 1];
         *reinterpret_cast<float2 *>(dI + hv) = make_float2(i0, i1);
         *reinterpret_cast<float2 *>(dQ + hv) = make_float2(q0, q1);
-        e_hist = wave_umax_bits(fmaxf(fabsf(q0), fabsf(q1))) >> 23;
+        b_hist = wave_umax_bits(fmaxf(fabsf(q0), fabsf(q1)));
     }
+    GuardPass gd{ 0.0f, 1ull, 0u };                                   // parity guard: one DSP block per pass
+    if (blockIdx.x == 0 && lane == 0 && p.rerun_cnt_other) *p.rerun_cnt_other = 0u;     // the next launch's rerun counter
     const uint32_t ph0 = NCO ? p.phase[c] : 0u, step = NCO ? p.step[c] : 0u;
     float gain = p.gain[c];
     const int mcol = lane & 15, rg = lane >> 4;
@@ -1199,8 +1277,10 @@ __global__ __launch_bounds__(64, 2) void k_hilb_split16(RxParams p, FusedArgs fa
                 mq = fmaxf(mq, m2);
                 mt = fmaxf(mt, n >= 256 - GH::HH ? m2 : 0.0f);          // HH is even: a pair is inside or outside as a whole
             }
-            const uint32_t e_tail = wave_umax_bits(mt) >> 23;
-            const uint32_t e_need = max(max(wave_umax_bits(mq) >> 23, e_tail), e_hist);
+            const uint32_t b_tail = wave_umax_bits(mt);
+            const uint32_t b_need = max(max(wave_umax_bits(mq), b_tail), b_hist);      // the largest |Q| the matrix product sees
+            const uint32_t e_need = b_need >> 23;
+            gd.thr = __uint_as_float(b_need) * p.guard_ratio;
             int s_new = 141 - (int)e_need;
             s_new = s_new > 127 ? 127 : (s_new < -126 ? -126 : s_new);
             if (s_new != s_cur) {                                     // wave-uniform; always in the first pass
@@ -1208,7 +1288,7 @@ __global__ __launch_bounds__(64, 2) void k_hilb_split16(RxParams p, FusedArgs fa
                 put(hv, hq.x, hq.y, __uint_as_float((uint32_t)(s_new + 127) << 23));
                 s_cur = s_new;
             }
-            e_hist = e_tail;
+            b_hist = b_tail;
             const float pre = __uint_as_float((uint32_t)(s_cur + 127) << 23);
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
@@ -1242,10 +1322,10 @@ __global__ __launch_bounds__(64, 2) void k_hilb_split16(RxParams p, FusedArgs fa
         }
         // ---- 4.-5. AGC on the DSP block (= the pass), coalesced store ----
         {
-            const float4 o4 = *reinterpret_cast<const float4 *>(O + 4 * lane);
+            const float4 o4 = lds_ld4f(O + 4 * lane);
             au[0] = o4.x; au[1] = o4.y; au[2] = o4.z; au[3] = o4.w;
         }
-        agc_pass<64>(p.agcp, p.agc, lane, 64, au, gain);
+        agc_pass<64>(p.agcp, p.agc, lane, 64, au, gain, 1, gd);   // (AM: exact arithmetic, thr stays 0: never guarded)
         {
             const float z = __builtin_fmaf(au[3], 0.0f, __builtin_fmaf(au[2], 0.0f, __builtin_fmaf(au[1], 0.0f, au[0] * 0.0f)));
             nonfinite = nonfinite || (z != z);
@@ -1264,6 +1344,23 @@ __global__ __launch_bounds__(64, 2) void k_hilb_split16(RxParams p, FusedArgs fa
             *reinterpret_cast<uint32_t *>(Xl + GH::phys(hv)) = tl;
         }
         lds_order();
+    }
+    // ---- parity guard: count; SELENITE_ARITH_AUTO: a guarded channel keeps its pre-call state and joins the rerun list ----
+    if (gd.n != 0u) {                                                 // wave-uniform, rare
+        const bool keep_state = p.rerun_list != nullptr;
+        if (lane == 0) {
+            atomicAdd(reinterpret_cast<unsigned long long *>(p.flags + kFlagGuardBlocks), (unsigned long long)gd.n);
+            atomicAdd(reinterpret_cast<unsigned long long *>(p.flags + kFlagGuardCalls), 1ull);
+            if (p.guard_ch) p.guard_ch[c] += gd.n;
+            if (keep_state) {
+                atomicAdd(reinterpret_cast<unsigned long long *>(p.flags + kFlagRerunCalls), 1ull);
+                p.rerun_list[atomicAdd(p.rerun_cnt, 1u)] = c;
+            }
+        }
+        if (keep_state) {
+            if (nonfinite) p.flags[0] = 1u;
+            return;
+        }
     }
     // ---- epilogue: arm_fir_f32 pState tails (the last NH-1 samples of each rail), exact f32 ----
     if constexpr (AM == 0) {
@@ -1346,9 +1443,12 @@ static hipError_t launch_io(const RxParams &p, const FusedArgs &fa, const void *
 template <int ND, int M, int NH>
 static hipError_t launch_nco(const RxParams &p, const FusedArgs &fa, const void *src, bool q15, void *dst, hipStream_t st)
 {
-    if constexpr (Geo<ND, M, NH>::T % 256 == 0)
+    if constexpr (Geo<ND, M, NH>::T % 256 == 0) {
         if (p.nco == 2 && p.lo_period == 256)      // LO held in registers
             return q15 ? launch_io<3, ND, M, NH, int16_t, int16_t>(p, fa, src, dst, st) : launch_io<3, ND, M, NH, float, float>(p, fa, src, dst, st);
+        if (p.nco == 1 && p.lo_period == 256)      // every channel its own LO on the fs / 256 grid: in registers, computed once per channel
+            return q15 ? launch_io<4, ND, M, NH, int16_t, int16_t>(p, fa, src, dst, st) : launch_io<4, ND, M, NH, float, float>(p, fa, src, dst, st);
+    }
     if (p.nco == 2) return q15 ? launch_io<2, ND, M, NH, int16_t, int16_t>(p, fa, src, dst, st) : launch_io<2, ND, M, NH, float, float>(p, fa, src, dst, st);
     if (p.nco == 1) return q15 ? launch_io<1, ND, M, NH, int16_t, int16_t>(p, fa, src, dst, st) : launch_io<1, ND, M, NH, float, float>(p, fa, src, dst, st);
     return q15 ? launch_io<0, ND, M, NH, int16_t, int16_t>(p, fa, src, dst, st) : launch_io<0, ND, M, NH, float, float>(p, fa, src, dst, st);
@@ -1374,9 +1474,11 @@ hipError_t launch_ssb_split16(int nd, int m, int nh, const RxParams &p, const Fu
                               void *dst, hipStream_t st)
 {
 #ifdef SRX_SPLIT16_BENCH_ONLY     // A/B builds: only the bench.py default kernel
-    if (nd == 256 && m == 4 && nh == 63 && p.nco == 2 && !q15 && !fa.am && fa.group == 16)
+    if (nd == 256 && m == 4 && nh == 63 && p.nco == 2 && !fa.am && fa.group == 16) {
+        if (q15) return p.lo_period == 256 ? launch_k<3, 256, 4, 63, int16_t, int16_t, 0, 16>(p, fa, src, dst, st) : hipErrorNotSupported;
         return p.lo_period == 256 ? launch_k<3, 256, 4, 63, float, float, 0, 16>(p, fa, src, dst, st)
                                   : launch_k<2, 256, 4, 63, float, float, 0, 16>(p, fa, src, dst, st);
+    }
     return hipErrorNotSupported;
 #else
 #define X(ND_, M_, NH_) if (nd == ND_ && m == M_ && nh == NH_) return launch_nco<ND_, M_, NH_>(p, fa, src, q15, dst, st);

@@ -152,7 +152,7 @@ __global__ __launch_bounds__(64, 2) void k_tx_fused(TxParams p, uint32_t delay_i
             constexpr int C = (kNH - 1) / 2;
 #pragma unroll
             for (int t = 0; t <= (kHH4 + 3) / 4; ++t) {
-                const float4 W = *reinterpret_cast<const float4 *>(HQ + 4 * lane + 4 * t);
+                const float4 W = lds_ld4f(HQ + 4 * lane + 4 * t);
                 const float w[4] = { W.x, W.y, W.z, W.w };
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
@@ -404,7 +404,7 @@ __global__ __launch_bounds__(64, 2) void k_tx_split16(TxParams p, uint32_t delay
             constexpr int C = (kNH - 1) / 2;
 #pragma unroll
             for (int t = 0; t <= (kHH4 + 3) / 4; ++t) {
-                const float4 W = *reinterpret_cast<const float4 *>(HQ + 4 * lane + 4 * t);
+                const float4 W = lds_ld4f(HQ + 4 * lane + 4 * t);
                 const float w[4] = { W.x, W.y, W.z, W.w };
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
@@ -490,7 +490,7 @@ __global__ __launch_bounds__(64, 2) void k_tx_split16(TxParams p, uint32_t delay
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const uint32_t o = 2u * (64u * j + lane);                 // two complex outputs per lane and step
-                const float4 t = *reinterpret_cast<const float4 *>(T + 2 * o);
+                const float4 t = lds_ld4f(T + 2 * o);
                 float2 y0 = make_float2(t.x, t.y), y1 = make_float2(t.z, t.w);
                 if constexpr (NCO == 2) {
                     const float4 l = *reinterpret_cast<const float4 *>(lo + (size_t)pass * kPass * kL + o);

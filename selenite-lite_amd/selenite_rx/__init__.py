@@ -17,7 +17,7 @@ if os.environ.get("SELENITE_RX_LIB"):            # A/B experiments: another buil
     LIB_PATH = os.environ["SELENITE_RX_LIB"]
 
 MODE_LSB, MODE_USB, MODE_CW, MODE_CWR, MODE_AM, MODE_FM, MODE_DIG, MODE_PKT = 0, 1, 2, 3, 4, 8, 0x0A, 0x0C
-ARITH_CMSIS, ARITH_FMA, ARITH_SPLIT16 = 0, 1, 2
+ARITH_CMSIS, ARITH_FMA, ARITH_SPLIT16, ARITH_AUTO = 0, 1, 2, 3
 SUCCESS, ARGUMENT_ERROR, LENGTH_ERROR, NANINF, DEVICE_ERROR = 0, -1, -2, -4, -7
 
 f32p = C.POINTER(C.c_float)
@@ -62,6 +62,7 @@ ABI_SYMBOLS = [
     "selenite_rx_abi_version",
     "selenite_rx_global_process_f32_device",
     "selenite_rx_host_alloc", "selenite_rx_host_free", "selenite_rx_host_register", "selenite_rx_host_unregister",
+    "selenite_rx_set_guard_ratio", "selenite_rx_guard_stats", "selenite_rx_guard_channels", "selenite_rx_guard_clear",
 ]
 
 class TxConfig(C.Structure):
@@ -159,6 +160,11 @@ def lib():
         L.selenite_rx_nco_path.restype = C.c_char_p
         L.selenite_rx_algorithmic_bytes.argtypes = [C.POINTER(Config), C.c_uint32, C.POINTER(C.c_uint64)]
         L.selenite_rx_algorithmic_bytes.restype = C.c_uint64
+        u64p = C.POINTER(C.c_uint64)
+        L.selenite_rx_set_guard_ratio.argtypes = [vp, C.c_float]
+        L.selenite_rx_guard_stats.argtypes = [vp, u64p, u64p, u64p]
+        L.selenite_rx_guard_channels.argtypes = [vp, u32p]
+        L.selenite_rx_guard_clear.argtypes = [vp]
         L.selenite_rx_design_lowpass.argtypes = [f32p, C.c_uint32, C.c_double]
         L.selenite_rx_design_hilbert.argtypes = [f32p, f32p, C.c_uint32]
         L.selenite_rx_design_bandpass.argtypes = [f32p, C.c_uint32, C.c_double, C.c_double]
@@ -340,6 +346,30 @@ class Rx:
 
     def kernel_name(self):
         return self.L.selenite_rx_kernel_name(self.h).decode()
+
+    # -- parity guard of the split-precision arithmetic ----------------------------------------
+    def set_guard_ratio(self, ratio):
+        rc = self.L.selenite_rx_set_guard_ratio(self.h, ratio)
+        if rc:
+            raise RxError(rc, "selenite_rx_set_guard_ratio")
+
+    def guard_stats(self):
+        """dict(blocks, channel_calls, rerun_channel_calls) since init / the last guard_clear()."""
+        b, c, r = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        rc = self.L.selenite_rx_guard_stats(self.h, C.byref(b), C.byref(c), C.byref(r))
+        if rc:
+            raise RxError(rc, self.error())
+        return dict(blocks=int(b.value), channel_calls=int(c.value), rerun_channel_calls=int(r.value))
+
+    def guard_channels(self):
+        out = np.zeros(self.cfg.channels, np.uint32)
+        rc = self.L.selenite_rx_guard_channels(self.h, out.ctypes.data_as(u32p))
+        if rc:
+            raise RxError(rc, self.error())
+        return out
+
+    def guard_clear(self):
+        return self.L.selenite_rx_guard_clear(self.h)
 
     def nco_path(self):
         return self.L.selenite_rx_nco_path(self.h).decode()

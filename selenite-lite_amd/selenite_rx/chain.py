@@ -9,7 +9,7 @@ import ctypes as C
 
 import numpy as np
 
-from . import (ARITH_CMSIS, ARITH_FMA, ARITH_SPLIT16, MODE_CW, MODE_USB, Config, f32p, u32p)  # noqa: F401
+from . import (ARITH_AUTO, ARITH_CMSIS, ARITH_FMA, ARITH_SPLIT16, MODE_CW, MODE_USB, Config, f32p, u32p)  # noqa: F401
 
 SEED = 0x5E1E917E            # synthetic I/Q generator seed
 

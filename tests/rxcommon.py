@@ -18,7 +18,7 @@ if PKG_DIR not in sys.path:
     sys.path.insert(0, PKG_DIR)
 
 MODE_LSB, MODE_USB, MODE_CW, MODE_CWR, MODE_AM, MODE_FM, MODE_DIG, MODE_PKT = 0, 1, 2, 3, 4, 8, 0x0A, 0x0C
-ARITH_CMSIS, ARITH_FMA, ARITH_SPLIT16 = 0, 1, 2
+ARITH_CMSIS, ARITH_FMA, ARITH_SPLIT16, ARITH_AUTO = 0, 1, 2, 3
 SUCCESS, ARGUMENT_ERROR, LENGTH_ERROR, NANINF, DEVICE_ERROR = 0, -1, -2, -4, -7
 SEED = 0x5E1E917E
 

@@ -1,0 +1,292 @@
+"""SELENITE_ARITH_AUTO and the parity guard of the split-precision kernels (include/selenite_rx.h).
+
+The split16 kernels count every DSP block whose envelope is more than 12 dB under the largest sample their matrix
+product saw (the only region where 1e-5 of the block maximum against CMSIS is not guaranteed); SELENITE_ARITH_AUTO
+recomputes the channels that own such blocks with the bit-exact kernel, from their pre-call state, inside the same call.
+Here: the PLAIN north-star bar, max|gpu - ref| <= 1e-5 * max|ref| per DSP block, on inputs chosen to
+sit in the conditional zone (empty pass bands, LSB cancelling the main tone, level steps), against the CMSIS arithmetic of
+the oracle (arm_fir_decimate_f32.c:193-284 accumulation order)."""
+import os
+
+import numpy as np
+import pytest
+
+import rxcommon as rc
+from rxcommon import ARITH_AUTO, ARITH_CMSIS, ARITH_SPLIT16, CpuChain, bits_equal, synth_iq
+
+pytestmark = pytest.mark.gpu
+
+
+def per_block(yg, yo, na):
+    nch = yo.shape[0]
+    d = np.abs(yg.astype(np.float64) - yo).reshape(nch, -1, na).max(axis=2)
+    m = np.abs(yo).reshape(nch, -1, na).max(axis=2)
+    return d, m
+
+
+def spec_of(shape, nch, arith, mode=rc.MODE_USB, block=256, **kw):
+    nd, M, nh = shape
+    return rc.ChainSpec(nch, block, M, nd, nh, 0, mode, arith, **kw)
+
+
+@pytest.mark.parametrize("shape", [(256, 4, 63), (128, 2, 63), (0, 1, 127), (128, 4, 31), (256, 2, 127), (0, 1, 63)])
+@pytest.mark.parametrize("q15", [False, True])
+def test_auto_with_every_block_guarded_is_the_bit_exact_chain(shape, q15):
+    """guard ratio +inf: every channel with non-zero input lands on the rerun list, so the call's audio AND state must be
+    the CMSIS arithmetic's bit for bit -- the split16 kernel left the pre-call state alone, the list held every channel
+    once, the bit-exact kernel read the right state; over several calls (the two rerun counters alternate)."""
+    import selenite_rx as sr
+    nch = 77
+    steps = (np.arange(nch, dtype=np.uint64) * 0x9E3779B1 % (1 << 32)).astype(np.uint32)
+    kw = dict(nco=True, nco_steps=steps)
+    g = sr.Rx(spec_of(shape, nch, ARITH_AUTO, **kw).config())
+    assert "split16" in g.kernel_name() and "exact rerun" in g.kernel_name()
+    g.set_guard_ratio(float("inf"))
+    o = CpuChain(spec_of(shape, nch, ARITH_CMSIS, **kw), "orc")
+    pos = 0
+    for call, bs in enumerate((1024, 2048, 1024, 4096)):
+        iq = synth_iq(0, nch, pos, bs)
+        pos += bs
+        if q15:
+            iq16 = np.clip(np.round(iq * 20000.0), -32768, 32767).astype(np.int16)
+            assert np.array_equal(g.process_q15(iq16), o.process_q15(iq16)), call
+        else:
+            assert bits_equal(g.process(iq), o.process(iq)), call
+    sg, so = g.state(), o.state()
+    for key in sg:
+        assert (bits_equal(sg[key], so[key]) if sg[key].dtype == np.float32 else np.array_equal(sg[key], so[key])), key
+    st = g.guard_stats()
+    assert st["rerun_channel_calls"] == 4 * nch and st["channel_calls"] == 4 * nch
+    assert (g.guard_channels() > 0).all()
+    g.close()
+
+
+@pytest.mark.parametrize("agc", [False, True])
+@pytest.mark.parametrize("shape,mode", [((256, 4, 63), rc.MODE_USB), ((256, 4, 127), rc.MODE_LSB), ((128, 2, 63), rc.MODE_USB),
+                                        ((0, 1, 127), rc.MODE_LSB), ((0, 1, 63), rc.MODE_USB)])
+def test_auto_holds_the_plain_bar_where_split16_alone_does_not_have_to(shape, mode, agc):
+    """Every channel its own random NCO step: most pass bands are empty (audio 20-45 dB under the input), the case on which
+    plain SPLIT16 reaches 2.7e-5 of the block maximum (profiles/r2/split16_accuracy.txt).  AUTO: <= 1e-5 on EVERY block,
+    AGC on or off; the channels it did not rerun are bit-identical to plain SPLIT16."""
+    import selenite_rx as sr
+    nch, na = 192, 256 // shape[1]
+    rng = np.random.default_rng(5)
+    steps = rng.integers(0, 1 << 32, nch, dtype=np.uint64).astype(np.uint32)
+    kw = dict(nco=True, nco_steps=steps, agc=agc)
+    ga = sr.Rx(spec_of(shape, nch, ARITH_AUTO, mode, **kw).config())
+    gs = sr.Rx(spec_of(shape, nch, ARITH_SPLIT16, mode, **kw).config())
+    o = CpuChain(spec_of(shape, nch, ARITH_CMSIS, mode, **kw), "orc")
+    worst, worst_s, rerun_any = 0.0, 0.0, np.zeros(nch, bool)
+    for call in range(3):
+        iq = synth_iq(0, nch, call * 4096, 4096)
+        before = ga.guard_channels()
+        ya, ys, yo = ga.process(iq), gs.process(iq), o.process(iq)
+        rerun = ga.guard_channels() > before
+        if call > 0:          # (the first call from the zero state guards everybody: the filters ramp up through its first blocks)
+            rerun_any |= rerun
+        d, m = per_block(ya, yo, na)
+        assert (d <= 1e-5 * m).all(), "call %d worst %.3g" % (call, (d / np.maximum(m, 1e-30)).max())
+        worst = max(worst, float((d / np.maximum(m, 1e-30)).max()))
+        ds, ms = per_block(ys, yo, na)
+        worst_s = max(worst_s, float((ds / np.maximum(ms, 1e-30)).max()))
+        if call == 0:         # same state going in: un-guarded channels took the same path
+            assert bits_equal(ya[~rerun], ys[~rerun])
+            assert bits_equal(ya[rerun], yo[rerun])           # first call from the initial state: the rerun IS the oracle
+    st = ga.guard_stats()
+    assert st["rerun_channel_calls"] == st["channel_calls"] > 0 and st["blocks"] >= st["channel_calls"]
+    assert 0 < rerun_any.sum() and (shape[0] == 0 or rerun_any.sum() < nch)    # decimating shapes: the in-band channels stayed on the matrix pipe
+    assert gs.guard_stats()["rerun_channel_calls"] == 0 and gs.guard_stats()["blocks"] > 0      # plain SPLIT16 counts, never reruns
+    print("shape %s mode %#x agc %d: AUTO worst %.2e (split16 alone %.2e), %d of %d channels rerun after the first call"
+          % (shape, mode, agc, worst, worst_s, rerun_any.sum(), nch))
+    ga.close(); gs.close()
+
+
+def test_guard_counts_follow_the_definition():
+    """selenite_rx_guard_channels against the definition evaluated on the oracle's audio: a DSP block is guarded when its
+    envelope (before the AGC) is under 0.25 x the largest |component| of the mixed samples of its pass and of the decimator
+    history in front of it.  Blocks well inside / outside the zone must agree (the GPU decides on its own audio, which
+    differs from the oracle's in the 7th digit, so a +-10 % band around the threshold is left open)."""
+    import selenite_rx as sr
+    nch, bs = 128, 4096
+    rng = np.random.default_rng(9)
+    steps = rng.integers(0, 1 << 32, nch, dtype=np.uint64).astype(np.uint32)
+    kw = dict(nco=True, nco_steps=steps, agc=False)
+    g = sr.Rx(spec_of((256, 4, 63), nch, ARITH_SPLIT16, **kw).config())
+    o = CpuChain(spec_of((256, 4, 63), nch, ARITH_CMSIS, **kw), "orc")
+    iq = synth_iq(0, nch, 0, 2 * bs)
+    o.process(iq[:, :bs]); g.process(iq[:, :bs])          # second call: the history is live
+    g.guard_clear()
+    hist = o.state()["dec_state"]                         # [nch][2][255] mixed samples in front of the call
+    yo = o.process(iq[:, bs:])
+    g.process(iq[:, bs:])
+    mixed_tail = o.state()["dec_state"]
+    # mixed samples of the call: |component| maxima per pass of 1024 need the mixed signal; the decimator state gives the
+    # last 255 of them, the rest comes from the NCO model of test_gpu_truth (oracle's LO + f32 complex multiply)
+    L = rc.oracle_lib()
+    L.orc_nco_lo.argtypes = [rc.C.c_void_p, rc.C.c_uint32, rc.C.c_void_p]
+    L.orc_nco_lo.restype = None
+    mixed = np.empty((nch, bs, 2), np.float32)
+    for c in range(nch):
+        ph = ((np.arange(bs, dtype=np.uint64) + bs) * int(steps[c])).astype(np.uint32)
+        lo = np.empty((bs, 2), np.float32)
+        L.orc_nco_lo(ph.ctypes.data, bs, lo.ctypes.data)
+        a, b, lc, ls = iq[c, bs:, 0], iq[c, bs:, 1], lo[:, 0], lo[:, 1]
+        mixed[c, :, 0] = a * lc - b * ls
+        mixed[c, :, 1] = a * ls + b * lc
+    assert np.array_equal(mixed[:, -255:, 0], mixed_tail[:, 0])
+    full = np.concatenate([np.stack([hist[:, 0], hist[:, 1]], axis=2), mixed], axis=1)        # [nch][255 + bs][2]
+    env = np.abs(yo).reshape(nch, -1, 64).max(axis=2)                                         # 16 DSP blocks per channel, 4 per pass
+    pm = np.stack([np.abs(full[:, 1024 * p: 1024 * p + 1024 + 255]).reshape(nch, -1).max(axis=1) for p in range(bs // 1024)], axis=1)
+    ratio = env / np.repeat(pm, 4, axis=1)
+    sure, never = (ratio < 0.225).sum(axis=1), (ratio < 0.275).sum(axis=1)
+    cnt = g.guard_channels()
+    assert (cnt >= sure).all() and (cnt <= never).all()
+    assert cnt.sum() > 0 and (cnt == 0).any()
+    assert g.guard_stats()["blocks"] == cnt.sum() and g.guard_stats()["channel_calls"] == (cnt > 0).sum()
+    g.set_guard_ratio(0.0)                                # guard off: nothing is counted any more
+    g.guard_clear()
+    g.process(iq[:, :bs])
+    assert g.guard_stats()["blocks"] == 0
+    g.close()
+
+
+def test_auto_on_the_bench_workload_guards_nothing_in_the_steady_state():
+    """The bench workload (cfg3, every channel one tone in band): after the start-up transient of the first call no block is
+    guarded, so AUTO costs one empty rerun launch; and the plain bar holds on every block."""
+    import selenite_rx as sr
+    nch, bs = 1024, 4096
+    g = sr.Rx(rc.baseline_spec("cfg3", nch, ARITH_AUTO).config())
+    o = CpuChain(rc.baseline_spec("cfg3", nch, ARITH_CMSIS), "orc")
+    iq = synth_iq(0, nch, 0, bs)
+    for call in range(3):
+        if call == 1:
+            g.guard_clear()
+        d, m = per_block(g.process(iq), o.process(iq, 8), 64)
+        assert (d <= 1e-5 * m).all(), (call, (d / np.maximum(m, 1e-30)).max())
+    assert g.guard_stats() == dict(blocks=0, channel_calls=0, rerun_channel_calls=0)
+    g.close()
+
+
+def test_auto_partial_passes_global_gain_and_shapes_without_a_matrix_kernel():
+    import selenite_rx as sr
+    nch = 40
+    rng = np.random.default_rng(3)
+    steps = rng.integers(0, 1 << 32, nch, dtype=np.uint64).astype(np.uint32)
+    # (a) a call that is not a whole number of 1024-sample passes: whole passes fused (+ rerun), the rest on the generic
+    #     kernels in the CMSIS arithmetic
+    kw = dict(nco=True, nco_steps=steps)
+    g = sr.Rx(spec_of((256, 4, 63), nch, ARITH_AUTO, **kw).config())
+    o = CpuChain(spec_of((256, 4, 63), nch, ARITH_CMSIS, **kw), "orc")
+    pos = 0
+    for bs in (4352, 256, 1280):
+        iq = synth_iq(0, nch, pos, bs)
+        pos += bs
+        d, m = per_block(g.process(iq), o.process(iq), 64)
+        assert (d <= 1e-5 * m).all(), bs
+    g.close()
+    # (b) global gain: the envelope is folded after the rerun
+    kw = dict(nco=True, nco_steps=steps, agc_global=True)
+    g = sr.Rx(spec_of((256, 4, 63), nch, ARITH_AUTO, **kw).config())
+    o = CpuChain(spec_of((256, 4, 63), nch, ARITH_CMSIS, **kw), "orc")
+    for call in range(2):
+        iq = synth_iq(0, nch, 2048 * call, 2048)
+        yo, _ = o.process_env(iq)
+        d, m = per_block(g.process(iq), yo, 64)
+        assert (d <= 1e-5 * m).all(), call
+    g.close()
+    # (c) decimation by 8: no split-precision kernel -- AUTO is the bit-exact kernel there
+    g = sr.Rx(spec_of((256, 8, 63), nch, ARITH_AUTO, **dict(nco=True, nco_steps=steps)).config())
+    o = CpuChain(spec_of((256, 8, 63), nch, ARITH_CMSIS, **dict(nco=True, nco_steps=steps)), "orc")
+    assert g.kernel_name() == "k_ssb_fused<256,8,63>"
+    iq = synth_iq(0, nch, 0, 4096)
+    assert bits_equal(g.process(iq), o.process(iq))
+    g.close()
+
+
+@pytest.mark.parametrize("shape", [(256, 4, 63), (128, 4, 127), (256, 2, 63)])
+@pytest.mark.parametrize("q15", [False, True])
+def test_per_channel_lo_on_the_fs256_grid_is_held_in_registers_and_bit_identical(shape, q15):
+    """Every channel its own NCO step, all of them multiples of 2^24 (a channeliser on the fs/256 grid), random phases: the
+    split16 kernel computes each channel's two LO quads once per call (NCO == 4) instead of arm_sin/cos_f32 per sample
+    (arm_sin_f32.c:88-115, arm_cos_f32.c:81-107) -- same bits as the per-sample flavour, output and state."""
+    import selenite_rx as sr
+    nch = 70
+    rng = np.random.default_rng(17)
+    steps = (rng.integers(0, 256, nch).astype(np.uint32) << 24).astype(np.uint32)
+    phases = rng.integers(0, 1 << 32, nch, dtype=np.uint64).astype(np.uint32)
+    kw = dict(nco=True, nco_steps=steps, agc=True)
+    os.environ["SELENITE_RX_NO_PERIODIC_LO"] = "1"
+    g1 = sr.Rx(spec_of(shape, nch, ARITH_SPLIT16, **kw).config())
+    del os.environ["SELENITE_RX_NO_PERIODIC_LO"]
+    g4 = sr.Rx(spec_of(shape, nch, ARITH_SPLIT16, **kw).config())
+    o = CpuChain(spec_of(shape, nch, ARITH_CMSIS, **kw), "orc")
+    st = o.state(); st["nco_phase"] = phases
+    o.L.orc_rx_set_state(o.h, rc.C.byref(rc.state_view(st)))
+    g1.set_state(st); g4.set_state(st)
+    assert g1.nco_path() == "per-channel arm_sin/cos_f32 in the kernel"
+    assert g4.nco_path().startswith("per-channel LO, period 256 samples")
+    pos = 0
+    for bs in (1024, 4096 + (256 if shape[1] == 4 else 0), 2048):      # incl. a partial last pass
+        iq = synth_iq(0, nch, pos, bs)
+        pos += bs
+        if q15:
+            iq16 = np.clip(np.round(iq * 20000.0), -32768, 32767).astype(np.int16)
+            assert np.array_equal(g1.process_q15(iq16), g4.process_q15(iq16))
+            o.process_q15(iq16)
+        else:
+            assert bits_equal(g1.process(iq), g4.process(iq))
+            o.process(iq)
+    s1, s4, so = g1.state(), g4.state(), o.state()
+    for key in s1:
+        assert np.array_equal(s1[key].view(np.uint32), s4[key].view(np.uint32)), key
+    assert bits_equal(s4["dec_state"], so["dec_state"]) and np.array_equal(s4["nco_phase"], so["nco_phase"])     # mixed samples exact
+    g1.close(); g4.close()
+
+
+def test_global_gain_on_a_decimate_by_2_shape_with_16_lane_blocks():
+    """Advisor finding (round 2): agc_global + split16 on a /2 shape with DSP block 128 (16 lanes per block) asked the
+    kernel for block maxima that only the /4 launches provide -> DEVICE_ERROR.  Must run, and match the oracle."""
+    import selenite_rx as sr
+    nch = 24
+    kw = dict(nco=True, nco_step_all=0x02000000, agc_global=True)
+    g = sr.Rx(spec_of((256, 2, 63), nch, ARITH_SPLIT16, block=128, **kw).config())
+    o = CpuChain(spec_of((256, 2, 63), nch, ARITH_CMSIS, block=128, **kw), "orc")
+    for call in range(2):
+        iq = synth_iq(0, nch, 2048 * call, 2048)
+        yo, _ = o.process_env(iq)
+        assert rc.rel_err(g.process(iq), yo) <= 1e-5
+    g.close()
+
+
+def test_periodic_lo_with_calls_shorter_than_one_lo_period():
+    """Advisor finding (round 2): the register-resident LO reads LO[0..255]; a 128-sample call used to build a 128-entry
+    table.  DSP block 128, 128-tap /4 decimator, calls of 128 / 384 samples (single partial passes)."""
+    import selenite_rx as sr
+    nch = 20
+    kw = dict(nco=True, nco_step_all=0x03000000, agc=False)
+    g = sr.Rx(spec_of((128, 4, 63), nch, ARITH_SPLIT16, block=128, **kw).config())
+    o = CpuChain(spec_of((128, 4, 63), nch, ARITH_CMSIS, block=128, **kw), "orc")
+    pos = 0
+    for bs in (128, 384, 128, 1024):
+        iq = synth_iq(0, nch, pos, bs)
+        pos += bs
+        yg, yo = g.process(iq), o.process(iq)
+        im = np.abs(iq).max()
+        assert np.abs(yg - yo).max() <= 1e-5 * np.abs(yo).max() + 1e-6 * im, bs
+        assert bits_equal(g.state()["dec_state"], o.state()["dec_state"]), bs
+    g.close()
+
+
+def test_non_finite_input_raises_naninf_in_every_fused_kernel():
+    """ARM_MATH_NANINF (arm_math.h:405) from the exact / fma kernels too (round 2: split16 only)."""
+    import selenite_rx as sr
+    for arith in (ARITH_CMSIS, rc.ARITH_FMA, ARITH_SPLIT16, ARITH_AUTO):
+        for shape in ((256, 4, 63), (0, 1, 127)):
+            g = sr.Rx(spec_of(shape, 8, arith, nco=True, nco_step_all=0x01000000).config())
+            iq = synth_iq(0, 8, 0, 1024)
+            g.process(iq)
+            iq[3, 500, 0] = np.inf
+            with pytest.raises(sr.RxError) as e:
+                g.process(iq)
+            assert e.value.code == rc.NANINF, (arith, shape)
+            g.close()

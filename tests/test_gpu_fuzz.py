@@ -1,7 +1,9 @@
 """Randomised configurations of the fused kernels against the oracle (fixed seed): shape, arithmetic, channel count,
 call lengths (whole passes, partial last passes, single DSP blocks), slot format, NCO flavour, AGC, mode.  The exact modes
-must be bit-exact, output and state; split16 within the north-star tolerance with bit-exact mixed samples (decimator
-state).  SELENITE_FUZZ_CASES=<n> runs more cases."""
+must be bit-exact, output and state; SELENITE_ARITH_AUTO within the PLAIN north-star bar -- max|gpu - ref| <= 1e-5 max|ref|
+per DSP block, AGC on or off, any NCO -- and raw SELENITE_ARITH_SPLIT16 within its documented input-referred bar
+(1e-5 of the block maximum + 1e-6 of the input level: the blocks it counts as guarded are the ones that need the second
+term); both with bit-exact mixed samples (decimator state).  SELENITE_FUZZ_CASES=<n> runs more cases."""
 import os
 
 import numpy as np
@@ -22,7 +24,7 @@ SPLIT_SHAPES = {(256, 4, 63), (128, 4, 63), (256, 4, 127), (128, 4, 127), (256, 
 def one_case(rng, idx):
     import selenite_rx as sr
     nd, M, nh = SHAPES[int(rng.integers(len(SHAPES)))]
-    arith = [ARITH_CMSIS, ARITH_FMA, rc.ARITH_SPLIT16][int(rng.integers(3))]
+    arith = [ARITH_CMSIS, ARITH_FMA, rc.ARITH_SPLIT16, rc.ARITH_AUTO, rc.ARITH_AUTO][int(rng.integers(5))]
     nch = int(rng.choice([1, 2, 3, 15, 16, 17, 31, 33, 63, 64, 65, 100, 129]))
     q15 = bool(rng.integers(2))
     mode = int(rng.choice([rc.MODE_USB, rc.MODE_LSB, rc.MODE_AM, rc.MODE_DIG]))
@@ -35,17 +37,19 @@ def one_case(rng, idx):
         agc = False
     kw = dict(agc=agc)
     if nco == "periodic":
-        k = int(rng.integers(1, 3)) if arith == rc.ARITH_SPLIT16 else int(rng.integers(1, 200))     # split16: keep the tone in band
+        k = int(rng.integers(1, 3)) if arith == rc.ARITH_SPLIT16 else int(rng.integers(1, 200))     # raw split16: keep the tone in band
         kw.update(nco=True, nco_step_all=k << 24)
     elif nco == "table":
         kw.update(nco=True, nco_step_all=int(rng.integers(1, 1 << 32)) | 1)
     elif nco == "per_channel":
         kw.update(nco=True, nco_steps=rng.integers(0, 1 << 32, nch, dtype=np.uint64).astype(np.uint32))
-    split = arith == rc.ARITH_SPLIT16 and (nd, M, nh) in SPLIT_SHAPES and not (nd == 0 and mode == rc.MODE_AM and False)
     spec_g = rc.ChainSpec(nch, 256, M, nd, nh, 0, mode, arith, **kw)
     g = sr.Rx(spec_g.config())
-    tol_mode = arith == rc.ARITH_SPLIT16 and "split16" in g.kernel_name()
-    ref_arith = ARITH_CMSIS if tol_mode else (ARITH_FMA if arith == rc.ARITH_SPLIT16 else arith)
+    tol_mode = arith in (rc.ARITH_SPLIT16, rc.ARITH_AUTO) and "split16" in g.kernel_name()
+    auto = arith == rc.ARITH_AUTO
+    assert ("split16" in g.kernel_name()) == (arith in (rc.ARITH_SPLIT16, rc.ARITH_AUTO) and (nd, M, nh) in SPLIT_SHAPES)
+    # AUTO without a matrix kernel of its own is the bit-exact kernel; raw split16 without one runs as fma
+    ref_arith = ARITH_CMSIS if (tol_mode or auto) else (ARITH_FMA if arith == rc.ARITH_SPLIT16 else arith)
     o = CpuChain(rc.ChainSpec(nch, 256, M, nd, nh, 0, mode, ref_arith, **kw), "orc")
     desc = "case %d: shape %s arith %d nch %d q15 %d mode %#x nco %s agc %d kernel %s" % (idx, (nd, M, nh), arith, nch, q15, mode, nco, agc, g.kernel_name())
     assert g.kernel_name() != "generic", desc
@@ -68,7 +72,9 @@ def one_case(rng, idx):
                 im = np.abs(iq).reshape(nch, -1).max(axis=1)
                 d = np.abs(yg.astype(np.float64) - yo).reshape(nch, -1, na).max(axis=2)
                 m = np.abs(yo).reshape(nch, -1, na).max(axis=2)
-                assert (d <= 1e-5 * m + 1e-6 * im[:, None]).all(), desc + " worst %.3g" % (d / np.maximum(m, 1e-30)).max()
+                bar = 1e-5 * m if auto else 1e-5 * m + 1e-6 * im[:, None]
+                assert (d <= bar).all(), desc + " worst %.3g" % (d / np.maximum(m, 1e-30)).max()
+                WORST[0] = max(WORST[0], float((d / np.maximum(m, 1e-30)).max())) if auto else WORST[0]
             else:
                 assert bits_equal(yg, yo), desc
     sg, so = g.state(), o.state()
@@ -81,10 +87,14 @@ def one_case(rng, idx):
     g.close()
 
 
+WORST = [0.0]
+
+
 def test_random_configurations_of_the_fused_kernels():
     rng = np.random.default_rng(20261002)
     for idx in range(int(os.environ.get("SELENITE_FUZZ_CASES", "150"))):
         one_case(rng, idx)
+    print("worst per-block relative error of the SELENITE_ARITH_AUTO cases: %.3g (bar 1e-5)" % WORST[0])
 
 
 def test_random_configurations_of_the_cw_kernel():
