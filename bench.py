@@ -18,7 +18,9 @@ optional global-gain AGC (--global-gain): 4 bytes per DSP block all-reduced with
 
 Rank 0 prints ONE JSON line (see the driver contract in the task statement) carrying `roofline`
 and, at N=1, `cpu_baseline` (the CMSIS-DSP chain timed on this box's host cores, single core and all
-cores, on a bounded sample of the same workload).
+cores, on a bounded sample of the same workload) and `parity` (the timed arithmetic against that CMSIS chain on a
+sample of the workload, per DSP block).  Every side leg (`other_*`) gets its own clock spin-up and >= 100 launches and
+reports the MEDIAN of per-launch HIP-event durations, so the line reproduces run to run.
 """
 import argparse
 import json
@@ -31,7 +33,9 @@ sys.path.insert(0, os.path.join(ROOT, "selenite-lite_amd"))
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 F32_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: f32 vector (= f32 MFMA) peak
-TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r2", "traffic.json")
+TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r3", "traffic.json")
+if not os.path.exists(TRAFFIC_JSON):
+    TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r2", "traffic.json")
 
 WORKLOAD_TEXT = {"cfg3": "NCO + 256-tap arm_fir_decimate/4 + 63-tap Hilbert SSB (USB) + AGC",
                  "cfg2": "127-tap Hilbert SSB (USB) + AGC",
@@ -48,7 +52,7 @@ def pmc_traffic(workload, arith_name, kernel, channels, bs, workloads):
         t = json.load(open(TRAFFIC_JSON))
     except (OSError, ValueError):
         return None
-    e = t.get(workload + "_" + arith_name) or t.get(workload)
+    e = t.get(workload + "_" + arith_name) or t.get(workload + "_" + {"auto": "split16"}.get(arith_name, arith_name)) or t.get(workload)
     if not e or (channels, bs) != workloads[workload][1:]:
         return None
     if kernel.split("<")[0] not in e["kernel"]:
@@ -112,14 +116,59 @@ def cpu_baseline(name, workloads, budget_s=10.0):
             "seconds": round(e1 + en, 2)}
 
 
+def parity_check(name, workloads, arith, q15, nch=64, calls=2):
+    """The timed arithmetic against the CMSIS chain (oracle/_ref when present, else the pinned restatement) on a sample of the
+    workload: first `nch` channels, `calls` calls of the bench call length (4096 at most), per DSP block
+    max|gpu - ref| / max|ref|.  Part of the cpu_baseline leg: the oracle is the checker here, never timed
+    as the product."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy as np
+    import rxcommon as rc
+    import selenite_rx as sr
+    kind, which = ("reference", "ref") if rc.ref_available() else ("port", "orc")
+    cfg_name, _, bs = workloads[name]
+    bs = min(bs, 4096)
+    g = sr.Rx(rc.baseline_spec(cfg_name, nch, arith).config())
+    o = rc.CpuChain(rc.baseline_spec(cfg_name, nch, rc.ARITH_CMSIS), which)
+    na = g.cfg.block // g.cfg.decim
+    worst, blocks = 0.0, 0
+    for call in range(calls):
+        iq = rc.synth_iq(0, nch, call * bs, bs, rc.SEED)
+        if q15:
+            iq16 = np.clip(np.trunc(iq * np.float32(32768.0)), -32768, 32767).astype(np.int16)
+            yg, yo = g.process_q15(iq16).astype(np.float64), o.process_q15(iq16).astype(np.float64)
+        else:
+            yg, yo = g.process(iq).astype(np.float64), o.process(iq).astype(np.float64)
+        d = np.abs(yg - yo).reshape(nch, -1, na).max(axis=2)
+        m = np.abs(yo).reshape(nch, -1, na).max(axis=2)
+        worst = max(worst, float((d / np.maximum(m, 1e-30)).max()))
+        blocks += d.size
+    st = g.guard_stats()
+    g.close()
+    o.close()
+    return {"worst_rel": worst, "bar": 1e-5 if not q15 else None, "unit": "max|gpu-ref|/max|ref| per DSP block" + (" (int16 LSBs matter: q15 output)" if q15 else ""),
+            "blocks": blocks, "channels": nch, "calls": calls, "against": kind, "kernel": None, "guard_blocks": st["blocks"],
+            "rerun_channel_calls": st["rerun_channel_calls"]}
+
+
+def dist_block(env, devices, collectives_per_step, per_rank_ms):
+    """What lets the driver verify the ranks of an N > 1 line: backend, world, one device per rank, collectives per step."""
+    return {"backend": env.backend or "none", "world": env.world, "devices": devices,
+            "collectives_per_step": collectives_per_step, "per_rank_ms_per_step": per_rank_ms}
+
+
 def selftest_launch(env, args):
     """--selftest-launch: the launcher / rendezvous / collective plumbing of the N > 1 path without a GPU
-    (CPU tests): no library call, gloo only."""
+    (CPU tests): no library call, gloo only.  Emits the same `dist` block as a real line."""
     env.init_process_group("gloo", use_gpu=False)
     env.barrier()
-    worst = env.max_over_ranks(0.001 * (env.rank + 1))
+    mine = 0.001 * (env.rank + 1)
+    worst = env.max_over_ranks(mine)
+    devices = env.gather_objects("cpu:%d" % env.local_rank)
+    per_rank = env.gather_objects(round(mine * 1e3, 4))
     if env.rank == 0:
         print(json.dumps({"selftest": "launch", "n_gpus": args.gpus, "world": env.world, "max_over_ranks_s": worst,
+                          "dist": dist_block(env, devices, 1 if args.global_gain else 0, per_rank),
                           "config": {"parallelism": "channels sharded x%d, no data-path collective" % env.world}}), flush=True)
     env.close()
 
@@ -136,10 +185,12 @@ def main():
     ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOAD_TEXT))
     ap.add_argument("--channels", type=int, default=0, help="channels per GPU (default: workload's)")
     ap.add_argument("--block-size", type=int, default=0)
-    ap.add_argument("--arith", default=os.environ.get("SELENITE_BENCH_ARITH", "split16"), choices=["cmsis", "fma", "split16", "auto"],
-                    help="split16 (default): many-tap FIR as f16 hi/lo split-precision MFMA product with a per-pass block "
-                         "exponent, <=1e-5 rel vs CMSIS at any input level (north-star tolerance); fma: FIR tap loops "
-                         "fused, bit-exact vs the fmaf oracle; cmsis: bit-exact CMSIS-DSP arithmetic")
+    ap.add_argument("--arith", default=os.environ.get("SELENITE_BENCH_ARITH", "auto"), choices=["cmsis", "fma", "split16", "auto"],
+                    help="auto (default): many-tap FIR as f16 hi/lo split-precision MFMA product with a per-pass block exponent; "
+                         "channels with a DSP block under the parity guard (envelope more than 12 dB under the input) are recomputed "
+                         "in the same call by the bit-exact kernel: <=1e-5 rel vs CMSIS on every block; split16: the same "
+                         "without the rerun (guarded blocks only counted); fma: FIR tap loops fused, bit-exact vs the fmaf "
+                         "oracle; cmsis: bit-exact CMSIS-DSP arithmetic")
     ap.add_argument("--global-gain", action="store_true")
     ap.add_argument("--io", default="f32", choices=["f32", "q15"],
                     help="f32: the canonical float I/Q in / float audio out signature (headline); q15: the firmware's "
@@ -220,13 +271,30 @@ def main():
         else:
             rx.process_device(d_in.ptr, d_out.ptr, bs)
 
-    spin_t0 = time.perf_counter()
-    while (time.perf_counter() - spin_t0) * 1e3 < args.spinup_ms:      # clock ramp, untimed (see --spinup-ms)
-        for _ in range(16):
-            step()
-        rx.sync()
+    def spin(fn, sync, ms):                                 # clock ramp, untimed (see --spinup-ms)
+        t = time.perf_counter()
+        while (time.perf_counter() - t) * 1e3 < ms:
+            for _ in range(16):
+                fn()
+            sync()
+
+    def leg(rx_x, iters=None, src=None):
+        """One side leg on the resident data: its own spin-up (a third of the headline's), then >= 100 launches with a HIP event
+        between launches; the MEDIAN per-launch duration is the figure, mean / min / p90 beside it."""
+        src = d_in.ptr if src is None else src
+        iters = iters or max(100, args.steps // 4)
+        spin(lambda: rx_x.process_q15_device(src, d_out.ptr, bs) if q15 else rx_x.process_device(src, d_out.ptr, bs),
+             rx_x.sync, args.spinup_ms / 3.0)
+        ms = np.sort(rx_x.time_process_each(src, d_out.ptr, bs, iters, q15))
+        med = float(ms[len(ms) // 2])
+        return {"value": round(channels * bs / (med * 1e-3) / 1e6, 2), "unit": "Msamples/s", "ms_per_step": round(med, 4),
+                "ms_mean": round(float(ms.mean()), 4), "ms_min": round(float(ms[0]), 4), "ms_p90": round(float(ms[int(0.9 * len(ms))]), 4),
+                "launches": int(iters), "kernel": rx_x.kernel_name(), "nco": rx_x.nco_path()}
+
+    spin(step, rx.sync, args.spinup_ms)
     for _ in range(args.warmup):
         step()
+    rx.guard_clear()
     sync_all()
     t0 = time.perf_counter()
     if gg is not None:
@@ -240,7 +308,15 @@ def main():
     sync_all()
     t1 = time.perf_counter()
     rx.check()
+    guard = rx.guard_stats()
     elapsed = env.max_over_ranks(t1 - t0)
+    per_rank_ms = env.gather_objects(round((t1 - t0) * 1e3 / args.steps, 4))
+    devices = env.gather_objects(sr.device_pci_bus_id(local_rank))
+    # per-launch durations (one HIP event between launches), after the timed region: the median SURVEY.md 8d asks for
+    each = None
+    if gg is None and rank == 0:
+        each = np.sort(rx.time_process_each(d_in.ptr, d_out.ptr, bs, min(max(args.steps, 20), 200), q15))
+    env.barrier()
 
     if rank == 0:
         ms_per_step = elapsed * 1e3 / args.steps
@@ -257,82 +333,106 @@ def main():
         shared_lo = rx.nco_path().startswith("shared")
         fps = ch.flops_per_sample(spec, 6.0 if shared_lo else 20.0)
         fl = fps * channels * bs
-        traffic = None if q15 else pmc_traffic(args.workload, args.arith, rx.kernel_name(), channels, bs, ch.WORKLOADS)
+        traffic = pmc_traffic(args.workload + ("_q15" if q15 else ""), args.arith, rx.kernel_name(), channels, bs,
+                              dict(ch.WORKLOADS, **{k + "_q15": v for k, v in ch.WORKLOADS.items()}))
+        split_kernel = arith in (sr.ARITH_SPLIT16, sr.ARITH_AUTO) and "split16" in rx.kernel_name()
         out = {
             "metric": "Msamples/s complex I/Q through full RX chain (whole job)",
             "value": round(value, 2), "unit": "Msamples/s", "n_gpus": args.gpus, "steps": args.steps,
             "warmup": args.warmup, "spinup_ms": args.spinup_ms, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
             "dtype": ("f32 in / out / accumulate; FIR multiplicands as exact f16 hi+lo pairs (~22 bits) on the matrix cores"
-                      if arith in (sr.ARITH_SPLIT16, sr.ARITH_AUTO) and "split16" in rx.kernel_name() else "f32"),
+                      if split_kernel else "f32"),
             "data": "synthetic", "io": args.io,
             "config": {"workload": "%s: %d channels/GPU x %d complex samples/call, %s" % (
                            args.workload, channels, bs, WORKLOAD_TEXT[args.workload]),
                        "arith": {sr.ARITH_CMSIS: "cmsis-exact (mul,add)", sr.ARITH_FMA: "fma (<=1e-5 rel vs CMSIS)",
-                                 sr.ARITH_SPLIT16: "split16 (f16 hi/lo x3 MFMA FIR, block floating point, <=1e-5 rel vs CMSIS)",
-                                 sr.ARITH_AUTO: "auto (split16 + bit-exact rerun of the channels under the parity guard)"}[arith],
+                                 sr.ARITH_SPLIT16: "split16 (f16 hi/lo x3 MFMA FIR, block floating point; <=1e-5 rel vs CMSIS on blocks within 12 dB of the input level, the others are counted: `guard`)",
+                                 sr.ARITH_AUTO: "auto (split16 + bit-exact rerun of the channels under the parity guard: <=1e-5 rel vs CMSIS on every DSP block)"}[arith],
                        "kernel": rx.kernel_name(), "agc": "global" if args.global_gain else "per-channel",
                        "nco": rx.nco_path(),
+                       "nco_note": ("headline shape of BASELINE cfg3: ONE NCO step for all channels, on the fs/256 grid -- the LO is computed once "
+                                    "and lives in registers, the timed kernel evaluates no sin/cos; `other_nco_modes` times per-channel steps "
+                                    "(arm_sin/cos_f32 per sample: what the cpu_baseline does) on the same data") if shared_lo else None,
                        "parallelism": "channels sharded x%d, no data-path collective" % world},
             "per_gpu_msamples_s": round(value / world, 2),
+            "guard": dict(guard, ratio=0.25, note="DSP blocks of the timed steps under the parity guard (envelope < ratio x pass maximum); "
+                                                  "auto: their channels were recomputed bit-exactly inside the call"),
+            "guard_blocks": guard["blocks"],
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": traffic,
-                         "traffic_source": None if traffic is None else "profiles/r2/traffic.json (committed rocprofv3 --pmc passes of this kernel and shape; not measured in this run)",
+                         "traffic_source": None if traffic is None else os.path.relpath(TRAFFIC_JSON, ROOT) + " (committed rocprofv3 --pmc passes of this kernel and shape; not measured in this run)",
                          "algorithmic_bytes_per_launch": alg_bytes, "read_bytes_per_launch": rd_bytes,
                          "read_frac": round(rd_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                         "launch_ms_hip_events": round(k_ms, 4)},
+                         "launch_ms_hip_events": round(k_ms, 4),
+                         "launch_ms_median": None if each is None else round(float(each[len(each) // 2]), 4),
+                         "launch_ms_min": None if each is None else round(float(each[0]), 4),
+                         "launch_ms_p90": None if each is None else round(float(each[int(0.9 * len(each))]), 4),
+                         "frac_median": None if each is None else round(alg_bytes / (float(each[len(each) // 2]) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
             "fma_roof": {"achieved": round(fl / (k_ms * 1e-3) / 1e12, 2), "peak": F32_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(fl / (k_ms * 1e-3) / 1e12 / F32_PEAK_TFLOPS, 4),
                          "flops_per_sample": fps,
                          "note": ("algorithmic f32 flops of the chain against the f32 vector / f32-MFMA peak (SURVEY 8d: cfg3 is "
                                   "FMA-bound in direct-form f32)" + ("; the split16 kernel executes the FIR on the f16 matrix pipe "
-                                  "instead (three f16 MFMAs per product), so this roof does not bind it"
-                                  if arith == sr.ARITH_SPLIT16 and "split16" in rx.kernel_name() else ""))},
+                                  "instead (three f16 MFMAs per product), so this roof does not bind it" if split_kernel else ""))},
         }
-        if world == 1 and not args.global_gain and not args.main_only and not q15:
-            # the same workload in the other arithmetic contracts and with the general (per-channel) NCO, outside the
-            # timed region, for the record
+        if world > 1 or env.dist is not None:
+            out["dist"] = dist_block(env, devices, 1 if args.global_gain else 0, per_rank_ms)
+        if world == 1 and not args.global_gain and not args.main_only:
+            # the same workload in the other arithmetic contracts and with the general NCO flavours, outside the timed
+            # region; every leg: own spin-up, >= 100 launches, median of per-launch HIP-event durations
             others = {}
-            for nm, ar in (("fma", sr.ARITH_FMA), ("cmsis", sr.ARITH_CMSIS)):
+            for nm, ar in (("split16", sr.ARITH_SPLIT16), ("auto", sr.ARITH_AUTO), ("fma", sr.ARITH_FMA), ("cmsis", sr.ARITH_CMSIS)):
                 if ar == arith:
                     continue
                 rx_x = sr.Rx(ch.baseline_spec(cfg_name, channels, ar).config())
-                rx_x.time_process(d_in.ptr, d_out.ptr, bs, max(2, args.warmup))
-                ms_x = rx_x.time_process(d_in.ptr, d_out.ptr, bs, max(3, args.steps // 2))
-                others[nm] = {"value": round(channels * bs / (ms_x * 1e-3) / 1e6, 2), "unit": "Msamples/s",
-                              "ms_per_step": round(ms_x, 4), "kernel": rx_x.kernel_name()}
+                others[nm] = leg(rx_x)
                 rx_x.close()
-            others["note"] = ("fma: bit-exact vs the oracle's fmaf restatement; cmsis: bit-exact (0 ULP) vs CMSIS-DSP 1.5.3 "
-                              "arithmetic; split16: tolerance-based, <=1e-5 relative per DSP block")
+            others["note"] = ("auto: split16 + bit-exact rerun of guarded channels; split16: tolerance-based, guarded blocks only counted; "
+                              "fma: bit-exact vs the oracle's fmaf restatement; cmsis: bit-exact (0 ULP) vs CMSIS-DSP 1.5.3 arithmetic")
             out["other_arith_modes"] = others
-            if spec.nco:
-                # every channel with its own NCO step: arm_sin_f32 / arm_cos_f32 per sample inside the kernel
-                # (arm_sin_f32.c:72-119), no shared LO table
+            if spec.nco and cfg_name == "cfg3":
+                frac = lambda r: round(alg_bytes / (r["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                nm = {}
+                raw = sr.ARITH_SPLIT16 if arith == sr.ARITH_AUTO else arith     # NCO cost alone: no reruns in these legs
+                # every channel its own NCO step: arm_sin_f32 / arm_cos_f32 per sample inside the kernel (arm_sin_f32.c:72-119)
                 steps_pc = (np.arange(channels, dtype=np.uint64) * 0x9E3779B1 % (1 << 26) + 0x00800000).astype(np.uint32)
-                rx_p = sr.Rx(ch.baseline_spec(cfg_name, channels, arith, nco_steps=steps_pc).config())
-                rx_p.time_process(d_in.ptr, d_out.ptr, bs, max(2, args.warmup))
-                ms_p = rx_p.time_process(d_in.ptr, d_out.ptr, bs, max(3, args.steps // 2))
-                out["other_nco_modes"] = {"per_channel": {
-                    "value": round(channels * bs / (ms_p * 1e-3) / 1e6, 2), "unit": "Msamples/s", "ms_per_step": round(ms_p, 4),
-                    "kernel": rx_p.kernel_name(), "roofline_frac": round(alg_bytes / (ms_p * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                    "note": "every channel its own NCO step; table-lerp sin/cos per sample in the kernel"}}
+                rx_p = sr.Rx(ch.baseline_spec(cfg_name, channels, raw, nco_steps=steps_pc).config())
+                nm["per_channel"] = dict(leg(rx_p), note="every channel its own arbitrary NCO step; table-lerp sin/cos per sample in the kernel")
                 rx_p.close()
+                # every channel its own step ON the fs/256 grid (a channeliser): the channel's LO period is computed once per call
+                steps_g = ((np.arange(channels, dtype=np.uint64) * 0x9E3779B1 >> 7) % 256 << 24).astype(np.uint32)
+                rx_g = sr.Rx(ch.baseline_spec(cfg_name, channels, raw, nco_steps=steps_g).config())
+                nm["per_channel_grid"] = dict(leg(rx_g), note="every channel its own NCO step, all multiples of fs/256: LO of one 256-sample period computed per channel and call (arm_sin/cos_f32 arithmetic), held in registers")
+                rx_g.close()
                 if "registers" in rx.nco_path():
                     # the same shared LO read as a per-call table from L2 (what a step off the fs / 256 grid gets)
                     os.environ["SELENITE_RX_NO_PERIODIC_LO"] = "1"
-                    rx_t = sr.Rx(spec.config())
+                    rx_t = sr.Rx(ch.baseline_spec(cfg_name, channels, raw).config())
                     del os.environ["SELENITE_RX_NO_PERIODIC_LO"]
-                    rx_t.time_process(d_in.ptr, d_out.ptr, bs, max(2, args.warmup))
-                    ms_t = rx_t.time_process(d_in.ptr, d_out.ptr, bs, max(3, args.steps // 2))
-                    out["other_nco_modes"]["shared_table"] = {
-                        "value": round(channels * bs / (ms_t * 1e-3) / 1e6, 2), "unit": "Msamples/s", "ms_per_step": round(ms_t, 4),
-                        "kernel": rx_t.kernel_name(), "nco": rx_t.nco_path(),
-                        "roofline_frac": round(alg_bytes / (ms_t * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                        "note": "one NCO step for all channels that is NOT a multiple of fs / 256: LO table computed per call, read from L2"}
+                    nm["shared_table"] = dict(leg(rx_t), note="one NCO step for all channels that is NOT a multiple of fs / 256: LO table computed per call, read from L2")
                     rx_t.close()
+                for v in nm.values():
+                    v["roofline_frac"] = frac(v)
+                out["other_nco_modes"] = nm
+                if arith == sr.ARITH_AUTO and not q15:
+                    # what AUTO costs when the guard fires: the per_channel_grid steps move most channels' tone out of the pass
+                    # band (audio 20-45 dB under the input), the worst case for an output-relative bar
+                    rx_a = sr.Rx(ch.baseline_spec(cfg_name, channels, sr.ARITH_AUTO, nco_steps=steps_g).config())
+                    r = leg(rx_a)
+                    rx_a.guard_clear()
+                    rx_a.process_device(d_in.ptr, d_out.ptr, bs)
+                    g1 = rx_a.guard_stats()
+                    rx_a.close()
+                    out["auto_stopband_cost"] = dict(r, roofline_frac=frac(r), rerun_fraction=round(g1["rerun_channel_calls"] / channels, 4),
+                                                     note="SELENITE_ARITH_AUTO on the per_channel_grid workload: the guarded fraction of the channels "
+                                                          "is recomputed by the bit-exact kernel every call")
         if world == 1 and not args.no_cpu_baseline and not args.main_only:
             out["cpu_baseline"] = cpu_baseline(args.workload, ch.WORKLOADS)
+            if not args.global_gain:
+                out["parity"] = dict(parity_check(args.workload, ch.WORKLOADS, arith, q15), kernel=rx.kernel_name())
+                out["parity_worst_rel"] = out["parity"]["worst_rel"]
         print(json.dumps(out), flush=True)
 
     rx.close()

@@ -263,6 +263,14 @@ int  selenite_rx_time_process_q15_device(selenite_rx_instance *S, const int16_t 
                                          int16_t *dDstAudio, uint32_t blockSize, uint32_t iters,
                                          float *ms_per_call);
 
+/* The same with a HIP event between consecutive calls: ms_each[iters] receives the duration of every call (SURVEY.md 8d asks
+ * for the median of >= 20 launches).  q15 != 0: the buffers are the int16 slot format.  The extra events cost a little
+ * overlap between consecutive launches; bench.py reports both this median and the plain mean above. */
+int  selenite_rx_time_process_each_device(selenite_rx_instance *S, const void *dSrcIQ, void *dDstAudio, uint32_t blockSize,
+                                          uint32_t iters, float *ms_each, int q15);
+/* PCI bus id ("0000:05:00.0") of HIP device `ordinal` into buf; bench.py lists the devices of the ranks with it. */
+int  selenite_rx_device_pci_bus_id(int ordinal, char *buf, size_t len);
+
 /* Name of the kernel variant process_f32_device dispatches to for this instance
  * (e.g. "rx_ssb_fused<256,4,63>" or "generic"); for logs and profiles. */
 const char *selenite_rx_kernel_name(const selenite_rx_instance *S);

@@ -110,7 +110,7 @@ static void classify_coeffs(selenite_rx_instance *S)
 
 static void free_device(selenite_rx_instance *S)
 {
-    void *ptrs[] = { S->d_flags, S->d_guard_ch, S->d_rerun_list, S->d_dec_c, S->d_hilb_c, S->d_delay_c, S->d_biq_c, S->d_sintab, S->d_step, S->d_phase,
+    void *ptrs[] = { S->d_flags, S->d_guard_ch, S->d_rerun_flag, S->d_dec_c, S->d_hilb_c, S->d_delay_c, S->d_biq_c, S->d_sintab, S->d_step, S->d_phase,
                      S->d_dec_state, S->d_fir_state, S->d_biq_state, S->d_gain, S->d_scratch, S->d_env, S->d_env_part,
                      S->d_io_in, S->d_io_out, S->d_lo, S->pipe.d_in[0], S->pipe.d_in[1], S->pipe.d_out[0], S->pipe.d_out[1] };
     for (void *p : ptrs)
@@ -137,8 +137,8 @@ static int reset_state(selenite_rx_instance *S)
     if (g.n_biquad) HIPCHK(S, hipMemsetAsync(S->d_biq_state, 0, C * 4 * g.n_biquad * sizeof(float), S->stream));
     HIPCHK(S, hipMemsetAsync(S->d_phase, 0, C * sizeof(uint32_t), S->stream));
     HIPCHK(S, hipMemsetAsync(S->d_flags, 0, kFlagWords * sizeof(uint32_t), S->stream));
-    HIPCHK(S, hipMemsetAsync(S->d_guard_ch, 0, C * sizeof(uint32_t), S->stream));
-    S->rerun_parity = 0;
+    HIPCHK(S, hipMemsetAsync(S->d_guard_ch, 0, 2 * C * sizeof(uint32_t), S->stream));
+    if (S->d_rerun_flag) HIPCHK(S, hipMemsetAsync(S->d_rerun_flag, 0, C * sizeof(uint32_t), S->stream));
     std::vector<float> gi(C, g.agc_gain_init);
     HIPCHK(S, hipMemcpyAsync(S->d_gain, gi.data(), C * sizeof(float), hipMemcpyHostToDevice, S->stream));
     HIPCHK(S, hipStreamSynchronize(S->stream));
@@ -255,8 +255,8 @@ extern "C" int selenite_rx_init(selenite_rx_instance **out, const selenite_rx_co
     INITCHK(dev_alloc(&S->d_biq_state, C * 4 * cfg->n_biquad));
     INITCHK(dev_alloc(&S->d_gain, C));
     INITCHK(dev_alloc(&S->d_flags, (size_t)kFlagWords));
-    INITCHK(dev_alloc(&S->d_guard_ch, C));
-    INITCHK(dev_alloc(&S->d_rerun_list, cfg->arith == SELENITE_ARITH_AUTO ? C : 0));
+    INITCHK(dev_alloc(&S->d_guard_ch, 2 * C));
+    INITCHK(dev_alloc(&S->d_rerun_flag, cfg->arith == SELENITE_ARITH_AUTO ? C : 0));
 #undef INITCHK
     classify_coeffs(S);
     if (plan_fused(S->cfg, S->delay_is_impulse, S->delay_index, S->hilb_odd_only, S->plan) != hipSuccess) {
@@ -376,12 +376,16 @@ extern "C" int selenite_rx_guard_stats(selenite_rx_instance *S, uint64_t *guard_
     if (!S) return SELENITE_RX_ARGUMENT_ERROR;
     HIPCHK(S, hipSetDevice(S->device));
     HIPCHK(S, hipStreamSynchronize(S->stream));
-    uint32_t w[kFlagWords];
-    HIPCHK(S, hipMemcpy(w, S->d_flags, sizeof w, hipMemcpyDeviceToHost));
-    auto u64 = [&](int i) { return (uint64_t)w[i] | ((uint64_t)w[i + 1] << 32); };
-    if (guard_blocks) *guard_blocks = u64(kFlagGuardBlocks);
-    if (guard_channel_calls) *guard_channel_calls = u64(kFlagGuardCalls);
-    if (rerun_channel_calls) *rerun_channel_calls = u64(kFlagRerunCalls);
+    // the kernels keep two words per channel (no atomics on shared counters); summed here, on the host
+    const size_t C = S->cfg.channels;
+    std::vector<uint32_t> w(2 * C);
+    HIPCHK(S, hipMemcpy(w.data(), S->d_guard_ch, 2 * C * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    uint64_t blocks = 0, calls = 0;
+    for (size_t c = 0; c < C; ++c) { blocks += w[c]; calls += w[C + c]; }
+    if (guard_blocks) *guard_blocks = blocks;
+    if (guard_channel_calls) *guard_channel_calls = calls;
+    // SELENITE_ARITH_AUTO recomputes every guarded channel-call (the counts only ever come from the split-precision kernels)
+    if (rerun_channel_calls) *rerun_channel_calls = S->cfg.arith == SELENITE_ARITH_AUTO ? calls : 0;
     return SELENITE_RX_SUCCESS;
 }
 
@@ -398,9 +402,7 @@ extern "C" int selenite_rx_guard_clear(selenite_rx_instance *S)
 {
     if (!S) return SELENITE_RX_ARGUMENT_ERROR;
     HIPCHK(S, hipSetDevice(S->device));
-    // the three 64-bit counters only: the rerun counters of the launches in flight stay
-    HIPCHK(S, hipMemsetAsync(S->d_flags + kFlagGuardBlocks, 0, 6 * sizeof(uint32_t), S->stream));
-    HIPCHK(S, hipMemsetAsync(S->d_guard_ch, 0, (size_t)S->cfg.channels * sizeof(uint32_t), S->stream));
+    HIPCHK(S, hipMemsetAsync(S->d_guard_ch, 0, 2 * (size_t)S->cfg.channels * sizeof(uint32_t), S->stream));
     return SELENITE_RX_SUCCESS;
 }
 
@@ -427,10 +429,11 @@ static RxParams make_params(selenite_rx_instance *S, uint32_t block_size)
     p.flags = S->d_flags;
     p.guard_ratio = S->guard_ratio;
     p.guard_ch = S->d_guard_ch;
+    p.guard_calls = S->d_guard_ch + g.channels;
     if (S->sub_count) {                                     // a contiguous channel range of the instance: every per-channel array moves with it
         const size_t c0 = S->sub_first;
         p.channels = S->sub_count;
-        p.step += c0; p.phase += c0; p.gain += c0; p.guard_ch += c0;
+        p.step += c0; p.phase += c0; p.gain += c0; p.guard_ch += c0; p.guard_calls += c0;
         if (p.dec_state) p.dec_state += c0 * 2 * (g.nd_taps - 1);
         if (p.fir_state) p.fir_state += c0 * 2 * (g.nh_taps - 1);
         if (p.biq_state) p.biq_state += c0 * 4 * g.n_biquad;
@@ -528,12 +531,9 @@ static int run_part(selenite_rx_instance *S, const void *src, bool src_q15, void
             pf.lo_period = 256u;                          // pf.nco stays 1: every channel computes its own period once
         }
         if (arith == SELENITE_ARITH_AUTO && ssb_fused) {
-            // the split16 kernel appends the channels it guards to d_rerun_list (counter of this launch: d_flags[kFlagRerunCnt0 +
-            // parity]; it zeroes the OTHER counter for the next launch) and the bit-exact kernel recomputes them (launch_fused)
-            pf.rerun_list = S->d_rerun_list;
-            pf.rerun_cnt = S->d_flags + kFlagRerunCnt0 + S->rerun_parity;
-            pf.rerun_cnt_other = S->d_flags + kFlagRerunCnt0 + (S->rerun_parity ^ 1u);
-            S->rerun_parity ^= 1u;
+            // the split16 kernel raises the rerun flag of the channels it guards and leaves their state alone; the bit-exact
+            // kernel then recomputes the flagged channels (launch_fused)
+            pf.rerun_flag = S->d_rerun_flag + (S->sub_count ? S->sub_first : 0u);
         }
         void *fdst = dst;
         bool fq15 = dst_q15;
@@ -971,6 +971,36 @@ extern "C" int selenite_rx_time_process_q15_device(selenite_rx_instance *S, cons
                                                    uint32_t blockSize, uint32_t iters, float *ms_per_call)
 {
     return time_process(S, dSrcIQ, dDstAudio, true, blockSize, iters, ms_per_call, "selenite_rx_time_process_q15_device");
+}
+
+extern "C" int selenite_rx_time_process_each_device(selenite_rx_instance *S, const void *dSrcIQ, void *dDstAudio, uint32_t blockSize,
+                                                    uint32_t iters, float *ms_each, int q15)
+{
+    if (!S || !ms_each || iters == 0) return SELENITE_RX_ARGUMENT_ERROR;
+    if (!block_size_ok(S, blockSize, "selenite_rx_time_process_each_device")) return S->status;
+    HIPCHK(S, hipSetDevice(S->device));
+    struct Events {                                        // destroyed on every exit path
+        std::vector<hipEvent_t> e;
+        ~Events() { for (hipEvent_t x : e) if (x) (void)hipEventDestroy(x); }
+    } ev;
+    ev.e.assign((size_t)iters + 1, nullptr);
+    for (auto &x : ev.e) HIPCHK(S, hipEventCreate(&x));
+    HIPCHK(S, hipEventRecord(ev.e[0], S->stream));
+    for (uint32_t i = 0; i < iters; ++i) {
+        int rc = run_chain(S, dSrcIQ, q15 != 0, dDstAudio, q15 != 0, blockSize, kAll, nullptr);
+        if (rc) return rc;
+        HIPCHK(S, hipEventRecord(ev.e[i + 1], S->stream));
+    }
+    HIPCHK(S, hipEventSynchronize(ev.e[iters]));
+    for (uint32_t i = 0; i < iters; ++i) HIPCHK(S, hipEventElapsedTime(&ms_each[i], ev.e[i], ev.e[i + 1]));
+    return SELENITE_RX_SUCCESS;
+}
+
+extern "C" int selenite_rx_device_pci_bus_id(int ordinal, char *buf, size_t len)
+{
+    if (!buf || len < 13) return SELENITE_RX_ARGUMENT_ERROR;
+    HIPCHK(nullptr, hipDeviceGetPCIBusId(buf, (int)len, ordinal));
+    return SELENITE_RX_SUCCESS;
 }
 
 extern "C" uint64_t selenite_rx_algorithmic_bytes(const selenite_rx_config *g, uint32_t blockSize, uint64_t *read_bytes)

@@ -167,14 +167,28 @@ __global__ __launch_bounds__(64, 2) void k_ssb_fused(RxParams p, FusedArgs fa, c
     float *dI = D, *dQ = D + G::DLEN;
     constexpr int NLD = G::T / 128;                      // raw loads per lane per pass
     bool nonfinite = false;                              // any audio sample of this workgroup NaN / Inf
-    // One channel per workgroup, c = blockIdx.x -- or, as the rerun pass of SELENITE_ARITH_AUTO (p.chan_list: the channels
-    // whose split-precision result fell under the parity guard, appended by the split16 kernel of the same call), the list
-    // entries blockIdx.x, blockIdx.x + gridDim.x, ...: the count is only known on the device.
-    uint32_t li = blockIdx.x;
-    const uint32_t ln = p.chan_list ? *p.chan_count : 0u;
-    if (p.chan_list && li >= ln) return;
+    // One channel per workgroup, c = blockIdx.x -- or, as the rerun pass of SELENITE_ARITH_AUTO (p.chan_flags: one word per
+    // channel, raised by the split16 kernel of the same call for the channels whose result fell under the parity guard), the
+    // flagged channels of the 16-channel windows blockIdx.x, blockIdx.x + gridDim.x, ...: which channels, and how many,
+    // is only known on the device.
+    uint32_t win = blockIdx.x;                           // current window
+    uint64_t todo = 0;                                   // flagged channels of the window still to do (bit = channel - 16 win)
   for (;;) {
-    const uint32_t c = p.chan_list ? p.chan_list[li] : li;
+    uint32_t c = blockIdx.x;
+    if (p.chan_flags) {
+        const uint32_t nwin = (p.channels + 15u) / 16u;
+        while (todo == 0) {                              // wave-uniform
+            if (win >= nwin) break;
+            const uint32_t ci = 16u * win + (uint32_t)(lane & 15);
+            const uint32_t f = (lane < 16 && ci < p.channels) ? p.chan_flags[ci] : 0u;
+            todo = __builtin_amdgcn_ballot_w64(f != 0u);
+            if (todo == 0) win += gridDim.x;
+        }
+        if (todo == 0) break;
+        c = 16u * win + (uint32_t)__builtin_ctzll(todo);
+        todo &= todo - 1;
+        if (todo == 0) win += gridDim.x;
+    }
 
     const size_t in_base = (size_t)c * p.in_stride, out_base = (size_t)c * p.out_stride;
     const uint32_t npass = p.nout / G::P;
@@ -333,9 +347,7 @@ __global__ __launch_bounds__(64, 2) void k_ssb_fused(RxParams p, FusedArgs fa, c
         if constexpr (NCO != 0) p.phase[c] = ph0 + p.block_size * step;
         if (p.agc) p.gain[c] = gain;
     }
-    if (!p.chan_list) break;
-    li += gridDim.x;
-    if (li >= ln) break;
+    if (!p.chan_flags) break;
     wave_lds_sync();                                     // the state reads above before the next channel's prologue fills
   }
     if (nonfinite) p.flags[kFlagNanInf] = 1u;            // ARM_MATH_NANINF, read by selenite_rx_sync
@@ -764,8 +776,10 @@ static hipError_t launch_one(const RxParams &p, const FusedArgs &fa, const void 
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    // (rerun pass of SELENITE_ARITH_AUTO: the list length is only known on the device -- a resident-sized grid strides over it)
-    const uint32_t grid = p.chan_list ? (p.channels < 2048u ? p.channels : 2048u) : p.channels;
+    // (rerun pass of SELENITE_ARITH_AUTO: which channels are flagged is only known on the device -- a resident-sized grid strides
+    // over the 16-channel windows of the flag array)
+    const uint32_t nwin = (p.channels + 15u) / 16u;
+    const uint32_t grid = p.chan_flags ? (nwin < 2048u ? nwin : 2048u) : p.channels;
     hipLaunchKernelGGL(k, dim3(grid), dim3(64), lds, st, p, fa, static_cast<const TIn *>(src),
                        static_cast<TOut *>(dst));
     return hipGetLastError();
@@ -812,26 +826,26 @@ static hipError_t launch_shape(const RxParams &p, const FusedArgs &fa, const Fus
     if (src_q15 != dst_q15) return hipErrorNotSupported;
     const bool auto_ = arith == SELENITE_ARITH_AUTO;
     const bool split = arith == SELENITE_ARITH_SPLIT16 || auto_;
-    // SELENITE_ARITH_AUTO, second launch: the bit-exact kernel over the channels the split16 kernel put on the rerun list
+    // SELENITE_ARITH_AUTO, second launch: the bit-exact kernel over the channels whose rerun flag the split16 kernel raised
     // (their streaming state is still the pre-call state; audio and state are recomputed in the CMSIS arithmetic)
     auto rerun = [&]() -> hipError_t {
         RxParams p2 = p;
-        p2.chan_list = p.rerun_list; p2.chan_count = p.rerun_cnt;
-        p2.rerun_list = nullptr; p2.rerun_cnt = nullptr; p2.rerun_cnt_other = nullptr; p2.guard_ch = nullptr;
+        p2.chan_flags = p.rerun_flag;
+        p2.rerun_flag = nullptr; p2.guard_ch = nullptr; p2.guard_calls = nullptr;
         if (src_q15) return launch_one<0, ND, M, NH, int16_t, int16_t>(p2, fa, src, dst, st);
         return launch_one<0, ND, M, NH, float, float>(p2, fa, src, dst, st);
     };
     if constexpr (ND > 0 && (M == 4 || M == 2) && NH > 0) {
         if (split && plan.d_btab16) {
             hipError_t e = launch_ssb_split16(ND, M, NH, p, fa, src, src_q15, dst, st);      // rx_split16.hip
-            if (e == hipSuccess && auto_ && p.rerun_list) e = rerun();
+            if (e == hipSuccess && auto_ && p.rerun_flag) e = rerun();
             return e;
         }
     }
     if constexpr (ND == 0 && M == 1 && NH > 0) {
         if (split && plan.d_btab16 && fa.group == 64) {
             hipError_t e = launch_hilb_split16(NH, p, fa, src, src_q15, dst, st);            // rx_split16.hip
-            if (e == hipSuccess && auto_ && p.rerun_list) e = rerun();
+            if (e == hipSuccess && auto_ && p.rerun_flag) e = rerun();
             return e;
         }
     }

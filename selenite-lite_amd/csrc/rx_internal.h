@@ -46,20 +46,19 @@ struct RxParams {
     // rounding noise of ~1e-7 of the INPUT, may differ by more than 1e-5 of the (small) block maximum.
     float guard_ratio;
     uint32_t *guard_ch;    // [channels] sticky count of guarded DSP blocks per channel, or NULL
+    uint32_t *guard_calls; // [channels] sticky count of process calls in which the channel had a guarded block, or NULL
     // SELENITE_ARITH_AUTO: a channel with a guarded block in this call keeps its pre-call streaming state (the split16
-    // kernel does not write it back) and is appended to rerun_list; a second launch of the bit-exact kernel (chan_list =
-    // that list) recomputes the call for those channels -- audio and state -- in the CMSIS arithmetic
-    uint32_t *rerun_list;  // [channels] or NULL (plain SPLIT16: count only)
-    uint32_t *rerun_cnt;   // entries in rerun_list (device counter of THIS launch)
-    uint32_t *rerun_cnt_other;   // the other launch parity's counter: zeroed by this launch for the next one
-    const uint32_t *chan_list;   // exact kernels: process channels chan_list[0 .. *chan_count) instead of 0 .. channels-1
-    const uint32_t *chan_count;
+    // kernel does not write it back) and raises rerun_flag[channel] (every channel's flag is rewritten every call: plain
+    // stores, no atomics -- 48 k atomics on one counter cost 0.7 ms per launch when most channels were guarded); a second
+    // launch of the bit-exact kernel (chan_flags = those flags) recomputes the call for the flagged channels -- audio and
+    // state -- in the CMSIS arithmetic
+    uint32_t *rerun_flag;        // [channels] or NULL (plain SPLIT16: count only)
+    const uint32_t *chan_flags;  // exact kernels: process only the channels whose flag is set (16-channel windows, grid-stride)
     AgcParams agcp;
 };
 
 // words of RxParams::flags
-enum { kFlagNanInf = 0, kFlagGuardBlocks = 2 /* u64 */, kFlagGuardCalls = 4 /* u64 */, kFlagRerunCalls = 6 /* u64 */,
-       kFlagRerunCnt0 = 8, kFlagRerunCnt1 = 9, kFlagWords = 16 };
+enum { kFlagNanInf = 0, kFlagWords = 4 };
 
 __host__ __device__ inline bool mode_is_cw(uint32_t m) { return m == SELENITE_MODE_CW || m == SELENITE_MODE_CWR; }
 __host__ __device__ inline bool mode_is_upper(uint32_t m)
@@ -140,9 +139,8 @@ struct selenite_rx_instance {
     uint32_t *d_step = nullptr, *d_phase = nullptr;
     float *d_dec_state = nullptr, *d_fir_state = nullptr, *d_biq_state = nullptr, *d_gain = nullptr;
     uint32_t *d_flags = nullptr;       // kFlagWords words
-    uint32_t *d_guard_ch = nullptr;    // [channels] guarded DSP blocks per channel (sticky)
-    uint32_t *d_rerun_list = nullptr;  // [channels] SELENITE_ARITH_AUTO: channels of the current call to recompute exactly
-    uint32_t rerun_parity = 0;
+    uint32_t *d_guard_ch = nullptr;    // [2][channels] guarded DSP blocks per channel | process calls with a guarded block (sticky)
+    uint32_t *d_rerun_flag = nullptr;  // [channels] SELENITE_ARITH_AUTO: 1 = recompute this channel's current call exactly
     float guard_ratio = 0.25f;         // -12 dB
     bool steps_grid256 = false;        // every NCO step is a multiple of 2^24: every channel's LO repeats every 256 samples
     float *d_scratch = nullptr;  size_t scratch_bytes = 0;   // intermediate f32 audio

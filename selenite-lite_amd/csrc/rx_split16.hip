@@ -384,7 +384,6 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
         gd.first = 0ull;
         for (int l = 0; l < 64; l += (int)fa.group) gd.first |= 1ull << l;
     }
-    if (blockIdx.x == 0 && lane == 0 && p.rerun_cnt_other) *p.rerun_cnt_other = 0u;     // the next launch's rerun counter
     auto install_state = [&]() {
         float mh = 0.0f;
 #pragma unroll
@@ -765,19 +764,12 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
         store_audio(npass - 1, au);
         STAMP(0);
 
-        // ---- parity guard: count; SELENITE_ARITH_AUTO: a guarded channel keeps its pre-call state and joins the rerun list ----
-        bool keep_state = false;
-        if (gd.n != 0u) {                                             // wave-uniform, rare
-            keep_state = p.rerun_list != nullptr;
-            if (lane == 0) {
-                atomicAdd(reinterpret_cast<unsigned long long *>(p.flags + kFlagGuardBlocks), (unsigned long long)gd.n);
-                atomicAdd(reinterpret_cast<unsigned long long *>(p.flags + kFlagGuardCalls), 1ull);
-                if (p.guard_ch) p.guard_ch[c] += gd.n;
-                if (keep_state) {
-                    atomicAdd(reinterpret_cast<unsigned long long *>(p.flags + kFlagRerunCalls), 1ull);
-                    p.rerun_list[atomicAdd(p.rerun_cnt, 1u)] = c;
-                }
-            }
+        // ---- parity guard: count (per-channel words: no atomics); SELENITE_ARITH_AUTO: a guarded channel keeps its pre-call
+        // state and raises its rerun flag (the flag of every channel is rewritten every call) ----
+        const bool keep_state = gd.n != 0u && p.rerun_flag != nullptr;   // wave-uniform
+        if (lane == 0) {
+            if (gd.n != 0u && p.guard_ch) { p.guard_ch[c] += gd.n; p.guard_calls[c] += 1u; }
+            if (p.rerun_flag) p.rerun_flag[c] = keep_state ? 1u : 0u;
         }
         // ---- streaming state of the channel back to HBM (exact f32) ----
         lds_order();
@@ -1230,7 +1222,6 @@ __global__ __launch_bounds__(64, 2) void k_hilb_split16(RxParams p, FusedArgs fa
         b_hist = wave_umax_bits(fmaxf(fabsf(q0), fabsf(q1)));
     }
     GuardPass gd{ 0.0f, 1ull, 0u };                                   // parity guard: one DSP block per pass
-    if (blockIdx.x == 0 && lane == 0 && p.rerun_cnt_other) *p.rerun_cnt_other = 0u;     // the next launch's rerun counter
     const uint32_t ph0 = NCO ? p.phase[c] : 0u, step = NCO ? p.step[c] : 0u;
     float gain = p.gain[c];
     const int mcol = lane & 15, rg = lane >> 4;
@@ -1345,17 +1336,13 @@ __global__ __launch_bounds__(64, 2) void k_hilb_split16(RxParams p, FusedArgs fa
         }
         lds_order();
     }
-    // ---- parity guard: count; SELENITE_ARITH_AUTO: a guarded channel keeps its pre-call state and joins the rerun list ----
-    if (gd.n != 0u) {                                                 // wave-uniform, rare
-        const bool keep_state = p.rerun_list != nullptr;
+    // ---- parity guard: count (per-channel words: no atomics); SELENITE_ARITH_AUTO: a guarded channel keeps its pre-call state
+    // and raises its rerun flag (the flag of every channel is rewritten every call) ----
+    {
+        const bool keep_state = gd.n != 0u && p.rerun_flag != nullptr;   // wave-uniform
         if (lane == 0) {
-            atomicAdd(reinterpret_cast<unsigned long long *>(p.flags + kFlagGuardBlocks), (unsigned long long)gd.n);
-            atomicAdd(reinterpret_cast<unsigned long long *>(p.flags + kFlagGuardCalls), 1ull);
-            if (p.guard_ch) p.guard_ch[c] += gd.n;
-            if (keep_state) {
-                atomicAdd(reinterpret_cast<unsigned long long *>(p.flags + kFlagRerunCalls), 1ull);
-                p.rerun_list[atomicAdd(p.rerun_cnt, 1u)] = c;
-            }
+            if (gd.n != 0u && p.guard_ch) { p.guard_ch[c] += gd.n; p.guard_calls[c] += 1u; }
+            if (p.rerun_flag) p.rerun_flag[c] = keep_state ? 1u : 0u;
         }
         if (keep_state) {
             if (nonfinite) p.flags[0] = 1u;

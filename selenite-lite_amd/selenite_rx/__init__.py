@@ -62,6 +62,7 @@ ABI_SYMBOLS = [
     "selenite_rx_abi_version",
     "selenite_rx_global_process_f32_device",
     "selenite_rx_host_alloc", "selenite_rx_host_free", "selenite_rx_host_register", "selenite_rx_host_unregister",
+    "selenite_rx_time_process_each_device", "selenite_rx_device_pci_bus_id",
     "selenite_rx_set_guard_ratio", "selenite_rx_guard_stats", "selenite_rx_guard_channels", "selenite_rx_guard_clear",
 ]
 
@@ -161,6 +162,8 @@ def lib():
         L.selenite_rx_algorithmic_bytes.argtypes = [C.POINTER(Config), C.c_uint32, C.POINTER(C.c_uint64)]
         L.selenite_rx_algorithmic_bytes.restype = C.c_uint64
         u64p = C.POINTER(C.c_uint64)
+        L.selenite_rx_time_process_each_device.argtypes = [vp, vp, vp, C.c_uint32, C.c_uint32, f32p, C.c_int]
+        L.selenite_rx_device_pci_bus_id.argtypes = [C.c_int, C.c_char_p, C.c_size_t]
         L.selenite_rx_set_guard_ratio.argtypes = [vp, C.c_float]
         L.selenite_rx_guard_stats.argtypes = [vp, u64p, u64p, u64p]
         L.selenite_rx_guard_channels.argtypes = [vp, u32p]
@@ -174,6 +177,12 @@ def lib():
 
 def _fp(a):
     return a.ctypes.data_as(f32p)
+
+
+def device_pci_bus_id(ordinal):
+    buf = C.create_string_buffer(32)
+    rc = lib().selenite_rx_device_pci_bus_id(ordinal, buf, 32)
+    return buf.value.decode() if rc == 0 else "unknown"
 
 
 def design_lowpass(num_taps, cutoff):
@@ -389,6 +398,14 @@ class Rx:
         if rc:
             raise RxError(rc, self.error())
         return ms.value
+
+    def time_process_each(self, d_src, d_dst, block_size, iters, q15=False):
+        """per-call durations (ms) of `iters` back-to-back device calls, one HIP event between calls"""
+        ms = np.zeros(iters, np.float32)
+        rc = self.L.selenite_rx_time_process_each_device(self.h, d_src, d_dst, block_size, iters, _fp(ms), int(q15))
+        if rc:
+            raise RxError(rc, self.error())
+        return ms
 
     def synth_device(self, d_iq, first_channel, nch, first_sample, nsamp, seed):
         rc = self.L.selenite_rx_synth_iq_device(self.h, d_iq, first_channel, nch, first_sample, nsamp, seed)

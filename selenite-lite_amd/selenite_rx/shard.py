@@ -93,6 +93,14 @@ class RankEnv:
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return float(t.item())
 
+    def gather_objects(self, obj):
+        """[obj of rank 0, obj of rank 1, ...] on every rank (one small pickled message per rank; outside any timed region)."""
+        if self.dist is None:
+            return [obj]
+        out = [None] * self.world
+        self.dist.all_gather_object(out, obj)
+        return out
+
     def close(self):
         if self.dist is not None:
             self.dist.barrier()

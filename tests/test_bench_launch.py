@@ -27,6 +27,13 @@ def test_bench_starts_its_own_ranks_when_no_launcher_did():
     assert d["n_gpus"] == 2 and d["world"] == 2
     assert d["config"]["parallelism"].startswith("channels sharded x2")
     assert abs(d["max_over_ranks_s"] - 0.002) < 1e-9                     # MAX over the ranks, not rank 0's own value
+    # the block an N > 1 line carries so the driver can verify the ranks: gathered over the process group
+    ds = d["dist"]
+    assert ds == {"backend": "gloo", "world": 2, "devices": ["cpu:0", "cpu:1"], "collectives_per_step": 0,
+                  "per_rank_ms_per_step": [1.0, 2.0]}
+    g = json.loads([l for l in run(["--gpus", "2", "--dist-backend", "gloo", "--selftest-launch", "--global-gain"]).stdout.splitlines()
+                    if l.startswith("{")][0])
+    assert g["dist"]["collectives_per_step"] == 1
 
 
 def test_bench_refuses_a_world_size_that_differs_from_gpus():

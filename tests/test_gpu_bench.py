@@ -41,6 +41,20 @@ def test_bench_json_contract_default_shape():
     assert c["kind"] in ("reference", "port") and c["cores"] == os.cpu_count() and c["value"] > 0 and "sample" in c
     assert c["single_core"]["cores"] == 1 and 0 < c["single_core"]["value"] <= c["value"]
     assert d["other_nco_modes"]["per_channel"]["value"] > 0 and d["config"]["nco"].startswith("shared LO")
+    # round 3: the default arithmetic is AUTO (plain 1e-5 bar on every block), the line says what the guard saw and how
+    # the timed arithmetic compares with the CMSIS chain; side legs: own spin-up, >= 100 launches, median per launch
+    assert d["config"]["kernel"].startswith("k_ssb_split16<256,4,63>+exact rerun") and d["config"]["arith"].startswith("auto")
+    assert d["guard_blocks"] == d["guard"]["blocks"] == 0 and d["guard"]["rerun_channel_calls"] == 0      # steady state of the bench signal
+    assert d["parity"]["worst_rel"] == d["parity_worst_rel"] <= 1e-5 and d["parity"]["blocks"] > 0 and d["parity"]["against"] in ("reference", "port")
+    assert r["launch_ms_median"] > 0 and r["launch_ms_min"] <= r["launch_ms_median"] <= r["launch_ms_p90"]
+    for grp, names in (("other_arith_modes", ("split16", "fma", "cmsis")), ("other_nco_modes", ("per_channel", "per_channel_grid", "shared_table"))):
+        for n in names:
+            e = d[grp][n]
+            assert e["launches"] >= 100 and e["ms_min"] <= e["ms_per_step"] <= e["ms_p90"] and e["value"] > 0, (grp, n)
+    assert d["other_nco_modes"]["per_channel_grid"]["nco"].startswith("per-channel LO, period 256")
+    assert d["other_nco_modes"]["per_channel"]["nco"].startswith("per-channel arm_sin/cos_f32")
+    assert d["other_nco_modes"]["shared_table"]["nco"] == "shared LO table per call"
+    assert 0 < d["auto_stopband_cost"]["rerun_fraction"] <= 1 and d["auto_stopband_cost"]["value"] > 0
     assert d["fma_roof"]["flops_per_sample"] == 293.5                  # shared LO: 6 NCO flops per sample, not 20
     assert d["value"] > 0 and d["ms_per_step"] > 0
 
@@ -52,7 +66,7 @@ def test_bench_q15_slots_cw_shape_and_global_gain():
     cw = run_bench("--workload", "cfg4", "--arith", "cmsis", "--no-cpu-baseline")
     assert cw["config"]["kernel"] == "k_cw_fused<4,256>"
     g = run_bench("--global-gain", "--no-cpu-baseline", "--main-only")
-    assert g["config"]["agc"] == "global" and g["config"]["kernel"] == "k_ssb_split16<256,4,63>"
+    assert g["config"]["agc"] == "global" and g["config"]["kernel"].startswith("k_ssb_split16<256,4,63>")
 
 
 def test_pure_c_host_benchmark_agrees_with_the_python_driven_one():
@@ -79,11 +93,17 @@ def test_bench_launches_its_own_ranks_and_shards_the_channels():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["parallelism"].startswith("channels sharded x2")
     assert abs(d["per_gpu_msamples_s"] * 2 - d["value"]) <= 0.01 * d["value"]
+    # what lets the driver verify the ranks: backend, world, one PCI bus id per rank, collectives per step, per-rank times
+    ds = d["dist"]
+    assert ds["backend"] == "gloo" and ds["world"] == 2 and len(ds["devices"]) == 2 and ds["collectives_per_step"] == 0
+    assert all(":" in x for x in ds["devices"]) and len(ds["per_rank_ms_per_step"]) == 2
+    assert max(ds["per_rank_ms_per_step"]) <= d["ms_per_step"] * 1.001 + 1e-3
     g = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--dist-backend", "gloo", "--steps", "3", "--warmup", "1",
                         "--spinup-ms", "0", "--channels", "1024", "--main-only", "--global-gain"], capture_output=True,
                        text=True, timeout=900, env=env)
     assert g.returncode == 0, g.stderr[-2000:]
-    assert json.loads([l for l in g.stdout.splitlines() if l.startswith("{")][0])["config"]["agc"] == "global"
+    gd = json.loads([l for l in g.stdout.splitlines() if l.startswith("{")][0])
+    assert gd["config"]["agc"] == "global" and gd["dist"]["collectives_per_step"] == 1
 
 
 def test_global_gain_ranks_on_one_stream_match_the_unsharded_oracle():
