@@ -192,6 +192,11 @@ def main():
                          "without the rerun (guarded blocks only counted); fma: FIR tap loops fused, bit-exact vs the fmaf "
                          "oracle; cmsis: bit-exact CMSIS-DSP arithmetic")
     ap.add_argument("--global-gain", action="store_true")
+    ap.add_argument("--nco", default="default", choices=["default", "per_channel", "per_channel_grid", "shared_table"],
+                    help="NCO flavour of the TIMED instance (cfg3; the same flavours are side legs of the default run): per_channel = every "
+                         "channel its own arbitrary step (arm_sin/cos_f32 per sample in the kernel); per_channel_grid = every channel its "
+                         "own step on the fs/256 grid (LO period computed once per channel and call); shared_table = one step off that "
+                         "grid for all channels (LO table per call, read from L2)")
     ap.add_argument("--io", default="f32", choices=["f32", "q15"],
                     help="f32: the canonical float I/Q in / float audio out signature (headline); q15: the firmware's "
                          "int16 slot format either side (dsp_if.c:286-289, arm_q15_to_float / arm_float_to_q15 fused in)")
@@ -230,8 +235,27 @@ def main():
     channels = args.channels or channels
     bs = args.block_size or bs
     sr.lib().selenite_rx_set_device(local_rank)
+    def nco_steps(kind):
+        """per-channel NCO steps of the side legs / --nco: (steps or None, environment for the instance's construction)"""
+        if kind == "per_channel":
+            return (np.arange(channels, dtype=np.uint64) * 0x9E3779B1 % (1 << 26) + 0x00800000).astype(np.uint32), {}
+        if kind == "per_channel_grid":
+            return ((np.arange(channels, dtype=np.uint64) * 0x9E3779B1 >> 7) % 256 << 24).astype(np.uint32), {}
+        if kind == "shared_table":
+            return None, {"SELENITE_RX_NO_PERIODIC_LO": "1"}
+        return None, {}
+
+    def make_rx(ar, kind="default", **kw):
+        steps, envx = nco_steps(kind)
+        os.environ.update(envx)
+        try:
+            return sr.Rx(ch.baseline_spec(cfg_name, channels, ar, **(dict(kw, nco_steps=steps) if steps is not None else kw)).config())
+        finally:
+            for k in envx:
+                os.environ.pop(k, None)
+
     spec = ch.baseline_spec(cfg_name, channels, arith, agc_global=args.global_gain)
-    rx = sr.Rx(spec.config())
+    rx = make_rx(arith, args.nco, agc_global=args.global_gain)
     nout = bs // spec.decim
 
     d_in = sr.DeviceBuffer(channels * bs * 8)
@@ -330,7 +354,7 @@ def main():
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9
         # flops the timed kernel executes: with one LO shared by all channels (the default shape) the NCO costs the
         # complex multiply only (6 flops per sample); the per-sample table-lerp sin/cos is the "per_channel" leg below
-        shared_lo = rx.nco_path().startswith("shared")
+        shared_lo = rx.nco_path().startswith("shared") or "period 256" in rx.nco_path()
         fps = ch.flops_per_sample(spec, 6.0 if shared_lo else 20.0)
         fl = fps * channels * bs
         traffic = pmc_traffic(args.workload + ("_q15" if q15 else ""), args.arith, rx.kernel_name(), channels, bs,
@@ -386,31 +410,27 @@ def main():
             for nm, ar in (("split16", sr.ARITH_SPLIT16), ("auto", sr.ARITH_AUTO), ("fma", sr.ARITH_FMA), ("cmsis", sr.ARITH_CMSIS)):
                 if ar == arith:
                     continue
-                rx_x = sr.Rx(ch.baseline_spec(cfg_name, channels, ar).config())
+                rx_x = make_rx(ar)
                 others[nm] = leg(rx_x)
                 rx_x.close()
             others["note"] = ("auto: split16 + bit-exact rerun of guarded channels; split16: tolerance-based, guarded blocks only counted; "
                               "fma: bit-exact vs the oracle's fmaf restatement; cmsis: bit-exact (0 ULP) vs CMSIS-DSP 1.5.3 arithmetic")
             out["other_arith_modes"] = others
-            if spec.nco and cfg_name == "cfg3":
+            if spec.nco and cfg_name == "cfg3" and args.nco == "default":
                 frac = lambda r: round(alg_bytes / (r["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
                 nm = {}
                 raw = sr.ARITH_SPLIT16 if arith == sr.ARITH_AUTO else arith     # NCO cost alone: no reruns in these legs
                 # every channel its own NCO step: arm_sin_f32 / arm_cos_f32 per sample inside the kernel (arm_sin_f32.c:72-119)
-                steps_pc = (np.arange(channels, dtype=np.uint64) * 0x9E3779B1 % (1 << 26) + 0x00800000).astype(np.uint32)
-                rx_p = sr.Rx(ch.baseline_spec(cfg_name, channels, raw, nco_steps=steps_pc).config())
+                rx_p = make_rx(raw, "per_channel")
                 nm["per_channel"] = dict(leg(rx_p), note="every channel its own arbitrary NCO step; table-lerp sin/cos per sample in the kernel")
                 rx_p.close()
                 # every channel its own step ON the fs/256 grid (a channeliser): the channel's LO period is computed once per call
-                steps_g = ((np.arange(channels, dtype=np.uint64) * 0x9E3779B1 >> 7) % 256 << 24).astype(np.uint32)
-                rx_g = sr.Rx(ch.baseline_spec(cfg_name, channels, raw, nco_steps=steps_g).config())
+                rx_g = make_rx(raw, "per_channel_grid")
                 nm["per_channel_grid"] = dict(leg(rx_g), note="every channel its own NCO step, all multiples of fs/256: LO of one 256-sample period computed per channel and call (arm_sin/cos_f32 arithmetic), held in registers")
                 rx_g.close()
                 if "registers" in rx.nco_path():
                     # the same shared LO read as a per-call table from L2 (what a step off the fs / 256 grid gets)
-                    os.environ["SELENITE_RX_NO_PERIODIC_LO"] = "1"
-                    rx_t = sr.Rx(ch.baseline_spec(cfg_name, channels, raw).config())
-                    del os.environ["SELENITE_RX_NO_PERIODIC_LO"]
+                    rx_t = make_rx(raw, "shared_table")
                     nm["shared_table"] = dict(leg(rx_t), note="one NCO step for all channels that is NOT a multiple of fs / 256: LO table computed per call, read from L2")
                     rx_t.close()
                 for v in nm.values():
@@ -419,7 +439,7 @@ def main():
                 if arith == sr.ARITH_AUTO and not q15:
                     # what AUTO costs when the guard fires: the per_channel_grid steps move most channels' tone out of the pass
                     # band (audio 20-45 dB under the input), the worst case for an output-relative bar
-                    rx_a = sr.Rx(ch.baseline_spec(cfg_name, channels, sr.ARITH_AUTO, nco_steps=steps_g).config())
+                    rx_a = make_rx(sr.ARITH_AUTO, "per_channel_grid")
                     r = leg(rx_a)
                     rx_a.guard_clear()
                     rx_a.process_device(d_in.ptr, d_out.ptr, bs)

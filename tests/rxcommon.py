@@ -12,6 +12,11 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
+# SELENITE_ORACLE_SAN=1: the AddressSanitizer / UBSan builds of the same libraries (make -C oracle SAN=1 -> oracle/_san/;
+# python needs libasan preloaded: tools/run_cpu_tests_sanitized.sh)
+SAN = os.environ.get("SELENITE_ORACLE_SAN") == "1"
+LIB_DIR = os.path.join(ORACLE_DIR, "_san") if SAN else ORACLE_DIR
+REF_DIR = os.path.join(ORACLE_DIR, "_san" if SAN else "_ref")
 GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
 PKG_DIR = os.path.join(ROOT, "selenite-lite_amd")
 if PKG_DIR not in sys.path:
@@ -47,7 +52,7 @@ def state_view(arrs):
 # ---------------------------------------------------------------------------------------------
 def build_oracle():
     """(Re)build oracle/librx_oracle.so (gcc) and, where /root/reference exists, oracle/_ref."""
-    subprocess.run(["make", "-s", "-C", ORACLE_DIR], check=True,
+    subprocess.run(["make", "-s", "-C", ORACLE_DIR] + (["SAN=1"] if SAN else []), check=True,
                    stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
 
 
@@ -58,7 +63,7 @@ _ref = None
 def oracle_lib():
     global _oracle
     if _oracle is None:
-        path = os.path.join(ORACLE_DIR, "librx_oracle.so")
+        path = os.path.join(LIB_DIR, "librx_oracle.so")
         src_m = max(os.path.getmtime(os.path.join(ORACLE_DIR, f)) for f in ("rx_oracle.c", "rx_oracle.h"))
         if not os.path.exists(path) or os.path.getmtime(path) < src_m:
             build_oracle()
@@ -102,14 +107,14 @@ def oracle_lib():
 
 
 def ref_available():
-    return os.path.exists(os.path.join(ORACLE_DIR, "_ref", "libcmsis_ref.so"))
+    return os.path.exists(os.path.join(REF_DIR, "libcmsis_ref.so"))
 
 
 def ref_lib():
     """Real CMSIS-DSP 1.5.3 (+ composition harness).  Build container only."""
     global _ref
     if _ref is None:
-        L = C.CDLL(os.path.join(ORACLE_DIR, "_ref", "libcmsis_ref.so"))
+        L = C.CDLL(os.path.join(REF_DIR, "libcmsis_ref.so"))
         L.ref_sin_table.restype = f32p
         L.ref_rx_create.argtypes = [C.POINTER(C.c_void_p), C.POINTER(Config)]
         L.ref_rx_destroy.argtypes = [C.c_void_p]
@@ -217,9 +222,9 @@ _ring_lib = None
 def ring_oracle_lib():
     global _ring_lib
     if _ring_lib is None:
-        path = os.path.join(ROOT, "oracle", "libring_oracle.so")
+        path = os.path.join(LIB_DIR, "libring_oracle.so")
         if not os.path.exists(path):
-            subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "libring_oracle.so"], check=True)
+            build_oracle()
         L = C.CDLL(path)
         L.orc_ring_new.restype = C.c_void_p
         L.orc_ring_new.argtypes = [C.c_uint32, C.c_uint32]
@@ -237,7 +242,7 @@ def ring_oracle_lib():
 
 
 def ring_ref_available():
-    return os.path.exists(os.path.join(ORACLE_DIR, "_ref", "libdsp_if_ref.so"))
+    return os.path.exists(os.path.join(REF_DIR, "libdsp_if_ref.so"))
 
 
 class RefRing:
@@ -248,7 +253,7 @@ class RefRing:
 
     def __init__(self, channels, frames=None):
         # RTLD_LAZY: dsp_if.c / main.c also hold functions that call the HAL; the harness never reaches them
-        self.L = C.CDLL(os.path.join(ORACLE_DIR, "_ref", "libdsp_if_ref.so"), mode=os.RTLD_LAZY)
+        self.L = C.CDLL(os.path.join(REF_DIR, "libdsp_if_ref.so"), mode=os.RTLD_LAZY)
         vp, L = C.c_void_p, self.L
         L.ref_ring_set.argtypes = [C.c_int, vp, vp, C.c_uint8, C.c_uint16, C.c_uint16]
         L.ref_ring_get.argtypes = [C.c_int, vp, vp, C.POINTER(C.c_uint8), C.POINTER(C.c_uint16), C.POINTER(C.c_uint16)]
