@@ -255,8 +255,9 @@ void orc_float_to_q15(const float *src, int16_t *dst, uint32_t n)
     for (uint32_t i = 0; i < n; ++i) {
         float v = src[i] * 32768.0f;
         int32_t q;
-        if (v >= 2147483648.0f) q = INT32_MAX;          /* out of int32 range is UB in C; the */
-        else if (v <= -2147483648.0f) q = INT32_MIN;     /* chain never produces it (|audio| small) */
+        if (v != v) q = 0;                              /* NaN: UB in C; the firmware's VCVT.S32.F32 (and v_cvt_i32_f32) give 0 */
+        else if (v >= 2147483648.0f) q = INT32_MAX;     /* out of int32 range is UB in C too: the FPU saturates */
+        else if (v <= -2147483648.0f) q = INT32_MIN;
         else q = (int32_t)v;
         if (q > 32767) q = 32767;
         if (q < -32768) q = -32768;

@@ -77,7 +77,8 @@ template <int ARITH, int GROUP, int ND, int M, int NH, typename TOut, int AM = 0
 __device__ __forceinline__ void demod_agc_store(const RxParams &p, const FusedArgs &fa, const float *dI,
                                                 const float *dQ, int lane, int group,
                                                 const float (&hreg)[(NH + 63) / 64 ? (NH + 63) / 64 : 1], float &gain,
-                                                TOut *__restrict__ dst, size_t out_index, bool &nonfinite)
+                                                TOut *__restrict__ dst, size_t out_index, bool &nonfinite,
+                                                int nvb = 64)        // DSP blocks of this pass that exist (whole passes: all of them)
 {
     using G = Geo<ND, M, NH>;
     float au[4];
@@ -119,14 +120,22 @@ __device__ __forceinline__ void demod_agc_store(const RxParams &p, const FusedAr
                 dsr[b] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine_d), b * GROUP));
 #pragma unroll
             for (int b = 0; b < 64 / GROUP; ++b) {
-                g = agc_step(p.agcp, g, dsr[b]);
+                const float gn = agc_step(p.agcp, g, dsr[b]);
+                g = b < nvb ? gn : g;                             // blocks past the end of the call leave the gain alone
                 mine = (b == myblk) ? g : mine;
             }
         } else {
+            const int myblk = lane / group;
+            if ((group & (group - 1)) == 0) {                     // power of two: butterfly
 #pragma unroll
-            for (int off = 1; off < 64; off <<= 1)
-                if (off < group) m = fmaxf(m, __shfl_xor(m, off, 64));
-            const int nblk = 64 / group, myblk = lane / group;
+                for (int off = 1; off < 64; off <<= 1)
+                    if (off < group) m = fmaxf(m, __shfl_xor(m, off, 64));
+            } else {                                              // e.g. 6 lanes: the firmware's 96-frame blocks by 4 (dsp_if.h:69-73)
+                float mm = 0.0f;
+                for (int j = 0; j < group; ++j) mm = fmaxf(mm, __shfl(m, (myblk * group + j) & 63, 64));
+                m = mm;
+            }
+            const int nblk = min(64 / group, nvb);
             for (int b = 0; b < nblk; ++b) {
                 const float env = __shfl(m, b * group, 64);
                 g = agc_update<0>(p.agcp, g, env);
@@ -137,18 +146,21 @@ __device__ __forceinline__ void demod_agc_store(const RxParams &p, const FusedAr
 #pragma unroll
         for (int r = 0; r < 4; ++r) au[r] = au[r] * mine;
     }
+    const bool live = lane < nvb * (GROUP ? GROUP : group);       // this lane's four samples exist
     {   // ARM_MATH_NANINF: x * 0 is NaN iff x is not finite
         const float z = __builtin_fmaf(au[3], 0.0f, __builtin_fmaf(au[2], 0.0f, __builtin_fmaf(au[1], 0.0f, au[0] * 0.0f)));
-        nonfinite = nonfinite || (z != z);
+        nonfinite = nonfinite || (live && z != z);
     }
     const size_t o = out_index + 4 * lane;
-    if constexpr (sizeof(TOut) == 4) {
-        *reinterpret_cast<float4 *>(reinterpret_cast<float *>(dst) + o) = make_float4(au[0], au[1], au[2], au[3]);
-    } else {
-        short4 s4;
-        s4.x = float_to_q15(au[0]); s4.y = float_to_q15(au[1]);
-        s4.z = float_to_q15(au[2]); s4.w = float_to_q15(au[3]);
-        *reinterpret_cast<short4 *>(reinterpret_cast<int16_t *>(dst) + o) = s4;
+    if (live) {
+        if constexpr (sizeof(TOut) == 4) {
+            *reinterpret_cast<float4 *>(reinterpret_cast<float *>(dst) + o) = make_float4(au[0], au[1], au[2], au[3]);
+        } else {
+            short4 s4;
+            s4.x = float_to_q15(au[0]); s4.y = float_to_q15(au[1]);
+            s4.z = float_to_q15(au[2]); s4.w = float_to_q15(au[3]);
+            *reinterpret_cast<short4 *>(reinterpret_cast<int16_t *>(dst) + o) = s4;
+        }
     }
 }
 
@@ -157,10 +169,17 @@ __global__ __launch_bounds__(64, 2) void k_ssb_fused(RxParams p, FusedArgs fa, c
                                                      TOut *__restrict__ dst)
 {
     using G = Geo<ND, M, NH>;
-    using R = Raw<TIn>;
+    using R = BRaw<TIn>;
     static_assert(ND == 0 ? M == 1 : (M == 2 || M == 4 || M == 8), "fused kernel: no decimator, or decimate by 2, 4 or 8");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x;
+    // Passes of VARIABLE length (round 3): a full pass produces pq = fa.pass_out audio samples -- the largest whole number of
+    // DSP blocks in 256 (256 itself when block / M divides 256; 240 = 10 blocks of the firmware's 96-frame geometry by 4,
+    // dsp_if.h:69-73) -- and the last pass of a call whatever is left (a call is a whole number of DSP blocks, not of
+    // passes).  The arithmetic always covers the whole 256-output tile: input beyond the call reads as zeros (buffer range
+    // check), outputs beyond the pass are not stored and do not move the AGC, and the history copies take the samples behind
+    // the last one that exists.  Per output the operation order is the reference's in every case.
+    const uint32_t pq = fa.pass_out, tq = pq * M;
     float *tab = lds + G::oTab;
     float *S = lds + G::oS;
     float *D = lds + G::oD;
@@ -190,11 +209,13 @@ __global__ __launch_bounds__(64, 2) void k_ssb_fused(RxParams p, FusedArgs fa, c
         if (todo == 0) win += gridDim.x;
     }
 
-    const size_t in_base = (size_t)c * p.in_stride, out_base = (size_t)c * p.out_stride;
-    const uint32_t npass = p.nout / G::P;
+    const size_t out_base = (size_t)c * p.out_stride;
+    const uint32_t npass = (p.nout + pq - 1) / pq;
+    const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(src + (size_t)c * p.in_stride * 2, p.block_size * (R::kBytes / 2));
+    const __amdgpu_buffer_rsrc_t rs_lo = make_rsrc(p.lo, NCO == 2 ? p.block_size * 8u : 0u);
     typename R::type raw[NLD];
 #pragma unroll
-    for (int i = 0; i < NLD; ++i) raw[i] = R::load(src, in_base + 128u * i + 2u * lane);
+    for (int i = 0; i < NLD; ++i) raw[i] = R::load(rs_in, lane * R::kBytes + i * 64 * R::kBytes, 0);
 
     // ---- prologue: tables and streaming state into LDS / registers ----
     if constexpr (NCO == 1)
@@ -233,24 +254,29 @@ __global__ __launch_bounds__(64, 2) void k_ssb_fused(RxParams p, FusedArgs fa, c
     wave_lds_sync();
 
     for (uint32_t pass = 0; pass < npass; ++pass) {
-        const uint32_t n0 = pass * G::T;
+        const uint32_t n0 = pass * tq;
+        const uint32_t cur = (pass + 1 == npass) ? p.nout - pass * pq : pq;      // audio samples of this pass (whole DSP blocks)
         // ---- 1. NCO mix of the prefetched samples, scatter into the LDS image ----
-        float4 lo4[NLD];
+        u4v lo4[NLD];
         if constexpr (NCO == 2) {                                     // shared LO table (L2 resident):
 #pragma unroll
             for (int i = 0; i < NLD; ++i)                             // all loads of the pass in flight at once
-                lo4[i] = *reinterpret_cast<const float4 *>(p.lo + n0 + 128u * i + 2u * lane);
+                lo4[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_lo, lane * 16 + i * 1024, (int)(n0 * 8u), 0);
             __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
             const uint32_t n = 128u * i + 2u * lane;                  // even sample index in the pass
             float2 a, b;
-            R::unpack(raw[i], a, b);
+            {
+                v2f va, vb;
+                R::unpack(raw[i], va, vb);
+                a = make_float2(va.x, va.y); b = make_float2(vb.x, vb.y);
+            }
             if constexpr (NCO == 2) {
-                const float4 l2 = lo4[i];
-                a = cmul<0>(a, make_float2(l2.x, l2.y));
-                b = cmul<0>(b, make_float2(l2.z, l2.w));
+                const u4v l2 = lo4[i];
+                a = cmul<0>(a, make_float2(__uint_as_float(l2.x), __uint_as_float(l2.y)));
+                b = cmul<0>(b, make_float2(__uint_as_float(l2.z), __uint_as_float(l2.w)));
             } else if constexpr (NCO == 1) {
                 lo_v2f la, lb;                                            // arm_sin/cos_f32 restated for the vector ALU: same bits (rx_device.h)
                 const uint32_t pe = ph0 + (n0 + n) * step;
@@ -269,11 +295,9 @@ __global__ __launch_bounds__(64, 2) void k_ssb_fused(RxParams p, FusedArgs fa, c
             }
         }
         wave_lds_sync();
-        // ---- prefetch the next pass while this one computes ----
-        if (pass + 1 < npass) {
+        // ---- prefetch the next pass while this one computes (beyond the call: zeros, no traffic) ----
 #pragma unroll
-            for (int i = 0; i < NLD; ++i) raw[i] = R::load(src, in_base + n0 + G::T + 128u * i + 2u * lane);
-        }
+        for (int i = 0; i < NLD; ++i) raw[i] = R::load(rs_in, lane * R::kBytes + i * 64 * R::kBytes, (int)((n0 + tq) * (R::kBytes / 2)));
         // ---- 2. arm_fir_decimate_f32 on both rails, 4 adjacent outputs per lane ----
         if constexpr (ND > 0) {
             v2f acc[4] = { { 0.0f, 0.0f }, { 0.0f, 0.0f }, { 0.0f, 0.0f }, { 0.0f, 0.0f } };
@@ -283,12 +307,13 @@ __global__ __launch_bounds__(64, 2) void k_ssb_fused(RxParams p, FusedArgs fa, c
             wave_lds_sync();
         }
         // ---- 3-5. Hilbert pair + sideband, AGC, store ----
+        const int nvb = (int)(cur / (4u * (uint32_t)group));          // DSP blocks of this pass
         if (group == 16)
-            demod_agc_store<ARITH, 16, ND, M, NH, TOut, AM>(p, fa, dI, dQ, lane, group, hreg, gain, dst, out_base + (size_t)pass * G::P, nonfinite);
+            demod_agc_store<ARITH, 16, ND, M, NH, TOut, AM>(p, fa, dI, dQ, lane, group, hreg, gain, dst, out_base + (size_t)pass * pq, nonfinite, nvb);
         else if (group == 64)
-            demod_agc_store<ARITH, 64, ND, M, NH, TOut, AM>(p, fa, dI, dQ, lane, group, hreg, gain, dst, out_base + (size_t)pass * G::P, nonfinite);
+            demod_agc_store<ARITH, 64, ND, M, NH, TOut, AM>(p, fa, dI, dQ, lane, group, hreg, gain, dst, out_base + (size_t)pass * pq, nonfinite, nvb);
         else
-            demod_agc_store<ARITH, 0, ND, M, NH, TOut, AM>(p, fa, dI, dQ, lane, group, hreg, gain, dst, out_base + (size_t)pass * G::P, nonfinite);
+            demod_agc_store<ARITH, 0, ND, M, NH, TOut, AM>(p, fa, dI, dQ, lane, group, hreg, gain, dst, out_base + (size_t)pass * pq, nonfinite, nvb);
         wave_lds_sync();
         // ---- 6. history copy-back (arm_fir_decimate_f32.c:396-426, arm_fir_f32.c:947-978) ----
         if constexpr (ND > 0) {
@@ -298,8 +323,8 @@ __global__ __launch_bounds__(64, 2) void k_ssb_fused(RxParams p, FusedArgs fa, c
 #pragma unroll
             for (int k = 0; k < NK; ++k) {
                 const int i = k * 64 + lane;
-                if (i < NG) {
-                    const float *sp = S + (i / (G::HQ4 / 4)) * G::PSF + 12 * (G::P / 4 + i % (G::HQ4 / 4));
+                if (i < NG) {                                         // the HQ4 phase-samples behind the last one that exists
+                    const float *sp = S + (i / (G::HQ4 / 4)) * G::PSF + 12 * (cur / 4 + i % (G::HQ4 / 4));
                     t0[k] = lds_ld4f(sp);
                     t1[k] = lds_ld4f(sp + 4);
                 }
@@ -320,7 +345,7 @@ __global__ __launch_bounds__(64, 2) void k_ssb_fused(RxParams p, FusedArgs fa, c
             static_assert(NV <= 64, "Hilbert history move assumes <= 64 float4");
             float4 tmp;
             const int rail = lane / (G::HH4 / 4), v = lane % (G::HH4 / 4);
-            if (lane < NV) tmp = lds_ld4f(D + rail * G::DLEN + G::P + 4 * v);
+            if (lane < NV) tmp = lds_ld4f(D + rail * G::DLEN + cur + 4 * v);
             wave_lds_sync();
             if (lane < NV) *reinterpret_cast<float4 *>(D + rail * G::DLEN + 4 * v) = tmp;
         }
@@ -835,15 +860,21 @@ static hipError_t launch_shape(const RxParams &p, const FusedArgs &fa, const Fus
         if (src_q15) return launch_one<0, ND, M, NH, int16_t, int16_t>(p2, fa, src, dst, st);
         return launch_one<0, ND, M, NH, float, float>(p2, fa, src, dst, st);
     };
+    // what the matrix kernels take: DSP blocks that divide the 256-output pass; whole passes (k_ssb_mfma, k_hilb_split16), or a
+    // partial last pass that holds a whole decimator history (k_ssb_split16).  Everything else -- short calls, the firmware's
+    // 96-frame blocks -- runs on k_ssb_fused, whose passes have variable length.
+    const bool whole = fa.pass_out == 256 && p.nout % 256 == 0;
+    constexpr uint32_t kHS = ND ? (uint32_t)(((((ND - 1 + M - 1) / M) + 3) & ~3) * M) : 0u;      // GeoS::HS: decimator history in the image
+    const bool split_ok = fa.pass_out == 256 && (whole || p.block_size % (256u * M) >= kHS);
     if constexpr (ND > 0 && (M == 4 || M == 2) && NH > 0) {
-        if (split && plan.d_btab16) {
+        if (split && plan.d_btab16 && split_ok) {
             hipError_t e = launch_ssb_split16(ND, M, NH, p, fa, src, src_q15, dst, st);      // rx_split16.hip
             if (e == hipSuccess && auto_ && p.rerun_flag) e = rerun();
             return e;
         }
     }
     if constexpr (ND == 0 && M == 1 && NH > 0) {
-        if (split && plan.d_btab16 && fa.group == 64) {
+        if (split && plan.d_btab16 && fa.group == 64 && whole) {
             hipError_t e = launch_hilb_split16(NH, p, fa, src, src_q15, dst, st);            // rx_split16.hip
             if (e == hipSuccess && auto_ && p.rerun_flag) e = rerun();
             return e;
@@ -852,7 +883,7 @@ static hipError_t launch_shape(const RxParams &p, const FusedArgs &fa, const Fus
     if (auto_) arith = SELENITE_ARITH_CMSIS;      // no split-precision kernel for this launch: the bit-exact one
     if constexpr (ND > 0 && M == 4) {
         static_assert(kMfmaWaves == 1, "one channel per workgroup: any channel count launches (plan.name says k_ssb_mfma)");
-        if (arith != SELENITE_ARITH_CMSIS && plan.use_mfma) {
+        if (arith != SELENITE_ARITH_CMSIS && plan.use_mfma && whole) {
             if (src_q15) return launch_mfma<ND, M, NH, int16_t, int16_t>(p, fa, plan.d_btab, src, dst, st);
             return launch_mfma<ND, M, NH, float, float>(p, fa, plan.d_btab, src, dst, st);
         }
@@ -886,8 +917,10 @@ hipError_t plan_fused(const selenite_rx_config &g, bool delay_is_impulse, int de
     plan.kind = 0;
     plan.name = "generic";
     if (!fused_mode_ok(g) || !g.nh_taps || !delay_is_impulse || !hilb_odd_only) return hipSuccess;
+    // DSP blocks of 4 .. 256 audio samples, four per lane; a power of two divides the 256-output pass, anything else (the
+    // firmware's 96 frames: 24 or 96 audio samples) runs with passes of the largest whole number of blocks (k_ssb_fused)
     const uint32_t na = g.block / g.decim;
-    if (na < 4 || na > 256 || (na & (na - 1)) != 0) return hipSuccess;
+    if (na < 4 || na > 256 || na % 4 != 0) return hipSuccess;
     int kind = 0;
     const char *name = nullptr;
 #define X(ND_, M_, NH_, ID_) \
@@ -911,7 +944,8 @@ hipError_t plan_fused(const selenite_rx_config &g, bool delay_is_impulse, int de
     (void)name;
     if (plan.use_mfma && g.arith != SELENITE_ARITH_CMSIS) plan.name_buf = "k_ssb_mfma" + shape;     // split16 without a matrix kernel of its own runs as fma
     if (g.arith == SELENITE_ARITH_AUTO) plan.name_buf = "k_ssb_fused" + shape;                      // without a matrix kernel of its own: bit-exact
-    if (plan.d_btab16 && (g.arith == SELENITE_ARITH_SPLIT16 || g.arith == SELENITE_ARITH_AUTO)) {
+    if (256 % na != 0) plan.name_buf = "k_ssb_fused" + shape;                                        // DSP blocks that do not divide a pass: variable-length passes
+    else if (plan.d_btab16 && (g.arith == SELENITE_ARITH_SPLIT16 || g.arith == SELENITE_ARITH_AUTO)) {
         const char *tail = g.arith == SELENITE_ARITH_AUTO ? "+exact rerun of guarded channels" : "";
         if (g.nd_taps) plan.name_buf = "k_ssb_split16" + shape + tail;
         else if (na == 256) plan.name_buf = "k_hilb_split16<" + std::to_string(g.nh_taps) + ">" + tail;
@@ -934,16 +968,10 @@ void free_fused(FusedPlan &plan)
 
 bool fused_block_size_ok(const FusedPlan &plan, const selenite_rx_config &g, uint32_t block_size)
 {
-    const uint32_t nout = block_size / g.decim;
-    if (nout % 256 == 0) return true;                // whole passes
-    // k_ssb_split16 also takes a partial last pass when it holds a whole decimator history (rx_split16.hip); the
-    // other fused kernels get the whole passes and the generic kernels the rest (run_chain)
-    if (g.arith == SELENITE_ARITH_SPLIT16 && g.nd_taps && plan.d_btab16) {
-        const uint32_t hq = (g.nd_taps - 1 + g.decim - 1) / g.decim, hs = ((hq + 3) & ~3u) * g.decim;    // Geo::HQ4 * M
-        const uint32_t tail_in = block_size % (256u * g.decim);
-        return tail_in >= hs;
-    }
-    return false;
+    // every call length (a whole number of DSP blocks) since round 3: k_ssb_fused takes passes of variable length, and
+    // launch_shape sends the matrix kernels only the launches they cover
+    (void)plan; (void)g; (void)block_size;
+    return true;
 }
 
 hipError_t launch_fused(const FusedPlan &plan, const RxParams &p, int arith, const void *src, bool src_q15,
@@ -955,6 +983,7 @@ hipError_t launch_fused(const FusedPlan &plan, const RxParams &p, int arith, con
     fa.upper = mode_is_upper(p.mode) ? 1u : 0u;
     fa.am = p.mode == SELENITE_MODE_AM ? 1u : 0u;
     fa.group = (p.block / p.decim) / 4;
+    fa.pass_out = 256u / (p.block / p.decim) * (p.block / p.decim);
     fa.btab16 = plan.d_btab16;
     fa.split_post = plan.split_post;
     fa.split_sc = plan.split_sc;

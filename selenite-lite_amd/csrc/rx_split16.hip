@@ -54,67 +54,6 @@
 
 namespace srx {
 
-typedef unsigned int u4v __attribute__((ext_vector_type(4)));
-typedef unsigned int u2v __attribute__((ext_vector_type(2)));
-
-// Raw buffer resource over a wave-uniform byte range (cdna_hip_programming.md T8): loads beyond the
-// range return 0 WITHOUT memory traffic and stores beyond it are dropped, so "prefetch the next pass"
-// needs no branch in the last pass -- the scalar offset is simply pushed out of range.
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *base, uint32_t bytes)
-{
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)bytes, 0x00020000);
-}
-
-// two complex samples per lane per load (sample n = 128 i + 2 lane of a pass)
-template <typename T> struct BRaw;
-template <> struct BRaw<float> {
-    typedef u4v type;
-    static constexpr int kBytes = 16;
-    static __device__ __forceinline__ type load(__amdgpu_buffer_rsrc_t r, int voff, int soff)
-    {
-        return __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, SRX_IN_AUX);      // nt: streamed once
-    }
-    static __device__ __forceinline__ void unpack(const type &r, v2f &a, v2f &b)
-    {
-        a = v2f{ __uint_as_float(r.x), __uint_as_float(r.y) };
-        b = v2f{ __uint_as_float(r.z), __uint_as_float(r.w) };
-    }
-};
-template <> struct BRaw<int16_t> {
-    typedef u2v type;
-    static constexpr int kBytes = 8;
-    static __device__ __forceinline__ type load(__amdgpu_buffer_rsrc_t r, int voff, int soff)
-    {
-        return __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, SRX_IN_AUX);
-    }
-    static __device__ __forceinline__ void unpack(const type &r, v2f &a, v2f &b)
-    {
-        a = v2f{ q15_to_float((int16_t)(r.x & 0xffffu)), q15_to_float((int16_t)(r.x >> 16)) };
-        b = v2f{ q15_to_float((int16_t)(r.y & 0xffffu)), q15_to_float((int16_t)(r.y >> 16)) };
-    }
-};
-
-// four audio samples per lane per store
-template <typename T> struct BOut;
-template <> struct BOut<float> {
-    static constexpr int kBytes = 16;
-    static __device__ __forceinline__ void store(__amdgpu_buffer_rsrc_t r, int voff, int soff, const float (&au)[4])
-    {
-        const u4v v = { __float_as_uint(au[0]), __float_as_uint(au[1]), __float_as_uint(au[2]), __float_as_uint(au[3]) };
-        __builtin_amdgcn_raw_buffer_store_b128(v, r, voff, soff, 0);
-    }
-};
-template <> struct BOut<int16_t> {
-    static constexpr int kBytes = 8;
-    static __device__ __forceinline__ void store(__amdgpu_buffer_rsrc_t r, int voff, int soff, const float (&au)[4])
-    {
-        const uint32_t a = (uint16_t)float_to_q15(au[0]), b = (uint16_t)float_to_q15(au[1]);
-        const uint32_t c = (uint16_t)float_to_q15(au[2]), d = (uint16_t)float_to_q15(au[3]);
-        const u2v v = { a | (b << 16), c | (d << 16) };
-        __builtin_amdgcn_raw_buffer_store_b64(v, r, voff, soff, 0);
-    }
-};
-
 __device__ __forceinline__ float amax2(v2f x, float m) { return fmaxf(fmaxf(fabsf(x.x), fabsf(x.y)), m); }
 
 // memory-order point for the single-wave workgroups of this file: LDS operations of a wave execute in

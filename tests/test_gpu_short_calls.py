@@ -1,0 +1,104 @@
+"""Short calls and the firmware's own block geometry on the fused kernels (VERDICT r2 #4 / #6b).
+
+The I2S half-buffer of the firmware carries 96 I/Q frames per millisecond (Core/Inc/dsp_if.h:69-73, the callbacks at
+Core/Src/dsp_if.c:50-67): a DSP block of 96 inputs is 24 audio samples behind the /4 decimator -- not a divisor of the
+256-output pass of the fused kernels, which therefore used to hand such configurations (and every call that was not a whole
+number of passes, in the exact / fma arithmetic) to the generic kernels.  k_ssb_fused now runs passes of variable length
+(the largest whole number of DSP blocks in 256 outputs; the call's last pass whatever is left).  Exact arithmetic: bit-exact
+against the oracle, output and state, for any sequence of call lengths."""
+import numpy as np
+import pytest
+
+import rxcommon as rc
+from rxcommon import ARITH_AUTO, ARITH_CMSIS, ARITH_FMA, CpuChain, bits_equal, synth_iq
+
+pytestmark = pytest.mark.gpu
+
+
+def run_pair(spec_g, spec_o, lengths, q15=False, exact=True, na=None):
+    import selenite_rx as sr
+    g, o = sr.Rx(spec_g.config()), CpuChain(spec_o, "orc")
+    nch, pos = spec_g.channels, 0
+    for bs in lengths:
+        iq = synth_iq(0, nch, pos, bs)
+        pos += bs
+        if q15:
+            iq16 = np.clip(np.round(iq * 20000.0), -32768, 32767).astype(np.int16)
+            yg, yo = g.process_q15(iq16), o.process_q15(iq16)
+            assert np.array_equal(yg, yo) if exact else np.abs(yg.astype(np.int32) - yo).max() <= 1, bs
+        else:
+            yg, yo = g.process(iq), o.process(iq)
+            if exact:
+                assert bits_equal(yg, yo), (bs, rc.rel_err(yg, yo))
+            else:
+                d = np.abs(yg.astype(np.float64) - yo).reshape(nch, -1, na).max(axis=2)
+                m = np.abs(yo).reshape(nch, -1, na).max(axis=2)
+                assert (d <= 1e-5 * m).all(), (bs, (d / np.maximum(m, 1e-30)).max())
+    sg, so = g.state(), o.state()
+    if exact:
+        for key in sg:
+            assert (bits_equal(sg[key], so[key]) if sg[key].dtype == np.float32 else np.array_equal(sg[key], so[key])), key
+    else:
+        assert bits_equal(sg["dec_state"], so["dec_state"]) and np.array_equal(sg["nco_phase"], so["nco_phase"])
+    name = g.kernel_name()
+    g.close()
+    return name
+
+
+@pytest.mark.parametrize("shape", [(256, 4, 63), (128, 2, 63), (256, 8, 63), (0, 1, 127), (64, 4, 63), (128, 4, 31)])
+@pytest.mark.parametrize("arith", [ARITH_CMSIS, ARITH_FMA])
+@pytest.mark.parametrize("nco", ["shared", "per_channel"])
+def test_any_call_length_on_the_exact_fused_kernels(shape, arith, nco):
+    """Calls of 1, 2, 3, 5, 17 DSP blocks in any order (never a whole number of passes except by accident)."""
+    nd, M, nh = shape
+    nch = 37
+    kw = dict(nco=True, nco_step_all=0x01234567) if nco == "shared" else \
+        dict(nco=True, nco_steps=(np.arange(nch, dtype=np.uint64) * 0x9E3779B1 % (1 << 32)).astype(np.uint32))
+    mk = lambda: rc.ChainSpec(nch, 256, M, nd, nh, 0, rc.MODE_USB, arith, **kw)
+    name = run_pair(mk(), mk(), [256, 512, 768, 256, 1280, 4352, 256, 2048])
+    assert name.startswith("k_ssb_fused") or name.startswith("k_ssb_mfma")
+
+
+@pytest.mark.parametrize("shape,block", [((256, 4, 63), 96), ((0, 1, 63), 96), ((128, 2, 63), 96), ((256, 4, 127), 192), ((0, 1, 127), 48)])
+@pytest.mark.parametrize("arith", [ARITH_CMSIS, ARITH_FMA, ARITH_AUTO])
+@pytest.mark.parametrize("q15", [False, True])
+def test_the_firmware_block_geometry_runs_on_the_fused_kernel(shape, block, arith, q15):
+    """DSP blocks of 96 (192, 48) frames: AGC groups of 6 (12, 24, 48) lanes, passes of 240 (192) audio samples.  Calls of one
+    slot (96 frames, dsp_if.c:50-67), two, ten, eleven, fifty.  AUTO has no matrix kernel for these: bit-exact."""
+    nd, M, nh = shape
+    nch = 21
+    kw = dict(nco=True, nco_step_all=0x00c00000, agc=True)
+    ref = ARITH_CMSIS if arith == ARITH_AUTO else arith
+    name = run_pair(rc.ChainSpec(nch, block, M, nd, nh, 0, rc.MODE_LSB, arith, **kw),
+                    rc.ChainSpec(nch, block, M, nd, nh, 0, rc.MODE_LSB, ref, **kw),
+                    [block, 2 * block, 10 * block, 11 * block, block, 50 * block], q15=q15)
+    assert name == "k_ssb_fused<%d,%d,%d>" % shape
+
+
+@pytest.mark.parametrize("q15", [False, True])
+def test_auto_on_short_calls(q15):
+    """256 / 512 / 768-sample calls of the cfg3 chain in SELENITE_ARITH_AUTO: a partial pass that holds a whole decimator history
+    goes to the matrix kernel (+ rerun of guarded channels through the variable-length pass of k_ssb_fused); plain 1e-5 bar."""
+    nch = 48
+    rng = np.random.default_rng(2)
+    steps = rng.integers(0, 1 << 32, nch, dtype=np.uint64).astype(np.uint32)
+    kw = dict(nco=True, nco_steps=steps)
+    mk = lambda a: rc.ChainSpec(nch, 256, 4, 256, 63, 0, rc.MODE_USB, a, **kw)
+    run_pair(mk(ARITH_AUTO), mk(ARITH_CMSIS), [256, 512, 768, 256, 1024, 1280, 256, 256], q15=q15, exact=False, na=64)
+
+
+def test_am_and_global_gain_with_partial_passes():
+    import selenite_rx as sr
+    nch = 19
+    kw = dict(nco=True, nco_step_all=0x01000000)
+    mk = lambda a, **k: rc.ChainSpec(nch, 256, 4, 256, 63, 0, rc.MODE_AM, a, **dict(kw, **k))
+    run_pair(mk(ARITH_CMSIS), mk(ARITH_CMSIS), [768, 256, 1280])
+    g = sr.Rx(rc.ChainSpec(nch, 256, 4, 256, 63, 0, rc.MODE_USB, ARITH_CMSIS, agc_global=True, **kw).config())
+    o = CpuChain(rc.ChainSpec(nch, 256, 4, 256, 63, 0, rc.MODE_USB, ARITH_CMSIS, agc_global=True, **kw), "orc")
+    pos = 0
+    for bs in (768, 256, 2304):
+        iq = synth_iq(0, nch, pos, bs)
+        pos += bs
+        yo, _ = o.process_env(iq)
+        assert bits_equal(g.process(iq), yo), bs
+    g.close()
