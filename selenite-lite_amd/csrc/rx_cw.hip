@@ -103,6 +103,7 @@ __global__ __launch_bounds__(64) void k_cw_fused(RxParams p, const TIn *__restri
     float4 st = *reinterpret_cast<const float4 *>(p.biq_state + ((size_t)c * NS + s) * 4);
     float x1 = st.x, x2 = st.y, y1 = st.z, y2 = st.w;
     float gain = p.agc ? p.gain[c] : 1.0f;
+    bool nonfinite = false;                                           // any audio sample of this wavefront NaN / Inf
     // load-phase geometry: load j of a chunk covers channel CPL*j + lane/LPC, samples 2*(lane%LPC), +1
     const int lch = lane / CG::LPC, lsm = 2 * (lane % CG::LPC);
     const uint32_t ph_own = NCO ? p.phase[c] : 0u, st_own = NCO ? p.step[c] : 0u;
@@ -282,6 +283,10 @@ __global__ __launch_bounds__(64) void k_cw_fused(RxParams p, const TIn *__restri
                 if (t < BLK && c0 + r < p.channels) {
                     float4 v = lds_ld4f(tile + r * RS + t);
                     v.x = v.x * g; v.y = v.y * g; v.z = v.z * g; v.w = v.w * g;
+                    {   // ARM_MATH_NANINF (arm_math.h:405): x * 0 is NaN iff x is not finite
+                        const float z = __builtin_fmaf(v.w, 0.0f, __builtin_fmaf(v.z, 0.0f, __builtin_fmaf(v.y, 0.0f, v.x * 0.0f)));
+                        nonfinite = nonfinite || (z != z);
+                    }
                     const size_t o = (size_t)(c0 + r) * p.out_stride + n0 + t;
                     if constexpr (sizeof(TOut) == 4) {
                         *reinterpret_cast<float4 *>(reinterpret_cast<float *>(dst) + o) = v;
@@ -296,6 +301,7 @@ __global__ __launch_bounds__(64) void k_cw_fused(RxParams p, const TIn *__restri
         }
         cw_lds_sync();
     }
+    if (nonfinite) p.flags[kFlagNanInf] = 1u;                         // read by selenite_rx_sync / the host-pointer calls
     if (!live) return;
     *reinterpret_cast<float4 *>(p.biq_state + ((size_t)c * NS + s) * 4) = make_float4(x1, x2, y1, y2);
     if (s == NS - 1) {

@@ -116,8 +116,19 @@ int main(int argc, char **argv)
         }
         if (memcmp(h_ref, h_got, (size_t)total * nout * sizeof(float)) != 0) bad = 1;
     }
-    printf("{\"host\": \"C\", \"ranks\": %d, \"channels\": %u, \"samples_per_call\": %u, \"calls\": %d, \"collective\": \"ncclAllReduce(ncclMax), %u floats per call\", "
-           "\"sharded_equals_unsharded\": %s}\n", ndev, total, bs, calls, bs / 256, bad ? "false" : "true");
+    /* one device per rank, by PCI bus id, and what RCCL itself reports for the communicator: lets a reader verify the ranks */
+    printf("{\"host\": \"C\", \"ranks\": %d, \"devices\": [", ndev);
+    for (int r = 0; r < ndev; ++r) {
+        char bus[32] = "unknown";
+        int nr = -1, ur = -1;
+        (void)selenite_rx_device_pci_bus_id(r, bus, sizeof bus);
+        (void)ncclCommCount(comm[r], &nr);
+        (void)ncclCommUserRank(comm[r], &ur);
+        printf("%s{\"rank\": %d, \"pci_bus_id\": \"%s\", \"nccl_comm_count\": %d, \"nccl_user_rank\": %d, \"channels\": %u}", r ? ", " : "", r, bus, nr, ur,
+               first[r + 1] - first[r]);
+    }
+    printf("], \"channels\": %u, \"samples_per_call\": %u, \"calls\": %d, \"collective\": \"ncclAllReduce(ncclMax), %u floats per call\", "
+           "\"collectives_per_call\": 1, \"sharded_equals_unsharded\": %s}\n", total, bs, calls, bs / 256, bad ? "false" : "true");
     for (int r = 0; r < ndev; ++r) { selenite_rx_free(rx[r]); ncclCommDestroy(comm[r]); }
     selenite_rx_free(whole);
     return bad;

@@ -290,3 +290,12 @@ def test_non_finite_input_raises_naninf_in_every_fused_kernel():
                 g.process(iq)
             assert e.value.code == rc.NANINF, (arith, shape)
             g.close()
+    g = sr.Rx(rc.baseline_spec("cfg4", 20).config())                    # k_cw_fused
+    assert g.kernel_name().startswith("k_cw_fused")
+    iq = synth_iq(0, 20, 0, 1024)
+    g.process(iq)
+    iq[7, 300, 1] = np.nan
+    with pytest.raises(sr.RxError) as e:
+        g.process(iq)
+    assert e.value.code == rc.NANINF
+    g.close()

@@ -124,3 +124,6 @@ def test_plain_c_host_runs_the_global_gain_path_over_rccl():
     assert out.returncode == 0, out.stderr[-2000:]
     d = json.loads(out.stdout.strip().splitlines()[-1])
     assert d["host"] == "C" and d["ranks"] >= 1 and d["sharded_equals_unsharded"] is True
+    assert len(d["devices"]) == d["ranks"] and all(":" in x["pci_bus_id"] and x["nccl_comm_count"] == d["ranks"] and
+                                                      x["nccl_user_rank"] == x["rank"] for x in d["devices"])
+    assert sum(x["channels"] for x in d["devices"]) == d["channels"] and d["collectives_per_call"] == 1
