@@ -496,7 +496,7 @@ static int run_part(selenite_rx_instance *S, const void *src, bool src_q15, void
     // (the fused kernels convert in and out symmetrically: int16 slots with a global gain, which
     // needs f32 audio between the two phases, stay on the generic kernels)
     const bool fusable = phase != kPhase2 && !S->force_generic && !(global && src_q15);
-    const bool ssb_fused = fusable && S->plan.kind != 0 && fused_block_size_ok(S->plan, g, block_size);
+    const bool ssb_fused = fusable && S->plan.kind != 0;
     const bool cw_fused = fusable && cw_fused_ok(g, block_size);
     float *audio = (float *)dst;      // un-scaled audio: dst itself when dst is f32, else scratch
     if (dst_q15 && (global || !(ssb_fused || cw_fused))) {
@@ -587,20 +587,18 @@ static int run_part(selenite_rx_instance *S, const void *src, bool src_q15, void
     return SELENITE_RX_SUCCESS;
 }
 
-// Entry of every process call.  The decimating fused kernels work in passes of 256 outputs; a call
-// whose length is a multiple of cfg.block but not of a pass is split: the whole passes go through the
-// fused kernel, the remaining DSP blocks through the generic kernels on the same streaming state (both
-// parts address the caller's buffers with the full per-channel stride).
+// Entry of every process call.  Any call length (a whole number of DSP blocks) runs on the fused kernels; a
+// split-precision call that ends in a partial pass too short for the matrix kernel is cut in two launches on the same
+// streaming state (fused_tail_split; both parts address the caller's buffers with the full per-channel stride).
 static int run_chain(selenite_rx_instance *S, const void *src, bool src_q15, void *dst, bool dst_q15,
                      uint32_t block_size, Phase phase, float *ext_env)
 {
     const selenite_rx_config &g = S->cfg;
     const uint32_t nout = block_size / g.decim;
     const bool global = g.agc_enable && g.agc_global;
-    if (phase == kAll && !global && !S->force_generic && S->plan.kind != 0 && g.nd_taps &&
-        !fused_block_size_ok(S->plan, g, block_size)) {
+    if (phase == kAll && !global && !S->force_generic && S->plan.kind != 0 && fused_tail_split(S->plan, g, block_size)) {
         const uint32_t unit = 256u * g.decim, bs1 = block_size / unit * unit;
-        if (bs1 > 0) {
+        {
             int rc = run_part(S, src, src_q15, dst, dst_q15, bs1, kAll, nullptr, block_size, nout);
             if (rc) return rc;
             const size_t ein = src_q15 ? sizeof(int16_t) : sizeof(float), eout = dst_q15 ? sizeof(int16_t) : sizeof(float);

@@ -966,12 +966,17 @@ void free_fused(FusedPlan &plan)
     plan.kind = 0;
 }
 
-bool fused_block_size_ok(const FusedPlan &plan, const selenite_rx_config &g, uint32_t block_size)
+bool fused_tail_split(const FusedPlan &plan, const selenite_rx_config &g, uint32_t block_size)
 {
-    // every call length (a whole number of DSP blocks) since round 3: k_ssb_fused takes passes of variable length, and
-    // launch_shape sends the matrix kernels only the launches they cover
-    (void)plan; (void)g; (void)block_size;
-    return true;
+    // Every call length (a whole number of DSP blocks) runs on the fused kernels since round 3 (k_ssb_fused: variable-length
+    // passes).  One case is better served in two launches: a split-precision instance whose call ends in a partial pass too
+    // short for k_ssb_split16 (it wants a whole decimator history in it; only DSP blocks shorter than that history get there):
+    // the whole passes stay on the matrix kernel, the tail goes to k_ssb_fused -- true when the call should be cut that way.
+    if (!(g.arith == SELENITE_ARITH_SPLIT16 || g.arith == SELENITE_ARITH_AUTO) || !plan.d_btab16 || !g.nd_taps) return false;
+    const uint32_t na = g.block / g.decim, unit = 256u * g.decim;
+    if (256u % na != 0 || block_size % unit == 0 || block_size < unit) return false;
+    const uint32_t hq = (g.nd_taps - 1 + g.decim - 1) / g.decim, hs = ((hq + 3) & ~3u) * g.decim;    // GeoS::HS
+    return block_size % unit < hs;
 }
 
 hipError_t launch_fused(const FusedPlan &plan, const RxParams &p, int arith, const void *src, bool src_q15,

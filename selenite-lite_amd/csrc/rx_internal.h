@@ -101,7 +101,7 @@ struct FusedPlan {
 hipError_t plan_fused(const selenite_rx_config &cfg, bool delay_is_impulse, int delay_index,
                       bool hilb_odd_only, FusedPlan &plan);
 void free_fused(FusedPlan &plan);
-bool fused_block_size_ok(const FusedPlan &plan, const selenite_rx_config &cfg, uint32_t block_size);
+bool fused_tail_split(const FusedPlan &plan, const selenite_rx_config &cfg, uint32_t block_size);
 hipError_t launch_fused(const FusedPlan &plan, const RxParams &p, int arith, const void *src,
                         bool src_q15, void *dst, bool dst_q15, int delay_index, hipStream_t st);
 

@@ -66,16 +66,17 @@ class FullRun:
 
 
 @pytest.mark.parametrize("name,arith", [
-    ("cfg3", ARITH_CMSIS), ("cfg3", ARITH_FMA), ("cfg3", rc.ARITH_SPLIT16),
+    ("cfg3", ARITH_CMSIS), ("cfg3", ARITH_FMA), ("cfg3", rc.ARITH_SPLIT16), ("cfg3", rc.ARITH_AUTO),
     ("cfg4", ARITH_CMSIS), ("cfg4", ARITH_FMA),
-    ("cfg2", ARITH_CMSIS), ("cfg2", ARITH_FMA), ("cfg2", rc.ARITH_SPLIT16),
-    ("cfg5", ARITH_CMSIS), ("cfg5", rc.ARITH_SPLIT16),
+    ("cfg2", ARITH_CMSIS), ("cfg2", ARITH_FMA), ("cfg2", rc.ARITH_SPLIT16), ("cfg2", rc.ARITH_AUTO),
+    ("cfg5", ARITH_CMSIS), ("cfg5", rc.ARITH_SPLIT16), ("cfg5", rc.ARITH_AUTO),
 ])
 def test_full_size_sampled_channels_match_oracle(name, arith):
     run = FullRun(name, arith)
     assert run.rx.kernel_name() != "generic"
     chans = sample_channels(run.nch)
-    ref_arith = ARITH_CMSIS if arith == rc.ARITH_SPLIT16 else arith
+    tol_mode = arith in (rc.ARITH_SPLIT16, rc.ARITH_AUTO)
+    ref_arith = ARITH_CMSIS if tol_mode else arith
     o = CpuChain(baseline_spec(run.chain, len(chans), ref_arith), "orc")
     na = run.spec.block // run.spec.decim
     for k in range(2):
@@ -83,7 +84,7 @@ def test_full_size_sampled_channels_match_oracle(name, arith):
         assert np.isfinite(y).all()
         iq = np.concatenate([synth_iq(c, 1, k * run.bs, run.bs) for c in chans], axis=0)
         yo = o.process(iq)
-        if arith == rc.ARITH_SPLIT16:
+        if tol_mode:
             yg = y[chans]
             for b in range(yo.shape[1] // na):
                 for i in range(len(chans)):
@@ -93,7 +94,7 @@ def test_full_size_sampled_channels_match_oracle(name, arith):
     sg, so = run.rx.state(), o.state()
     for key in sg:
         a = sg[key][chans]
-        if arith == rc.ARITH_SPLIT16 and key in ("fir_state", "agc_gain") and not (key == "fir_state" and run.spec.nd_taps == 0):
+        if tol_mode and key in ("fir_state", "agc_gain") and not (key == "fir_state" and run.spec.nd_taps == 0):
             assert rel_err(a, so[key]) <= TOL, key
         elif a.dtype == np.float32:
             assert bits_equal(a, so[key]), key
@@ -101,7 +102,7 @@ def test_full_size_sampled_channels_match_oracle(name, arith):
             assert np.array_equal(a, so[key]), key
 
 
-@pytest.mark.parametrize("name,arith", [("cfg3", rc.ARITH_SPLIT16), ("cfg3", ARITH_CMSIS), ("cfg4", ARITH_CMSIS),
+@pytest.mark.parametrize("name,arith", [("cfg3", rc.ARITH_SPLIT16), ("cfg3", rc.ARITH_AUTO), ("cfg3", ARITH_CMSIS), ("cfg4", ARITH_CMSIS),
                                         ("cfg5", ARITH_FMA)])
 def test_full_size_determinism_and_block_partition_invariance(name, arith):
     run = FullRun(name, arith)
@@ -113,17 +114,28 @@ def test_full_size_determinism_and_block_partition_invariance(name, arith):
     step = 1024 if run.bs > 1024 else 256
     parts = [run.call(0, bs=step, first_sample=s) for s in range(0, run.bs, step)]
     y2 = np.concatenate(parts, axis=1)
+    if arith == rc.ARITH_AUTO:
+        # AUTO recomputes a guarded channel for the whole CALL: cutting the stream differently moves the boundary between the
+        # split-precision and the bit-exact arithmetic (here: the start-up blocks of the first piece), so the bits may differ --
+        # by less than the bar both results hold against CMSIS; channels no call guarded are bit-identical
+        na = run.spec.block // run.spec.decim
+        d = np.abs(y1.astype(np.float64) - y2).reshape(run.nch, -1, na).max(axis=2)
+        m = np.abs(y1).reshape(run.nch, -1, na).max(axis=2)
+        assert (d <= 2e-5 * m).all()
+        return
     assert checksum(y2) == c1, "streaming in %d-sample calls changed the result" % step
     assert bits_equal(y1, y2)
 
 
-def test_every_channel_of_the_bench_workload_split16_within_the_north_star_tolerance():
-    """The bench.py default (cfg3, 65 536 channels x 4096 samples, split16, one NCO step for all channels): EVERY DSP
-    block of EVERY channel against the oracle (all host cores), two streamed calls -- 8.4 M blocks -- plus the
-    end-of-call state of every channel."""
+@pytest.mark.parametrize("arith", [rc.ARITH_AUTO, rc.ARITH_SPLIT16])
+def test_every_channel_of_the_bench_workload_split16_within_the_north_star_tolerance(arith):
+    """The bench.py default (cfg3, 65 536 channels x 4096 samples, AUTO -- and raw split16 --, one NCO step for all channels):
+    EVERY DSP block of EVERY channel against the oracle (all host cores), two streamed calls -- 2.1 M blocks -- plus the
+    end-of-call state of every channel.  AUTO: the first call's start-up blocks are recomputed exactly, the second call
+    guards nothing."""
     import os
-    run = FullRun("cfg3", rc.ARITH_SPLIT16)
-    assert run.rx.kernel_name() == "k_ssb_split16<256,4,63>" and "registers" in run.rx.nco_path()
+    run = FullRun("cfg3", arith)
+    assert run.rx.kernel_name().startswith("k_ssb_split16<256,4,63>") and "registers" in run.rx.nco_path()
     o = CpuChain(baseline_spec("cfg3", run.nch, ARITH_CMSIS), "orc")
     na = run.spec.block // run.spec.decim
     worst = 0.0
@@ -138,7 +150,11 @@ def test_every_channel_of_the_bench_workload_split16_within_the_north_star_toler
         e = d / m
         worst = max(worst, float(e.max()))
         assert (e <= TOL).all(), "call %d: %d blocks over, worst %.3g" % (k, int((e > TOL).sum()), e.max())
-    print("bench workload, all %d blocks: worst per-block relative error %.3g" % (2 * run.nch * run.nout // na, worst))
+        if arith == rc.ARITH_AUTO:
+            st = run.rx.guard_stats()
+            assert st["rerun_channel_calls"] == st["channel_calls"] and (k == 0 or st["channel_calls"] == 0), (k, st)
+            run.rx.guard_clear()
+    print("bench workload, arith %d, all %d blocks: worst per-block relative error %.3g" % (arith, 2 * run.nch * run.nout // na, worst))
     sg, so = run.rx.state(), o.state()
     assert bits_equal(sg["dec_state"], so["dec_state"])
     assert np.array_equal(sg["nco_phase"], so["nco_phase"])

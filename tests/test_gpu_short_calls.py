@@ -102,3 +102,27 @@ def test_am_and_global_gain_with_partial_passes():
         yo, _ = o.process_env(iq)
         assert bits_equal(g.process(iq), yo), bs
     g.close()
+
+
+@pytest.mark.parametrize("arith", [rc.ARITH_SPLIT16, ARITH_AUTO])
+def test_a_tail_too_short_for_the_matrix_kernel_is_cut_off_and_runs_on_the_variable_length_kernel(arith):
+    """DSP block 128 behind the 256-tap /4 decimator: a call of 1024 k + 128 samples ends in a partial pass that holds less than
+    a decimator history -- the whole passes stay on k_ssb_split16, the tail goes to k_ssb_fused (fused_tail_split), same
+    streaming state.  Raw split16: input-referred bar; AUTO: plain bar."""
+    import selenite_rx as sr
+    nch, na = 33, 32
+    kw = dict(nco=True, nco_step_all=0x01000000, agc=arith == ARITH_AUTO)
+    g = sr.Rx(rc.ChainSpec(nch, 128, 4, 256, 63, 0, rc.MODE_USB, arith, **kw).config())
+    o = CpuChain(rc.ChainSpec(nch, 128, 4, 256, 63, 0, rc.MODE_USB, ARITH_CMSIS, **kw), "orc")
+    assert g.kernel_name().startswith("k_ssb_split16<256,4,63>")
+    pos = 0
+    for bs in (1152, 128, 2176, 1024, 3200):
+        iq = synth_iq(0, nch, pos, bs)
+        pos += bs
+        yg, yo = g.process(iq), o.process(iq)
+        d = np.abs(yg.astype(np.float64) - yo).reshape(nch, -1, na).max(axis=2)
+        m = np.abs(yo).reshape(nch, -1, na).max(axis=2)
+        bar = 1e-5 * m if arith == ARITH_AUTO else 1e-5 * m + 1e-6 * np.abs(iq).max()
+        assert (d <= bar).all(), (bs, (d / np.maximum(m, 1e-30)).max())
+        assert bits_equal(g.state()["dec_state"], o.state()["dec_state"]), bs
+    g.close()
