@@ -302,8 +302,11 @@ extern "C" const char *selenite_rx_kernel_name(const selenite_rx_instance *S)
     if (!S) return "";
     if (S->force_generic) return "generic";
     if (S->plan.kind != 0) return S->plan.name;
-    if (cw_fused_ok(S->cfg, S->cfg.block))
-        return S->cfg.n_biquad == 2 ? "k_cw_fused<2,256>" : (S->cfg.n_biquad == 8 ? "k_cw_fused<8,256>" : "k_cw_fused<4,256>");
+    if (cw_fused_ok(S->cfg, S->cfg.block)) {
+        static thread_local std::string name;
+        name = "k_cw_fused<" + std::to_string(S->cfg.n_biquad) + "," + std::to_string(S->cfg.block) + ">";
+        return name.c_str();
+    }
     return "generic";
 }
 

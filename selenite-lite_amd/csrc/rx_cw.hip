@@ -310,10 +310,21 @@ __global__ __launch_bounds__(64) void k_cw_fused(RxParams p, const TIn *__restri
     }
 }
 
+// DSP blocks the systolic kernel is instantiated for: whole input chunks of CS = 1024 / (64 / NS) samples (32 / 64 / 128 for
+// 2 / 4 / 8 stages) and a tile of (64 / NS) x (BLK + 4) floats inside the 64 KB of static LDS -- 128, 192, 256, 512 where that
+// holds, and the firmware's 96-frame slot (Core/Inc/dsp_if.h:69-73) for 2 stages
+static bool cw_block_ok(uint32_t ns, uint32_t blk)
+{
+    if (ns == 2) return blk == 96 || blk == 128 || blk == 192 || blk == 256;
+    if (ns == 4) return blk == 128 || blk == 192 || blk == 256 || blk == 512;
+    if (ns == 8) return blk == 128 || blk == 256 || blk == 512;
+    return false;
+}
+
 bool cw_fused_ok(const selenite_rx_config &g, uint32_t block_size)
 {
-    return mode_is_cw(g.mode) && g.nd_taps == 0 && g.decim == 1 && g.nh_taps == 0 &&
-           (g.n_biquad == 2 || g.n_biquad == 4 || g.n_biquad == 8) && g.block == 256 && block_size % g.block == 0;
+    return mode_is_cw(g.mode) && g.nd_taps == 0 && g.decim == 1 && g.nh_taps == 0 && cw_block_ok(g.n_biquad, g.block) &&
+           block_size % g.block == 0;
 }
 
 template <int NS, int NCO, typename TIn, typename TOut>
@@ -321,9 +332,20 @@ static hipError_t cw_launch(const RxParams &p, const void *src, void *dst, hipSt
 {
     constexpr int CH = CwGeo<NS>::CH;
     static const size_t pad = std::getenv("SELENITE_RX_CW_LDS_PAD") ? (size_t)std::atoi(std::getenv("SELENITE_RX_CW_LDS_PAD")) : 0;   // occupancy experiments
-    hipLaunchKernelGGL((k_cw_fused<NS, NCO, 256, TIn, TOut>), dim3((p.channels + CH - 1) / CH), dim3(64), pad, st, p,
-                       static_cast<const TIn *>(src), static_cast<TOut *>(dst));
-    return hipGetLastError();
+    const dim3 grid((p.channels + CH - 1) / CH);
+#define CW_BLK(B_)                                                                                                          \
+    if (p.block == B_) {                                                                                                    \
+        hipLaunchKernelGGL((k_cw_fused<NS, NCO, B_, TIn, TOut>), grid, dim3(64), pad, st, p, static_cast<const TIn *>(src), \
+                           static_cast<TOut *>(dst));                                                                      \
+        return hipGetLastError();                                                                                           \
+    }
+    CW_BLK(256)
+    CW_BLK(128)
+    if constexpr (NS != 8) { CW_BLK(192) }
+    if constexpr (NS != 2) { CW_BLK(512) }
+    if constexpr (NS == 2) { CW_BLK(96) }
+#undef CW_BLK
+    return hipErrorNotSupported;
 }
 
 template <int NS>

@@ -126,3 +126,18 @@ def test_a_tail_too_short_for_the_matrix_kernel_is_cut_off_and_runs_on_the_varia
         assert (d <= bar).all(), (bs, (d / np.maximum(m, 1e-30)).max())
         assert bits_equal(g.state()["dec_state"], o.state()["dec_state"]), bs
     g.close()
+
+
+@pytest.mark.parametrize("stages,block", [(2, 96), (2, 128), (2, 192), (4, 128), (4, 192), (4, 512), (8, 128), (8, 512)])
+@pytest.mark.parametrize("q15", [False, True])
+def test_cw_kernel_for_other_dsp_blocks(stages, block, q15):
+    """k_cw_fused instantiated for DSP blocks of 96 (two stages: one firmware slot), 128, 192 and 512 samples beside the
+    BASELINE 256: the systolic array needs whole input chunks of 1024 / (64 / stages) samples.  Bit-exact like cfg4
+    (arm_biquad_cascade_df1_f32.c:165-407), ragged channel counts, per-channel NCO."""
+    import selenite_rx as sr
+    nch = 37
+    kw = dict(nco=True, nco_steps=(np.arange(nch, dtype=np.uint32) * np.uint32(0x00123457) + np.uint32(0x00400000)), agc=True,
+              bp_q=2.0 if stages == 8 else 4.0)
+    spec = rc.ChainSpec(nch, block, 1, 0, 0, stages, rc.MODE_CW, ARITH_CMSIS, **kw)
+    name = run_pair(spec, spec, [block, 3 * block, 2 * block, 7 * block], q15=q15)
+    assert name == "k_cw_fused<%d,%d>" % (stages, block)
