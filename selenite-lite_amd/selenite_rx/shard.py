@@ -98,7 +98,11 @@ class RankEnv:
         if self.dist is None:
             return [obj]
         out = [None] * self.world
-        self.dist.all_gather_object(out, obj)
+        try:
+            self.dist.all_gather_object(out, obj)
+        except Exception as e:                      # diagnostics must never cost the measurement
+            sys.stderr.write("RankEnv.gather_objects: %s\n" % e)
+            return [obj if r == self.rank else None for r in range(self.world)]
         return out
 
     def close(self):

@@ -106,6 +106,22 @@ def test_bench_launches_its_own_ranks_and_shards_the_channels():
     assert gd["config"]["agc"] == "global" and gd["dist"]["collectives_per_step"] == 1
 
 
+def test_bench_under_the_nccl_backend_with_one_rank_carries_the_dist_block():
+    """The RCCL process group of an N > 1 run, exercised with the one rank a one-GPU box allows (SELENITE_BENCH_FORCE_DIST):
+    init over nccl, barriers, the MAX all-reduce of the times, the object gathers of the `dist` block, the global-gain
+    all-reduce on the library's stream."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env.update(SELENITE_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29611", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for extra, coll in (([], 0), (["--global-gain"], 1)):
+        out = subprocess.run([sys.executable, BENCH, "--steps", "3", "--warmup", "1", "--spinup-ms", "0", "--channels", "1024",
+                              "--main-only"] + extra, capture_output=True, text=True, timeout=900, env=env)
+        assert out.returncode == 0, out.stderr[-2000:]
+        d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+        ds = d["dist"]
+        assert ds["backend"] == "nccl" and ds["world"] == 1 and ds["collectives_per_step"] == coll
+        assert len(ds["devices"]) == 1 and ":" in ds["devices"][0] and len(ds["per_rank_ms_per_step"]) == 1
+
+
 def test_global_gain_ranks_on_one_stream_match_the_unsharded_oracle():
     """Two gloo ranks on the one GPU run bench.py's GlobalGainStepper (phase 1 -> all-reduce -> phase 2 without host
     synchronisation) and compare with the unsharded oracle: tests/dist_global_gain_worker.py."""
