@@ -322,14 +322,19 @@ static bool periodic_lo(const selenite_rx_instance *S)
     return g.arith != SELENITE_ARITH_CMSIS && S->plan.use_mfma && g.nd_taps && g.decim == 4;
 }
 
-// every channel has its own LO, each of them periodic in 256 samples (all steps multiples of 2^24), and the split16 kernel
-// of this instance computes it once per channel and keeps it in registers (its NCO == 4 flavour)
+// every channel has its own LO, each of them periodic in 256 samples (all steps multiples of 2^24), and the kernel that serves
+// this instance's whole-pass calls computes one period per channel and call and keeps it in registers (NCO == 4 flavour of
+// k_ssb_split16 and of k_ssb_fused; k_ssb_mfma and k_hilb_split16 have none: per-sample NCO there)
 static bool periodic_lo_per_channel(const selenite_rx_instance *S)
 {
     const selenite_rx_config &g = S->cfg;
-    return g.nco_enable && S->steps_grid256 && !S->no_periodic_lo && g.nd_taps && S->plan.d_btab16 &&
-           (g.arith == SELENITE_ARITH_SPLIT16 || g.arith == SELENITE_ARITH_AUTO) &&
-           ssb_split16_periodic_lo((int)g.nd_taps, (int)g.decim, (int)g.nh_taps);
+    if (!(g.nco_enable && S->steps_grid256 && !S->no_periodic_lo && S->plan.kind != 0)) return false;
+    if (256u % (g.block / g.decim) != 0) return false;                       // passes of 256 outputs only
+    const bool split = (g.arith == SELENITE_ARITH_SPLIT16 || g.arith == SELENITE_ARITH_AUTO) && S->plan.d_btab16;
+    if (split && g.nd_taps) return ssb_split16_periodic_lo((int)g.nd_taps, (int)g.decim, (int)g.nh_taps);
+    if (split) return false;                                                 // k_hilb_split16: per-sample NCO (and its AUTO rerun with it)
+    const bool exact = g.arith == SELENITE_ARITH_CMSIS || g.arith == SELENITE_ARITH_AUTO;
+    return exact || !(S->plan.use_mfma && g.decim == 4);                     // k_ssb_fused; the fma arithmetic by 4 runs k_ssb_mfma
 }
 
 extern "C" const char *selenite_rx_nco_path(const selenite_rx_instance *S)
@@ -530,7 +535,7 @@ static int run_part(selenite_rx_instance *S, const void *src, bool src_q15, void
             // a step that is a multiple of 2^24 repeats the LO every 256 samples (channelised receivers: LO
             // frequencies on a grid of fs / 256): k_ssb_split16 then keeps it in registers (its NCO == 3 flavour)
             pf.lo_period = periodic_lo(S) ? 256u : 0u;
-        } else if (ssb_fused && periodic_lo_per_channel(S)) {
+        } else if (ssb_fused && g.nco_enable && periodic_lo_per_channel(S)) {
             pf.lo_period = 256u;                          // pf.nco stays 1: every channel computes its own period once
         }
         if (arith == SELENITE_ARITH_AUTO && ssb_fused) {

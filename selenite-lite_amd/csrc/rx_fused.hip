@@ -218,7 +218,7 @@ __global__ __launch_bounds__(64, 2) void k_ssb_fused(RxParams p, FusedArgs fa, c
     for (int i = 0; i < NLD; ++i) raw[i] = R::load(rs_in, lane * R::kBytes + i * 64 * R::kBytes, 0);
 
     // ---- prologue: tables and streaming state into LDS / registers ----
-    if constexpr (NCO == 1)
+    if constexpr (NCO == 1 || NCO == 4)
         for (int i = lane; i < 513; i += kWave) tab[i] = p.sintab[i];
     float creg[G::NCR > 0 ? G::NCR : 1];
     if constexpr (ND > 0) {
@@ -252,6 +252,16 @@ __global__ __launch_bounds__(64, 2) void k_ssb_fused(RxParams p, FusedArgs fa, c
     float gain = p.agc ? p.gain[c] : 1.0f;
     const int group = (int)fa.group;
     wave_lds_sync();
+    // NCO == 4 (round 3; as in k_ssb_split16): the channel's own step is a multiple of 2^24, so its LO repeats every 256 samples
+    // whatever its phase, and a pass (256 M inputs: the host selects this flavour only with 256-output passes) is a whole number
+    // of periods: load i of any pass multiplies by LO[(128 i + 2 lane, + 1) mod 256] -- two register quads, computed once per
+    // channel and call with the arithmetic of the per-sample flavour (same phases modulo 2^32: same bits)
+    lo_v2f lo_per[4];
+    if constexpr (NCO == 4) {
+        const uint32_t pe = ph0 + 2u * lane * step;
+        nco_lo_pair(tab, pe, pe + step, lo_per[0], lo_per[1]);
+        nco_lo_pair(tab, pe + 128u * step, pe + 129u * step, lo_per[2], lo_per[3]);
+    }
 
     for (uint32_t pass = 0; pass < npass; ++pass) {
         const uint32_t n0 = pass * tq;
@@ -281,6 +291,10 @@ __global__ __launch_bounds__(64, 2) void k_ssb_fused(RxParams p, FusedArgs fa, c
                 lo_v2f la, lb;                                            // arm_sin/cos_f32 restated for the vector ALU: same bits (rx_device.h)
                 const uint32_t pe = ph0 + (n0 + n) * step;
                 nco_lo_pair(tab, pe, pe + step, la, lb);
+                a = cmul<0>(a, make_float2(la.x, la.y));
+                b = cmul<0>(b, make_float2(lb.x, lb.y));
+            } else if constexpr (NCO == 4) {
+                const lo_v2f la = lo_per[2 * (i & 1)], lb = lo_per[2 * (i & 1) + 1];
                 a = cmul<0>(a, make_float2(la.x, la.y));
                 b = cmul<0>(b, make_float2(lb.x, lb.y));
             }
@@ -792,10 +806,14 @@ static hipError_t launch_one(const RxParams &p, const FusedArgs &fa, const void 
 {
     using G = Geo<ND, M, NH>;
     constexpr size_t lds = (size_t)G::total * sizeof(float);
+    // per-channel LO with a period of 256 samples (every step a multiple of 2^24) and 256-output passes: one period per channel in registers
+    const bool per4 = p.nco == 1 && p.lo_period == 256 && fa.pass_out == 256;
     auto k = fa.am ? (p.nco == 2 ? k_ssb_fused<ARITH, 2, ND, M, NH, TIn, TOut, 1>
-                         : (p.nco == 1 ? k_ssb_fused<ARITH, 1, ND, M, NH, TIn, TOut, 1> : k_ssb_fused<ARITH, 0, ND, M, NH, TIn, TOut, 1>))
+                         : (per4 ? k_ssb_fused<ARITH, 4, ND, M, NH, TIn, TOut, 1>
+                         : (p.nco == 1 ? k_ssb_fused<ARITH, 1, ND, M, NH, TIn, TOut, 1> : k_ssb_fused<ARITH, 0, ND, M, NH, TIn, TOut, 1>)))
                    : (p.nco == 2 ? k_ssb_fused<ARITH, 2, ND, M, NH, TIn, TOut, 0>
-                         : (p.nco == 1 ? k_ssb_fused<ARITH, 1, ND, M, NH, TIn, TOut, 0> : k_ssb_fused<ARITH, 0, ND, M, NH, TIn, TOut, 0>));
+                         : (per4 ? k_ssb_fused<ARITH, 4, ND, M, NH, TIn, TOut, 0>
+                         : (p.nco == 1 ? k_ssb_fused<ARITH, 1, ND, M, NH, TIn, TOut, 0> : k_ssb_fused<ARITH, 0, ND, M, NH, TIn, TOut, 0>)));
     if constexpr (lds > 48 * 1024) {                      // per device and per kernel: set on every launch (cheap)
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -299,3 +299,36 @@ def test_non_finite_input_raises_naninf_in_every_fused_kernel():
         g.process(iq)
     assert e.value.code == rc.NANINF
     g.close()
+
+
+@pytest.mark.parametrize("shape", [(256, 4, 63), (128, 8, 63), (0, 1, 63), (256, 2, 127)])
+@pytest.mark.parametrize("arith", [ARITH_CMSIS, rc.ARITH_FMA, ARITH_AUTO])
+def test_per_channel_grid_lo_on_the_exact_kernels(shape, arith):
+    """The NCO == 4 flavour of k_ssb_fused (round 3): per-channel steps on the fs/256 grid, random phases, in the exact arithmetic
+    modes and as the rerun pass of AUTO (guard ratio +inf: every channel) -- bit-exact against the oracle, which evaluates
+    arm_sin_f32 / arm_cos_f32 per sample (arm_sin_f32.c:72-119); whole and partial passes."""
+    import selenite_rx as sr
+    nch = 45
+    rng = np.random.default_rng(23)
+    steps = (rng.integers(0, 256, nch).astype(np.uint32) << 24).astype(np.uint32)
+    phases = rng.integers(0, 1 << 32, nch, dtype=np.uint64).astype(np.uint32)
+    kw = dict(nco=True, nco_steps=steps)
+    g = sr.Rx(spec_of(shape, nch, arith, **kw).config())
+    o = CpuChain(spec_of(shape, nch, ARITH_CMSIS if arith == ARITH_AUTO else arith, **kw), "orc")
+    if arith == ARITH_AUTO:
+        g.set_guard_ratio(float("inf"))
+    st = o.state(); st["nco_phase"] = phases
+    o.L.orc_rx_set_state(o.h, rc.C.byref(rc.state_view(st)))
+    g.set_state(st)
+    mfma = arith == rc.ARITH_FMA and shape[1] == 4 and shape[0] > 0            # k_ssb_mfma has no such flavour
+    hilb_split = arith == ARITH_AUTO and shape[0] == 0                         # nor has k_hilb_split16 (and so its rerun)
+    assert g.nco_path().startswith("per-channel LO, period 256") == (not mfma and not hilb_split), (g.nco_path(), g.kernel_name())
+    pos = 0
+    for bs in (1024, 768, 2048, 256):
+        iq = synth_iq(0, nch, pos, bs)
+        pos += bs
+        assert bits_equal(g.process(iq), o.process(iq)), bs
+    sg, so = g.state(), o.state()
+    for key in sg:
+        assert (bits_equal(sg[key], so[key]) if sg[key].dtype == np.float32 else np.array_equal(sg[key], so[key])), key
+    g.close()
