@@ -19,7 +19,9 @@
 #include "selenite_rx.h"
 
 #define DSP_CHANNELS   64u      /* independent receivers handled per callback */
-#define DSP_BLOCK      256u     /* complex samples per DSP block (AGC update) */
+#define DSP_BLOCK      96u      /* complex samples per DSP block (AGC update) = one I2S half-buffer: 192 uint16 words, 96 I/Q
+                                 * frames per millisecond at 96 kHz (Core/Inc/dsp_if.h:69-73); 24 audio samples behind the /4
+                                 * decimator.  Round 3: this geometry runs on the fused kernel (passes of ten blocks) */
 #define DSP_DECIM      4u
 #define DSP_ND_TAPS    256u
 #define DSP_NH_TAPS    63u
@@ -60,7 +62,7 @@ void DSP_Process_Block(const int16_t *pbuf_in, int16_t *pbuf_out, uint16_t frame
 
 int main(void)
 {
-    const uint32_t frames = 4u * DSP_BLOCK;
+    const uint32_t frames = DSP_BLOCK;                       /* one slot per call, as the firmware's callback gets it */
     int rc = DSP_Init();
     if (rc != SELENITE_RX_SUCCESS) {
         fprintf(stderr, "DSP_Init failed: %d (%s)\n", rc, selenite_rx_error_string(NULL));
@@ -69,10 +71,10 @@ int main(void)
     float *f = malloc(sizeof(float) * DSP_CHANNELS * frames * 2);
     int16_t *in = malloc(sizeof(int16_t) * DSP_CHANNELS * frames * 2);
     int16_t *out = malloc(sizeof(int16_t) * DSP_CHANNELS * frames / DSP_DECIM);
-    for (int call = 0; call < 3; ++call) {
+    for (int call = 0; call < 24; ++call) {                  /* 24 ms of signal */
         selenite_rx_synth_iq_host(f, 0, DSP_CHANNELS, (uint64_t)call * frames, frames, 0x5E1E917Eull);
         for (size_t i = 0; i < (size_t)DSP_CHANNELS * frames * 2; ++i) in[i] = (int16_t)(f[i] * 32768.0f);
-        if (call == 2) DSP_Set_Mode(SELENITE_MODE_USB);
+        if (call == 16) DSP_Set_Mode(SELENITE_MODE_USB);
         DSP_Process_Block(in, out, (uint16_t)frames);
         if (selenite_rx_status(rx) != SELENITE_RX_SUCCESS) {
             fprintf(stderr, "process failed: %s\n", selenite_rx_error_string(rx));
@@ -81,7 +83,7 @@ int main(void)
         long peak = 0;
         for (size_t i = 0; i < (size_t)DSP_CHANNELS * frames / DSP_DECIM; ++i)
             if (labs(out[i]) > peak) peak = labs(out[i]);
-        printf("call %d: kernel %s, audio peak %ld / 32768\n", call, selenite_rx_kernel_name(rx), peak);
+        if (call % 8 == 7) printf("call %d: kernel %s, audio peak %ld / 32768\n", call, selenite_rx_kernel_name(rx), peak);
     }
     selenite_rx_free(rx);
     free(f); free(in); free(out);
