@@ -17,7 +17,11 @@
  *
  * Shapes: pSrcAudio [channels][blockSize] (float or q15), pDstIQ [channels][blockSize*interp][2].
  * blockSize counts AUDIO samples and must be a multiple of cfg.block (the ALC block).
- * Status codes, mode bytes and arithmetic modes are selenite_rx.h's (SPLIT16 behaves as FMA here).
+ * Status codes, mode bytes and arithmetic modes are selenite_rx.h's: SELENITE_ARITH_CMSIS (bit-exact), _FMA (bit-exact vs the
+ * fmaf restatement), _SPLIT16 (the interpolator as a split-precision matrix product for the BASELINE-like shape, <=1e-5 of the
+ * output block's maximum + 1e-6 of the input level; other shapes run as _FMA).  SELENITE_ARITH_AUTO is an RX mode (its parity
+ * guard compares the audio envelope the RX AGC computes anyway with the input level; the TX interpolator's output sits at its
+ * input's level for in-band audio): selenite_tx_init returns SELENITE_RX_ARGUMENT_ERROR for it.
  * No CPU fallback: init fails with SELENITE_RX_DEVICE_ERROR without a HIP device.
  */
 #ifndef SELENITE_TX_H
