@@ -11,14 +11,22 @@ d=json.loads(sys.stdin.read())
 print('%-34s | %10.1f  %.4f  %.4f  %s  [%s]' % ('$*' or '(default)', d['value'], d['roofline']['launch_ms_hip_events'], d['roofline']['frac'], d['config']['kernel'], d['config']['nco']))" >> $OUT
 }
 run
-SELENITE_RX_NO_PERIODIC_LO=1 run --steps 400
+run --arith split16
+run --nco shared_table
+run --nco per_channel_grid --arith split16
+run --nco per_channel --arith split16
+run --nco per_channel_grid
+run --nco per_channel_grid --arith cmsis
 run --io q15
 run --global-gain
+run --global-gain --arith split16
 run --arith fma
 run --arith cmsis
 run --workload cfg2
+run --workload cfg2 --arith split16
 run --workload cfg2 --io q15
 run --workload cfg5
-run --workload cfg4 --arith cmsis
-run --workload cfg4 --arith cmsis --io q15
+run --workload cfg5 --arith split16
+run --workload cfg4
+run --workload cfg4 --io q15
 cat $OUT
