@@ -1,0 +1,23 @@
+// rx_fused_exact.hip -- the SELENITE_ARITH_CMSIS instantiations of k_ssb_fused (rx_fused_kernels.h): product rounded, then sum
+// rounded, taps ascending from +0.0f -- bit-exact against the reference's arithmetic (arm_fir_decimate_f32.c:193-284,
+// arm_fir_f32.c:640-936).  Also the rerun pass of SELENITE_ARITH_AUTO (RxParams::chan_flags).  A translation unit of its own so
+// that it compiles beside rx_fused.hip (fma instantiations) instead of behind it.
+#include "rx_fused_kernels.h"
+
+#pragma clang fp contract(off)
+
+namespace srx {
+
+hipError_t launch_exact(int nd, int m, int nh, bool q15, const RxParams &p, const FusedArgs &fa, const void *src, void *dst,
+                        hipStream_t st)
+{
+#define X(ND_, M_, NH_, ID_)                                                                             \
+    if (nd == ND_ && m == M_ && nh == NH_)                                                               \
+        return q15 ? launch_one<0, ND_, M_, NH_, int16_t, int16_t>(p, fa, src, dst, st)                   \
+                   : launch_one<0, ND_, M_, NH_, float, float>(p, fa, src, dst, st);
+    SRX_SHAPES(X)
+#undef X
+    return hipErrorNotSupported;
+}
+
+}  // namespace srx

@@ -1,0 +1,415 @@
+// rx_fused_kernels.h -- k_ssb_fused (the fused SSB kernel on the vector ALU, both exact arithmetic contracts) and its launcher,
+// shared by the two translation units that instantiate it: rx_fused.hip (fma arithmetic; planning and dispatch; k_ssb_mfma) and
+// rx_fused_exact.hip (CMSIS arithmetic: the bit-exact kernels, also the rerun pass of SELENITE_ARITH_AUTO).  Two units so the
+// ~1000 instantiations compile in parallel (the single unit took 6 minutes).
+#pragma once
+#include "rx_fused_common.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+
+#pragma clang fp contract(off)
+
+namespace srx {
+
+
+// arm_fir_decimate_f32 on BOTH rails for the 4 adjacent outputs j = 4*lane + r.
+// Output j needs s[(j - HQ4 + q)*M + p] * cq[q*M + p], q = 0..HQ4 ascending, p ascending: the
+// loops below visit (q, p) in exactly that order for every r, so each accumulator sees the
+// reference's tap order.  Coefficients live lane-distributed in creg and reach the SGPR file by
+// v_readlane (no scalar-memory latency, one fetch serves both rails and up to 4 outputs).
+template <int ARITH, int ND, int M, int NH>
+__device__ __forceinline__ void decim_quad(const float *S, int lane, const float (&creg)[Geo<ND, M, NH>::NCR],
+                                           v2f (&acc)[4])
+{
+    using G = Geo<ND, M, NH>;
+    const float *base = S + 12 * lane;
+#pragma unroll
+    for (int o = 0; o < (G::HQ4 + 4) / 2; ++o) {
+        float4 W[M];
+#pragma unroll
+        for (int p = 0; p < M; ++p)
+            W[p] = lds_ld4f(base + p * G::PSF + 4 * (3 * (o >> 1) + (o & 1)));
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+#pragma unroll
+            for (int p = 0; p < M; ++p) {
+                const v2f w = e ? v2f{ W[p].z, W[p].w } : v2f{ W[p].x, W[p].y };
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int q = 2 * o + e - r;
+                    const int kk = q * M + p;
+                    if (q < 0 || q > G::HQ4 || (q == G::HQ4 && p > 0) || kk < G::F) continue;
+                    const float c = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(creg[kk >> 6]), kk & 63));
+                    acc[r] = mac2<ARITH>(acc[r], w, c);
+                }
+            }
+        }
+    }
+}
+
+// Steps 3-5 of a pass, shared by the VALU and the MFMA kernels: Hilbert FIR on Q (structural zeros
+// skipped) and unit-impulse delay on I from the decimated rails in LDS, sideband combine, AGC per
+// DSP block (group lanes), one 4-sample store per lane.
+// GROUP = lanes per DSP block as a compile-time constant (16: 64-sample blocks, 64: 256-sample blocks;
+// 0 = runtime `group`): constant lane indices turn the block-envelope broadcasts into v_readlane and
+// the lane reductions into DPP instead of ds_bpermute round trips.
+template <int ARITH, int GROUP, int ND, int M, int NH, typename TOut, int AM = 0>
+__device__ __forceinline__ void demod_agc_store(const RxParams &p, const FusedArgs &fa, const float *dI,
+                                                const float *dQ, int lane, int group,
+                                                const float (&hreg)[(NH + 63) / 64 ? (NH + 63) / 64 : 1], float &gain,
+                                                TOut *__restrict__ dst, size_t out_index, bool &nonfinite,
+                                                int nvb = 64)        // DSP blocks of this pass that exist (whole passes: all of them)
+{
+    using G = Geo<ND, M, NH>;
+    float au[4];
+    if constexpr (NH > 0 && AM != 0) {
+        // AM: envelope of the decimated rails; new sample n of a pass sits at HH4 + n
+        const float4 vi = lds_ld4f(dI + G::HH4 + 4 * lane);
+        const float4 vq = lds_ld4f(dQ + G::HH4 + 4 * lane);
+        au[0] = cmag<0>(vi.x, vq.x); au[1] = cmag<0>(vi.y, vq.y);
+        au[2] = cmag<0>(vi.z, vq.z); au[3] = cmag<0>(vi.w, vq.w);
+    } else if constexpr (NH > 0) {
+        float q2[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+        hilbert_quad<ARITH, ND, M, NH>(dQ, lane, hreg, q2);
+        const float *di = dI + G::FH + fa.delay_idx + 4 * lane;   // unit-impulse delay FIR
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float i2 = di[r] + 0.0f;                        // 0.0f + 1.0f*x of the dense loop
+            au[r] = fa.upper ? (i2 - q2[r]) : (i2 + q2[r]);       // arm_sub_f32 / arm_add_f32
+        }
+    } else {
+        const float4 v = lds_ld4f(dI + 4 * lane);
+        au[0] = v.x; au[1] = v.y; au[2] = v.z; au[3] = v.w;
+    }
+    // AGC: arm_abs + arm_max per DSP block (group lanes), gain law, arm_scale
+    if (p.agc) {
+        float m = fmaxf(fmaxf(fabsf(au[0]), fabsf(au[1])), fmaxf(fabsf(au[2]), fabsf(au[3])));
+        float g = gain, mine = gain;
+        if constexpr (GROUP > 0) {
+#pragma unroll
+            for (int off = 1; off < GROUP; off <<= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+            const int myblk = lane / GROUP;
+            // the divisions target/env of the blocks of this pass are independent of the gain
+            // recurrence: issue them together, then run the (cheap) recurrence
+            float dsr[64 / GROUP];
+            // every lane divides for its own block's envelope (one division sequence for the whole
+            // wavefront instead of one per block), then the per-block results are broadcast
+            const float mine_d = agc_desired(p.agcp, m);
+#pragma unroll
+            for (int b = 0; b < 64 / GROUP; ++b)
+                dsr[b] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine_d), b * GROUP));
+#pragma unroll
+            for (int b = 0; b < 64 / GROUP; ++b) {
+                const float gn = agc_step(p.agcp, g, dsr[b]);
+                g = b < nvb ? gn : g;                             // blocks past the end of the call leave the gain alone
+                mine = (b == myblk) ? g : mine;
+            }
+        } else {
+            const int myblk = lane / group;
+            if ((group & (group - 1)) == 0) {                     // power of two: butterfly
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1)
+                    if (off < group) m = fmaxf(m, __shfl_xor(m, off, 64));
+            } else {                                              // e.g. 6 lanes: the firmware's 96-frame blocks by 4 (dsp_if.h:69-73)
+                float mm = 0.0f;
+                for (int j = 0; j < group; ++j) mm = fmaxf(mm, __shfl(m, (myblk * group + j) & 63, 64));
+                m = mm;
+            }
+            const int nblk = min(64 / group, nvb);
+            for (int b = 0; b < nblk; ++b) {
+                const float env = __shfl(m, b * group, 64);
+                g = agc_update<0>(p.agcp, g, env);
+                if (b == myblk) mine = g;
+            }
+        }
+        gain = g;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) au[r] = au[r] * mine;
+    }
+    const bool live = lane < nvb * (GROUP ? GROUP : group);       // this lane's four samples exist
+    {   // ARM_MATH_NANINF: x * 0 is NaN iff x is not finite
+        const float z = __builtin_fmaf(au[3], 0.0f, __builtin_fmaf(au[2], 0.0f, __builtin_fmaf(au[1], 0.0f, au[0] * 0.0f)));
+        nonfinite = nonfinite || (live && z != z);
+    }
+    const size_t o = out_index + 4 * lane;
+    if (live) {
+        if constexpr (sizeof(TOut) == 4) {
+            *reinterpret_cast<float4 *>(reinterpret_cast<float *>(dst) + o) = make_float4(au[0], au[1], au[2], au[3]);
+        } else {
+            short4 s4;
+            s4.x = float_to_q15(au[0]); s4.y = float_to_q15(au[1]);
+            s4.z = float_to_q15(au[2]); s4.w = float_to_q15(au[3]);
+            *reinterpret_cast<short4 *>(reinterpret_cast<int16_t *>(dst) + o) = s4;
+        }
+    }
+}
+
+template <int ARITH, int NCO, int ND, int M, int NH, typename TIn, typename TOut, int AM = 0>
+__global__ __launch_bounds__(64, 2) void k_ssb_fused(RxParams p, FusedArgs fa, const TIn *__restrict__ src,
+                                                     TOut *__restrict__ dst)
+{
+    using G = Geo<ND, M, NH>;
+    using R = BRaw<TIn>;
+    static_assert(ND == 0 ? M == 1 : (M == 2 || M == 4 || M == 8), "fused kernel: no decimator, or decimate by 2, 4 or 8");
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x;
+    // Passes of VARIABLE length (round 3): a full pass produces pq = fa.pass_out audio samples -- the largest whole number of
+    // DSP blocks in 256 (256 itself when block / M divides 256; 240 = 10 blocks of the firmware's 96-frame geometry by 4,
+    // dsp_if.h:69-73) -- and the last pass of a call whatever is left (a call is a whole number of DSP blocks, not of
+    // passes).  The arithmetic always covers the whole 256-output tile: input beyond the call reads as zeros (buffer range
+    // check), outputs beyond the pass are not stored and do not move the AGC, and the history copies take the samples behind
+    // the last one that exists.  Per output the operation order is the reference's in every case.
+    const uint32_t pq = fa.pass_out, tq = pq * M;
+    float *tab = lds + G::oTab;
+    float *S = lds + G::oS;
+    float *D = lds + G::oD;
+    float *dI = D, *dQ = D + G::DLEN;
+    constexpr int NLD = G::T / 128;                      // raw loads per lane per pass
+    bool nonfinite = false;                              // any audio sample of this workgroup NaN / Inf
+    // One channel per workgroup, c = blockIdx.x -- or, as the rerun pass of SELENITE_ARITH_AUTO (p.chan_flags: one word per
+    // channel, raised by the split16 kernel of the same call for the channels whose result fell under the parity guard), the
+    // flagged channels of the 16-channel windows blockIdx.x, blockIdx.x + gridDim.x, ...: which channels, and how many,
+    // is only known on the device.
+    uint32_t win = blockIdx.x;                           // current window
+    uint64_t todo = 0;                                   // flagged channels of the window still to do (bit = channel - 16 win)
+  for (;;) {
+    uint32_t c = blockIdx.x;
+    if (p.chan_flags) {
+        const uint32_t nwin = (p.channels + 15u) / 16u;
+        while (todo == 0) {                              // wave-uniform
+            if (win >= nwin) break;
+            const uint32_t ci = 16u * win + (uint32_t)(lane & 15);
+            const uint32_t f = (lane < 16 && ci < p.channels) ? p.chan_flags[ci] : 0u;
+            todo = __builtin_amdgcn_ballot_w64(f != 0u);
+            if (todo == 0) win += gridDim.x;
+        }
+        if (todo == 0) break;
+        c = 16u * win + (uint32_t)__builtin_ctzll(todo);
+        todo &= todo - 1;
+        if (todo == 0) win += gridDim.x;
+    }
+
+    const size_t out_base = (size_t)c * p.out_stride;
+    const uint32_t npass = (p.nout + pq - 1) / pq;
+    const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(src + (size_t)c * p.in_stride * 2, p.block_size * (R::kBytes / 2));
+    const __amdgpu_buffer_rsrc_t rs_lo = make_rsrc(p.lo, NCO == 2 ? p.block_size * 8u : 0u);
+    typename R::type raw[NLD];
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) raw[i] = R::load(rs_in, lane * R::kBytes + i * 64 * R::kBytes, 0);
+
+    // ---- prologue: tables and streaming state into LDS / registers ----
+    if constexpr (NCO == 1 || NCO == 4)
+        for (int i = lane; i < 513; i += kWave) tab[i] = p.sintab[i];
+    float creg[G::NCR > 0 ? G::NCR : 1];
+    if constexpr (ND > 0) {
+#pragma unroll
+        for (int v = 0; v < G::NCR; ++v) creg[v] = fa.cq[64 * v + lane];
+        // history element (phase pp, index m) holds sample s = (m*M + pp) - F of the CMSIS state
+        // (oldest first); slots before the state (s < 0) only ever meet zero-padded taps
+        batched_fill<2 * M * G::HQ4>(lane, p.dec_state + (size_t)c * 2 * (ND - 1),
+            [&](int i) {
+                const int rail = i / (M * G::HQ4), sidx = i % (M * G::HQ4) - G::F;
+                return sidx >= 0 ? rail * (ND - 1) + sidx : -1;
+            },
+            [&](int i, float v) {
+                const int rail = i / (M * G::HQ4), rem = i % (M * G::HQ4);
+                S[(rem % M) * G::PSF + G::elem(rem / M) + rail] = v;
+            });
+    }
+    if constexpr (NH > 0) {
+        batched_fill<2 * G::HH4>(lane, p.fir_state + (size_t)c * 2 * G::HH,
+            [&](int i) {
+                const int rail = i / G::HH4, sidx = i % G::HH4 - G::FH;
+                return sidx >= 0 ? rail * G::HH + sidx : -1;
+            },
+            [&](int i, float v) { D[(i / G::HH4) * G::DLEN + i % G::HH4] = v; });
+    }
+    float hreg[(NH + 63) / 64 ? (NH + 63) / 64 : 1];
+#pragma unroll
+    for (int v = 0; v < (NH + 63) / 64; ++v) hreg[v] = (64 * v + lane < NH) ? p.hilb_c[64 * v + lane] : 0.0f;
+    const uint32_t ph0 = NCO ? p.phase[c] : 0u;
+    const uint32_t step = NCO ? p.step[c] : 0u;
+    float gain = p.agc ? p.gain[c] : 1.0f;
+    const int group = (int)fa.group;
+    wave_lds_sync();
+    // NCO == 4 (round 3; as in k_ssb_split16): the channel's own step is a multiple of 2^24, so its LO repeats every 256 samples
+    // whatever its phase, and a pass (256 M inputs: the host selects this flavour only with 256-output passes) is a whole number
+    // of periods: load i of any pass multiplies by LO[(128 i + 2 lane, + 1) mod 256] -- two register quads, computed once per
+    // channel and call with the arithmetic of the per-sample flavour (same phases modulo 2^32: same bits)
+    lo_v2f lo_per[4];
+    if constexpr (NCO == 4) {
+        const uint32_t pe = ph0 + 2u * lane * step;
+        nco_lo_pair(tab, pe, pe + step, lo_per[0], lo_per[1]);
+        nco_lo_pair(tab, pe + 128u * step, pe + 129u * step, lo_per[2], lo_per[3]);
+    }
+
+    for (uint32_t pass = 0; pass < npass; ++pass) {
+        const uint32_t n0 = pass * tq;
+        const uint32_t cur = (pass + 1 == npass) ? p.nout - pass * pq : pq;      // audio samples of this pass (whole DSP blocks)
+        // ---- 1. NCO mix of the prefetched samples, scatter into the LDS image ----
+        u4v lo4[NLD];
+        if constexpr (NCO == 2) {                                     // shared LO table (L2 resident):
+#pragma unroll
+            for (int i = 0; i < NLD; ++i)                             // all loads of the pass in flight at once
+                lo4[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_lo, lane * 16 + i * 1024, (int)(n0 * 8u), 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const uint32_t n = 128u * i + 2u * lane;                  // even sample index in the pass
+            float2 a, b;
+            {
+                v2f va, vb;
+                R::unpack(raw[i], va, vb);
+                a = make_float2(va.x, va.y); b = make_float2(vb.x, vb.y);
+            }
+            if constexpr (NCO == 2) {
+                const u4v l2 = lo4[i];
+                a = cmul<0>(a, make_float2(__uint_as_float(l2.x), __uint_as_float(l2.y)));
+                b = cmul<0>(b, make_float2(__uint_as_float(l2.z), __uint_as_float(l2.w)));
+            } else if constexpr (NCO == 1) {
+                lo_v2f la, lb;                                            // arm_sin/cos_f32 restated for the vector ALU: same bits (rx_device.h)
+                const uint32_t pe = ph0 + (n0 + n) * step;
+                nco_lo_pair(tab, pe, pe + step, la, lb);
+                a = cmul<0>(a, make_float2(la.x, la.y));
+                b = cmul<0>(b, make_float2(lb.x, lb.y));
+            } else if constexpr (NCO == 4) {
+                const lo_v2f la = lo_per[2 * (i & 1)], lb = lo_per[2 * (i & 1) + 1];
+                a = cmul<0>(a, make_float2(la.x, la.y));
+                b = cmul<0>(b, make_float2(lb.x, lb.y));
+            }
+            if constexpr (ND > 0) {
+                const int m = G::HQ4 + (int)(n / M), pp = (int)(n % M);   // n even: pp in {0,2}
+                float *d = S + pp * G::PSF + G::elem(m);
+                *reinterpret_cast<float2 *>(d) = a;
+                *reinterpret_cast<float2 *>(d + G::PSF) = b;
+            } else {
+                *reinterpret_cast<float2 *>(dI + G::HH4 + n) = make_float2(a.x, b.x);
+                *reinterpret_cast<float2 *>(dQ + G::HH4 + n) = make_float2(a.y, b.y);
+            }
+        }
+        wave_lds_sync();
+        // ---- prefetch the next pass while this one computes (beyond the call: zeros, no traffic) ----
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) raw[i] = R::load(rs_in, lane * R::kBytes + i * 64 * R::kBytes, (int)((n0 + tq) * (R::kBytes / 2)));
+        // ---- 2. arm_fir_decimate_f32 on both rails, 4 adjacent outputs per lane ----
+        if constexpr (ND > 0) {
+            v2f acc[4] = { { 0.0f, 0.0f }, { 0.0f, 0.0f }, { 0.0f, 0.0f }, { 0.0f, 0.0f } };
+            decim_quad<ARITH, ND, M, NH>(S, lane, creg, acc);
+            *reinterpret_cast<float4 *>(dI + G::HH4 + 4 * lane) = make_float4(acc[0].x, acc[1].x, acc[2].x, acc[3].x);
+            *reinterpret_cast<float4 *>(dQ + G::HH4 + 4 * lane) = make_float4(acc[0].y, acc[1].y, acc[2].y, acc[3].y);
+            wave_lds_sync();
+        }
+        // ---- 3-5. Hilbert pair + sideband, AGC, store ----
+        const int nvb = (int)(cur / (4u * (uint32_t)group));          // DSP blocks of this pass
+        if (group == 16)
+            demod_agc_store<ARITH, 16, ND, M, NH, TOut, AM>(p, fa, dI, dQ, lane, group, hreg, gain, dst, out_base + (size_t)pass * pq, nonfinite, nvb);
+        else if (group == 64)
+            demod_agc_store<ARITH, 64, ND, M, NH, TOut, AM>(p, fa, dI, dQ, lane, group, hreg, gain, dst, out_base + (size_t)pass * pq, nonfinite, nvb);
+        else
+            demod_agc_store<ARITH, 0, ND, M, NH, TOut, AM>(p, fa, dI, dQ, lane, group, hreg, gain, dst, out_base + (size_t)pass * pq, nonfinite, nvb);
+        wave_lds_sync();
+        // ---- 6. history copy-back (arm_fir_decimate_f32.c:396-426, arm_fir_f32.c:947-978) ----
+        if constexpr (ND > 0) {
+            constexpr int NG = M * (G::HQ4 / 4);                      // 48-byte groups to move
+            constexpr int NK = (NG + 63) / 64;
+            float4 t0[NK], t1[NK];
+#pragma unroll
+            for (int k = 0; k < NK; ++k) {
+                const int i = k * 64 + lane;
+                if (i < NG) {                                         // the HQ4 phase-samples behind the last one that exists
+                    const float *sp = S + (i / (G::HQ4 / 4)) * G::PSF + 12 * (cur / 4 + i % (G::HQ4 / 4));
+                    t0[k] = lds_ld4f(sp);
+                    t1[k] = lds_ld4f(sp + 4);
+                }
+            }
+            wave_lds_sync();
+#pragma unroll
+            for (int k = 0; k < NK; ++k) {
+                const int i = k * 64 + lane;
+                if (i < NG) {
+                    float *dp = S + (i / (G::HQ4 / 4)) * G::PSF + 12 * (i % (G::HQ4 / 4));
+                    *reinterpret_cast<float4 *>(dp) = t0[k];
+                    *reinterpret_cast<float4 *>(dp + 4) = t1[k];
+                }
+            }
+        }
+        if constexpr (NH > 0) {
+            constexpr int NV = 2 * (G::HH4 / 4);
+            static_assert(NV <= 64, "Hilbert history move assumes <= 64 float4");
+            float4 tmp;
+            const int rail = lane / (G::HH4 / 4), v = lane % (G::HH4 / 4);
+            if (lane < NV) tmp = lds_ld4f(D + rail * G::DLEN + cur + 4 * v);
+            wave_lds_sync();
+            if (lane < NV) *reinterpret_cast<float4 *>(D + rail * G::DLEN + 4 * v) = tmp;
+        }
+        wave_lds_sync();
+    }
+
+    // ---- epilogue: streaming state back to HBM ----
+    if constexpr (ND > 0) {
+        for (int i = lane; i < 2 * M * G::HQ4; i += kWave) {
+            const int rail = i / (M * G::HQ4), rem = i % (M * G::HQ4);
+            const int s = rem - G::F, pp = rem % M, m = rem / M;
+            if (s >= 0) p.dec_state[((size_t)c * 2 + rail) * (ND - 1) + s] = S[pp * G::PSF + G::elem(m) + rail];
+        }
+    }
+    if constexpr (NH > 0) {
+        if constexpr (AM == 0) {                                      // AM never ran the Hilbert pair: its state stays
+            for (int i = lane; i < 2 * G::HH4; i += kWave) {
+                const int rail = i / G::HH4, m = i % G::HH4, s = m - G::FH;
+                if (s >= 0) p.fir_state[((size_t)c * 2 + rail) * G::HH + s] = D[rail * G::DLEN + m];
+            }
+        }
+    }
+    if (lane == 0) {
+        if constexpr (NCO != 0) p.phase[c] = ph0 + p.block_size * step;
+        if (p.agc) p.gain[c] = gain;
+    }
+    if (!p.chan_flags) break;
+    wave_lds_sync();                                     // the state reads above before the next channel's prologue fills
+  }
+    if (nonfinite) p.flags[kFlagNanInf] = 1u;            // ARM_MATH_NANINF, read by selenite_rx_sync
+}
+
+
+template <int ARITH, int ND, int M, int NH, typename TIn, typename TOut>
+static hipError_t launch_one(const RxParams &p, const FusedArgs &fa, const void *src, void *dst, hipStream_t st)
+{
+    using G = Geo<ND, M, NH>;
+    constexpr size_t lds = (size_t)G::total * sizeof(float);
+    // per-channel LO with a period of 256 samples (every step a multiple of 2^24) and 256-output passes: one period per channel in registers
+    const bool per4 = p.nco == 1 && p.lo_period == 256 && fa.pass_out == 256;
+    auto k = fa.am ? (p.nco == 2 ? k_ssb_fused<ARITH, 2, ND, M, NH, TIn, TOut, 1>
+                         : (per4 ? k_ssb_fused<ARITH, 4, ND, M, NH, TIn, TOut, 1>
+                         : (p.nco == 1 ? k_ssb_fused<ARITH, 1, ND, M, NH, TIn, TOut, 1> : k_ssb_fused<ARITH, 0, ND, M, NH, TIn, TOut, 1>)))
+                   : (p.nco == 2 ? k_ssb_fused<ARITH, 2, ND, M, NH, TIn, TOut, 0>
+                         : (per4 ? k_ssb_fused<ARITH, 4, ND, M, NH, TIn, TOut, 0>
+                         : (p.nco == 1 ? k_ssb_fused<ARITH, 1, ND, M, NH, TIn, TOut, 0> : k_ssb_fused<ARITH, 0, ND, M, NH, TIn, TOut, 0>)));
+    if constexpr (lds > 48 * 1024) {                      // per device and per kernel: set on every launch (cheap)
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    // (rerun pass of SELENITE_ARITH_AUTO: which channels are flagged is only known on the device -- a resident-sized grid strides
+    // over the 16-channel windows of the flag array)
+    const uint32_t nwin = (p.channels + 15u) / 16u;
+    const uint32_t grid = p.chan_flags ? (nwin < 2048u ? nwin : 2048u) : p.channels;
+    hipLaunchKernelGGL(k, dim3(grid), dim3(64), lds, st, p, fa, static_cast<const TIn *>(src),
+                       static_cast<TOut *>(dst));
+    return hipGetLastError();
+}
+
+// the instantiated shapes: BASELINE.json cfg1 / cfg2 / cfg3 (+ cfg5 = cfg2 chain) and their neighbours in both
+// tap counts -- decimator 128 / 256 taps by 4, Hilbert pair 31 / 63 / 127 taps, with or without the decimator
+#define SRX_SHAPES(X) X(256, 4, 63, 1) X(0, 1, 63, 2) X(0, 1, 127, 3) X(128, 4, 63, 4) X(256, 4, 127, 5) X(128, 4, 127, 6) X(256, 4, 31, 7) X(0, 1, 31, 8) \
+                      X(256, 2, 63, 9) X(256, 8, 63, 10) X(64, 4, 63, 11) X(128, 2, 63, 12) X(128, 8, 63, 13) X(64, 2, 63, 14) X(64, 8, 63, 15) \
+                      X(128, 4, 31, 16) X(256, 2, 127, 17) X(128, 2, 127, 18) X(256, 2, 31, 19) X(128, 2, 31, 20)
+
+// the CMSIS-arithmetic instantiations live in rx_fused_exact.hip
+hipError_t launch_exact(int nd, int m, int nh, bool q15, const RxParams &p, const FusedArgs &fa, const void *src, void *dst,
+                        hipStream_t st);
+
+}  // namespace srx

@@ -1,0 +1,1363 @@
+// rx_split16_kernels.h -- the SELENITE_ARITH_SPLIT16 kernels (k_ssb_split16, k_hilb_split16) and their launchers, shared by
+// rx_split16.hip (f32 slots, the no-decimator kernels, dispatch) and rx_split16_q15.hip (int16 slots).
+#pragma once
+#include "rx_fused_common.h"
+
+#include <cstdlib>
+#include <type_traits>
+
+#pragma clang fp contract(off)
+
+// tuning knobs of k_ssb_split16 (tools/build_variants.sh builds A/B libraries from them)
+#ifndef SRX_SPLIT16_VPM
+#define SRX_SPLIT16_VPM 0        // vector instructions scheduled under each MFMA of the matrix stage (0: compiler's choice; 3 measured 2 % slower)
+#endif
+#ifndef SRX_MIXSPLIT
+#define SRX_MIXSPLIT 0           // f16 hi/lo split by v_fma_mixlo/hi_f16 (1; 8 instead of 12 instructions per sample pair, measured 1 % slower) or convert / subtract / convert (0)
+#endif
+#ifndef SRX_ACC4
+#define SRX_ACC4 0               // separate accumulators for the big and the small terms (1) or one per rail (0)
+#endif
+#ifndef SRX_IN_AUX
+#define SRX_IN_AUX 2             // cache policy of the streamed input loads (2 = nt)
+#endif
+#ifndef SRX_LO_AUX
+#define SRX_LO_AUX 0             // cache policy of the shared-LO loads
+#endif
+#ifndef SRX_SPLIT16_W2
+#define SRX_SPLIT16_W2 0         // 1: also build k_ssb_split16w2 (two waves per channel); measured equal to the one-wave kernel -- both sit at the package power cap
+#endif
+#ifndef SRX_HS_SGPR
+#define SRX_HS_SGPR 0            // Hilbert taps resident in SGPRs (1; 32 fewer v_readlane per pass, 29 SGPR spills, measured 5 % slower) or v_readlane per use (0)
+#endif
+
+namespace srx {
+
+__device__ __forceinline__ float amax2(v2f x, float m) { return fmaxf(fmaxf(fabsf(x.x), fabsf(x.y)), m); }
+
+// memory-order point for the single-wave workgroups of this file: LDS operations of a wave execute in
+// issue order, so all that is needed is that the compiler keeps the program order of the memory
+// operations on either side.  Unlike wave_lds_sync() this is NOT a scheduling barrier for ALU and
+// matrix instructions: the phases on either side may overlap.
+__device__ __forceinline__ void lds_order()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// AGC of one pass (256 audio samples, 4 per lane): arm_abs + arm_max per DSP block of GROUP lanes,
+// gain law, arm_scale with the updated gain.  GROUP = 16 / 64: lane reductions by DPP, the block
+// envelopes broadcast by v_readlane; GROUP = 0: any power-of-two `group` (run time).
+// Parity guard: `gd.thr` = guard ratio x the largest |component| the pass's matrix product saw; every DSP block of the pass
+// whose envelope (max |audio| before the gain) is below it is counted in gd.n (gd.first: the first lane of every DSP block).
+struct GuardPass {
+    float thr;
+    uint64_t first;
+    uint32_t n;
+};
+template <int GROUP>
+__device__ __forceinline__ void agc_pass(const AgcParams &ap, uint32_t agc_on, int lane, int group, float (&au)[4], float &gain,
+                                         int nvb, GuardPass &gd)   // nvb: DSP blocks of the pass that exist (a call's last pass may be partial)
+{
+    float m = fmaxf(fmaxf(fabsf(au[0]), fabsf(au[1])), fmaxf(fabsf(au[2]), fabsf(au[3])));
+    float g = gain, mine = gain;
+    auto guard = [&](float env) {                    // env: the block envelope, in (at least) the first lane of every block
+        const int lanes = nvb * (GROUP ? GROUP : group);
+        const uint64_t exist = lanes >= 64 ? ~0ull : ((1ull << lanes) - 1ull);
+        gd.n += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(env < gd.thr) & gd.first & exist);
+    };
+    if constexpr (GROUP == 16) {
+        m = row16_fmax(m);
+        guard(m);
+        const float d = agc_desired(ap, m);          // one division sequence serves the four blocks
+        float ds[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) ds[b] = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(d), 16 * b));
+        const int myblk = lane >> 4;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const float gn = agc_step(ap, g, ds[b]);
+            g = b < nvb ? gn : g;                    // blocks past the end of the call leave the gain alone
+            mine = (b == myblk) ? g : mine;
+        }
+    } else if constexpr (GROUP == 32) {
+        // two DSP blocks of two 16-lane rows each (decimation by 2): row maxima by DPP, the two rows of a block joined on
+        // the scalar unit (|.| >= 0: the bit patterns order like the values), one division sequence for both blocks
+        m = row16_fmax(m);
+        const uint32_t r0 = __builtin_amdgcn_readlane(__float_as_uint(m), 0), r1 = __builtin_amdgcn_readlane(__float_as_uint(m), 16);
+        const uint32_t r2 = __builtin_amdgcn_readlane(__float_as_uint(m), 32), r3 = __builtin_amdgcn_readlane(__float_as_uint(m), 48);
+        const float e0 = __uint_as_float(r0 > r1 ? r0 : r1), e1 = __uint_as_float(r2 > r3 ? r2 : r3);
+        guard(lane < 32 ? e0 : e1);
+        const float d = agc_desired(ap, lane < 32 ? e0 : e1);
+        const float ds[2] = { __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(d), 0)),
+                              __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(d), 32)) };
+        const int myblk = lane >> 5;
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const float gn = agc_step(ap, g, ds[b]);
+            g = b < nvb ? gn : g;
+            mine = (b == myblk) ? g : mine;
+        }
+    } else if constexpr (GROUP == 64) {
+        m = __uint_as_float(wave_umax_bits(m));
+        guard(m);
+        g = agc_step(ap, g, agc_desired(ap, m));
+        mine = g;
+    } else {
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1)
+            if (off < group) m = fmaxf(m, __shfl_xor(m, off, 64));
+        guard(m);
+        const int nblk = min(64 / group, nvb), myblk = lane / group;
+        for (int b = 0; b < nblk; ++b) {
+            const float env = __shfl(m, b * group, 64);
+            g = agc_update<0>(ap, g, env);
+            if (b == myblk) mine = g;
+        }
+    }
+    gain = agc_on ? g : gain;
+    mine = agc_on ? mine : 1.0f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) au[r] = au[r] * mine;
+}
+
+// ------------------------------------------------------------------------------------------
+// k_ssb_split16
+//
+// One wavefront per channel, passes of 1024 complex inputs -> 256 audio samples, software-pipelined:
+//
+//   mix(p):    buffer-loaded I/Q (prefetched a pass ahead) x LO (shared table, prefetched) by packed
+//              complex multiplies; wave maximum -> block exponent; x 2^s; f16 hi/lo split straight
+//              into the four LDS images (I/Q x hi/lo, 64-sample rows padded to 80 halfs: the A-fragment
+//              ds_read_b128 of lane l sits at 160 (l&15) + 16 (l>>4) + imm, conflict free); the last
+//              ND-1 mixed samples also as f32 (history copy).
+//   mfma(p):   KS k-steps x 6 MFMAs (big: hi*hi; small: hi*lo + lo*hi; both rails), B fragments resident
+//              in 8*KS VGPRs, A fragments read one k-step ahead.
+//   demod(p-1) runs in the SAME basic block as mfma(p): Hilbert FIR on Q (structural zeros skipped), unit
+//              delay on I, sideband combine, AGC (DPP / readlane), audio store.  Nothing but true data
+//              dependencies orders the two, so the VALU work of one pass fills the issue slots under
+//              the matrix work of the next.
+//   The pass loop body is branch-free apart from the (rare) history re-split: no exec-masked copy
+//   loops, no conditional prefetch (buffer range check instead), state written after the loop.
+// ------------------------------------------------------------------------------------------
+template <int NCO, int ND, int M, int NH, typename TIn, typename TOut, int AM, int GROUP, int ENV = 0>
+__global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa, const TIn *__restrict__ src,
+                                                       TOut *__restrict__ dst)
+{
+    using G = Geo<ND, M, NH>;
+    using GS = GeoS<NCO, ND, M, NH>;
+    using R = BRaw<TIn>;
+    using W = BOut<TOut>;
+    static_assert(ND > 0 && (M == 4 || M == 2) && NH > 0 && G::T % 128 == 0 && GS::HS % 128 == 0, "split16 decimator: /4 or /2, + Hilbert");
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x;
+    uint32_t c = blockIdx.x;                                      // persistent: this workgroup runs channels c, c + gridDim.x, ...
+#ifdef SRX_STAMP       // diagnostics build (make STAMP=1): s_memtime stamps of one wave in 1024 (tools/stamp_split16.py)
+    unsigned long long *stamp_p = (fa.dbg && (c & 1023u) == 511u) ? fa.dbg + (c >> 10) * 64 : nullptr;
+    int stamp_i = 0;
+#define STAMP(drain)                                                                   \
+    do {                                                                               \
+        if (drain) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    \
+        if (stamp_p && stamp_i < 64) stamp_p[stamp_i] = __builtin_amdgcn_s_memtime();  \
+        ++stamp_i;                                                                     \
+    } while (0)
+#else
+#define STAMP(drain) do { } while (0)
+#endif
+    STAMP(0);
+    float *tab = lds + GS::oTab;
+    _Float16 *X = reinterpret_cast<_Float16 *>(lds + GS::oX);     // [rail][hi/lo][IMG]
+    v2f *Hf = reinterpret_cast<v2f *>(lds + GS::oHf);             // f32 (I, Q) history, HS samples
+    float *D = lds + GS::oD;
+    float *dI = D, *dQ = D + G::DLEN;
+    constexpr int NLD = G::T / 128;                               // loads per lane per pass
+    constexpr int NTL = GS::HS / 128;                             // ... of which the last NTL hold the next history
+    static_assert(GS::HS % 128 == 0 && NTL >= 1 && NTL <= NLD, "history is a whole number of wave loads");
+
+    // passes of the call; the last one may be partial (a call is a whole number of DSP blocks, not of passes): its
+    // missing input reads as zeros and its surplus audio is dropped by the buffer range checks, the streaming state
+    // and the AGC are taken from the part that exists (the host side sends such calls here only when that part holds
+    // a whole decimator history: tail_in >= HS)
+    const uint32_t npass = (p.nout + G::P - 1) / G::P;
+    const uint32_t tail_out = p.nout - (npass - 1) * G::P;       // audio samples of the last pass: P when the call is whole passes
+    auto in_rsrc = [&](uint32_t ch) {                             // a channel past the last one: empty range, loads return zeros
+        return make_rsrc(src + (size_t)ch * p.in_stride * 2, ch < p.channels ? p.block_size * (R::kBytes / 2) : 0u);
+    };
+    __amdgpu_buffer_rsrc_t rs_in = in_rsrc(c), rs_in_next = in_rsrc(c + gridDim.x);
+    __amdgpu_buffer_rsrc_t rs_out = make_rsrc(dst + (size_t)c * p.out_stride, p.nout * (W::kBytes / 4));
+    // global gain, phase 1: the kernel runs with its own AGC off and leaves max |audio| of every DSP block of every channel
+    // behind, so the envelope reduction does not have to read the audio again (GROUP == 16 launches with whole passes only)
+    // (ENV: its own instantiation -- the extra descriptor and branch cost the plain kernel 1.3 % when they were always compiled in)
+    const uint32_t env_nblk = ENV ? p.block_size / p.block : 0u;
+    auto env_rsrc = [&](uint32_t ch) { return make_rsrc(p.env_part + (size_t)ch * env_nblk, env_nblk * 4u); };
+    __amdgpu_buffer_rsrc_t rs_env = env_rsrc(ENV ? c : 0u);
+    const __amdgpu_buffer_rsrc_t rs_lo = make_rsrc(p.lo, NCO == 2 ? p.block_size * 8u : 0u);
+    constexpr int kInPass = G::T * (R::kBytes / 2);               // input bytes of one pass
+
+    typename R::type raw[NLD];
+    // shared LO (NCO == 2): an L2-resident table, so only LOD wave loads are kept in flight: the first LOD of a
+    // pass are issued with the pass's input prefetch, the others by the mix stage as it frees the slots
+    constexpr int LOD = 3;
+    u4v lo4[LOD];
+    auto lo_load = [&](int slot, int i, int sl) {
+        lo4[slot] = __builtin_amdgcn_raw_buffer_load_b128(rs_lo, lane * 16 + i * 1024, sl, SRX_LO_AUX);
+    };
+    auto lo_base = [&](uint32_t pass) { return pass < npass ? (int)pass * G::T * 8 : 0; };   // pass == npass: the next channel's pass 0
+    // periodic shared LO (NCO == 3: the table repeats every 256 samples and a pass is a whole number of periods): load
+    // i of any pass multiplies by LO[(128 i + 2 lane, + 1) mod 256] -- two register quads for the whole kernel
+    // (NCO == 4: the same for a PER-CHANNEL step that is a multiple of 2^24 -- every channel on the fs / 256 grid with its own LO:
+    // the two quads are computed once per channel, in install_state, with the arithmetic of the per-sample NCO (nco_lo_pair))
+    u4v lo_per[2];
+    static_assert((NCO != 3 && NCO != 4) || G::T % 256 == 0, "a pass is a whole number of LO periods");
+    if constexpr (NCO == 3) {
+        lo_per[0] = *reinterpret_cast<const u4v *>(p.lo + 2 * lane);
+        lo_per[1] = *reinterpret_cast<const u4v *>(p.lo + 128 + 2 * lane);
+    }
+    auto prefetch = [&](uint32_t pass) {                          // pass == npass: pass 0 of this workgroup's next channel
+        const int so = pass < npass ? (int)pass * kInPass : 0;
+        const __amdgpu_buffer_rsrc_t rs = pass < npass ? rs_in : rs_in_next;
+#pragma unroll
+#ifdef SRX_X_NOINPUT
+        for (int i = 0; i < NLD; ++i) { raw[i] = typename R::type{}; asm volatile("" : "+v"(raw[i])); }
+        (void)rs; (void)so;
+#else
+        for (int i = 0; i < NLD; ++i) raw[i] = R::load(rs, lane * R::kBytes + i * 64 * R::kBytes, so);      // (BRaw: aux = SRX_IN_AUX)
+#endif
+#ifndef SRX_X_NOLO
+        if constexpr (NCO == 2) {
+#pragma unroll
+            for (int i = 0; i < LOD; ++i) lo_load(i, i, lo_base(pass));
+        }
+#endif
+    };
+    prefetch(0);
+
+    // Toeplitz B fragments (8 halfs per lane): [kk][hi/lo]
+    h8 Bh[GS::KS], Bl[GS::KS];
+    {
+        const h8 *bt = static_cast<const h8 *>(fa.btab16);
+#pragma unroll
+        for (int kk = 0; kk < GS::KS; ++kk) {
+            Bh[kk] = bt[(2 * kk + 0) * 64 + lane];
+            Bl[kk] = bt[(2 * kk + 1) * 64 + lane];
+        }
+    }
+    // Hilbert taps: wave-uniform values held in scalar registers for the whole kernel (only the structurally
+    // non-zero ones are ever referenced: (NH + 1) / 2 SGPRs), so a tap costs no v_readlane per pass
+    float hreg[(NH + 63) / 64];
+#pragma unroll
+    for (int v = 0; v < (NH + 63) / 64; ++v) hreg[v] = (64 * v + lane < NH) ? p.hilb_c[64 * v + lane] : 0.0f;
+#if SRX_HS_SGPR
+    float hs[NH];
+#pragma unroll
+    for (int k = 0; k < NH; ++k) hs[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(hreg[k >> 6]), k & 63));
+    auto htap = [&](int k) { return hs[k]; };
+#else
+    auto htap = [&](int k) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(hreg[k >> 6]), k & 63)); };
+#endif
+    if constexpr (NCO == 1 || NCO == 4)
+        for (int i = lane; i < 513; i += kWave) tab[i] = p.sintab[i];
+
+    // ---- streaming state of a channel: loaded into registers (for the next channel of this workgroup while
+    // the current one is still in its last pass), installed into LDS when the channel starts.  Flat history
+    // sample f in [0, HS) is CMSIS state sample s = f - F (older slots meet zero taps only); all loads are
+    // unconditional from a clamped index (one memory round trip for the lot).
+    constexpr int NHI = GS::HS / kWave, NFI = 2 * G::HH4 / kWave;
+    static_assert(GS::HS % kWave == 0 && (2 * G::HH4) % kWave == 0, "state fills are whole wave loads");
+    v2f st_hv[NHI];
+    float st_fv[NFI], st_gain;
+    uint32_t st_ph0, st_step;
+    auto load_state = [&](uint32_t ch) {
+        ch = ch < p.channels ? ch : p.channels - 1;               // past the last channel: harmless reload, never installed
+        const float *stI = p.dec_state + (size_t)ch * 2 * (ND - 1), *stQ = stI + (ND - 1);
+        const float *stF = p.fir_state + (size_t)ch * 2 * G::HH;
+#pragma unroll
+        for (int j = 0; j < NHI; ++j) {
+            const int s = j * kWave + lane - G::F, sc = s < 0 ? 0 : s;
+            const float xi = stI[sc], xq = stQ[sc];
+            st_hv[j] = s < 0 ? v2f{ 0.0f, 0.0f } : v2f{ xi, xq };
+        }
+#pragma unroll
+        for (int j = 0; j < NFI; ++j) {
+            const int i = j * kWave + lane;
+            const int rail = i / G::HH4, sidx = i % G::HH4 - G::FH;
+            const float x = stF[rail * G::HH + (sidx < 0 ? 0 : sidx)];
+            st_fv[j] = sidx < 0 ? 0.0f : x;
+        }
+        st_ph0 = NCO ? p.phase[ch] : 0u;
+        st_step = NCO ? p.step[ch] : 0u;
+        st_gain = p.gain[ch];
+    };
+    uint32_t b_hist = 0, ph0 = 0, step = 0;                       // b_hist: bit pattern of the largest |history component|
+    float gain = 1.0f;
+    int s_cur = 0x7fff;                                               // sample scale exponent of the images (none yet)
+    // parity guard (GuardPass): thresholds of the pass being mixed and of the pass before it (whose demodulator runs later)
+    float thr_cur = 0.0f, thr_prev = 0.0f;
+    GuardPass gd;
+    gd.thr = 0.0f; gd.n = 0u;
+    if constexpr (GROUP == 16) gd.first = 0x0001000100010001ull;
+    else if constexpr (GROUP == 32) gd.first = 0x0000000100000001ull;
+    else if constexpr (GROUP == 64) gd.first = 1ull;
+    else {
+        gd.first = 0ull;
+        for (int l = 0; l < 64; l += (int)fa.group) gd.first |= 1ull << l;
+    }
+    auto install_state = [&]() {
+        float mh = 0.0f;
+#pragma unroll
+        for (int j = 0; j < NHI; ++j) {
+            Hf[j * kWave + lane] = st_hv[j];
+            mh = amax2(st_hv[j], mh);
+        }
+#pragma unroll
+        for (int j = 0; j < NFI; ++j) {
+            const int i = j * kWave + lane;
+            D[(i / G::HH4) * G::DLEN + i % G::HH4] = st_fv[j];
+        }
+        b_hist = wave_umax_bits(mh);
+        ph0 = st_ph0; step = st_step; gain = st_gain;
+        s_cur = 0x7fff;
+        gd.n = 0u;
+        if constexpr (NCO == 4) {
+            // LO of samples 2 lane, 2 lane + 1 and 128 + 2 lane, 129 + 2 lane of every 256-sample period: the phases the
+            // per-sample NCO (NCO == 1) would form for them in any pass, n0 * step and 256 * step being multiples of 2^32
+            const uint32_t pe = ph0 + 2u * lane * step;
+            v2f la, lb;
+            nco_lo_pair(tab, pe, pe + step, la, lb);
+            lo_per[0] = u4v{ __float_as_uint(la.x), __float_as_uint(la.y), __float_as_uint(lb.x), __float_as_uint(lb.y) };
+            nco_lo_pair(tab, pe + 128u * step, pe + 129u * step, la, lb);
+            lo_per[1] = u4v{ __float_as_uint(la.x), __float_as_uint(la.y), __float_as_uint(lb.x), __float_as_uint(lb.y) };
+        }
+    };
+    load_state(c);
+    const int group = (int)fa.group;
+    const int abase = GS::RSTR * (lane & 15) + 8 * (lane >> 4);       // A-fragment lane base (halfs): row l&15 of the output tile
+
+    // two (I, Q) samples f (even), f + 1, times the block scale `pre` -> one word in each of the four images:
+    //   hi = f16(x * pre), lo = f16(x * pre - hi), one v_fma_mixlo/hi_f16 each (the product with the power of
+    // two and the difference are exact inside the fused operation, so this IS convert / subtract / convert,
+    // bit for bit: tools/mix_split_check.hip) -- 8 plain vector instructions per sample pair instead of 12
+    // (4 of them packed) for scale, convert, convert back, subtract, convert.
+    auto put_iq = [&](int f, v2f a, v2f b, float pre) {
+        uint32_t hI, hQ, lI, lQ;
+#if SRX_MIXSPLIT
+        asm("v_fma_mixlo_f16 %0, %2, %6, 0\n\t"
+            "v_fma_mixlo_f16 %1, %3, %6, 0\n\t"
+            "v_fma_mixhi_f16 %0, %4, %6, 0\n\t"
+            "v_fma_mixhi_f16 %1, %5, %6, 0"
+            : "=&v"(hI), "=&v"(hQ) : "v"(a.x), "v"(a.y), "v"(b.x), "v"(b.y), "s"(pre));
+        asm("v_fma_mixlo_f16 %0, %2, %6, -%7 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n\t"
+            "v_fma_mixlo_f16 %1, %3, %6, -%8 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n\t"
+            "v_fma_mixhi_f16 %0, %4, %6, -%7 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+            "v_fma_mixhi_f16 %1, %5, %6, -%8 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+            : "=&v"(lI), "=&v"(lQ) : "v"(a.x), "v"(a.y), "v"(b.x), "v"(b.y), "s"(pre), "v"(hI), "v"(hQ));
+#else
+        const v2f pre2 = { pre, pre };
+        const v2f sa = a * pre2, sb = b * pre2;
+        const h2 hhI = __builtin_convertvector(v2f{ sa.x, sb.x }, h2), hhQ = __builtin_convertvector(v2f{ sa.y, sb.y }, h2);
+        const v2f ra = sa - v2f{ (float)hhI.x, (float)hhQ.x }, rb = sb - v2f{ (float)hhI.y, (float)hhQ.y };
+        const h2 llI = __builtin_convertvector(v2f{ ra.x, rb.x }, h2), llQ = __builtin_convertvector(v2f{ ra.y, rb.y }, h2);
+        hI = __builtin_bit_cast(uint32_t, hhI); hQ = __builtin_bit_cast(uint32_t, hhQ);
+        lI = __builtin_bit_cast(uint32_t, llI); lQ = __builtin_bit_cast(uint32_t, llQ);
+#endif
+        const int ph = GS::phys(f);
+        *reinterpret_cast<uint32_t *>(X + 0 * GS::IMG + ph) = hI;
+        *reinterpret_cast<uint32_t *>(X + 1 * GS::IMG + ph) = lI;
+        *reinterpret_cast<uint32_t *>(X + 2 * GS::IMG + ph) = hQ;
+        *reinterpret_cast<uint32_t *>(X + 3 * GS::IMG + ph) = lQ;
+    };
+
+    // ---- mix(p): NCO mix, block exponent, f16 split into the images, f32 history copy ----
+    auto mix = [&](uint32_t pass, auto partial_c) {
+        constexpr bool PARTIAL = decltype(partial_c)::value;     // the call's last pass, with fewer than T input samples
+        const uint32_t n0 = pass * G::T;
+        const uint32_t ph_lane = ph0 + 2u * lane * step;
+        v2f m[2 * NLD];
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            v2f a, b;
+            R::unpack(raw[i], a, b);
+#ifdef SRX_X_NOLO
+            if constexpr (NCO == 2) { m[2 * i] = a; m[2 * i + 1] = b; } else
+#else
+            if constexpr (NCO == 2) {
+                const u4v l = lo4[i % LOD];
+                cmul_pk2(a, b, v2f{ __uint_as_float(l.x), __uint_as_float(l.y) }, v2f{ __uint_as_float(l.z), __uint_as_float(l.w) },
+                         m[2 * i], m[2 * i + 1]);
+                if (i + LOD < NLD) lo_load(i % LOD, i + LOD, lo_base(pass));
+            } else if constexpr (NCO == 3 || NCO == 4) {
+                const u4v l = lo_per[i & 1];
+                cmul_pk2(a, b, v2f{ __uint_as_float(l.x), __uint_as_float(l.y) }, v2f{ __uint_as_float(l.z), __uint_as_float(l.w) },
+                         m[2 * i], m[2 * i + 1]);
+            } else
+#endif
+            if constexpr (NCO == 1) {
+                // phase of sample n0 + 128 i + 2 lane: a per-channel lane term plus a wave-uniform term
+                const uint32_t pe = ph_lane + (n0 + 128u * i) * step;
+                v2f la, lb;
+                nco_lo_pair(tab, pe, pe + step, la, lb);
+                cmul_pk2(a, b, la, lb, m[2 * i], m[2 * i + 1]);
+            } else {
+                m[2 * i] = a;
+                m[2 * i + 1] = b;
+            }
+        }
+        float mt = 0.0f, mh = 0.0f;                                   // |.| maxima: tail (next history), head
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            float &mm = (i >= NLD - NTL) ? mt : mh;
+            mm = amax2(m[2 * i], mm);
+            mm = amax2(m[2 * i + 1], mm);
+        }
+        const uint32_t b_tail = wave_umax_bits(mt);
+        const uint32_t b_need = max(max(wave_umax_bits(mh), b_tail), b_hist);       // the largest |component| the pass's images hold
+        const uint32_t e_need = b_need >> 23;
+        thr_prev = thr_cur;
+        thr_cur = __uint_as_float(b_need) * p.guard_ratio;
+        // largest |component| * 2^s in [2^14, 2^15):  s = 14 - (E - 127); 2^s must itself be a normal float
+        int s_new = 141 - (int)e_need;
+        s_new = s_new > 127 ? 127 : (s_new < -126 ? -126 : s_new);
+        if (s_new != s_cur) {                                         // wave-uniform; always taken in the first pass
+            const float pre = __uint_as_float((uint32_t)(s_new + 127) << 23);
+#pragma unroll
+            for (int j = 0; j < GS::HS / 128; ++j) {
+                const int f = 2 * (j * kWave + lane);
+                const float4 hq = lds_ld4f(reinterpret_cast<const float *>(Hf + f));
+                put_iq(f, v2f{ hq.x, hq.y }, v2f{ hq.z, hq.w }, pre);
+            }
+            s_cur = s_new;
+        }
+        b_hist = b_tail;
+        lds_order();                                                  // history reads above, history writes below
+        const float pre = __uint_as_float((uint32_t)(s_cur + 127) << 23);
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int n = 128 * i + 2 * lane;
+#ifdef SRX_X_NOSPLIT
+            asm volatile("" :: "v"(m[2 * i]), "v"(m[2 * i + 1]));
+#else
+            put_iq(GS::HS + n, m[2 * i], m[2 * i + 1], pre);
+#endif
+            if constexpr (PARTIAL) {                                  // the history is the last HS samples that exist
+                const int hidx = n - ((int)tail_out * M - GS::HS);
+                if (hidx >= 0 && hidx < GS::HS)
+                    *reinterpret_cast<float4 *>(Hf + hidx) = make_float4(m[2 * i].x, m[2 * i].y, m[2 * i + 1].x, m[2 * i + 1].y);
+            } else if (i >= NLD - NTL) {
+                *reinterpret_cast<float4 *>(Hf + (n - (G::T - GS::HS))) = make_float4(m[2 * i].x, m[2 * i].y, m[2 * i + 1].x, m[2 * i + 1].y);
+            }
+        }
+    };
+
+    // ---- mfma(p): the decimator, 3 f16 MFMAs per k-step and rail (hi*hi | hi*lo + lo*hi) ----
+    // one f32 accumulator per rail takes the big (hi*hi) and the two small (hi*lo, lo*hi) terms: the small terms are
+    // rounded at the accumulator's ulp as they arrive (~20 extra roundings of 2^-24 relative, against a 1e-5 bar)
+    // and the sum never has to be formed on the vector ALU
+    v4f accI, accQ;
+#if SRX_ACC4
+    v4f smlI, smlQ;
+#endif
+    constexpr int VPM = SRX_SPLIT16_VPM;                              // vector instructions issued under each MFMA (0: scheduler's choice)
+    auto mfma_phase = [&](auto &&side, int PIN) {
+        accI = accQ = v4f{ 0.0f, 0.0f, 0.0f, 0.0f };
+#if SRX_ACC4
+        smlI = smlQ = accI;
+#endif
+        const _Float16 *xIh = X + 0 * GS::IMG + abase, *xIl = X + 1 * GS::IMG + abase;
+        const _Float16 *xQh = X + 2 * GS::IMG + abase, *xQl = X + 3 * GS::IMG + abase;
+        auto offA = [](int kk) { return GS::phys(32 * kk); };                // fragments never straddle a row (GeoS)
+        h8 aIh = *reinterpret_cast<const h8 *>(xIh + offA(0)), aIl = *reinterpret_cast<const h8 *>(xIl + offA(0));
+        h8 aQh = *reinterpret_cast<const h8 *>(xQh + offA(0)), aQl = *reinterpret_cast<const h8 *>(xQl + offA(0));
+#pragma unroll
+        for (int kk = 0; kk < GS::KS; ++kk) {
+            h8 nIh = aIh, nIl = aIl, nQh = aQh, nQl = aQl;
+#ifdef SRX_X_NOAREAD
+            if (false) {
+#else
+            if (kk + 1 < GS::KS) {
+#endif
+                const int off = offA(kk + 1);
+                nIh = *reinterpret_cast<const h8 *>(xIh + off); nIl = *reinterpret_cast<const h8 *>(xIl + off);
+                nQh = *reinterpret_cast<const h8 *>(xQh + off); nQl = *reinterpret_cast<const h8 *>(xQl + off);
+            }
+#ifdef SRX_X_NOMFMA
+            asm volatile("" :: "v"(aIh), "v"(aIl), "v"(aQh), "v"(aQl));
+#elif SRX_ACC4
+            accI = __builtin_amdgcn_mfma_f32_16x16x32_f16(aIh, Bh[kk], accI, 0, 0, 0);
+            accQ = __builtin_amdgcn_mfma_f32_16x16x32_f16(aQh, Bh[kk], accQ, 0, 0, 0);
+            smlI = __builtin_amdgcn_mfma_f32_16x16x32_f16(aIh, Bl[kk], smlI, 0, 0, 0);
+            smlQ = __builtin_amdgcn_mfma_f32_16x16x32_f16(aQh, Bl[kk], smlQ, 0, 0, 0);
+            smlI = __builtin_amdgcn_mfma_f32_16x16x32_f16(aIl, Bh[kk], smlI, 0, 0, 0);
+            smlQ = __builtin_amdgcn_mfma_f32_16x16x32_f16(aQl, Bh[kk], smlQ, 0, 0, 0);
+#else
+            accI = __builtin_amdgcn_mfma_f32_16x16x32_f16(aIh, Bl[kk], accI, 0, 0, 0);     // small terms first
+            accQ = __builtin_amdgcn_mfma_f32_16x16x32_f16(aQh, Bl[kk], accQ, 0, 0, 0);
+            accI = __builtin_amdgcn_mfma_f32_16x16x32_f16(aIl, Bh[kk], accI, 0, 0, 0);
+            accQ = __builtin_amdgcn_mfma_f32_16x16x32_f16(aQl, Bh[kk], accQ, 0, 0, 0);
+            accI = __builtin_amdgcn_mfma_f32_16x16x32_f16(aIh, Bh[kk], accI, 0, 0, 0);
+            accQ = __builtin_amdgcn_mfma_f32_16x16x32_f16(aQh, Bh[kk], accQ, 0, 0, 0);
+#endif
+            aIh = nIh; aIl = nIl; aQh = nQh; aQl = nQl;
+            side(kk);                                                 // vector work that runs under this k-step's MFMAs
+            if constexpr (VPM > 0) {
+                // issue pattern of the k-step: the A fragments of the next k-step (and two LDS reads of whatever
+                // else the block holds: the demodulator of the previous pass), then every MFMA followed by VPM
+                // vector instructions of the demodulator -- a 16x16x32 MFMA occupies the matrix pipe for 16
+                // cycles, the wave's issue port for 4
+                if (kk + 1 < GS::KS) __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+                else __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+#pragma unroll
+                for (int j = 0; j < 6; ++j) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);
+                }
+                if (kk < PIN) __builtin_amdgcn_sched_barrier(0);      // the k-steps that carry Hilbert pieces do not mix
+            }
+        }
+    };
+    // decimated rails of the pass into D behind the Hilbert history (exact power-of-two rescale)
+    auto dwrite = [&]() {
+        const int o0 = G::HH4 + 64 * (lane >> 4) + (lane & 15);
+        const int ex = -(s_cur + fa.split_sc);
+#ifdef SRX_X_NODWRITE
+        asm volatile("" :: "v"(accI), "v"(accQ), "s"(ex)); (void)o0;
+        return;
+#endif
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#if SRX_ACC4
+            dI[o0 + 16 * r] = __builtin_ldexpf(accI[r] + smlI[r], ex);
+            dQ[o0 + 16 * r] = __builtin_ldexpf(accQ[r] + smlQ[r], ex);
+#else
+            dI[o0 + 16 * r] = __builtin_ldexpf(accI[r], ex);
+            dQ[o0 + 16 * r] = __builtin_ldexpf(accQ[r], ex);
+#endif
+        }
+    };
+    // history of the four images: last HS samples of the pass back to the front, 16 bytes per move
+    constexpr int CPI = GS::HS / 8, CPR = GS::RL / 8;                 // 16-byte chunks per image history / per physical row
+    constexpr int NCB = 4 * CPI / kWave;                              // moves per lane
+    static_assert((4 * CPI) % kWave == 0 && GS::HS % GS::RL == 0, "image history is a whole number of wave moves and of rows");
+    auto cb_addr = [&](int k) {                                       // halfs; chunk i -> (image, row, 8-half column group)
+        const int i = k * kWave + lane, img = i / CPI, rem = i % CPI;
+        return img * GS::IMG + GS::RSTR * (rem / CPR) + 8 * (rem % CPR);
+    };
+    auto cb_read = [&](u4v (&cb)[NCB]) {
+#ifdef SRX_X_NOCB
+        for (int k = 0; k < NCB; ++k) cb[k] = u4v{ 0u, 0u, 0u, 0u };
+        return;
+#endif
+#pragma unroll
+        for (int k = 0; k < NCB; ++k) cb[k] = *reinterpret_cast<const u4v *>(X + cb_addr(k) + GS::RSTR * (G::T / GS::RL));
+    };
+    auto cb_write = [&](const u4v (&cb)[NCB]) {
+#ifdef SRX_X_NOCB
+        return;
+#endif
+#pragma unroll
+        for (int k = 0; k < NCB; ++k) *reinterpret_cast<u4v *>(X + cb_addr(k)) = cb[k];
+    };
+    // Hilbert-pair history: last HH4 decimated samples of both rails to the front of D (every lane moves
+    // one float4; the upper half of the wave repeats the lower half's moves when 2*HH4/4 = 32)
+    constexpr int NDV = 2 * (G::HH4 / 4);
+    static_assert(NDV == 16 || NDV == 32 || NDV == 64, "Hilbert history move is one float4 per lane (lanes beyond NDV repeat the first ones)");
+    const int dt_off = ((lane % NDV) / (G::HH4 / 4)) * G::DLEN + 4 * (lane % (G::HH4 / 4));
+
+    // ---- demod: Hilbert pair + sideband (or AM envelope), AGC of the pass whose decimated rails are in D.
+    // Cut into KS pieces that sit, in program order, behind the MFMAs of the k-steps of the NEXT pass's matrix
+    // stage: TPK Hilbert read-and-accumulate steps per k-step, the rest (sideband, AGC) in the last pieces.
+    constexpr int NTS = HilbertSteps<ND, M, NH>::N;
+    constexpr int KH = GS::KS > 4 ? GS::KS - 3 : 1;                   // k-steps that carry Hilbert steps
+    constexpr int TPK = (NTS + KH - 1) / KH;
+    float q2[4];
+    auto demod_piece = [&](int kk, float (&au)[4], int nvb = 64) {
+        if constexpr (AM != 0) {
+            if (kk == 0) {
+                const float4 vi = lds_ld4f(dI + G::HH4 + 4 * lane);
+                const float4 vq = lds_ld4f(dQ + G::HH4 + 4 * lane);
+                au[0] = cmag<0>(vi.x, vq.x); au[1] = cmag<0>(vi.y, vq.y);
+                au[2] = cmag<0>(vi.z, vq.z); au[3] = cmag<0>(vi.w, vq.w);
+#ifndef SRX_X_NOAGC
+                agc_pass<GROUP>(p.agcp, p.agc, lane, group, au, gain, nvb, gd);
+#endif
+            }
+        } else {
+            if (kk == 0) q2[0] = q2[1] = q2[2] = q2[3] = 0.0f;
+#pragma unroll
+            for (int j = 0; j < TPK; ++j)
+#ifndef SRX_X_NOHILB
+                if (kk * TPK + j < NTS) hilbert_tstep<1, ND, M, NH>(kk * TPK + j, dQ, lane, htap, q2);
+#endif
+            if (kk == (NTS + TPK - 1) / TPK - 1 || (kk == GS::KS - 1 && (NTS + TPK - 1) / TPK > GS::KS)) {
+                const float *di = dI + G::FH + fa.delay_idx + 4 * lane;   // unit-impulse delay FIR
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+#ifdef SRX_X_NODI
+                    const float i2 = q2[(r + 1) & 3] + 0.0f; (void)di;
+#else
+                    const float i2 = di[r] + 0.0f;                    // 0.0f + 1.0f*x of the dense loop
+#endif
+                    au[r] = fa.upper ? (i2 - q2[r]) : (i2 + q2[r]);   // arm_sub_f32 / arm_add_f32
+                }
+#ifndef SRX_X_NOAGC
+                agc_pass<GROUP>(p.agcp, p.agc, lane, group, au, gain, nvb, gd);
+#endif
+            }
+        }
+    };
+    static_assert(TPK * GS::KS >= NTS, "every Hilbert step has a k-step");
+    auto demod = [&](float (&au)[4], int nvb) {                       // the whole demodulator in one piece (last pass)
+#pragma unroll
+        for (int kk = 0; kk < GS::KS; ++kk) demod_piece(kk, au, nvb);
+    };
+    bool nonfinite = false;                                           // any audio sample of this workgroup NaN / Inf (x * 0 is NaN iff x is)
+    auto store_audio = [&](uint32_t q, const float (&au)[4]) {
+        const float z = __builtin_fmaf(au[3], 0.0f, __builtin_fmaf(au[2], 0.0f, __builtin_fmaf(au[1], 0.0f, au[0] * 0.0f)));
+        nonfinite = nonfinite || (z != z);
+#ifdef SRX_X_NOSTORE
+        asm volatile("" :: "v"(au[0]), "v"(au[1]), "v"(au[2]), "v"(au[3]));
+#else
+        W::store(rs_out, lane * W::kBytes, (int)q * (G::P * (W::kBytes / 4)), au);
+#endif
+        if constexpr (GROUP == 16 && ENV != 0) {
+            {
+                const float m = row16_fmax(fmaxf(fmaxf(fabsf(au[0]), fabsf(au[1])), fmaxf(fabsf(au[2]), fabsf(au[3]))));
+                // block 4 q + (lane >> 4) from the first lane of its row; the other lanes point past the range (dropped)
+                const int voff = (lane & 15) == 0 ? (lane >> 4) * 4 : 0x40000000;
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(m), rs_env, voff, (int)q * 16, 0);
+            }
+        }
+    };
+
+    // ---- the pipeline, once per channel of this workgroup ----
+    // Audio of pass q is computed under the matrix stage of pass q+1 and stored right behind the mix stage of
+    // pass q+2 -- in FRONT of that pass's prefetch loads: loads and stores share one in-order counter (vmcnt),
+    // so a store issued shortly before loaded data is consumed makes the wave wait for the write acknowledge.
+    // The last pass of a channel prefetches the first pass and the state of the workgroup's next channel, so a
+    // channel switch costs no cold memory round trip and the Toeplitz fragments are loaded once per workgroup.
+    for (;;) {
+        install_state();
+        float au[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+        lds_order();
+        STAMP(0);
+        if (npass == 1 && tail_out != G::P) mix(0, std::true_type{});
+        else mix(0, std::false_type{});
+        STAMP(0);
+        prefetch(1);
+        lds_order();
+        {
+            u4v cb[NCB];
+            mfma_phase([](int) {}, 0);
+            cb_read(cb);
+            lds_order();
+            cb_write(cb);
+            dwrite();
+        }
+        lds_order();
+        STAMP(0);
+        for (uint32_t pass = 1; pass < npass; ++pass) {
+            STAMP(1);                                                 // wait for the prefetched pass
+            if (pass + 1 == npass && tail_out != G::P) mix(pass, std::true_type{});
+            else mix(pass, std::false_type{});
+            STAMP(0);
+            store_audio(pass - 2, au);                                // pass 1: offset -1 pass = out of range, dropped
+            prefetch(pass + 1);
+            lds_order();
+            u4v cb[NCB];
+            v4f dt = { 0.0f, 0.0f, 0.0f, 0.0f };
+            if constexpr (AM == 0) dt = *reinterpret_cast<const v4f *>(D + dt_off + G::P);
+            gd.thr = thr_prev;                                        // the demodulator below belongs to the pass before
+            mfma_phase([&](int kk) { demod_piece(kk, au); }, (NTS + TPK - 1) / TPK - 1);   // matrix pipe over the vector work of the pass before
+            cb_read(cb);
+            lds_order();
+            cb_write(cb);
+            if constexpr (AM == 0) *reinterpret_cast<v4f *>(D + dt_off) = dt;
+            dwrite();
+            lds_order();
+            STAMP(0);
+        }
+        store_audio(npass - 2, au);
+        load_state(c + gridDim.x);                                    // the next channel's state, under this channel's last demodulator pass
+        gd.thr = thr_cur;
+        demod(au, (int)(tail_out / (4u * (uint32_t)group)));          // DSP blocks of the last pass that exist
+        store_audio(npass - 1, au);
+        STAMP(0);
+
+        // ---- parity guard: count (per-channel words: no atomics); SELENITE_ARITH_AUTO: a guarded channel keeps its pre-call
+        // state and raises its rerun flag (the flag of every channel is rewritten every call) ----
+        const bool keep_state = gd.n != 0u && p.rerun_flag != nullptr;   // wave-uniform
+        if (lane == 0) {
+            if (gd.n != 0u && p.guard_ch) { p.guard_ch[c] += gd.n; p.guard_calls[c] += 1u; }
+            if (p.rerun_flag) p.rerun_flag[c] = keep_state ? 1u : 0u;
+        }
+        // ---- streaming state of the channel back to HBM (exact f32) ----
+        lds_order();
+        if (!keep_state) {
+            float *stI = p.dec_state + (size_t)c * 2 * (ND - 1), *stQ = stI + (ND - 1);
+#pragma unroll
+            for (int j = 0; j < GS::HS / kWave; ++j) {
+                const int s = j * kWave + lane - G::F;
+                const v2f h = Hf[j * kWave + lane];
+                if (s >= 0) { stI[s] = h.x; stQ[s] = h.y; }
+            }
+        }
+        if constexpr (AM == 0) {                                      // AM never ran the Hilbert pair: its state stays
+            if (!keep_state)
+                for (int i = lane; i < 2 * G::HH4; i += kWave) {
+                    const int rail = i / G::HH4, mi = i % G::HH4, s = mi - G::FH;
+                    if (s >= 0) p.fir_state[((size_t)c * 2 + rail) * G::HH + s] = D[rail * G::DLEN + tail_out + mi];
+                }
+        }
+        if (lane == 0 && !keep_state) {
+            if constexpr (NCO != 0) p.phase[c] = ph0 + p.block_size * step;
+            if (p.agc) p.gain[c] = gain;
+        }
+        c += gridDim.x;
+        if (c >= p.channels) break;
+        lds_order();                                                  // the state reads above before the next channel's installs
+        rs_in = rs_in_next;
+        rs_in_next = in_rsrc(c + gridDim.x);
+        rs_out = make_rsrc(dst + (size_t)c * p.out_stride, p.nout * (W::kBytes / 4));
+        if constexpr (ENV != 0) rs_env = env_rsrc(c);
+    }
+    if (nonfinite) p.flags[0] = 1u;                                   // ARM_MATH_NANINF, read by selenite_rx_sync
+    STAMP(1);
+#undef STAMP
+}
+
+// ------------------------------------------------------------------------------------------
+// k_ssb_split16w2 -- the same chain with TWO wavefronts per channel (128-thread workgroups).
+//
+// Counters of the one-wave kernel (profiles/r2): every unit under 55 % busy, the waves 34 % of their time in
+// s_waitcnt and 29 % stalled at issue -- two long dependent chains per SIMD cannot cover each other, and
+// 80 VGPRs of Toeplitz fragments pin the kernel at two waves per SIMD.  Here the matrix stage is split in K
+// between the two waves of a channel (half the fragments each, partial sums meet in LDS) and the vector work is
+// split by role: the FRONT wave streams the input (prefetch, NCO mix, block exponent, f16 split into the LDS
+// images), the BACK wave turns the decimated rails into audio (combine, Hilbert pair, AGC, store).  Two
+// s_barrier per pass; while the front wave mixes pass p+1 the back wave demodulates pass p.  Under 168 VGPRs:
+// three waves per SIMD, six channels in flight per CU, each with half the serial work per wave.
+// The block exponent of a pass comes from a BOUND on the mixed samples, |x * LO| <= 2 max(|I|, |Q|), taken on
+// the raw samples, so the complex multiplies do not wait for the wave reduction; the history part uses the
+// exact maximum of the mixed samples (what a call's prologue can recompute from the state: partition-invariant).
+// ------------------------------------------------------------------------------------------
+template <int NCO, int ND, int M, int NH, typename TIn, typename TOut, int AM, int GROUP>
+__global__ __launch_bounds__(128, 3) void k_ssb_split16w2(RxParams p, FusedArgs fa, const TIn *__restrict__ src,
+                                                          TOut *__restrict__ dst)
+{
+    using G = Geo<ND, M, NH>;
+    using GS = GeoS<NCO, ND, M, NH>;
+    using R = BRaw<TIn>;
+    using W = BOut<TOut>;
+    static_assert(ND > 0 && M == 4 && NH > 0 && G::T % 64 == 0 && GS::HS % 128 == 0 && GS::KS % 2 == 0, "split16 decimator: /4 + Hilbert");
+    constexpr int KH = GS::KS / 2;                                  // k-steps per wave
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t c = blockIdx.x;
+    float *tab = lds + GS::oTab;
+    _Float16 *X = reinterpret_cast<_Float16 *>(lds + GS::oX);     // [rail][hi/lo][IMG]
+    v2f *Hf = reinterpret_cast<v2f *>(lds + GS::oHf);             // f32 (I, Q) history, HS samples
+    float *D = lds + GS::oD;
+    float *dI = D, *dQ = D + G::DLEN;
+    float *P = lds + GS::total;                                   // front wave's partial sums [rail][lane][4]
+    int *SX = reinterpret_cast<int *>(P + 512);                   // block exponent of pass p at SX[p & 1]
+    constexpr int NLD = G::T / 128, NTL = GS::HS / 128;
+    const uint32_t npass = p.nout / G::P;
+    const int abase = 80 * (lane & 15) + 8 * (lane >> 4);         // A-fragment lane base (halfs)
+
+    // workgroup barrier that leaves the prefetch loads in flight: LDS traffic only is drained
+    auto wg_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+
+    // this wave's half of the Toeplitz B fragments
+    h8 Bh[KH], Bl[KH];
+    {
+        const h8 *bt = static_cast<const h8 *>(fa.btab16) + (size_t)wave * KH * 2 * 64;
+#pragma unroll
+        for (int kk = 0; kk < KH; ++kk) {
+            Bh[kk] = bt[(2 * kk + 0) * 64 + lane];
+            Bl[kk] = bt[(2 * kk + 1) * 64 + lane];
+        }
+    }
+    v4f accI, accQ;
+    auto mfma_half = [&](auto k0c) {                              // k-steps [K0, K0 + KH)
+        constexpr int K0 = decltype(k0c)::value;
+        accI = accQ = v4f{ 0.0f, 0.0f, 0.0f, 0.0f };
+        const _Float16 *xIh = X + 0 * GS::IMG + abase, *xIl = X + 1 * GS::IMG + abase;
+        const _Float16 *xQh = X + 2 * GS::IMG + abase, *xQl = X + 3 * GS::IMG + abase;
+        auto offA = [](int kk) { return 80 * (kk >> 1) + 32 * (kk & 1); };
+        h8 aIh = *reinterpret_cast<const h8 *>(xIh + offA(K0)), aIl = *reinterpret_cast<const h8 *>(xIl + offA(K0));
+        h8 aQh = *reinterpret_cast<const h8 *>(xQh + offA(K0)), aQl = *reinterpret_cast<const h8 *>(xQl + offA(K0));
+#pragma unroll
+        for (int j = 0; j < KH; ++j) {
+            h8 nIh = aIh, nIl = aIl, nQh = aQh, nQl = aQl;
+#ifdef SRX_X_NOAREAD
+            if (false) {
+#else
+            if (j + 1 < KH) {
+#endif
+                const int off = offA(K0 + j + 1);
+                nIh = *reinterpret_cast<const h8 *>(xIh + off); nIl = *reinterpret_cast<const h8 *>(xIl + off);
+                nQh = *reinterpret_cast<const h8 *>(xQh + off); nQl = *reinterpret_cast<const h8 *>(xQl + off);
+            }
+#ifdef SRX_X_NOMFMA
+            asm volatile("" :: "v"(aIh), "v"(aIl), "v"(aQh), "v"(aQl));
+#else
+            accI = __builtin_amdgcn_mfma_f32_16x16x32_f16(aIh, Bl[j], accI, 0, 0, 0);      // small terms first
+            accQ = __builtin_amdgcn_mfma_f32_16x16x32_f16(aQh, Bl[j], accQ, 0, 0, 0);
+            accI = __builtin_amdgcn_mfma_f32_16x16x32_f16(aIl, Bh[j], accI, 0, 0, 0);
+            accQ = __builtin_amdgcn_mfma_f32_16x16x32_f16(aQl, Bh[j], accQ, 0, 0, 0);
+            accI = __builtin_amdgcn_mfma_f32_16x16x32_f16(aIh, Bh[j], accI, 0, 0, 0);
+            accQ = __builtin_amdgcn_mfma_f32_16x16x32_f16(aQh, Bh[j], accQ, 0, 0, 0);
+#endif
+#ifndef SRX_X_NOAREAD
+            aIh = nIh; aIl = nIl; aQh = nQh; aQl = nQl;
+#endif
+        }
+    };
+
+    if (wave == 0) {
+        // =============================== FRONT wave: input side ===============================
+        const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(src + (size_t)c * p.in_stride * 2, p.block_size * (R::kBytes / 2));
+        const __amdgpu_buffer_rsrc_t rs_lo = make_rsrc(p.lo, NCO == 2 ? p.block_size * 8u : 0u);
+        constexpr int kInPass = G::T * (R::kBytes / 2);
+        const int in_end = (int)(p.block_size * (R::kBytes / 2));
+        typename R::type raw[NLD];
+        constexpr int LOD = 3;
+        u4v lo4[LOD];
+        auto lo_load = [&](int slot, int i, int sl) { lo4[slot] = __builtin_amdgcn_raw_buffer_load_b128(rs_lo, lane * 16 + i * 1024, sl, 0); };
+        auto lo_base = [&](uint32_t pass) { return pass < npass ? (int)pass * G::T * 8 : (int)p.block_size * 8; };
+        auto prefetch = [&](uint32_t pass) {
+            const int so = pass < npass ? (int)pass * kInPass : in_end;
+#pragma unroll
+            for (int i = 0; i < NLD; ++i) raw[i] = R::load(rs_in, lane * R::kBytes + i * 64 * R::kBytes, so);
+#ifndef SRX_X_NOLO
+            if constexpr (NCO == 2) {
+#pragma unroll
+                for (int i = 0; i < LOD; ++i) lo_load(i, i, lo_base(pass));
+            }
+#endif
+        };
+        prefetch(0);
+        if constexpr (NCO == 1)
+            for (int i = lane; i < 513; i += kWave) tab[i] = p.sintab[i];
+        uint32_t e_hist;
+        {   // CMSIS pState of the decimator -> f32 history; flat sample f is state sample f - F (older slots: zero)
+            constexpr int NHI = GS::HS / kWave;
+            const float *stI = p.dec_state + (size_t)c * 2 * (ND - 1), *stQ = stI + (ND - 1);
+            v2f hv[NHI];
+#pragma unroll
+            for (int j = 0; j < NHI; ++j) {
+                const int s = j * kWave + lane - G::F, sc = s < 0 ? 0 : s;
+                const float xi = stI[sc], xq = stQ[sc];
+                hv[j] = s < 0 ? v2f{ 0.0f, 0.0f } : v2f{ xi, xq };
+            }
+            float mh = 0.0f;
+#pragma unroll
+            for (int j = 0; j < NHI; ++j) {
+                Hf[j * kWave + lane] = hv[j];
+                mh = amax2(hv[j], mh);
+            }
+            e_hist = wave_umax_bits(mh) >> 23;
+        }
+        const uint32_t ph0 = NCO ? p.phase[c] : 0u;
+        const uint32_t step = NCO ? p.step[c] : 0u;
+        int s_cur = 0x7fff;
+        auto put_iq = [&](int f, v2f a, v2f b, float pre) {
+            const v2f pre2 = { pre, pre };
+            const v2f sa = a * pre2, sb = b * pre2;
+            const h2 hhI = __builtin_convertvector(v2f{ sa.x, sb.x }, h2), hhQ = __builtin_convertvector(v2f{ sa.y, sb.y }, h2);
+            const v2f ra = sa - v2f{ (float)hhI.x, (float)hhQ.x }, rb = sb - v2f{ (float)hhI.y, (float)hhQ.y };
+            const h2 llI = __builtin_convertvector(v2f{ ra.x, rb.x }, h2), llQ = __builtin_convertvector(v2f{ ra.y, rb.y }, h2);
+            const int ph = GS::phys(f);
+            *reinterpret_cast<h2 *>(X + 0 * GS::IMG + ph) = hhI;
+            *reinterpret_cast<h2 *>(X + 1 * GS::IMG + ph) = llI;
+            *reinterpret_cast<h2 *>(X + 2 * GS::IMG + ph) = hhQ;
+            *reinterpret_cast<h2 *>(X + 3 * GS::IMG + ph) = llQ;
+        };
+        auto mix = [&](uint32_t pass) {
+            const uint32_t n0 = pass * G::T;
+            // bound on the mixed samples from the raw ones: the complex multiplies below do not wait for it
+            float mr = 0.0f;
+#pragma unroll
+            for (int i = 0; i < NLD; ++i) {
+                v2f a, b;
+                R::unpack(raw[i], a, b);
+                mr = amax2(a, mr);
+                mr = amax2(b, mr);
+            }
+            const uint32_t e_raw = (wave_umax_bits(mr) >> 23) + (NCO != 0 ? 1u : 0u);
+            const uint32_t e_need = max(e_raw, e_hist);
+            int s_new = 141 - (int)e_need;
+            s_new = s_new > 127 ? 127 : (s_new < -126 ? -126 : s_new);
+            if (s_new != s_cur) {                                     // wave-uniform; always in the first pass
+                const float pre = __uint_as_float((uint32_t)(s_new + 127) << 23);
+#pragma unroll
+                for (int j = 0; j < GS::HS / 128; ++j) {
+                    const int f = 2 * (j * kWave + lane);
+                    const float4 hq = lds_ld4f(reinterpret_cast<const float *>(Hf + f));
+                    put_iq(f, v2f{ hq.x, hq.y }, v2f{ hq.z, hq.w }, pre);
+                }
+                s_cur = s_new;
+            }
+            if (lane == 0) SX[pass & 1] = s_cur;
+            lds_order();                                              // history reads above, history writes below
+            const float pre = __uint_as_float((uint32_t)(s_cur + 127) << 23);
+            float mt = 0.0f;
+#pragma unroll
+            for (int i = 0; i < NLD; ++i) {
+                v2f a, b, ma, mb;
+                R::unpack(raw[i], a, b);
+#ifdef SRX_X_NOLO
+                if constexpr (NCO == 2) { ma = a; mb = b; } else if
+#else
+                if constexpr (NCO == 2) {
+                    const u4v l = lo4[i % LOD];
+                    cmul_pk2(a, b, v2f{ __uint_as_float(l.x), __uint_as_float(l.y) }, v2f{ __uint_as_float(l.z), __uint_as_float(l.w) }, ma, mb);
+                    if (i + LOD < NLD) lo_load(i % LOD, i + LOD, lo_base(pass));
+                } else if
+#endif
+                constexpr (NCO == 1) {
+                    const uint32_t pe = ph0 + 2u * lane * step + (n0 + 128u * i) * step;
+                    v2f la, lb;
+                    nco_lo_pair(tab, pe, pe + step, la, lb);
+                    cmul_pk2(a, b, la, lb, ma, mb);
+                } else {
+                    ma = a; mb = b;
+                }
+                const int n = 128 * i + 2 * lane;
+#ifdef SRX_X_NOSPLIT
+                asm volatile("" :: "v"(ma), "v"(mb));
+#else
+                put_iq(GS::HS + n, ma, mb, pre);
+#endif
+                if (i >= NLD - NTL) {                                 // the next pass's history: exact f32 copy and exact maximum
+                    *reinterpret_cast<float4 *>(Hf + (n - (G::T - GS::HS))) = make_float4(ma.x, ma.y, mb.x, mb.y);
+                    mt = amax2(ma, mt);
+                    mt = amax2(mb, mt);
+                }
+            }
+            e_hist = wave_umax_bits(mt) >> 23;
+        };
+        constexpr int NCB = 4 * (GS::HS / 64) * 8 / kWave;
+        auto cb_addr = [&](int k) {
+            const int i = k * kWave + lane, img = i / (8 * (GS::HS / 64)), rem = i % (8 * (GS::HS / 64));
+            return img * GS::IMG + 80 * (rem >> 3) + 8 * (rem & 7);
+        };
+
+        lds_order();
+        mix(0);
+        prefetch(1);
+        wg_barrier();                                                 // X: images of pass 0 complete
+        for (uint32_t pass = 0; pass < npass; ++pass) {
+            mfma_half(std::integral_constant<int, 0>{});
+            u4v cb[NCB];
+#pragma unroll
+            for (int k = 0; k < NCB; ++k) cb[k] = *reinterpret_cast<const u4v *>(X + cb_addr(k) + 80 * (G::T / 64));
+            *reinterpret_cast<v4f *>(P + 4 * lane) = accI;
+            *reinterpret_cast<v4f *>(P + 256 + 4 * lane) = accQ;
+            wg_barrier();                                             // Y: partial sums out, every A read of the pass issued
+#pragma unroll
+            for (int k = 0; k < NCB; ++k) *reinterpret_cast<u4v *>(X + cb_addr(k)) = cb[k];
+            lds_order();
+            if (pass + 1 < npass) {
+                mix(pass + 1);
+                prefetch(pass + 2);
+            }
+            wg_barrier();                                             // X: images of the next pass complete
+        }
+        // ---- epilogue: decimator state back to HBM (exact f32) ----
+        {
+            float *stI = p.dec_state + (size_t)c * 2 * (ND - 1), *stQ = stI + (ND - 1);
+#pragma unroll
+            for (int j = 0; j < GS::HS / kWave; ++j) {
+                const int s = j * kWave + lane - G::F;
+                const v2f h = Hf[j * kWave + lane];
+                if (s >= 0) { stI[s] = h.x; stQ[s] = h.y; }
+            }
+        }
+        if (lane == 0) {
+            if constexpr (NCO != 0) p.phase[c] = ph0 + p.block_size * step;
+        }
+    } else {
+        // =============================== BACK wave: audio side ===============================
+        const __amdgpu_buffer_rsrc_t rs_out = make_rsrc(dst + (size_t)c * p.out_stride, p.nout * (W::kBytes / 4));
+        float hreg[(NH + 63) / 64];
+#pragma unroll
+        for (int v = 0; v < (NH + 63) / 64; ++v) hreg[v] = (64 * v + lane < NH) ? p.hilb_c[64 * v + lane] : 0.0f;
+        {
+            constexpr int NFI = 2 * G::HH4 / kWave;
+            static_assert((2 * G::HH4) % kWave == 0, "prologue fills are whole wave loads");
+            const float *stF = p.fir_state + (size_t)c * 2 * G::HH;
+            float fv[NFI];
+#pragma unroll
+            for (int j = 0; j < NFI; ++j) {
+                const int i = j * kWave + lane;
+                const int rail = i / G::HH4, sidx = i % G::HH4 - G::FH;
+                const float x = stF[rail * G::HH + (sidx < 0 ? 0 : sidx)];
+                fv[j] = sidx < 0 ? 0.0f : x;
+            }
+#pragma unroll
+            for (int j = 0; j < NFI; ++j) {
+                const int i = j * kWave + lane;
+                D[(i / G::HH4) * G::DLEN + i % G::HH4] = fv[j];
+            }
+        }
+        float gain = p.gain[c];
+        const int group = (int)fa.group;
+        constexpr int NDV = 2 * (G::HH4 / 4);
+        static_assert(NDV == 16 || NDV == 32 || NDV == 64, "Hilbert history move is one float4 per lane (lanes beyond NDV repeat the first ones)");
+        const int dt_off = ((lane % NDV) / (G::HH4 / 4)) * G::DLEN + 4 * (lane % (G::HH4 / 4));
+        auto htap = [&](int k) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(hreg[k >> 6]), k & 63)); };
+
+        wg_barrier();                                                 // X
+        for (uint32_t pass = 0; pass < npass; ++pass) {
+            mfma_half(std::integral_constant<int, KH>{});
+            wg_barrier();                                             // Y
+            // combine the two K halves, exact power-of-two rescale, decimated rails into D behind the Hilbert history
+            {
+                const v4f pI = *reinterpret_cast<const v4f *>(P + 4 * lane), pQ = *reinterpret_cast<const v4f *>(P + 256 + 4 * lane);
+                const int ex = -(SX[pass & 1] + fa.split_sc);
+                const int o0 = G::HH4 + 64 * (lane >> 4) + (lane & 15);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    dI[o0 + 16 * r] = __builtin_ldexpf(accI[r] + pI[r], ex);
+                    dQ[o0 + 16 * r] = __builtin_ldexpf(accQ[r] + pQ[r], ex);
+                }
+            }
+            lds_order();
+            float au[4];
+            if constexpr (AM != 0) {
+                const float4 vi = lds_ld4f(dI + G::HH4 + 4 * lane);
+                const float4 vq = lds_ld4f(dQ + G::HH4 + 4 * lane);
+                au[0] = cmag<0>(vi.x, vq.x); au[1] = cmag<0>(vi.y, vq.y);
+                au[2] = cmag<0>(vi.z, vq.z); au[3] = cmag<0>(vi.w, vq.w);
+            } else {
+                float q2[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+#ifndef SRX_X_NOHILB
+#pragma unroll
+                for (int t = 0; t < HilbertSteps<ND, M, NH>::N; ++t) hilbert_tstep<1, ND, M, NH>(t, dQ, lane, htap, q2);
+#endif
+                const float *di = dI + G::FH + fa.delay_idx + 4 * lane;   // unit-impulse delay FIR
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float i2 = di[r] + 0.0f;
+                    au[r] = fa.upper ? (i2 - q2[r]) : (i2 + q2[r]);
+                }
+                const v4f dt = *reinterpret_cast<const v4f *>(D + dt_off + G::P);   // Hilbert-pair history for the next pass
+                lds_order();
+                *reinterpret_cast<v4f *>(D + dt_off) = dt;
+            }
+            GuardPass gdw{ 0.0f, 0ull, 0u };                           // (experimental kernel: no parity guard)
+            agc_pass<GROUP>(p.agcp, p.agc, lane, group, au, gain, 64, gdw);
+            W::store(rs_out, lane * W::kBytes, (int)pass * (G::P * (W::kBytes / 4)), au);
+            wg_barrier();                                             // X
+        }
+        if constexpr (AM == 0) {                                      // AM never ran the Hilbert pair: its state stays
+            for (int i = lane; i < 2 * G::HH4; i += kWave) {
+                const int rail = i / G::HH4, mi = i % G::HH4, s = mi - G::FH;
+                if (s >= 0) p.fir_state[((size_t)c * 2 + rail) * G::HH + s] = D[rail * G::DLEN + mi];
+            }
+        }
+        if (lane == 0 && p.agc) p.gain[c] = gain;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_hilb_split16<NCO, NH, TIn, TOut, AM> -- SELENITE_ARITH_SPLIT16 for the no-decimator shapes
+// (BASELINE cfg1 / cfg2 / cfg5: M = 1, DSP block 256): the Hilbert FIR (arm_fir_f32.c:640-936) on the
+// 16-bit matrix pipe.  Those shapes are VALU-bound by the Hilbert tap loop (64 non-zero taps of 127 per
+// output); as a banded-Toeplitz product
+//     D[i][m] = sum_k A[i][k] B[k][m],   A[i][k] = st[16 i + k],   B[k][m] = h[k - m]
+// (st = [NH-1 history | 256 new samples] of the Q rail, 16 rows of 16 outputs, K = NH + 15) it is 3 MFMAs
+// per k-step of 32 with the f16 hi/lo split and the block floating point of k_ssb_split16: the scale 2^s
+// of a pass puts the largest |Q| of [history | new] into [2^14, 2^15); the Q history is kept in f32 beside
+// the images and re-split when s changes.  15 v_mfma_f32_16x16x32_f16 per pass instead of 128 v_pk_fma +
+// 64 v_readlane.  The I rail is a pure delay (unit-impulse FIR) and stays f32; the streaming state leaves
+// from the f32 rails, bit-exact.  The MFMA result layout (lane holds outputs 64(l>>4) + 16 r + (l&15)) goes
+// through a 1 KB LDS transpose so the audio leaves as one coalesced 16-byte store per lane.
+// ------------------------------------------------------------------------------------------
+template <int NCO, int NH, typename TIn, typename TOut, int AM = 0>
+__global__ __launch_bounds__(64, 2) void k_hilb_split16(RxParams p, FusedArgs fa, const TIn *__restrict__ src,
+                                                        TOut *__restrict__ dst)
+{
+    using GH = GeoH<NH>;
+    using R = BRaw<TIn>;
+    using W = BOut<TOut>;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x;
+    const uint32_t c = blockIdx.x;
+    float *tab = lds + GH::oTab;
+    _Float16 *Xh = reinterpret_cast<_Float16 *>(lds + GH::oX), *Xl = Xh + GH::IMG;
+    float *dI = lds + GH::oDI, *dQ = lds + GH::oDQ, *O = lds + GH::oO;      // f32 rails [HH history | 256 new]
+    const uint32_t npass = p.nout / 256;
+    const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(src + (size_t)c * p.in_stride * 2, p.block_size * (R::kBytes / 2));
+    const __amdgpu_buffer_rsrc_t rs_out = make_rsrc(dst + (size_t)c * p.out_stride, p.nout * (W::kBytes / 4));
+    const __amdgpu_buffer_rsrc_t rs_lo = make_rsrc(p.lo, NCO == 2 ? p.block_size * 8u : 0u);
+    constexpr int kInPass = 256 * (R::kBytes / 2);
+    typename R::type raw[2];
+    u4v lo4[2];
+    auto prefetch = [&](uint32_t pass) {                              // pass == npass: out of range, zeros, no traffic
+        const int so = pass < npass ? (int)pass * kInPass : (int)(p.block_size * (R::kBytes / 2));
+#pragma unroll
+        for (int i = 0; i < 2; ++i) raw[i] = R::load(rs_in, lane * R::kBytes + i * 64 * R::kBytes, so);
+        if constexpr (NCO == 2) {
+            const int sl = pass < npass ? (int)pass * 256 * 8 : (int)p.block_size * 8;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) lo4[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_lo, lane * 16 + i * 1024, sl, 0);
+        }
+    };
+    prefetch(0);
+
+    h8 Bh[GH::KS], Bl[GH::KS];
+    {
+        const h8 *bt = static_cast<const h8 *>(fa.btab16);
+#pragma unroll
+        for (int kk = 0; kk < GH::KS; ++kk) {
+            Bh[kk] = bt[(2 * kk + 0) * 64 + lane];
+            Bl[kk] = bt[(2 * kk + 1) * 64 + lane];
+        }
+    }
+    if constexpr (NCO == 1)
+        for (int i = lane; i < 513; i += kWave) tab[i] = p.sintab[i];
+    // image slots u (even), u + 1 of the Q rail <- two samples times the block scale
+    auto put = [&](int u, float x0, float x1, float pre) {
+        const v2f s = v2f{ x0, x1 } * v2f{ pre, pre };
+        const h2 h = __builtin_convertvector(s, h2);
+        const h2 l = __builtin_convertvector(s - __builtin_convertvector(h, v2f), h2);
+        const int ph = GH::phys(u);
+        *reinterpret_cast<h2 *>(Xh + ph) = h;
+        *reinterpret_cast<h2 *>(Xl + ph) = l;
+    };
+    // the read-only slack behind the samples meets zero taps only, but must hold finite numbers
+    for (int u = GH::HH + 256 + 2 * lane; u < GH::XN; u += 2 * kWave) put(u, 0.0f, 0.0f, 1.0f);
+    // state: both rails' histories in f32 (branch-free: lanes beyond the history repeat its last pair)
+    const int hv = 2 * lane < GH::HH ? 2 * lane : GH::HH - 2;       // this lane's history pair
+    uint32_t b_hist;                                                  // bit pattern of the largest |Q| of the history
+    {
+        const float *stI = p.fir_state + (size_t)c * 2 * GH::HH, *stQ = stI + GH::HH;
+        const float i0 = stI[hv], i1 = stI[hv + 1], q0 = stQ[hv], q1 = stQ[hv + 1];
+        *reinterpret_cast<float2 *>(dI + hv) = make_float2(i0, i1);
+        *reinterpret_cast<float2 *>(dQ + hv) = make_float2(q0, q1);
+        b_hist = wave_umax_bits(fmaxf(fabsf(q0), fabsf(q1)));
+    }
+    GuardPass gd{ 0.0f, 1ull, 0u };                                   // parity guard: one DSP block per pass
+    const uint32_t ph0 = NCO ? p.phase[c] : 0u, step = NCO ? p.step[c] : 0u;
+    float gain = p.gain[c];
+    const int mcol = lane & 15, rg = lane >> 4;
+    int s_cur = 0x7fff;
+    bool nonfinite = false;                                           // any audio sample NaN / Inf (x * 0 is NaN iff x is)
+    lds_order();
+
+    for (uint32_t pass = 0; pass < npass; ++pass) {
+        const uint32_t n0 = pass * 256u;
+        // ---- 1. NCO mix; both rails f32 into LDS; Q rail split into the f16 images at the block scale ----
+        v2f ma[2], mb[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            v2f a, b;
+            R::unpack(raw[i], a, b);
+            if constexpr (NCO == 2) {
+                cmul_pk2(a, b, v2f{ __uint_as_float(lo4[i].x), __uint_as_float(lo4[i].y) },
+                         v2f{ __uint_as_float(lo4[i].z), __uint_as_float(lo4[i].w) }, ma[i], mb[i]);
+            } else if constexpr (NCO == 1) {
+                const uint32_t pe = ph0 + 2u * lane * step + (n0 + 128u * i) * step;
+                v2f la, lb;
+                nco_lo_pair(tab, pe, pe + step, la, lb);
+                cmul_pk2(a, b, la, lb, ma[i], mb[i]);
+            } else {
+                ma[i] = a;
+                mb[i] = b;
+            }
+        }
+        prefetch(pass + 1);
+        float au[4];
+        if constexpr (AM != 0) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                *reinterpret_cast<float2 *>(O + 128 * i + 2 * lane) = make_float2(cmag<0>(ma[i].x, ma[i].y), cmag<0>(mb[i].x, mb[i].y));
+            lds_order();
+        } else {
+            // block exponent: the largest |Q| of the new samples and of the history; the new samples that will be
+            // the NEXT pass's history (the last HH of the pass) are tracked on the side
+            float mq = 0.0f, mt = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int n = 128 * i + 2 * lane;
+                const float m2 = fmaxf(fabsf(ma[i].y), fabsf(mb[i].y));
+                mq = fmaxf(mq, m2);
+                mt = fmaxf(mt, n >= 256 - GH::HH ? m2 : 0.0f);          // HH is even: a pair is inside or outside as a whole
+            }
+            const uint32_t b_tail = wave_umax_bits(mt);
+            const uint32_t b_need = max(max(wave_umax_bits(mq), b_tail), b_hist);      // the largest |Q| the matrix product sees
+            const uint32_t e_need = b_need >> 23;
+            gd.thr = __uint_as_float(b_need) * p.guard_ratio;
+            int s_new = 141 - (int)e_need;
+            s_new = s_new > 127 ? 127 : (s_new < -126 ? -126 : s_new);
+            if (s_new != s_cur) {                                     // wave-uniform; always in the first pass
+                const float2 hq = *reinterpret_cast<const float2 *>(dQ + hv);
+                put(hv, hq.x, hq.y, __uint_as_float((uint32_t)(s_new + 127) << 23));
+                s_cur = s_new;
+            }
+            b_hist = b_tail;
+            const float pre = __uint_as_float((uint32_t)(s_cur + 127) << 23);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int n = 128 * i + 2 * lane;
+                *reinterpret_cast<float2 *>(dI + GH::HH + n) = make_float2(ma[i].x, mb[i].x);
+                *reinterpret_cast<float2 *>(dQ + GH::HH + n) = make_float2(ma[i].y, mb[i].y);
+                put(GH::HH + n, ma[i].y, mb[i].y, pre);
+            }
+            lds_order();
+            // ---- 2. Hilbert FIR of the Q rail: 3 f16 MFMAs per k-step (small terms first, one accumulator) ----
+            v4f acc = { 0.0f, 0.0f, 0.0f, 0.0f };
+#pragma unroll
+            for (int kk = 0; kk < GH::KS; ++kk) {
+                const int u = 16 * mcol + 8 * rg + 32 * kk;                // A[i = l&15][k = 32kk + 8(l>>4) ..+7] = st[16 i + k]
+                const int ph = u + 8 * (u >> 7);
+                const h8 ah = *reinterpret_cast<const h8 *>(Xh + ph), al = *reinterpret_cast<const h8 *>(Xl + ph);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, Bl[kk], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, Bh[kk], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, Bh[kk], acc, 0, 0, 0);
+            }
+            // ---- 3. delay on I, sideband combine; transpose through LDS ----
+            const int ex = -(s_cur + fa.split_sc);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = 64 * rg + 16 * r + mcol;                     // D[row 4 rg + r][col mcol]
+                const float q2 = __builtin_ldexpf(acc[r], ex);
+                const float i2 = dI[n + fa.delay_idx] + 0.0f;
+                O[n] = fa.upper ? (i2 - q2) : (i2 + q2);
+            }
+            lds_order();
+        }
+        // ---- 4.-5. AGC on the DSP block (= the pass), coalesced store ----
+        {
+            const float4 o4 = lds_ld4f(O + 4 * lane);
+            au[0] = o4.x; au[1] = o4.y; au[2] = o4.z; au[3] = o4.w;
+        }
+        agc_pass<64>(p.agcp, p.agc, lane, 64, au, gain, 1, gd);   // (AM: exact arithmetic, thr stays 0: never guarded)
+        {
+            const float z = __builtin_fmaf(au[3], 0.0f, __builtin_fmaf(au[2], 0.0f, __builtin_fmaf(au[1], 0.0f, au[0] * 0.0f)));
+            nonfinite = nonfinite || (z != z);
+        }
+        W::store(rs_out, lane * W::kBytes, (int)pass * (256 * (W::kBytes / 4)), au);
+        // ---- 6. history: last NH-1 samples of both f32 rails and of both images to the front ----
+        if constexpr (AM == 0) {
+            const float2 ti = *reinterpret_cast<const float2 *>(dI + 256 + hv);
+            const float2 tq = *reinterpret_cast<const float2 *>(dQ + 256 + hv);
+            const uint32_t th = *reinterpret_cast<const uint32_t *>(Xh + GH::phys(256 + hv));
+            const uint32_t tl = *reinterpret_cast<const uint32_t *>(Xl + GH::phys(256 + hv));
+            lds_order();
+            *reinterpret_cast<float2 *>(dI + hv) = ti;
+            *reinterpret_cast<float2 *>(dQ + hv) = tq;
+            *reinterpret_cast<uint32_t *>(Xh + GH::phys(hv)) = th;
+            *reinterpret_cast<uint32_t *>(Xl + GH::phys(hv)) = tl;
+        }
+        lds_order();
+    }
+    // ---- parity guard: count (per-channel words: no atomics); SELENITE_ARITH_AUTO: a guarded channel keeps its pre-call state
+    // and raises its rerun flag (the flag of every channel is rewritten every call) ----
+    {
+        const bool keep_state = gd.n != 0u && p.rerun_flag != nullptr;   // wave-uniform
+        if (lane == 0) {
+            if (gd.n != 0u && p.guard_ch) { p.guard_ch[c] += gd.n; p.guard_calls[c] += 1u; }
+            if (p.rerun_flag) p.rerun_flag[c] = keep_state ? 1u : 0u;
+        }
+        if (keep_state) {
+            if (nonfinite) p.flags[0] = 1u;
+            return;
+        }
+    }
+    // ---- epilogue: arm_fir_f32 pState tails (the last NH-1 samples of each rail), exact f32 ----
+    if constexpr (AM == 0) {
+        if (2 * lane < GH::HH) {
+            float *stI = p.fir_state + (size_t)c * 2 * GH::HH, *stQ = stI + GH::HH;
+            const float2 ti = *reinterpret_cast<const float2 *>(dI + hv), tq = *reinterpret_cast<const float2 *>(dQ + hv);
+            stI[hv] = ti.x; stI[hv + 1] = ti.y;
+            stQ[hv] = tq.x; stQ[hv + 1] = tq.y;
+        }
+    }
+    if (nonfinite) p.flags[0] = 1u;                                   // ARM_MATH_NANINF, read by selenite_rx_sync
+    if (lane == 0) {
+        if constexpr (NCO != 0) p.phase[c] = ph0 + p.block_size * step;
+        if (p.agc) p.gain[c] = gain;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// host side: dispatch over the instantiated shapes
+// ------------------------------------------------------------------------------------------
+template <int NCO, int ND, int M, int NH, typename TIn, typename TOut, int AM, int GROUP>
+static hipError_t launch_k(const RxParams &p, const FusedArgs &fa, const void *src, void *dst, hipStream_t st)
+{
+    using GS = GeoS<NCO, ND, M, NH>;
+    constexpr size_t lds = (size_t)GS::total * sizeof(float);
+    static_assert(lds <= 48 * 1024, "k_ssb_split16 LDS image");
+#if SRX_SPLIT16_W2
+    if constexpr (GS::KS % 2 == 0 && NCO != 3 && M == 4) {
+        static const bool one_wave = std::getenv("SELENITE_RX_SPLIT16_W1") != nullptr;      // A/B: the one-wave kernel
+        if (!one_wave && p.nout % 256 == 0) {
+            constexpr size_t lds2 = lds + (512 + 4) * sizeof(float);                         // + partial sums + exponents
+            hipLaunchKernelGGL((k_ssb_split16w2<NCO, ND, M, NH, TIn, TOut, AM, GROUP>), dim3(p.channels), dim3(128), lds2, st, p, fa,
+                               static_cast<const TIn *>(src), static_cast<TOut *>(dst));
+            return hipGetLastError();
+        }
+    }
+#endif
+    // persistent grid: as many single-wave workgroups as the device keeps resident, each running channels
+    // b, b + grid, b + 2 grid, ...  (SELENITE_RX_SPLIT16_GRID=0: one workgroup per channel, the round-1 launch shape)
+    static int resident = 0;
+    if (resident == 0) {
+        int per_cu = 0, dev = 0;
+        hipDeviceProp_t prop;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_ssb_split16<NCO, ND, M, NH, TIn, TOut, AM, GROUP>, 64, lds) != hipSuccess ||
+            hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess || per_cu <= 0)
+            resident = -1;
+        else
+            resident = per_cu * prop.multiProcessorCount;
+        if (const char *e = std::getenv("SELENITE_RX_SPLIT16_GRID")) resident = std::atoi(e) > 0 ? std::atoi(e) : -1;
+    }
+    const uint32_t grid = resident > 0 && (uint32_t)resident < p.channels ? (uint32_t)resident : p.channels;
+    if constexpr (GROUP == 16 && AM == 0 && sizeof(TOut) == 4) {
+        if (p.env_part) {                         // global gain, phase 1: the flavour that also leaves the block maxima behind
+            hipLaunchKernelGGL((k_ssb_split16<NCO, ND, M, NH, TIn, TOut, AM, GROUP, 1>), dim3(grid), dim3(64), lds, st, p, fa,
+                               static_cast<const TIn *>(src), static_cast<TOut *>(dst));
+            return hipGetLastError();
+        }
+    }
+    if (p.env_part) return hipErrorNotSupported;  // the host side asks for the maxima only from launches that provide them
+    hipLaunchKernelGGL((k_ssb_split16<NCO, ND, M, NH, TIn, TOut, AM, GROUP>), dim3(grid), dim3(64), lds, st, p, fa,
+                       static_cast<const TIn *>(src), static_cast<TOut *>(dst));
+    return hipGetLastError();
+}
+
+// DSP-block geometry: 16 / 64 lanes per block (block = 256 / 1024 inputs) get the DPP reductions, any
+// other power of two the run-time variant; AM and the NCO-less chain (rare) only the run-time variant
+template <int NCO, int ND, int M, int NH, typename TIn, typename TOut>
+static hipError_t launch_io(const RxParams &p, const FusedArgs &fa, const void *src, void *dst, hipStream_t st)
+{
+    if (fa.am) return launch_k<NCO, ND, M, NH, TIn, TOut, 1, 0>(p, fa, src, dst, st);
+    if constexpr (NCO != 0 && M == 2) {
+        if (fa.group == 32) return launch_k<NCO, ND, M, NH, TIn, TOut, 0, 32>(p, fa, src, dst, st);      // DSP block 256 inputs / 2
+    } else if constexpr (NCO != 0) {
+        if (fa.group == 16) return launch_k<NCO, ND, M, NH, TIn, TOut, 0, 16>(p, fa, src, dst, st);
+        if (fa.group == 64) return launch_k<NCO, ND, M, NH, TIn, TOut, 0, 64>(p, fa, src, dst, st);
+    }
+    return launch_k<NCO, ND, M, NH, TIn, TOut, 0, 0>(p, fa, src, dst, st);
+}
+
+template <int ND, int M, int NH, typename T>
+static hipError_t launch_nco(const RxParams &p, const FusedArgs &fa, const void *src, void *dst, hipStream_t st)
+{
+    if constexpr (Geo<ND, M, NH>::T % 256 == 0) {
+        if (p.nco == 2 && p.lo_period == 256) return launch_io<3, ND, M, NH, T, T>(p, fa, src, dst, st);      // LO held in registers
+        if (p.nco == 1 && p.lo_period == 256) return launch_io<4, ND, M, NH, T, T>(p, fa, src, dst, st);      // every channel its own LO on the fs / 256 grid: in registers, computed once per channel
+    }
+    if (p.nco == 2) return launch_io<2, ND, M, NH, T, T>(p, fa, src, dst, st);
+    if (p.nco == 1) return launch_io<1, ND, M, NH, T, T>(p, fa, src, dst, st);
+    return launch_io<0, ND, M, NH, T, T>(p, fa, src, dst, st);
+}
+
+// the int16-slot instantiations of k_ssb_split16 live in rx_split16_q15.hip (a translation unit of its own: compiles in parallel)
+hipError_t launch_ssb_split16_q15(int nd, int m, int nh, const RxParams &p, const FusedArgs &fa, const void *src, void *dst, hipStream_t st);
+
+}  // namespace srx

@@ -6,7 +6,7 @@ set -e
 cd "$(dirname "$0")/../selenite-lite_amd"
 make -s -j8 libselenite_rx.so
 mkdir -p variants
-OTHERS=$(ls build/*.o | grep -v rx_split16)
+OTHERS=$(ls build/*.o | grep -v 'rx_split16.hip.o')       # (rx_split16_q15.hip.o, the int16 slots, comes from the regular build)
 for spec in "$@"; do
   name=${spec%%:*}; flags=${spec#*:}
   ( /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function --offload-arch=gfx950 \
