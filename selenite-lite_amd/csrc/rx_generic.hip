@@ -288,6 +288,41 @@ __global__ __launch_bounds__(64) void k_env_fold(const float *part, float *env, 
     if (threadIdx.x == 0) env[b] = m;
 }
 
+// The same for the common geometry -- f32 audio, DSP blocks of na audio samples with na | 256 and na >= 4, calls of whole
+// 256-sample rows -- with ONE wavefront streaming ONE channel in rows of 1 KiB (64 lanes x 16 bytes contiguous per
+// wave-instruction; the general kernel below gives a wavefront 64 / (na / 4) channels with 4 na bytes contiguous each: 256-byte
+// segments for na = 64, 4.0 TB/s).  The gains of the row's 256 / na blocks are wave-uniform: every lane runs the recurrence
+// (same operations, same order as k_agc_apply_global) and keeps the gain of the block its four samples belong to.
+template <int ARITH>
+__global__ __launch_bounds__(64) void k_agc_apply_global_rows(RxParams p, const float *audio, const float *env, float *dst)
+{
+    const int lane = threadIdx.x;
+    const uint32_t c = blockIdx.x;
+    const uint32_t na = p.block / p.decim, bpr = 256u / na, nrow = p.nout / 256u;      // blocks per row, rows per channel
+    const uint32_t myb = (4u * (uint32_t)lane) / na;                                  // this lane's block within a row
+    const float *a = audio + (size_t)c * p.out_stride + 4 * lane;
+    float *d = dst + (size_t)c * p.out_stride + 4 * lane;
+    float g = p.gain[c];
+    constexpr uint32_t RB = 4;                                                        // rows in flight (loads before stores: audio may alias dst)
+    for (uint32_t r0 = 0; r0 < nrow; r0 += RB) {
+        v4f v[RB];
+#pragma unroll
+        for (uint32_t k = 0; k < RB; ++k)
+            if (r0 + k < nrow) v[k] = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(a + (size_t)(r0 + k) * 256));
+#pragma unroll
+        for (uint32_t k = 0; k < RB; ++k)
+            if (r0 + k < nrow) {
+                float mine = g;
+                for (uint32_t b = 0; b < bpr; ++b) {
+                    g = agc_update<ARITH>(p.agcp, g, env[(r0 + k) * bpr + b]);
+                    mine = (b == myb) ? g : mine;
+                }
+                __builtin_nontemporal_store(v[k] * mine, reinterpret_cast<v4f *>(d + (size_t)(r0 + k) * 256));
+            }
+    }
+    if (lane == 0) p.gain[c] = g;
+}
+
 // gain recurrence on the shared envelope + arm_scale_f32 of every channel.  grid: one wavefront
 // per GlobalMap::cpw channels when na % 4 == 0 (launch_agc_apply_global sizes it), else per channel.
 template <int ARITH, typename TOut>
@@ -445,6 +480,11 @@ hipError_t launch_agc_apply_global(const RxParams &p, int arith, const float *au
                                    void *dst, bool dst_q15, hipStream_t st)
 {
     const uint32_t na = p.block / p.decim;
+    if (!dst_q15 && na >= 4 && 256u % na == 0 && p.nout % 256u == 0 && p.out_stride % 4u == 0) {     // 1 KiB rows, one wavefront per channel
+        if (arith != SELENITE_ARITH_CMSIS) hipLaunchKernelGGL(k_agc_apply_global_rows<1>, dim3(p.channels), dim3(64), 0, st, p, audio, env, (float *)dst);
+        else hipLaunchKernelGGL(k_agc_apply_global_rows<0>, dim3(p.channels), dim3(64), 0, st, p, audio, env, (float *)dst);
+        return hipGetLastError();
+    }
     const uint32_t cpw = (na % 4 == 0 && na / 4 < 64) ? 64 / (na / 4) : 1;
     const dim3 grid((p.channels + cpw - 1) / cpw), blk(64);
     if (arith != SELENITE_ARITH_CMSIS) {
