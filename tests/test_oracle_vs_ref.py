@@ -105,3 +105,26 @@ def test_chain_q15_and_global_gain(ref):
     a, b = rc.CpuChain(spec, "orc"), rc.CpuChain(spec, "ref")
     q = (np.random.default_rng(5).integers(-20000, 20000, (2, 512, 2))).astype(np.int16)
     assert np.array_equal(a.process_q15(q), b.process_q15(q))
+
+
+@pytest.mark.parametrize("shape,block", [((256, 4, 63), 96), ((0, 1, 63), 96), ((128, 2, 63), 96), ((256, 4, 127), 192), ((0, 1, 127), 48)])
+@pytest.mark.parametrize("q15", [False, True])
+def test_chain_in_the_firmware_block_geometry(shape, block, q15, ref):
+    """DSP blocks of 96 (192, 48) frames -- the I2S half-buffer of the firmware (Core/Inc/dsp_if.h:69-73), one slot per call and
+    several: the restatement against the composition of the real CMSIS-DSP primitives, bit for bit.  The GPU tests of
+    tests/test_gpu_short_calls.py compare the fused kernel with the restatement on exactly these configurations."""
+    nd, M, nh = shape
+    spec = rc.ChainSpec(5, block, M, nd, nh, 0, rc.MODE_LSB, rc.ARITH_CMSIS, nco=True, nco_step_all=0x00c00000, agc=True)
+    a, b = rc.CpuChain(spec, "orc"), rc.CpuChain(spec, "ref")
+    pos = 0
+    for bs in (block, 2 * block, 10 * block, 11 * block, block):
+        iq = rc.synth_iq(0, 5, pos, bs)
+        pos += bs
+        if q15:
+            q = np.clip(np.round(iq * 20000.0), -32768, 32767).astype(np.int16)
+            assert np.array_equal(a.process_q15(q), b.process_q15(q)), bs
+        else:
+            assert bits_equal(a.process(iq), b.process(iq)), bs
+    sa, sb = a.state(), b.state()
+    for k in sa:
+        assert np.array_equal(sa[k].view(np.uint32), sb[k].view(np.uint32)), k
