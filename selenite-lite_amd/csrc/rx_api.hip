@@ -547,6 +547,7 @@ static int run_part(selenite_rx_instance *S, const void *src, bool src_q15, void
         bool fq15 = dst_q15;
         if (global) {
             pf.agc = 0; fdst = audio; fq15 = false;
+            pf.out_cached = 1;                            // phase 2 (and, without block maxima from the kernel, the envelope fold) reads this audio back
             // k_ssb_split16 (16-lane DSP blocks, whole passes) leaves the block maxima of every channel behind: the
             // envelope reduction below then folds channels x blocks floats instead of reading the audio again
             if (ssb_fused && arith == SELENITE_ARITH_SPLIT16 && S->plan.d_btab16 && g.nd_taps && g.decim == 4 && (g.block / g.decim) / 4 == 16 &&

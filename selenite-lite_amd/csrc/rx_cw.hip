@@ -288,13 +288,15 @@ __global__ __launch_bounds__(64) void k_cw_fused(RxParams p, const TIn *__restri
                         nonfinite = nonfinite || (z != z);
                     }
                     const size_t o = (size_t)(c0 + r) * p.out_stride + n0 + t;
+                    // (non-temporal: written once, never read by the chain)
                     if constexpr (sizeof(TOut) == 4) {
-                        *reinterpret_cast<float4 *>(reinterpret_cast<float *>(dst) + o) = v;
+                        v4f *at = reinterpret_cast<v4f *>(reinterpret_cast<float *>(dst) + o);
+                        if (p.out_cached) *at = v4f{ v.x, v.y, v.z, v.w };       // global gain, phase 1: the gain pass reads it back
+                        else __builtin_nontemporal_store(v4f{ v.x, v.y, v.z, v.w }, at);
                     } else {
-                        short4 q4;
-                        q4.x = float_to_q15(v.x); q4.y = float_to_q15(v.y);
-                        q4.z = float_to_q15(v.z); q4.w = float_to_q15(v.w);
-                        *reinterpret_cast<short4 *>(reinterpret_cast<int16_t *>(dst) + o) = q4;
+                        typedef short s4v __attribute__((ext_vector_type(4)));
+                        __builtin_nontemporal_store(s4v{ float_to_q15(v.x), float_to_q15(v.y), float_to_q15(v.z), float_to_q15(v.w) },
+                                                    reinterpret_cast<s4v *>(reinterpret_cast<int16_t *>(dst) + o));
                     }
                 }
             }

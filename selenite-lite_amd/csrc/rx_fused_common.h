@@ -166,6 +166,11 @@ __device__ __forceinline__ void cmul_pk2(v2f A, v2f B, v2f LA, v2f LB, v2f &ra, 
 #ifndef SRX_IN_AUX
 #define SRX_IN_AUX 2             // cache policy of the streamed input loads (2 = nt)
 #endif
+#ifndef SRX_OUT_AUX
+#define SRX_OUT_AUX 2            // cache policy of the audio stores: 2 = nt.  Written once, never read by the chain: streaming them past the caches
+                                 // leaves the 256 MB Infinity Cache to the per-channel state, which IS read back by the next call (measured: -1.6 % time;
+                                 // the same policy on the state loads / stores costs +1.6 %: profiles/r3/README.md)
+#endif
 typedef unsigned int u4v __attribute__((ext_vector_type(4)));
 typedef unsigned int u2v __attribute__((ext_vector_type(2)));
 
@@ -210,20 +215,22 @@ template <> struct BRaw<int16_t> {
 template <typename T> struct BOut;
 template <> struct BOut<float> {
     static constexpr int kBytes = 16;
-    static __device__ __forceinline__ void store(__amdgpu_buffer_rsrc_t r, int voff, int soff, const float (&au)[4])
+    // cached: the audio will be read back (phase 1 of the global-gain call: the gain pass reads it) -- default policy instead of nt
+    static __device__ __forceinline__ void store(__amdgpu_buffer_rsrc_t r, int voff, int soff, const float (&au)[4], bool cached = false)
     {
         const u4v v = { __float_as_uint(au[0]), __float_as_uint(au[1]), __float_as_uint(au[2]), __float_as_uint(au[3]) };
-        __builtin_amdgcn_raw_buffer_store_b128(v, r, voff, soff, 0);
+        if (cached) __builtin_amdgcn_raw_buffer_store_b128(v, r, voff, soff, 0);
+        else __builtin_amdgcn_raw_buffer_store_b128(v, r, voff, soff, SRX_OUT_AUX);
     }
 };
 template <> struct BOut<int16_t> {
     static constexpr int kBytes = 8;
-    static __device__ __forceinline__ void store(__amdgpu_buffer_rsrc_t r, int voff, int soff, const float (&au)[4])
+    static __device__ __forceinline__ void store(__amdgpu_buffer_rsrc_t r, int voff, int soff, const float (&au)[4], bool = false)
     {
         const uint32_t a = (uint16_t)float_to_q15(au[0]), b = (uint16_t)float_to_q15(au[1]);
         const uint32_t c = (uint16_t)float_to_q15(au[2]), d = (uint16_t)float_to_q15(au[3]);
         const u2v v = { a | (b << 16), c | (d << 16) };
-        __builtin_amdgcn_raw_buffer_store_b64(v, r, voff, soff, 0);
+        __builtin_amdgcn_raw_buffer_store_b64(v, r, voff, soff, SRX_OUT_AUX);
     }
 };
 

@@ -135,13 +135,15 @@ __device__ __forceinline__ void demod_agc_store(const RxParams &p, const FusedAr
     }
     const size_t o = out_index + 4 * lane;
     if (live) {
+        // (non-temporal: the audio is written once and never read by the chain -- the caches are left to the streaming state)
         if constexpr (sizeof(TOut) == 4) {
-            *reinterpret_cast<float4 *>(reinterpret_cast<float *>(dst) + o) = make_float4(au[0], au[1], au[2], au[3]);
+            v4f *at = reinterpret_cast<v4f *>(reinterpret_cast<float *>(dst) + o);
+            if (p.out_cached) *at = v4f{ au[0], au[1], au[2], au[3] };          // global gain, phase 1: the gain pass reads it back
+            else __builtin_nontemporal_store(v4f{ au[0], au[1], au[2], au[3] }, at);
         } else {
-            short4 s4;
-            s4.x = float_to_q15(au[0]); s4.y = float_to_q15(au[1]);
-            s4.z = float_to_q15(au[2]); s4.w = float_to_q15(au[3]);
-            *reinterpret_cast<short4 *>(reinterpret_cast<int16_t *>(dst) + o) = s4;
+            typedef short s4v __attribute__((ext_vector_type(4)));
+            __builtin_nontemporal_store(s4v{ float_to_q15(au[0]), float_to_q15(au[1]), float_to_q15(au[2]), float_to_q15(au[3]) },
+                                        reinterpret_cast<s4v *>(reinterpret_cast<int16_t *>(dst) + o));
         }
     }
 }

@@ -27,6 +27,8 @@ struct RxParams {
     uint32_t in_stride;    // complex samples between consecutive channels in the source buffer (>= block_size)
     uint32_t out_stride;   // audio samples between consecutive channels in the destination buffer (>= nout)
     uint32_t pass_out;     // generic front kernel: decimated outputs per pass
+    uint32_t out_cached;   // 1: the audio this launch writes is read back by a later kernel of the same call (global gain, phase 1):
+                           // default store policy; 0: written once -- non-temporal stores
     const float *dec_c, *hilb_c, *delay_c, *biq_c, *sintab;
     const float2 *lo;      // nco == 2: LO[n] = (cos, -sin) for the samples of this call (all channels share it)
     uint32_t lo_period;    // nco == 2: 256 when LO[n + 256] == LO[n] for every n (NCO step a multiple of 2^24), else 0;

@@ -33,6 +33,29 @@
 
 namespace srx {
 
+// streaming state of a channel: written by one call and read back by the next -- 0.17 GB for 65 536 channels, which the 256 MB
+// Infinity Cache can hold between calls if nothing streams through it: plain (cacheable) accesses; the non-temporal variant
+// (A/B knob SRX_STATE_NT=1) measured 1.6 % slower
+#ifndef SRX_STATE_NT
+#define SRX_STATE_NT 0
+#endif
+__device__ __forceinline__ float st_ld(const float *p)
+{
+#if SRX_STATE_NT
+    return __builtin_nontemporal_load(p);
+#else
+    return *p;
+#endif
+}
+__device__ __forceinline__ void st_st(float *p, float v)
+{
+#if SRX_STATE_NT
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
+
 __device__ __forceinline__ float amax2(v2f x, float m) { return fmaxf(fmaxf(fabsf(x.x), fabsf(x.y)), m); }
 
 // memory-order point for the single-wave workgroups of this file: LDS operations of a wave execute in
@@ -274,14 +297,14 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
 #pragma unroll
         for (int j = 0; j < NHI; ++j) {
             const int s = j * kWave + lane - G::F, sc = s < 0 ? 0 : s;
-            const float xi = stI[sc], xq = stQ[sc];
+            const float xi = st_ld(stI + sc), xq = st_ld(stQ + sc);
             st_hv[j] = s < 0 ? v2f{ 0.0f, 0.0f } : v2f{ xi, xq };
         }
 #pragma unroll
         for (int j = 0; j < NFI; ++j) {
             const int i = j * kWave + lane;
             const int rail = i / G::HH4, sidx = i % G::HH4 - G::FH;
-            const float x = stF[rail * G::HH + (sidx < 0 ? 0 : sidx)];
+            const float x = st_ld(stF + rail * G::HH + (sidx < 0 ? 0 : sidx));
             st_fv[j] = sidx < 0 ? 0.0f : x;
         }
         st_ph0 = NCO ? p.phase[ch] : 0u;
@@ -616,7 +639,7 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
 #ifdef SRX_X_NOSTORE
         asm volatile("" :: "v"(au[0]), "v"(au[1]), "v"(au[2]), "v"(au[3]));
 #else
-        W::store(rs_out, lane * W::kBytes, (int)q * (G::P * (W::kBytes / 4)), au);
+        W::store(rs_out, lane * W::kBytes, (int)q * (G::P * (W::kBytes / 4)), au, ENV != 0);      // (ENV: phase 1 of the global-gain call -- the gain pass reads this audio back: default policy, known at compile time)
 #endif
         if constexpr (GROUP == 16 && ENV != 0) {
             {
@@ -697,14 +720,14 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
             for (int j = 0; j < GS::HS / kWave; ++j) {
                 const int s = j * kWave + lane - G::F;
                 const v2f h = Hf[j * kWave + lane];
-                if (s >= 0) { stI[s] = h.x; stQ[s] = h.y; }
+                if (s >= 0) { st_st(stI + s, h.x); st_st(stQ + s, h.y); }
             }
         }
         if constexpr (AM == 0) {                                      // AM never ran the Hilbert pair: its state stays
             if (!keep_state)
                 for (int i = lane; i < 2 * G::HH4; i += kWave) {
                     const int rail = i / G::HH4, mi = i % G::HH4, s = mi - G::FH;
-                    if (s >= 0) p.fir_state[((size_t)c * 2 + rail) * G::HH + s] = D[rail * G::DLEN + tail_out + mi];
+                    if (s >= 0) st_st(p.fir_state + ((size_t)c * 2 + rail) * G::HH + s, D[rail * G::DLEN + tail_out + mi]);
                 }
         }
         if (lane == 0 && !keep_state) {

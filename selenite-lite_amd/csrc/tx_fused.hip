@@ -50,6 +50,7 @@ __device__ __forceinline__ float lane_bcast(float v, int l)
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
 }
 
+typedef float tx_v4f __attribute__((ext_vector_type(4)));
 template <typename T> struct AudioIO;
 template <> struct AudioIO<float> {
     typedef float4 raw;
@@ -57,9 +58,9 @@ template <> struct AudioIO<float> {
     static __device__ __forceinline__ void unpack(const raw &r, float (&a)[4]) { a[0] = r.x; a[1] = r.y; a[2] = r.z; a[3] = r.w; }
     static __device__ __forceinline__ void store4(float *p, size_t cplx, const v2f (&o)[4])
     {
-        float4 *d = reinterpret_cast<float4 *>(p + 2 * cplx);
-        d[0] = make_float4(o[0].x, o[0].y, o[1].x, o[1].y);
-        d[1] = make_float4(o[2].x, o[2].y, o[3].x, o[3].y);
+        tx_v4f *d = reinterpret_cast<tx_v4f *>(p + 2 * cplx);                    // non-temporal: written once, never read back
+        __builtin_nontemporal_store(tx_v4f{ o[0].x, o[0].y, o[1].x, o[1].y }, d);
+        __builtin_nontemporal_store(tx_v4f{ o[2].x, o[2].y, o[3].x, o[3].y }, d + 1);
     }
 };
 template <> struct AudioIO<int16_t> {
@@ -509,7 +510,7 @@ __global__ __launch_bounds__(64, 2) void k_tx_split16(TxParams p, uint32_t delay
                 }
                 const size_t at = out_base + (size_t)pass * kPass * kL + o;
                 if constexpr (sizeof(TOut) == 4) {
-                    *reinterpret_cast<float4 *>(reinterpret_cast<float *>(dst) + 2 * at) = make_float4(y0.x, y0.y, y1.x, y1.y);
+                    __builtin_nontemporal_store(v4f{ y0.x, y0.y, y1.x, y1.y }, reinterpret_cast<v4f *>(reinterpret_cast<float *>(dst) + 2 * at));   // written once, never read back
                 } else {
                     short4 q;
                     q.x = float_to_q15(y0.x); q.y = float_to_q15(y0.y); q.z = float_to_q15(y1.x); q.w = float_to_q15(y1.y);
