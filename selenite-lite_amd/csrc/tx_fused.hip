@@ -54,7 +54,11 @@ typedef float tx_v4f __attribute__((ext_vector_type(4)));
 template <typename T> struct AudioIO;
 template <> struct AudioIO<float> {
     typedef float4 raw;
-    static __device__ __forceinline__ raw load(const float *p, size_t i) { return *reinterpret_cast<const float4 *>(p + i); }
+    static __device__ __forceinline__ raw load(const float *p, size_t i)      // non-temporal: streamed once
+    {
+        const tx_v4f v = __builtin_nontemporal_load(reinterpret_cast<const tx_v4f *>(p + i));
+        return make_float4(v.x, v.y, v.z, v.w);
+    }
     static __device__ __forceinline__ void unpack(const raw &r, float (&a)[4]) { a[0] = r.x; a[1] = r.y; a[2] = r.z; a[3] = r.w; }
     static __device__ __forceinline__ void store4(float *p, size_t cplx, const v2f (&o)[4])
     {
