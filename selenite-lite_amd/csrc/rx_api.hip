@@ -110,7 +110,7 @@ static void classify_coeffs(selenite_rx_instance *S)
 
 static void free_device(selenite_rx_instance *S)
 {
-    void *ptrs[] = { S->d_flags, S->d_guard_ch, S->d_rerun_flag, S->d_dec_c, S->d_hilb_c, S->d_delay_c, S->d_biq_c, S->d_sintab, S->d_step, S->d_phase,
+    void *ptrs[] = { S->d_flags, S->d_guard_ch, S->d_rerun_flag, S->d_conv_in, S->d_dec_c, S->d_hilb_c, S->d_delay_c, S->d_biq_c, S->d_sintab, S->d_step, S->d_phase,
                      S->d_dec_state, S->d_fir_state, S->d_biq_state, S->d_gain, S->d_scratch, S->d_env, S->d_env_part,
                      S->d_io_in, S->d_io_out, S->d_lo, S->pipe.d_in[0], S->pipe.d_in[1], S->pipe.d_out[0], S->pipe.d_out[1] };
     for (void *p : ptrs)
@@ -501,11 +501,22 @@ static int run_part(selenite_rx_instance *S, const void *src, bool src_q15, void
 
     // Fused kernels serve the global-gain variant too: they run with their own AGC off (un-scaled
     // audio out), then the envelope reduction and the gain pass below finish the call.
-    // (the fused kernels convert in and out symmetrically: int16 slots with a global gain, which
-    // needs f32 audio between the two phases, stay on the generic kernels)
-    const bool fusable = phase != kPhase2 && !S->force_generic && !(global && src_q15);
+    // (the fused kernels convert in and out symmetrically, and a global gain needs f32 audio between its two phases: int16 slots with
+    // a global gain get their input converted once, up front -- arm_q15_to_float over the whole buffer, the very operation the fused
+    // int16 load performs -- and run as an f32-input call whose gain pass stores int16; round 2 left them to the generic kernels)
+    const bool fusable = phase != kPhase2 && !S->force_generic;
     const bool ssb_fused = fusable && S->plan.kind != 0;
     const bool cw_fused = fusable && cw_fused_ok(g, block_size);
+    if (global && src_q15 && (ssb_fused || cw_fused)) {
+        const size_t nval = (size_t)p.channels * p.in_stride * 2;            // int16 values of the call (block_size % 4 == 0 for every fused shape)
+        if (nval % 8 == 0) {
+            int rc = ensure(S, (void **)&S->d_conv_in, &S->conv_in_bytes, nval * sizeof(float));
+            if (rc) return rc;
+            HIPCHK(S, launch_q15_to_f32(static_cast<const int16_t *>(src), S->d_conv_in, nval, S->stream));
+            src = S->d_conv_in;
+            src_q15 = false;
+        }
+    }
     float *audio = (float *)dst;      // un-scaled audio: dst itself when dst is f32, else scratch
     if (dst_q15 && (global || !(ssb_fused || cw_fused))) {
         const size_t need = (size_t)g.channels * p.out_stride * sizeof(float);

@@ -476,6 +476,31 @@ hipError_t launch_env_global(const RxParams &p, const float *audio, float *part,
     return hipGetLastError();
 }
 
+// arm_q15_to_float (SupportFunctions/arm_q15_to_float.c:87: (float)x / 32768.0f) over a whole buffer: eight values per thread and step,
+// streamed (non-temporal both ways).  Used for int16 slots with a global gain: the fused kernels convert in and out symmetrically,
+// and the global gain needs f32 audio between its two phases -- so the input is converted once, up front, and the call runs as an
+// f32-input call whose gain pass stores int16 (the same operations on the same values as the fused int16 load: bit-identical)
+__global__ __launch_bounds__(256) void k_q15_to_f32(const int16_t *__restrict__ src, float *__restrict__ dst, size_t n8)
+{
+    typedef short s8v __attribute__((ext_vector_type(8)));
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
+        const s8v v = __builtin_nontemporal_load(reinterpret_cast<const s8v *>(src) + i);
+        v4f a = { q15_to_float(v[0]), q15_to_float(v[1]), q15_to_float(v[2]), q15_to_float(v[3]) };
+        v4f b = { q15_to_float(v[4]), q15_to_float(v[5]), q15_to_float(v[6]), q15_to_float(v[7]) };
+        __builtin_nontemporal_store(a, reinterpret_cast<v4f *>(dst) + 2 * i);
+        __builtin_nontemporal_store(b, reinterpret_cast<v4f *>(dst) + 2 * i + 1);
+    }
+}
+
+hipError_t launch_q15_to_f32(const int16_t *src, float *dst, size_t n, hipStream_t st)
+{
+    if (n % 8 != 0) return hipErrorInvalidValue;
+    const size_t n8 = n / 8;
+    const unsigned grid = (unsigned)((n8 + 255) / 256 < 16384 ? (n8 + 255) / 256 : 16384);
+    hipLaunchKernelGGL(k_q15_to_f32, dim3(grid ? grid : 1), dim3(256), 0, st, src, dst, n8);
+    return hipGetLastError();
+}
+
 hipError_t launch_agc_apply_global(const RxParams &p, int arith, const float *audio, const float *env,
                                    void *dst, bool dst_q15, hipStream_t st)
 {

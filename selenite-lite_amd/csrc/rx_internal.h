@@ -73,6 +73,8 @@ __host__ __device__ inline bool mode_is_upper(uint32_t m)
 hipError_t launch_front_generic(const RxParams &p, int arith, const void *src, bool src_q15,
                                 float *audio, hipStream_t st);
 size_t front_generic_lds_bytes(const RxParams &p);
+// arm_q15_to_float over a whole buffer (SupportFunctions/arm_q15_to_float.c:87): n int16 values -> n floats
+hipError_t launch_q15_to_f32(const int16_t *src, float *dst, size_t n, hipStream_t st);
 // CW biquad cascade, in place on f32 audio
 hipError_t launch_biquad_generic(const RxParams &p, int arith, float *audio, hipStream_t st);
 // per-channel AGC (or plain copy/convert when p.agc == 0): audio -> dst
@@ -146,6 +148,7 @@ struct selenite_rx_instance {
     float guard_ratio = 0.25f;         // -12 dB
     bool steps_grid256 = false;        // every NCO step is a multiple of 2^24: every channel's LO repeats every 256 samples
     float *d_scratch = nullptr;  size_t scratch_bytes = 0;   // intermediate f32 audio
+    float *d_conv_in = nullptr;  size_t conv_in_bytes = 0;   // f32 copy of int16 input (int16 slots with a global gain on the fused kernels)
     float *d_env = nullptr;      size_t env_cap = 0;
     float *d_env_part = nullptr; size_t env_part_cap = 0;   // per-wavefront envelope maxima
     void *d_io_in = nullptr;     size_t io_in_bytes = 0;     // staging for the host-pointer entry points (global-gain calls)

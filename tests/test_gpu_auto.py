@@ -332,3 +332,26 @@ def test_per_channel_grid_lo_on_the_exact_kernels(shape, arith):
     for key in sg:
         assert (bits_equal(sg[key], so[key]) if sg[key].dtype == np.float32 else np.array_equal(sg[key], so[key])), key
     g.close()
+
+
+def test_int16_slots_with_a_global_gain_run_on_the_fused_kernels():
+    """Round 2 sent int16 slots with agc_global to the generic kernels (the fused kernels convert in and out symmetrically, the
+    global gain needs f32 audio between its phases): 4.5 ms for the bench shape.  Now the input is converted once
+    (arm_q15_to_float over the whole buffer) and the call runs fused: bit-exact in the exact modes, within one LSB in the
+    split-precision ones, CW included."""
+    import selenite_rx as sr
+    nch = 40
+    for name, arith, exact in (("cfg3", ARITH_CMSIS, True), ("cfg3", rc.ARITH_FMA, True), ("cfg3", ARITH_SPLIT16, False),
+                               ("cfg3", ARITH_AUTO, False), ("cfg4", ARITH_CMSIS, True), ("cfg2", ARITH_AUTO, False)):
+        g = sr.Rx(rc.baseline_spec(name, nch, arith, agc_global=True).config())
+        o = CpuChain(rc.baseline_spec(name, nch, arith if exact else ARITH_CMSIS, agc_global=True), "orc")
+        assert g.kernel_name() != "generic"
+        for call, bs in enumerate((1024, 2048, 768)):
+            iq = synth_iq(0, nch, 4096 * call, bs)
+            q = np.clip(np.trunc(iq * 32768.0), -32768, 32767).astype(np.int16)
+            yg, yo = g.process_q15(q), o.process_q15(q)
+            if exact:
+                assert np.array_equal(yg, yo), (name, arith, call)
+            else:
+                assert np.abs(yg.astype(np.int32) - yo).max() <= 1, (name, arith, call)
+        g.close()
