@@ -15,8 +15,8 @@ run --arith split16
 run --nco shared_table
 run --nco per_channel_grid --arith split16
 run --nco per_channel --arith split16
-run --nco per_channel_grid
-run --nco per_channel_grid --arith cmsis
+run --nco per_channel_grid_wide
+run --nco per_channel_grid_wide --arith cmsis
 run --io q15
 run --global-gain
 run --global-gain --arith split16
