@@ -561,7 +561,7 @@ static int run_part(selenite_rx_instance *S, const void *src, bool src_q15, void
             pf.out_cached = 1;                            // phase 2 (and, without block maxima from the kernel, the envelope fold) reads this audio back
             // k_ssb_split16 (16-lane DSP blocks, whole passes) leaves the block maxima of every channel behind: the
             // envelope reduction below then folds channels x blocks floats instead of reading the audio again
-            if (ssb_fused && arith == SELENITE_ARITH_SPLIT16 && S->plan.d_btab16 && g.nd_taps && g.decim == 4 && (g.block / g.decim) / 4 == 16 &&
+            if (ssb_fused && (arith == SELENITE_ARITH_SPLIT16 || arith == SELENITE_ARITH_AUTO) && S->plan.d_btab16 && g.nd_taps && g.decim == 4 && (g.block / g.decim) / 4 == 16 &&
                 (block_size / g.decim) % 256 == 0 && g.nco_enable && g.mode != SELENITE_MODE_AM) {   // the launches with the DPP block reductions (decimation by 4, 64-sample audio blocks)
                 const size_t need = sizeof(float) * env_fold_scratch_floats(p.channels, block_size / g.block);
                 int rc = ensure(S, (void **)&S->d_env_part, &S->env_part_cap, need);

@@ -60,7 +60,10 @@ __device__ __forceinline__ void demod_agc_store(const RxParams &p, const FusedAr
                                                 const float *dQ, int lane, int group,
                                                 const float (&hreg)[(NH + 63) / 64 ? (NH + 63) / 64 : 1], float &gain,
                                                 TOut *__restrict__ dst, size_t out_index, bool &nonfinite,
-                                                int nvb = 64)        // DSP blocks of this pass that exist (whole passes: all of them)
+                                                int nvb = 64,        // DSP blocks of this pass that exist (whole passes: all of them)
+                                                float *env_row = nullptr)   // global gain, phase 1, as the rerun pass of SELENITE_ARITH_AUTO:
+                                                                            // max |audio| of the pass's DSP blocks goes here (what the split16 kernel left
+                                                                            // for this channel came from the arithmetic being replaced)
 {
     using G = Geo<ND, M, NH>;
     float au[4];
@@ -82,6 +85,20 @@ __device__ __forceinline__ void demod_agc_store(const RxParams &p, const FusedAr
     } else {
         const float4 v = lds_ld4f(dI + 4 * lane);
         au[0] = v.x; au[1] = v.y; au[2] = v.z; au[3] = v.w;
+    }
+    if (env_row) {                                                // (wave-uniform; the AGC is off in this launch)
+        const int gl = GROUP ? GROUP : group;
+        float m = fmaxf(fmaxf(fabsf(au[0]), fabsf(au[1])), fmaxf(fabsf(au[2]), fabsf(au[3])));
+        if ((gl & (gl - 1)) == 0) {
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1)
+                if (off < gl) m = fmaxf(m, __shfl_xor(m, off, 64));
+        } else {
+            float mm = 0.0f;
+            for (int j = 0; j < gl; ++j) mm = fmaxf(mm, __shfl(m, ((lane / gl) * gl + j) & 63, 64));
+            m = mm;
+        }
+        if (lane % gl == 0 && lane / gl < nvb) env_row[lane / gl] = m;
     }
     // AGC: arm_abs + arm_max per DSP block (group lanes), gain law, arm_scale
     if (p.agc) {
@@ -306,12 +323,14 @@ __global__ __launch_bounds__(64, 2) void k_ssb_fused(RxParams p, FusedArgs fa, c
         }
         // ---- 3-5. Hilbert pair + sideband, AGC, store ----
         const int nvb = (int)(cur / (4u * (uint32_t)group));          // DSP blocks of this pass
+        // (rerun pass of AUTO inside a global-gain call whose split16 kernel emitted block maxima: refresh this channel's row)
+        float *env_row = (p.chan_flags && p.env_part) ? p.env_part + (size_t)c * (p.block_size / p.block) + (size_t)pass * (pq / (4u * (uint32_t)group)) : nullptr;
         if (group == 16)
-            demod_agc_store<ARITH, 16, ND, M, NH, TOut, AM>(p, fa, dI, dQ, lane, group, hreg, gain, dst, out_base + (size_t)pass * pq, nonfinite, nvb);
+            demod_agc_store<ARITH, 16, ND, M, NH, TOut, AM>(p, fa, dI, dQ, lane, group, hreg, gain, dst, out_base + (size_t)pass * pq, nonfinite, nvb, env_row);
         else if (group == 64)
-            demod_agc_store<ARITH, 64, ND, M, NH, TOut, AM>(p, fa, dI, dQ, lane, group, hreg, gain, dst, out_base + (size_t)pass * pq, nonfinite, nvb);
+            demod_agc_store<ARITH, 64, ND, M, NH, TOut, AM>(p, fa, dI, dQ, lane, group, hreg, gain, dst, out_base + (size_t)pass * pq, nonfinite, nvb, env_row);
         else
-            demod_agc_store<ARITH, 0, ND, M, NH, TOut, AM>(p, fa, dI, dQ, lane, group, hreg, gain, dst, out_base + (size_t)pass * pq, nonfinite, nvb);
+            demod_agc_store<ARITH, 0, ND, M, NH, TOut, AM>(p, fa, dI, dQ, lane, group, hreg, gain, dst, out_base + (size_t)pass * pq, nonfinite, nvb, env_row);
         wave_lds_sync();
         // ---- 6. history copy-back (arm_fir_decimate_f32.c:396-426, arm_fir_f32.c:947-978) ----
         if constexpr (ND > 0) {
