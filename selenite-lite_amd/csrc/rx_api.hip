@@ -316,7 +316,7 @@ static bool periodic_lo(const selenite_rx_instance *S)
     const selenite_rx_config &g = S->cfg;
     if (!(g.nco_enable && S->steps_uniform && (S->h_step[0] & 0x00FFFFFFu) == 0 && !S->no_periodic_lo)) return false;
     if ((g.arith == SELENITE_ARITH_SPLIT16 || g.arith == SELENITE_ARITH_AUTO) && S->plan.d_btab16 && g.nd_taps)
-        return ssb_split16_periodic_lo((int)g.nd_taps, (int)g.decim, (int)g.nh_taps);
+        return 256u % (g.block / g.decim) == 0 && ssb_split16_periodic_lo((int)g.nd_taps, (int)g.decim, (int)g.nh_taps);
     if (g.arith == SELENITE_ARITH_AUTO) return false;      // (runs the bit-exact k_ssb_fused)
     // k_ssb_mfma (fma arithmetic, and split16 shapes without a matrix kernel of their own): decimation by 4, 1024-sample passes
     return g.arith != SELENITE_ARITH_CMSIS && S->plan.use_mfma && g.nd_taps && g.decim == 4;
@@ -617,7 +617,7 @@ static int run_chain(selenite_rx_instance *S, const void *src, bool src_q15, voi
     const uint32_t nout = block_size / g.decim;
     const bool global = g.agc_enable && g.agc_global;
     if (phase == kAll && !global && !S->force_generic && S->plan.kind != 0 && fused_tail_split(S->plan, g, block_size)) {
-        const uint32_t unit = 256u * g.decim, bs1 = block_size / unit * unit;
+        const uint32_t na = g.block / g.decim, unit = 256u / na * na * g.decim, bs1 = block_size / unit * unit;
         {
             int rc = run_part(S, src, src_q15, dst, dst_q15, bs1, kAll, nullptr, block_size, nout);
             if (rc) return rc;

@@ -497,7 +497,10 @@ static hipError_t launch_shape(const RxParams &p, const FusedArgs &fa, const Fus
     // 96-frame blocks -- runs on k_ssb_fused, whose passes have variable length.
     const bool whole = fa.pass_out == 256 && p.nout % 256 == 0;
     constexpr uint32_t kHS = ND ? (uint32_t)(((((ND - 1 + M - 1) / M) + 3) & ~3) * M) : 0u;      // GeoS::HS: decimator history in the image
-    const bool split_ok = fa.pass_out == 256 && (whole || p.block_size % (256u * M) >= kHS);
+    // k_ssb_split16 also takes passes of fewer than 256 outputs when they are whole 16-output tiles (240 for the firmware's
+    // 96-frame blocks by 4, 192 for its 96-sample audio blocks): its run-time DSP-block flavour advances by pass_out * M samples
+    const uint32_t tq = fa.pass_out * M;
+    const bool split_ok = split16_pass_ok(fa.pass_out) && (p.block_size % tq == 0 || p.block_size % tq >= kHS);
     if constexpr (ND > 0 && (M == 4 || M == 2) && NH > 0) {
         if (split && plan.d_btab16 && split_ok) {
             hipError_t e = launch_ssb_split16(ND, M, NH, p, fa, src, src_q15, dst, st);      // rx_split16.hip
@@ -570,8 +573,9 @@ hipError_t plan_fused(const selenite_rx_config &g, bool delay_is_impulse, int de
     (void)name;
     if (plan.use_mfma && g.arith != SELENITE_ARITH_CMSIS) plan.name_buf = "k_ssb_mfma" + shape;     // split16 without a matrix kernel of its own runs as fma
     if (g.arith == SELENITE_ARITH_AUTO) plan.name_buf = "k_ssb_fused" + shape;                      // without a matrix kernel of its own: bit-exact
+    const bool split_pass = g.nd_taps ? split16_pass_ok(256u / na * na) : 256 % na == 0;
     if (256 % na != 0) plan.name_buf = "k_ssb_fused" + shape;                                        // DSP blocks that do not divide a pass: variable-length passes
-    else if (plan.d_btab16 && (g.arith == SELENITE_ARITH_SPLIT16 || g.arith == SELENITE_ARITH_AUTO)) {
+    if (split_pass && plan.d_btab16 && (g.arith == SELENITE_ARITH_SPLIT16 || g.arith == SELENITE_ARITH_AUTO)) {
         const char *tail = g.arith == SELENITE_ARITH_AUTO ? "+exact rerun of guarded channels" : "";
         if (g.nd_taps) plan.name_buf = "k_ssb_split16" + shape + tail;
         else if (na == 256) plan.name_buf = "k_hilb_split16<" + std::to_string(g.nh_taps) + ">" + tail;
@@ -599,8 +603,8 @@ bool fused_tail_split(const FusedPlan &plan, const selenite_rx_config &g, uint32
     // short for k_ssb_split16 (it wants a whole decimator history in it; only DSP blocks shorter than that history get there):
     // the whole passes stay on the matrix kernel, the tail goes to k_ssb_fused -- true when the call should be cut that way.
     if (!(g.arith == SELENITE_ARITH_SPLIT16 || g.arith == SELENITE_ARITH_AUTO) || !plan.d_btab16 || !g.nd_taps) return false;
-    const uint32_t na = g.block / g.decim, unit = 256u * g.decim;
-    if (256u % na != 0 || block_size % unit == 0 || block_size < unit) return false;
+    const uint32_t na = g.block / g.decim, pq = 256u / na * na, unit = pq * g.decim;
+    if (!split16_pass_ok(pq) || block_size % unit == 0 || block_size < unit) return false;
     const uint32_t hq = (g.nd_taps - 1 + g.decim - 1) / g.decim, hs = ((hq + 3) & ~3u) * g.decim;    // GeoS::HS
     return block_size % unit < hs;
 }

@@ -105,6 +105,8 @@ struct FusedPlan {
 hipError_t plan_fused(const selenite_rx_config &cfg, bool delay_is_impulse, int delay_index,
                       bool hilb_odd_only, FusedPlan &plan);
 void free_fused(FusedPlan &plan);
+// passes k_ssb_split16 runs: 256 audio samples, or fewer when the DSP block does not divide 256 -- whole 16-output tiles
+inline bool split16_pass_ok(uint32_t pass_out) { return pass_out != 0 && pass_out <= 256u && pass_out % 16u == 0; }
 bool fused_tail_split(const FusedPlan &plan, const selenite_rx_config &cfg, uint32_t block_size);
 hipError_t launch_fused(const FusedPlan &plan, const RxParams &p, int arith, const void *src,
                         bool src_q15, void *dst, bool dst_q15, int delay_index, hipStream_t st);

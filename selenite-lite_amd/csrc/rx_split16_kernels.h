@@ -127,9 +127,15 @@ __device__ __forceinline__ void agc_pass(const AgcParams &ap, uint32_t agc_on, i
         g = agc_step(ap, g, agc_desired(ap, m));
         mine = g;
     } else {
+        if ((group & (group - 1)) == 0) {
 #pragma unroll
-        for (int off = 1; off < 64; off <<= 1)
-            if (off < group) m = fmaxf(m, __shfl_xor(m, off, 64));
+            for (int off = 1; off < 64; off <<= 1)
+                if (off < group) m = fmaxf(m, __shfl_xor(m, off, 64));
+        } else {                                     // e.g. 6 lanes: the firmware's 96-frame blocks by 4 (dsp_if.h:69-73)
+            float mm = 0.0f;
+            for (int j = 0; j < group; ++j) mm = fmaxf(mm, __shfl(m, ((lane / group) * group + j) & 63, 64));
+            m = mm;
+        }
         guard(m);
         const int nblk = min(64 / group, nvb), myblk = lane / group;
         for (int b = 0; b < nblk; ++b) {
@@ -201,8 +207,13 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
     // missing input reads as zeros and its surplus audio is dropped by the buffer range checks, the streaming state
     // and the AGC are taken from the part that exists (the host side sends such calls here only when that part holds
     // a whole decimator history: tail_in >= HS)
-    const uint32_t npass = (p.nout + G::P - 1) / G::P;
-    const uint32_t tail_out = p.nout - (npass - 1) * G::P;       // audio samples of the last pass: P when the call is whole passes
+    // a full pass produces pq audio samples: 256, or (GROUP == 0 launches only) the largest whole number of DSP blocks in 256 when the
+    // block does not divide it -- 240 for the firmware's 96-frame blocks by 4 (dsp_if.h:69-73).  Such passes run the "partial" code
+    // path every time: the tile is computed in full, 16 of its outputs are dropped, the histories advance by pq * M samples.
+    const uint32_t pq = GROUP == 0 ? fa.pass_out : (uint32_t)G::P, tq = pq * M;
+    const uint32_t npass = (p.nout + pq - 1) / pq;
+    const uint32_t tail_out = p.nout - (npass - 1) * pq;         // audio samples of the last pass: pq when the call is whole passes
+    auto cur_out = [&](uint32_t pass) { return pass + 1 == npass ? tail_out : pq; };
     auto in_rsrc = [&](uint32_t ch) {                             // a channel past the last one: empty range, loads return zeros
         return make_rsrc(src + (size_t)ch * p.in_stride * 2, ch < p.channels ? p.block_size * (R::kBytes / 2) : 0u);
     };
@@ -215,7 +226,7 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
     auto env_rsrc = [&](uint32_t ch) { return make_rsrc(p.env_part + (size_t)ch * env_nblk, env_nblk * 4u); };
     __amdgpu_buffer_rsrc_t rs_env = env_rsrc(ENV ? c : 0u);
     const __amdgpu_buffer_rsrc_t rs_lo = make_rsrc(p.lo, NCO == 2 ? p.block_size * 8u : 0u);
-    constexpr int kInPass = G::T * (R::kBytes / 2);               // input bytes of one pass
+    const int kInPass = (int)tq * (R::kBytes / 2);                // input bytes a pass advances by
 
     typename R::type raw[NLD];
     // shared LO (NCO == 2): an L2-resident table, so only LOD wave loads are kept in flight: the first LOD of a
@@ -225,7 +236,7 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
     auto lo_load = [&](int slot, int i, int sl) {
         lo4[slot] = __builtin_amdgcn_raw_buffer_load_b128(rs_lo, lane * 16 + i * 1024, sl, SRX_LO_AUX);
     };
-    auto lo_base = [&](uint32_t pass) { return pass < npass ? (int)pass * G::T * 8 : 0; };   // pass == npass: the next channel's pass 0
+    auto lo_base = [&](uint32_t pass) { return pass < npass ? (int)(pass * tq) * 8 : 0; };   // pass == npass: the next channel's pass 0
     // periodic shared LO (NCO == 3: the table repeats every 256 samples and a pass is a whole number of periods): load
     // i of any pass multiplies by LO[(128 i + 2 lane, + 1) mod 256] -- two register quads for the whole kernel
     // (NCO == 4: the same for a PER-CHANNEL step that is a multiple of 2^24 -- every channel on the fs / 256 grid with its own LO:
@@ -393,7 +404,8 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
     // ---- mix(p): NCO mix, block exponent, f16 split into the images, f32 history copy ----
     auto mix = [&](uint32_t pass, auto partial_c) {
         constexpr bool PARTIAL = decltype(partial_c)::value;     // the call's last pass, with fewer than T input samples
-        const uint32_t n0 = pass * G::T;
+        const uint32_t n0 = pass * tq;
+        const uint32_t cur_in = cur_out(pass) * M;                    // input samples of this pass that belong to it
         const uint32_t ph_lane = ph0 + 2u * lane * step;
         v2f m[2 * NLD];
 #pragma unroll
@@ -450,7 +462,8 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
             }
             s_cur = s_new;
         }
-        b_hist = b_tail;
+        // (a partial pass: the next history is not the last loads of the tile -- the maximum of the whole tile is a safe bound)
+        b_hist = PARTIAL ? max(wave_umax_bits(mh), b_tail) : b_tail;
         lds_order();                                                  // history reads above, history writes below
         const float pre = __uint_as_float((uint32_t)(s_cur + 127) << 23);
 #pragma unroll
@@ -462,7 +475,7 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
             put_iq(GS::HS + n, m[2 * i], m[2 * i + 1], pre);
 #endif
             if constexpr (PARTIAL) {                                  // the history is the last HS samples that exist
-                const int hidx = n - ((int)tail_out * M - GS::HS);
+                const int hidx = n - ((int)cur_in - GS::HS);
                 if (hidx >= 0 && hidx < GS::HS)
                     *reinterpret_cast<float4 *>(Hf + hidx) = make_float4(m[2 * i].x, m[2 * i].y, m[2 * i + 1].x, m[2 * i + 1].y);
             } else if (i >= NLD - NTL) {
@@ -570,7 +583,7 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
         return;
 #endif
 #pragma unroll
-        for (int k = 0; k < NCB; ++k) cb[k] = *reinterpret_cast<const u4v *>(X + cb_addr(k) + GS::RSTR * (G::T / GS::RL));
+        for (int k = 0; k < NCB; ++k) cb[k] = *reinterpret_cast<const u4v *>(X + cb_addr(k) + GS::RSTR * (int)(tq / GS::RL));      // (whole rows: the host sends pq * M % RL == 0 only)
     };
     auto cb_write = [&](const u4v (&cb)[NCB]) {
 #ifdef SRX_X_NOCB
@@ -639,7 +652,9 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
 #ifdef SRX_X_NOSTORE
         asm volatile("" :: "v"(au[0]), "v"(au[1]), "v"(au[2]), "v"(au[3]));
 #else
-        W::store(rs_out, lane * W::kBytes, (int)q * (G::P * (W::kBytes / 4)), au, ENV != 0);      // (ENV: phase 1 of the global-gain call -- the gain pass reads this audio back: default policy, known at compile time)
+        // (pq < 256: the last lanes hold outputs of the NEXT pass's region, computed from its first samples -- not stored)
+        const int vo = (GROUP != 0 || (uint32_t)lane < pq / 4u) ? lane * W::kBytes : 0x40000000;
+        W::store(rs_out, vo, (int)(q * pq) * (W::kBytes / 4), au, ENV != 0);      // (ENV: phase 1 of the global-gain call -- the gain pass reads this audio back: default policy, known at compile time)
 #endif
         if constexpr (GROUP == 16 && ENV != 0) {
             {
@@ -662,7 +677,7 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
         float au[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
         lds_order();
         STAMP(0);
-        if (npass == 1 && tail_out != G::P) mix(0, std::true_type{});
+        if (cur_out(0) != G::P) mix(0, std::true_type{});
         else mix(0, std::false_type{});
         STAMP(0);
         prefetch(1);
@@ -679,7 +694,7 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
         STAMP(0);
         for (uint32_t pass = 1; pass < npass; ++pass) {
             STAMP(1);                                                 // wait for the prefetched pass
-            if (pass + 1 == npass && tail_out != G::P) mix(pass, std::true_type{});
+            if (cur_out(pass) != G::P) mix(pass, std::true_type{});
             else mix(pass, std::false_type{});
             STAMP(0);
             store_audio(pass - 2, au);                                // pass 1: offset -1 pass = out of range, dropped
@@ -687,9 +702,10 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
             lds_order();
             u4v cb[NCB];
             v4f dt = { 0.0f, 0.0f, 0.0f, 0.0f };
-            if constexpr (AM == 0) dt = *reinterpret_cast<const v4f *>(D + dt_off + G::P);
+            if constexpr (AM == 0) dt = *reinterpret_cast<const v4f *>(D + dt_off + pq);      // (the pass before this one was a full one)
             gd.thr = thr_prev;                                        // the demodulator below belongs to the pass before
-            mfma_phase([&](int kk) { demod_piece(kk, au); }, (NTS + TPK - 1) / TPK - 1);   // matrix pipe over the vector work of the pass before
+            const int nvb_full = GROUP == 0 ? (int)(pq / (4u * (uint32_t)group)) : 64;
+            mfma_phase([&](int kk) { demod_piece(kk, au, nvb_full); }, (NTS + TPK - 1) / TPK - 1);   // matrix pipe over the vector work of the pass before
             cb_read(cb);
             lds_order();
             cb_write(cb);
