@@ -500,7 +500,8 @@ static hipError_t launch_shape(const RxParams &p, const FusedArgs &fa, const Fus
     // k_ssb_split16 also takes passes of fewer than 256 outputs when they are whole 16-output tiles (240 for the firmware's
     // 96-frame blocks by 4, 192 for its 96-sample audio blocks): its run-time DSP-block flavour advances by pass_out * M samples
     const uint32_t tq = fa.pass_out * M;
-    const bool split_ok = split16_pass_ok(fa.pass_out) && (p.block_size % tq == 0 || p.block_size % tq >= kHS);
+    // (a last pass shorter than the decimator history: only as a call of its own -- fused_tail_split cuts it off)
+    const bool split_ok = split16_pass_ok(fa.pass_out) && (p.block_size % tq == 0 || p.block_size % tq >= kHS || p.block_size < tq);
     if constexpr (ND > 0 && (M == 4 || M == 2) && NH > 0) {
         if (split && plan.d_btab16 && split_ok) {
             hipError_t e = launch_ssb_split16(ND, M, NH, p, fa, src, src_q15, dst, st);      // rx_split16.hip

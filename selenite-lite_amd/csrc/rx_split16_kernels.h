@@ -132,15 +132,18 @@ __device__ __forceinline__ void agc_pass(const AgcParams &ap, uint32_t agc_on, i
             for (int off = 1; off < 64; off <<= 1)
                 if (off < group) m = fmaxf(m, __shfl_xor(m, off, 64));
         } else {                                     // e.g. 6 lanes: the firmware's 96-frame blocks by 4 (dsp_if.h:69-73)
-            float mm = 0.0f;
-            for (int j = 0; j < group; ++j) mm = fmaxf(mm, __shfl(m, ((lane / group) * group + j) & 63, 64));
-            m = mm;
+            // downward segmented scan: after ceil(log2(group)) steps the FIRST lane of every block holds the block maximum
+            const int seg_end = (lane / group + 1) * group;
+            for (int off = 1; off < group; off <<= 1) {
+                const float v = __shfl_down(m, off, 64);
+                m = lane + off < seg_end ? fmaxf(m, v) : m;
+            }
         }
         guard(m);
+        const float d = agc_desired(ap, m);          // one division sequence serves every block of the pass
         const int nblk = min(64 / group, nvb), myblk = lane / group;
-        for (int b = 0; b < nblk; ++b) {
-            const float env = __shfl(m, b * group, 64);
-            g = agc_update<0>(ap, g, env);
+        for (int b = 0; b < nblk; ++b) {             // (b * group is wave-uniform: v_readlane with a scalar lane select)
+            g = agc_step(ap, g, __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(d), b * group)));
             if (b == myblk) mine = g;
         }
     }
@@ -465,6 +468,24 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
         // (a partial pass: the next history is not the last loads of the tile -- the maximum of the whole tile is a safe bound)
         b_hist = PARTIAL ? max(wave_umax_bits(mh), b_tail) : b_tail;
         lds_order();                                                  // history reads above, history writes below
+        if constexpr (PARTIAL) {
+            // a pass shorter than the decimator history (one-pass calls only: the host cuts longer calls so that this is the
+            // whole call, e.g. one 96-frame slot): the next history keeps the last HS - cur_in samples of the present one
+            if (cur_in < (uint32_t)GS::HS) {                          // wave-uniform
+                float4 keep[GS::HS / 128];
+#pragma unroll
+                for (int j = 0; j < GS::HS / 128; ++j) {
+                    const int f = 2 * (j * kWave + lane) + (int)cur_in;
+                    keep[j] = f < GS::HS ? lds_ld4f(reinterpret_cast<const float *>(Hf + f)) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                }
+                lds_order();
+#pragma unroll
+                for (int j = 0; j < GS::HS / 128; ++j) {
+                    const int f = 2 * (j * kWave + lane);
+                    if (f + (int)cur_in < GS::HS) *reinterpret_cast<float4 *>(Hf + f) = keep[j];
+                }
+            }
+        }
         const float pre = __uint_as_float((uint32_t)(s_cur + 127) << 23);
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
