@@ -57,7 +57,12 @@ extern "C" {
 #define SELENITE_MODE_CW  0x02
 #define SELENITE_MODE_CWR 0x03
 #define SELENITE_MODE_AM  0x04
-#define SELENITE_MODE_FM  0x08   /* not demodulated: init/set_mode return ARGUMENT_ERROR */
+#define SELENITE_MODE_FM  0x08   /* round 3.  Build-defined (the reference has no FM demodulator, CMSIS-DSP 1.5.3 no arctangent):
+                                  * audio[n] = angle(z[n] * conj(z[n-1])) / pi on the decimated I/Q -- arm_cmplx_conj_f32,
+                                  * arm_cmplx_mult_cmplx_f32, a stated arctangent, arm_scale_f32.  The
+                                  * sample in front of a block comes from the delay lines of the FIR pair, which this mode keeps
+                                  * running without evaluating the taps: needs nh_taps >= 2 (ARGUMENT_ERROR otherwise).  Exact /
+                                  * fma kernels in every arithmetic mode (SPLIT16 runs as FMA, AUTO as CMSIS). */
 #define SELENITE_MODE_DIG 0x0A   /* = USB */
 #define SELENITE_MODE_PKT 0x0C   /* = LSB */
 

@@ -13,6 +13,7 @@
 #include "arm_math.h"
 #include "arm_common_tables.h"
 #include "../include/selenite_rx.h"
+#include "fm_atan.h"                    /* the build-defined arctangent of the FM discriminator: CMSIS-DSP 1.5.3 has none */
 
 #include <stdlib.h>
 #include <string.h>
@@ -40,8 +41,9 @@ static float *dupf(const float *p, size_t n)
     return q;
 }
 
-static int mode_valid(uint8_t m)
+static int mode_valid(uint8_t m, uint32_t nh_taps)
 {
+    if (m == SELENITE_MODE_FM) return nh_taps >= 2;
     return m == SELENITE_MODE_LSB || m == SELENITE_MODE_USB || m == SELENITE_MODE_CW ||
            m == SELENITE_MODE_CWR || m == SELENITE_MODE_AM || m == SELENITE_MODE_DIG ||
            m == SELENITE_MODE_PKT;
@@ -56,7 +58,7 @@ int ref_rx_create(ref_rx **out, const selenite_rx_config *cfg)
 {
     *out = NULL;
     if (!cfg || cfg->channels == 0 || cfg->block == 0 || cfg->decim == 0) return ARM_MATH_ARGUMENT_ERROR;
-    if (!mode_valid(cfg->mode)) return ARM_MATH_ARGUMENT_ERROR;
+    if (!mode_valid(cfg->mode, cfg->nh_taps)) return ARM_MATH_ARGUMENT_ERROR;
     if (cfg->arith != SELENITE_ARITH_CMSIS) return ARM_MATH_ARGUMENT_ERROR;  /* CMSIS has one arithmetic */
     if (cfg->nd_taps == 0 && cfg->decim != 1) return ARM_MATH_ARGUMENT_ERROR;
     ref_rx *S = (ref_rx *)calloc(1, sizeof(*S));
@@ -113,7 +115,7 @@ void ref_rx_destroy(ref_rx *S)
 
 int ref_rx_set_mode(ref_rx *S, uint8_t mode)
 {
-    if (!mode_valid(mode)) return ARM_MATH_ARGUMENT_ERROR;
+    if (!mode_valid(mode, S->cfg.nh_taps)) return ARM_MATH_ARGUMENT_ERROR;
     S->cfg.mode = mode;
     return ARM_MATH_SUCCESS;
 }
@@ -166,6 +168,23 @@ static void chain_block(ref_rx *S, uint32_t c, const float *iq, float *audio, fl
         float *z = mixed;
         for (uint32_t n = 0; n < na; ++n) { z[2 * n] = di[n]; z[2 * n + 1] = dq[n]; }
         arm_cmplx_mag_f32(z, audio, na);
+    } else if (g->mode == SELENITE_MODE_FM) {
+        /* the delay lines run: arm_fir_f32 itself moves the state (its output is not used); the sample in front of the
+         * block is the newest entry of the history, read before the call */
+        float *z = mixed, *zc = lo, *w = ri;
+        const uint32_t H = g->nh_taps - 1u;
+        const float pI = S->fir[2 * c].pState[H - 1u], pQ = S->fir[2 * c + 1].pState[H - 1u];
+        for (uint32_t n = 0; n < na; ++n) {
+            z[2 * n] = di[n];                      z[2 * n + 1] = dq[n];
+            zc[2 * n] = n ? di[n - 1u] : pI;       zc[2 * n + 1] = n ? dq[n - 1u] : pQ;
+        }
+        arm_fir_f32(&S->fir[2 * c], di, audio, na);
+        arm_fir_f32(&S->fir[2 * c + 1], dq, audio, na);
+        float *zk = di;                            /* (di, dq are contiguous and free now: [2 * nb]) */
+        arm_cmplx_conj_f32(zc, zk, na);
+        arm_cmplx_mult_cmplx_f32(z, zk, w, na);
+        for (uint32_t n = 0; n < na; ++n) audio[n] = fm_atan2_f32(w[2 * n + 1], w[2 * n]);
+        arm_scale_f32(audio, FM_AUDIO_SCALE, audio, na);
     } else if (g->nh_taps) {
         arm_fir_f32(&S->fir[2 * c], di, ri, na);
         arm_fir_f32(&S->fir[2 * c + 1], dq, rq, na);

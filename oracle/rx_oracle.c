@@ -10,6 +10,7 @@
  * All citations are relative to /root/reference/Drivers/CMSIS/DSP/Source unless stated.
  */
 #include "rx_oracle.h"
+#include "fm_atan.h"
 
 #include <math.h>
 #include <pthread.h>
@@ -130,6 +131,18 @@ void orc_cmplx_mult_cmplx_f32(const float *A, const float *B, float *dst, uint32
         dst[2 * i + 1] = ad + bc;
     }
 }
+
+/* ComplexMathFunctions/arm_cmplx_conj_f32.c:71-166: real part copied, imaginary part negated */
+void orc_cmplx_conj_f32(const float *src, float *dst, uint32_t n)
+{
+    for (uint32_t i = 0; i < n; ++i) {
+        dst[2 * i] = src[2 * i];
+        dst[2 * i + 1] = -src[2 * i + 1];
+    }
+}
+
+/* the build-defined arctangent of the FM discriminator (fm_atan.h; CMSIS-DSP 1.5.3 has none) */
+float orc_fm_atan2_f32(float y, float x) { return fm_atan2_f32(y, x); }
 
 /* ComplexMathFunctions/arm_cmplx_mag_f32.c:72-149; arm_sqrt_f32 = sqrtf for in >= 0
  * (Include/arm_math.h:5726-5752) */
@@ -297,8 +310,10 @@ struct orc_rx {
     size_t dec_stride, fir_stride;
 };
 
-static int mode_valid(uint8_t m)
+/* FM (rxtx_if.h:41) keeps its one-sample memory in the delay lines of the FIR pair: it needs them */
+static int mode_valid(uint8_t m, uint32_t nh_taps)
 {
+    if (m == SELENITE_MODE_FM) return nh_taps >= 2;
     return m == SELENITE_MODE_LSB || m == SELENITE_MODE_USB || m == SELENITE_MODE_CW ||
            m == SELENITE_MODE_CWR || m == SELENITE_MODE_AM || m == SELENITE_MODE_DIG ||
            m == SELENITE_MODE_PKT;
@@ -316,7 +331,7 @@ int orc_rx_create(orc_rx **out, const selenite_rx_config *cfg)
 {
     *out = NULL;
     if (!cfg || cfg->channels == 0 || cfg->block == 0 || cfg->decim == 0) return SELENITE_RX_ARGUMENT_ERROR;
-    if (!mode_valid(cfg->mode)) return SELENITE_RX_ARGUMENT_ERROR;
+    if (!mode_valid(cfg->mode, cfg->nh_taps)) return SELENITE_RX_ARGUMENT_ERROR;
     if (cfg->nd_taps == 0 && cfg->decim != 1) return SELENITE_RX_ARGUMENT_ERROR;
     if (cfg->nd_taps && !cfg->dec_coeffs) return SELENITE_RX_ARGUMENT_ERROR;
     if (cfg->nh_taps && (!cfg->hilb_coeffs || !cfg->delay_coeffs)) return SELENITE_RX_ARGUMENT_ERROR;
@@ -359,7 +374,7 @@ void orc_rx_destroy(orc_rx *S)
 
 int orc_rx_set_mode(orc_rx *S, uint8_t mode)
 {
-    if (!mode_valid(mode)) return SELENITE_RX_ARGUMENT_ERROR;
+    if (!mode_valid(mode, S->cfg.nh_taps)) return SELENITE_RX_ARGUMENT_ERROR;
     S->cfg.mode = mode;
     return SELENITE_RX_SUCCESS;
 }
@@ -416,6 +431,26 @@ static void chain_block(orc_rx *S, uint32_t c, const float *iq, float *audio, fl
         float *z = mixed;           /* re-interleave the decimated rails */
         for (uint32_t n = 0; n < na; ++n) { z[2 * n] = di[n]; z[2 * n + 1] = dq[n]; }
         orc_cmplx_mag_f32(z, audio, na, ar);
+    } else if (g->mode == SELENITE_MODE_FM) {
+        /* FM (build-defined): the decimated rails run through the delay lines of the FIR pair --
+         * the state update of arm_fir_f32 (arm_fir_f32.c:573-577 new samples behind the history, :947-978 copy-back),
+         * taps not evaluated -- and the discriminator takes z[n] * conj(z[n-1]) (arm_cmplx_conj_f32 +
+         * arm_cmplx_mult_cmplx_f32), its angle (fm_atan.h) in half turns (arm_scale_f32) */
+        const uint32_t H = g->nh_taps - 1u;
+        float *stI = S->fir_state + (size_t)c * 2 * S->fir_stride, *stQ = stI + S->fir_stride;
+        float *z = mixed, *zc = lo, *w = ri;    /* ri, rq are contiguous: [2 * nb] */
+        memcpy(stI + H, di, na * sizeof(float));
+        memcpy(stQ + H, dq, na * sizeof(float));
+        for (uint32_t n = 0; n < na; ++n) {
+            z[2 * n] = stI[H + n];          z[2 * n + 1] = stQ[H + n];
+            zc[2 * n] = stI[H + n - 1u];    zc[2 * n + 1] = stQ[H + n - 1u];
+        }
+        orc_cmplx_conj_f32(zc, zc, na);
+        orc_cmplx_mult_cmplx_f32(z, zc, w, na, ar);
+        for (uint32_t n = 0; n < na; ++n) audio[n] = orc_fm_atan2_f32(w[2 * n + 1], w[2 * n]);
+        orc_scale_f32(audio, FM_AUDIO_SCALE, audio, na);
+        memmove(stI, stI + na, (size_t)H * sizeof(float));
+        memmove(stQ, stQ + na, (size_t)H * sizeof(float));
     } else if (g->nh_taps) {
         float *st = S->fir_state + (size_t)c * 2 * S->fir_stride;
         orc_fir_f32(S->delay_coeffs, g->nh_taps, st, di, ri, na, ar);                 /* I' */

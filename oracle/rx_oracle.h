@@ -34,6 +34,8 @@ float orc_cos_f32(float x, int arith);
 void  orc_nco_lo(const uint32_t *phase, uint32_t n, float *lo);   /* lo[2n] = cos, lo[2n+1] = -sin of the chain's NCO */
 void  orc_cmplx_mult_cmplx_f32(const float *a, const float *b, float *dst, uint32_t n, int arith);
 void  orc_cmplx_mag_f32(const float *src, float *dst, uint32_t n, int arith);
+void  orc_cmplx_conj_f32(const float *src, float *dst, uint32_t n);
+float orc_fm_atan2_f32(float y, float x);             /* build-defined (fm_atan.h): CMSIS-DSP 1.5.3 has no arctangent */
 void  orc_fir_decimate_f32(const float *coeffs, uint32_t num_taps, uint32_t M, float *state,
                            const float *src, float *dst, uint32_t block, int arith);
 void  orc_fir_f32(const float *coeffs, uint32_t num_taps, float *state,

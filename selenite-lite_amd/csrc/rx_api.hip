@@ -54,8 +54,9 @@ const float *srx::host_sin_table()
     return table;
 }
 
-static bool mode_valid(uint8_t m)
+static bool mode_valid(uint8_t m, uint32_t nh_taps)
 {
+    if (m == SELENITE_MODE_FM) return nh_taps >= 2;        // the discriminator's one-sample memory lives in the FIR pair's delay lines
     return m == SELENITE_MODE_LSB || m == SELENITE_MODE_USB || m == SELENITE_MODE_CW ||
            m == SELENITE_MODE_CWR || m == SELENITE_MODE_AM || m == SELENITE_MODE_DIG ||
            m == SELENITE_MODE_PKT;
@@ -179,8 +180,8 @@ extern "C" int selenite_rx_init(selenite_rx_instance **out, const selenite_rx_co
         return fail(nullptr, SELENITE_RX_ARGUMENT_ERROR, "selenite_rx_init: bad config / struct_size");
     if (cfg->channels == 0 || cfg->block == 0 || cfg->decim == 0)
         return fail(nullptr, SELENITE_RX_ARGUMENT_ERROR, "selenite_rx_init: channels, block, decim must be non-zero");
-    if (!mode_valid(cfg->mode))
-        return fail(nullptr, SELENITE_RX_ARGUMENT_ERROR, "selenite_rx_init: unsupported mode (FM is not demodulated)");
+    if (!mode_valid(cfg->mode, cfg->nh_taps))
+        return fail(nullptr, SELENITE_RX_ARGUMENT_ERROR, "selenite_rx_init: unsupported mode (FM needs the FIR pair's delay lines: nh_taps >= 2)");
     if (cfg->arith != SELENITE_ARITH_CMSIS && cfg->arith != SELENITE_ARITH_FMA && cfg->arith != SELENITE_ARITH_SPLIT16 &&
         cfg->arith != SELENITE_ARITH_AUTO)
         return fail(nullptr, SELENITE_RX_ARGUMENT_ERROR, "selenite_rx_init: bad arith");
@@ -283,7 +284,7 @@ extern "C" void selenite_rx_free(selenite_rx_instance *S)
 extern "C" int selenite_rx_set_mode(selenite_rx_instance *S, uint8_t mode)
 {
     if (!S) return fail(nullptr, SELENITE_RX_ARGUMENT_ERROR, "selenite_rx_set_mode: S is NULL");
-    if (!mode_valid(mode)) {
+    if (!mode_valid(mode, S->cfg.nh_taps)) {
         g_last_error = "selenite_rx_set_mode: unsupported mode";
         return SELENITE_RX_ARGUMENT_ERROR;          // instance stays usable in its old mode
     }
@@ -562,7 +563,7 @@ static int run_part(selenite_rx_instance *S, const void *src, bool src_q15, void
             // k_ssb_split16 (16-lane DSP blocks, whole passes) leaves the block maxima of every channel behind: the
             // envelope reduction below then folds channels x blocks floats instead of reading the audio again
             if (ssb_fused && (arith == SELENITE_ARITH_SPLIT16 || arith == SELENITE_ARITH_AUTO) && S->plan.d_btab16 && g.nd_taps && g.decim == 4 && (g.block / g.decim) / 4 == 16 &&
-                (block_size / g.decim) % 256 == 0 && g.nco_enable && g.mode != SELENITE_MODE_AM) {   // the launches with the DPP block reductions (decimation by 4, 64-sample audio blocks)
+                (block_size / g.decim) % 256 == 0 && g.nco_enable && g.mode != SELENITE_MODE_AM && g.mode != SELENITE_MODE_FM) {   // the launches with the DPP block reductions (decimation by 4, 64-sample audio blocks)
                 const size_t need = sizeof(float) * env_fold_scratch_floats(p.channels, block_size / g.block);
                 int rc = ensure(S, (void **)&S->d_env_part, &S->env_part_cap, need);
                 if (rc) return rc;

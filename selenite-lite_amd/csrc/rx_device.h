@@ -142,6 +142,39 @@ __device__ __forceinline__ float cmag(float re, float im)
     return (s >= 0.0f) ? sqrtf(s) : 0.0f;   // correctly rounded (hipcc default); __fsqrt_rn is not
 }
 
+// FM discriminator (build-defined, DESIGN.md section 2 "FM"; oracle/fm_atan.h states the same operations): the arctangent
+// CMSIS-DSP 1.5.3 does not have -- t = min / max (correctly rounded), atan(t) / t as a degree-8 polynomial in t^2 by Horner
+// (product rounded, then sum rounded: no fused multiply-add in any arithmetic mode), octant fix-ups
+__device__ __forceinline__ float fm_atan2(float y, float x)
+{
+    const float ax = fabsf(x), ay = fabsf(y);
+    const float mx = ax > ay ? ax : ay, mn = ax > ay ? ay : ax;
+    if (mx == 0.0f) return 0.0f;
+    const float t = __fdiv_rn(mn, mx);
+    const float s = t * t;
+    constexpr float c[9] = { 0x1.000000p+0f, -0x1.5554a2p-2f, 0x1.997232p-3f, -0x1.22de60p-3f, 0x1.b3ae74p-4f,
+                             -0x1.330372p-4f, 0x1.5ce0b0p-5f, -0x1.0639f6p-6f, 0x1.73776ap-9f };
+    float p = c[8];
+#pragma unroll
+    for (int k = 7; k >= 0; --k) {
+        p = p * s;
+        p = p + c[k];
+    }
+    float r = p * t;
+    if (ay > ax) r = 0x1.921fb6p+0f - r;
+    if (x < 0.0f) r = 0x1.921fb6p+1f - r;
+    if (y < 0.0f) r = -r;
+    return r;
+}
+// z[n] * conj(z[n-1]) (arm_cmplx_conj_f32.c:161-162, arm_cmplx_mult_cmplx_f32.c:186-187), its angle in half turns (arm_scale_f32)
+__device__ __forceinline__ float fm_disc(float zr, float zi, float pr, float pi_)
+{
+    const float c = pr, d = -pi_;
+    const float ac = zr * c, bd = zi * d, ad = zr * d, bc = zi * c;
+    const float re = ac - bd, im = ad + bc;
+    return fm_atan2(im, re) * 0x1.45f306p-2f;
+}
+
 // FilteringFunctions/arm_biquad_cascade_df1_f32.c:220 -- one DF1 section, left-to-right sum,
 // feedback added
 template <int ARITH>

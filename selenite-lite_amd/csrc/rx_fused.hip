@@ -483,7 +483,8 @@ static hipError_t launch_shape(const RxParams &p, const FusedArgs &fa, const Fus
 {
     if (src_q15 != dst_q15) return hipErrorNotSupported;
     const bool auto_ = arith == SELENITE_ARITH_AUTO;
-    const bool split = arith == SELENITE_ARITH_SPLIT16 || auto_;
+    const bool fm = fa.am == 2u;                  // the discriminator divides by |z|: no parity bar holds on a split product -- exact / fma kernels only
+    const bool split = (arith == SELENITE_ARITH_SPLIT16 || auto_) && !fm;
     // SELENITE_ARITH_AUTO, second launch: the bit-exact kernel over the channels whose rerun flag the split16 kernel raised
     // (their streaming state is still the pre-call state; audio and state are recomputed in the CMSIS arithmetic)
     auto rerun = [&]() -> hipError_t {
@@ -519,7 +520,7 @@ static hipError_t launch_shape(const RxParams &p, const FusedArgs &fa, const Fus
     if (auto_) arith = SELENITE_ARITH_CMSIS;      // no split-precision kernel for this launch: the bit-exact one
     if constexpr (ND > 0 && M == 4) {
         static_assert(kMfmaWaves == 1, "one channel per workgroup: any channel count launches (plan.name says k_ssb_mfma)");
-        if (arith != SELENITE_ARITH_CMSIS && plan.use_mfma && whole) {
+        if (arith != SELENITE_ARITH_CMSIS && plan.use_mfma && whole && !fm) {
             if (src_q15) return launch_mfma<ND, M, NH, int16_t, int16_t>(p, fa, plan.d_btab, src, dst, st);
             return launch_mfma<ND, M, NH, float, float>(p, fa, plan.d_btab, src, dst, st);
         }
@@ -537,7 +538,7 @@ static bool fused_mode_ok(const selenite_rx_config &g)
     const uint32_t m = g.mode;
     const bool ssb = m == SELENITE_MODE_USB || m == SELENITE_MODE_LSB || m == SELENITE_MODE_DIG || m == SELENITE_MODE_PKT;
     const bool cw_plain = mode_is_cw(m) && g.n_biquad == 0;
-    return ssb || cw_plain || m == SELENITE_MODE_AM;
+    return ssb || cw_plain || m == SELENITE_MODE_AM || m == SELENITE_MODE_FM;
 }
 
 hipError_t plan_fused(const selenite_rx_config &g, bool delay_is_impulse, int delay_index, bool hilb_odd_only,
@@ -581,6 +582,7 @@ hipError_t plan_fused(const selenite_rx_config &g, bool delay_is_impulse, int de
         if (g.nd_taps) plan.name_buf = "k_ssb_split16" + shape + tail;
         else if (na == 256) plan.name_buf = "k_hilb_split16<" + std::to_string(g.nh_taps) + ">" + tail;
     }
+    if (g.mode == SELENITE_MODE_FM) plan.name_buf = "k_ssb_fused" + shape;                           // FM: the exact / fma kernel in every arithmetic mode
     plan.name = plan.name_buf.c_str();
     return hipSuccess;
 }
@@ -617,7 +619,7 @@ hipError_t launch_fused(const FusedPlan &plan, const RxParams &p, int arith, con
     fa.cq = plan.d_cq;
     fa.delay_idx = (uint32_t)delay_index;
     fa.upper = mode_is_upper(p.mode) ? 1u : 0u;
-    fa.am = p.mode == SELENITE_MODE_AM ? 1u : 0u;
+    fa.am = p.mode == SELENITE_MODE_AM ? 1u : (p.mode == SELENITE_MODE_FM ? 2u : 0u);      // (FM: a run-time flavour of the AM instantiations of k_ssb_fused)
     fa.group = (p.block / p.decim) / 4;
     fa.pass_out = 256u / (p.block / p.decim) * (p.block / p.decim);
     fa.btab16 = plan.d_btab16;

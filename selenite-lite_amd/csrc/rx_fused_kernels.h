@@ -71,8 +71,16 @@ __device__ __forceinline__ void demod_agc_store(const RxParams &p, const FusedAr
         // AM: envelope of the decimated rails; new sample n of a pass sits at HH4 + n
         const float4 vi = lds_ld4f(dI + G::HH4 + 4 * lane);
         const float4 vq = lds_ld4f(dQ + G::HH4 + 4 * lane);
-        au[0] = cmag<0>(vi.x, vq.x); au[1] = cmag<0>(vi.y, vq.y);
-        au[2] = cmag<0>(vi.z, vq.z); au[3] = cmag<0>(vi.w, vq.w);
+        if (fa.am == 2u) {
+            // FM (a run-time flavour of the AM instantiations): z[n] * conj(z[n-1]); the sample in front of the pass is the
+            // newest entry of the Hilbert-pair history, which this mode keeps running (and writes back)
+            const float pi0 = dI[G::HH4 + 4 * lane - 1], pq0 = dQ[G::HH4 + 4 * lane - 1];
+            au[0] = fm_disc(vi.x, vq.x, pi0, pq0);  au[1] = fm_disc(vi.y, vq.y, vi.x, vq.x);
+            au[2] = fm_disc(vi.z, vq.z, vi.y, vq.y); au[3] = fm_disc(vi.w, vq.w, vi.z, vq.z);
+        } else {
+            au[0] = cmag<0>(vi.x, vq.x); au[1] = cmag<0>(vi.y, vq.y);
+            au[2] = cmag<0>(vi.z, vq.z); au[3] = cmag<0>(vi.w, vq.w);
+        }
     } else if constexpr (NH > 0) {
         float q2[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
         hilbert_quad<ARITH, ND, M, NH>(dQ, lane, hreg, q2);
@@ -378,7 +386,7 @@ __global__ __launch_bounds__(64, 2) void k_ssb_fused(RxParams p, FusedArgs fa, c
         }
     }
     if constexpr (NH > 0) {
-        if constexpr (AM == 0) {                                      // AM never ran the Hilbert pair: its state stays
+        if (AM == 0 || fa.am == 2u) {                                 // AM never ran the Hilbert pair: its state stays (FM keeps the delay lines running)
             for (int i = lane; i < 2 * G::HH4; i += kWave) {
                 const int rail = i / G::HH4, m = i % G::HH4, s = m - G::FH;
                 if (s >= 0) p.fir_state[((size_t)c * 2 + rail) * G::HH + s] = D[rail * G::DLEN + m];

@@ -88,6 +88,7 @@ __global__ __launch_bounds__(64) void k_front_generic(RxParams p, const TIn *__r
     const uint32_t M = p.decim, nd = p.nd, nh = p.nh, P = p.pass_out;
     const uint32_t Hd = nd ? nd - 1 : 0, Hh = nh ? nh - 1 : 0;
     const bool am = (p.mode == SELENITE_MODE_AM);
+    const bool fm = (p.mode == SELENITE_MODE_FM);          // the delay lines of the FIR pair run, the taps are not evaluated
     const bool use_fir = nh && !am;
     const bool upper = mode_is_upper(p.mode);
     const FrontLds L = front_layout(nd, nh, M, P, p.nco != 0);
@@ -156,6 +157,9 @@ __global__ __launch_bounds__(64) void k_front_generic(RxParams p, const TIn *__r
             if (am) {
                 const v2f d = D[fo + j];
                 a = cmag<ARITH>(d.x, d.y);
+            } else if (fm) {
+                const v2f z = D[fo + j], zp = D[fo + j - 1];     // (nh >= 2: fo >= 1; the sample in front of the call is the newest history entry)
+                a = fm_disc(z.x, z.y, zp.x, zp.y);
             } else if (use_fir) {
                 v2f acc = { 0.0f, 0.0f };                   // arm_fir_f32 x2: y[n] = sum_k c[k] s[n+k]; I: delay taps, Q: Hilbert taps
 #pragma unroll 4

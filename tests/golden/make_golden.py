@@ -39,6 +39,9 @@ CHAIN_CASES = {
                               nco=True, nco_step_all=0x01234567, bp_f0=0.05, bp_q=3.0), 3, 5, 2),
     "am_full": ("spec", dict(block=64, decim=4, nd_taps=48, nh_taps=31, n_biquad=2, mode=rc.MODE_AM,
                              nco=True, nco_step_all=0x01234567, bp_f0=0.05, bp_q=3.0), 3, 5, 2),
+    "fm_full": ("spec", dict(block=64, decim=4, nd_taps=48, nh_taps=31, n_biquad=2, mode=rc.MODE_FM,
+                             nco=True, nco_step_all=0x01234567, bp_f0=0.05, bp_q=3.0), 3, 5, 2),
+    "fm_nodec": ("spec", dict(block=96, decim=1, nd_taps=0, nh_taps=3, mode=rc.MODE_FM, nco=False, agc=False), 2, 3, 3),
     "global_gain": ("spec", dict(block=64, decim=2, nd_taps=21, nh_taps=15, mode=rc.MODE_USB, nco=True,
                                  nco_step_all=0x02000000, agc_global=True), 6, 4, 3),
 }
@@ -152,13 +155,15 @@ def main():
     b = rng.standard_normal(2 * n).astype(np.float32)
     a[5], a[6], b[7] = 0.0, -0.0, -0.0
     f32p, u32p, i16p = rc.f32p, rc.u32p, rc.i16p
-    for fn in ("arm_cmplx_mult_cmplx_f32", "arm_cmplx_mag_f32", "arm_add_f32", "arm_sub_f32", "arm_abs_f32",
+    for fn in ("arm_cmplx_mult_cmplx_f32", "arm_cmplx_mag_f32", "arm_cmplx_conj_f32", "arm_add_f32", "arm_sub_f32", "arm_abs_f32",
                "arm_scale_f32", "arm_max_f32", "arm_q15_to_float", "arm_float_to_q15"):
         getattr(R, fn).restype = None
     cm = np.empty(2 * n, np.float32)
     R.arm_cmplx_mult_cmplx_f32(fptr(a), fptr(b), fptr(cm), C.c_uint32(n))
     mag = np.empty(n, np.float32)
     R.arm_cmplx_mag_f32(fptr(a), fptr(mag), C.c_uint32(n))
+    cj = np.empty(2 * n, np.float32)
+    R.arm_cmplx_conj_f32(fptr(a), fptr(cj), C.c_uint32(n))
     add, sub, ab, sc = (np.empty(2 * n, np.float32) for _ in range(4))
     R.arm_add_f32(fptr(a), fptr(b), fptr(add), C.c_uint32(2 * n))
     R.arm_sub_f32(fptr(a), fptr(b), fptr(sub), C.c_uint32(2 * n))
@@ -176,7 +181,7 @@ def main():
                                                           np.float32)]).astype(np.float32)
     fq = np.empty(fq_in.size, np.int16)
     R.arm_float_to_q15(fptr(fq_in), fq.ctypes.data_as(i16p), C.c_uint32(fq_in.size))
-    out.update(ew_a=a, ew_b=b, ew_cmul=cm, ew_mag=mag, ew_add=add, ew_sub=sub, ew_abs=ab, ew_scale=sc,
+    out.update(ew_a=a, ew_b=b, ew_cmul=cm, ew_mag=mag, ew_conj=cj, ew_add=add, ew_sub=sub, ew_abs=ab, ew_scale=sc,
                ew_max_in=tie, ew_max=np.array([mx.value], np.float32), ew_max_idx=np.array([mi.value], np.uint32),
                q15_in=q, q15_f=qf, fq_in=fq_in, fq_out=fq)
     np.savez_compressed(os.path.join(HERE, "primitives.npz"), **out)

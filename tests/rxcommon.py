@@ -75,6 +75,8 @@ def oracle_lib():
         L.orc_cos_f32.argtypes = [C.c_float, C.c_int]
         L.orc_agc_update.restype = C.c_float
         L.orc_agc_update.argtypes = [C.POINTER(Config), C.c_float, C.c_float, C.c_int]
+        L.orc_fm_atan2_f32.restype = C.c_float
+        L.orc_fm_atan2_f32.argtypes = [C.c_float, C.c_float]
         L.orc_rx_create.argtypes = [C.POINTER(C.c_void_p), C.POINTER(Config)]
         L.orc_rx_destroy.argtypes = [C.c_void_p]
         L.orc_rx_set_mode.argtypes = [C.c_void_p, C.c_uint8]

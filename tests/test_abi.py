@@ -108,7 +108,8 @@ def test_init_argument_validation_precedes_device_use():
     ok = rc.baseline_spec("cfg3", 2)
     assert init_rc(ok, lambda g: setattr(g, "struct_size", 12)) == rc.ARGUMENT_ERROR
     assert init_rc(ok, lambda g: setattr(g, "channels", 0)) == rc.ARGUMENT_ERROR
-    assert init_rc(ok, lambda g: setattr(g, "mode", rc.MODE_FM)) == rc.ARGUMENT_ERROR
+    assert init_rc(ok, lambda g: (setattr(g, "mode", rc.MODE_FM), setattr(g, "nh_taps", 0))) == rc.ARGUMENT_ERROR   # FM needs the FIR pair's delay lines
+    assert init_rc(ok, lambda g: setattr(g, "mode", 0x05)) == rc.ARGUMENT_ERROR          # not a value of the firmware's Mode enum (rxtx_if.h:33-43)
     assert init_rc(ok, lambda g: setattr(g, "arith", 7)) == rc.ARGUMENT_ERROR
     assert init_rc(ok, lambda g: setattr(g, "nd_taps", 0)) == rc.ARGUMENT_ERROR        # decim 4 without decimator
     assert init_rc(ok, lambda g: setattr(g, "hilb_coeffs", None)) == rc.ARGUMENT_ERROR

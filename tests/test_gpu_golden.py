@@ -35,7 +35,7 @@ def test_library_sin_table_is_the_reference_table():
     assert bits_equal(buf.download((64, 4096, 2), np.float32), rc.synth_iq(0, 64, 0, 4096))
 
 
-@pytest.mark.parametrize("name", ["cfg1", "cfg2", "cfg3", "cfg4", "lsb_full", "cwr_full", "am_full", "global_gain"])
+@pytest.mark.parametrize("name", ["cfg1", "cfg2", "cfg3", "cfg4", "lsb_full", "cwr_full", "am_full", "fm_full", "fm_nodec", "global_gain"])
 @pytest.mark.parametrize("generic", [False, True])
 def test_chain_fixture(name, generic):
     import selenite_rx as sr

@@ -91,12 +91,12 @@ def test_set_mode_keeps_state_and_matches():
     g = gpu_rx(spec)
     o = CpuChain(spec, "orc")
     n0 = 0
-    for mode in [MODE_USB, MODE_LSB, MODE_CW, MODE_AM, MODE_CWR, MODE_USB]:
+    for mode in [MODE_USB, MODE_LSB, MODE_CW, MODE_AM, rc.MODE_FM, MODE_CWR, rc.MODE_FM, MODE_USB]:
         assert g.set_mode(mode) == 0 and o.set_mode(mode) == 0
         iq = synth_iq(0, 2, n0, 256)
         n0 += 256
         assert bits_equal(g.process(iq), o.process(iq)), "after set_mode(%d)" % mode
-    assert g.set_mode(rc.MODE_FM) == rc.ARGUMENT_ERROR          # FM is not demodulated
+    assert g.set_mode(0x05) == rc.ARGUMENT_ERROR                # not a Mode value: the instance keeps its mode
     assert_state_equal(g, o)
 
 

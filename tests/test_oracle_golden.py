@@ -98,6 +98,8 @@ def test_elementwise_statistics_and_q15(oracle, prim):
     mag = np.empty(n, np.float32)
     oracle.orc_cmplx_mag_f32(fptr(a), fptr(mag), n, A0)
     assert bits_equal(mag, prim["ew_mag"])
+    oracle.orc_cmplx_conj_f32(fptr(a), fptr(out), n)
+    assert bits_equal(out, prim["ew_conj"])                      # arm_cmplx_conj_f32 (FM discriminator)
     oracle.orc_add_f32(fptr(a), fptr(b), fptr(out), n2)
     assert bits_equal(out, prim["ew_add"])
     oracle.orc_sub_f32(fptr(a), fptr(b), fptr(out), n2)
@@ -123,6 +125,44 @@ def test_elementwise_statistics_and_q15(oracle, prim):
     assert list(fq[-2:]) == [0, 0]                                            # truncation toward zero
 
 
+def test_fm_arctangent_accuracy(oracle):
+    """The build-defined arctangent of the FM discriminator (oracle/fm_atan.h = csrc/rx_device.h fm_atan2) against atan2 in double:
+    the whole plane incl. the axes, the octant seams, tiny and huge magnitudes; <= 4e-7 rad."""
+    rng = np.random.default_rng(7)
+    pts = [(0.0, 0.0), (0.0, 1.0), (0.0, -1.0), (1.0, 0.0), (-1.0, 0.0), (1.0, 1.0), (-1.0, 1.0), (1.0, -1.0), (-1.0, -1.0),
+           (1e-30, 1e-30), (1e30, -1e30), (1e-38, 1.0), (1.0, 1e-38), (3e-39, 2e-39)]
+    th = rng.uniform(-np.pi, np.pi, 20000)
+    r = 10.0 ** rng.uniform(-20, 20, th.size)
+    pts += list(zip((r * np.sin(th)).astype(np.float32).tolist(), (r * np.cos(th)).astype(np.float32).tolist()))
+    seam = np.linspace(-1e-3, 1e-3, 2001)
+    pts += [(float(np.float32(np.sin(a + k * np.pi / 4))), float(np.float32(np.cos(a + k * np.pi / 4)))) for k in range(8) for a in seam]
+    worst = 0.0
+    for y, x in pts:
+        y, x = float(np.float32(y)), float(np.float32(x))
+        got = oracle.orc_fm_atan2_f32(y, x)
+        want = np.arctan2(y, x) if (x != 0.0 or y != 0.0) else 0.0
+        d = abs(got - want)
+        if x < 0 and y == 0.0:
+            d = min(d, abs(got - np.pi))          # (the sign of zero is not looked at: y = -0 gives +pi)
+        worst = max(worst, d)
+    assert worst <= 4e-7, worst
+
+
+def test_fm_of_a_tone_is_its_frequency(oracle):
+    """Known answer: a complex tone at f cycles per sample, no NCO, no decimator: audio = 2 f (phase step in half turns), from the
+    second sample on (the first one sees the zero delay line: angle of z[0] * conj(0) = 0)."""
+    nh = 3
+    spec = rc.ChainSpec(1, 64, 1, 0, nh, 0, rc.MODE_FM, rc.ARITH_CMSIS, agc=False)
+    for f in (0.01, -0.2, 0.25, 0.4999, -0.37):
+        ch = rc.CpuChain(spec, "orc")
+        n = np.arange(256)
+        iq = np.stack([np.cos(2 * np.pi * f * n), np.sin(2 * np.pi * f * n)], axis=-1).astype(np.float32)[None]
+        y = ch.process(iq)[0]
+        assert y[0] == 0.0
+        assert np.abs(y[1:] - 2 * f).max() < 1e-6, (f, np.abs(y[1:] - 2 * f).max())
+        ch.close()
+
+
 def _chain_cases():
     import importlib.util
     spec = importlib.util.spec_from_file_location("make_golden", os.path.join(G, "make_golden.py"))
@@ -131,7 +171,7 @@ def _chain_cases():
     return m
 
 
-@pytest.mark.parametrize("name", ["cfg1", "cfg2", "cfg3", "cfg4", "lsb_full", "cwr_full", "am_full", "global_gain"])
+@pytest.mark.parametrize("name", ["cfg1", "cfg2", "cfg3", "cfg4", "lsb_full", "cwr_full", "am_full", "fm_full", "fm_nodec", "global_gain"])
 def test_chain_against_cmsis_composition(name):
     mg = _chain_cases()
     kind, arg, channels, nblocks, ncalls = mg.CHAIN_CASES[name]

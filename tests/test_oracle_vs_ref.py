@@ -84,7 +84,7 @@ def test_chain_streaming(name, ref):
         assert np.array_equal(sa[k].view(np.uint32), sb[k].view(np.uint32)), k
 
 
-@pytest.mark.parametrize("mode", [rc.MODE_LSB, rc.MODE_USB, rc.MODE_CW, rc.MODE_CWR, rc.MODE_AM, rc.MODE_DIG, rc.MODE_PKT])
+@pytest.mark.parametrize("mode", [rc.MODE_LSB, rc.MODE_USB, rc.MODE_CW, rc.MODE_CWR, rc.MODE_AM, rc.MODE_FM, rc.MODE_DIG, rc.MODE_PKT])
 def test_chain_all_modes_and_mode_switch(mode, ref):
     spec = rc.ChainSpec(2, 96, decim=3, nd_taps=40, nh_taps=33, n_biquad=3, mode=mode, nco=True,
                         nco_steps=np.array([0x00123456, 0xFFF00000], np.uint32), bp_f0=0.04, bp_q=5.0)
@@ -93,6 +93,32 @@ def test_chain_all_modes_and_mode_switch(mode, ref):
         a.set_mode(m2), b.set_mode(m2)
         iq = rc.synth_iq(0, 2, call * 192, 192)
         assert bits_equal(a.process(iq), b.process(iq))
+
+
+@pytest.mark.parametrize("blk,M,nd,nh", [(64, 4, 48, 31), (256, 4, 256, 63), (256, 1, 0, 127), (96, 4, 256, 63), (64, 2, 128, 3), (5, 1, 3, 3)])
+def test_fm_chain_against_the_cmsis_composition(blk, M, nd, nh, ref):
+    """FM (rxtx_if.h:41; build-defined chain): the real arm_cmplx_conj_f32 + arm_cmplx_mult_cmplx_f32 + arm_scale_f32
+    and the real arm_fir_f32 moving the delay lines, around the stated arctangent -- against the restatement, output and state, across
+    calls of different lengths (the sample in front of a block comes from the delay line)."""
+    mk = lambda: rc.ChainSpec(5, blk, M, nd, nh, 0, rc.MODE_FM, rc.ARITH_CMSIS, nco=True, nco_step_all=0x01234567, agc=True)
+    a, b = rc.CpuChain(mk(), "orc"), rc.CpuChain(mk(), "ref")
+    assert a.ok() and b.ok()
+    pos = 0
+    for bs in (blk, 3 * blk, 8 * blk, blk):
+        iq = rc.synth_iq(0, 5, pos, bs)
+        pos += bs
+        assert bits_equal(a.process(iq), b.process(iq)), bs
+    sa, sb = a.state(), b.state()
+    for k in sa:
+        assert np.array_equal(sa[k].view(np.uint32), sb[k].view(np.uint32)), k
+
+
+def test_fm_needs_the_delay_lines(ref):
+    for which in ("orc", "ref"):
+        assert not rc.CpuChain(rc.ChainSpec(1, 64, 1, 0, 0, 0, rc.MODE_FM), which).ok()
+        assert not rc.CpuChain(rc.ChainSpec(1, 64, 1, 0, 1, 0, rc.MODE_FM), which).ok()
+        ch = rc.CpuChain(rc.ChainSpec(1, 64, 1, 0, 0, 0, rc.MODE_USB), which)
+        assert ch.ok() and ch.set_mode(rc.MODE_FM) == rc.ARGUMENT_ERROR and ch.set_mode(rc.MODE_AM) == 0
 
 
 def test_chain_q15_and_global_gain(ref):
