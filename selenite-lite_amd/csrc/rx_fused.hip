@@ -312,7 +312,7 @@ __global__ __launch_bounds__(64 * kMfmaWaves, 2) void k_ssb_mfma(RxParams p, Fus
         if (s >= 0) p.dec_state[((size_t)c * 2 + rail) * (ND - 1) + s] = (rail ? XQ : XI)[GM::phys(f)];
     }
     if constexpr (NH > 0) {
-        if constexpr (AM == 0) {                                      // AM never ran the Hilbert pair: its state stays
+        if (AM == 0 || fa.am == 2u) {                                 // AM never ran the Hilbert pair: its state stays (FM keeps the delay lines running)
             for (int i = lane; i < 2 * G::HH4; i += kWave) {
                 const int rail = i / G::HH4, m = i % G::HH4, s = m - G::FH;
                 if (s >= 0) p.fir_state[((size_t)c * 2 + rail) * G::HH + s] = D[rail * G::DLEN + m];
@@ -483,7 +483,7 @@ static hipError_t launch_shape(const RxParams &p, const FusedArgs &fa, const Fus
 {
     if (src_q15 != dst_q15) return hipErrorNotSupported;
     const bool auto_ = arith == SELENITE_ARITH_AUTO;
-    const bool fm = fa.am == 2u;                  // the discriminator divides by |z|: no parity bar holds on a split product -- exact / fma kernels only
+    const bool fm = fa.am == 2u;                  // the discriminator divides by |z|: no parity bar holds on a split product -- exact / fma kernels only (k_ssb_fused, k_ssb_mfma)
     const bool split = (arith == SELENITE_ARITH_SPLIT16 || auto_) && !fm;
     // SELENITE_ARITH_AUTO, second launch: the bit-exact kernel over the channels whose rerun flag the split16 kernel raised
     // (their streaming state is still the pre-call state; audio and state are recomputed in the CMSIS arithmetic)
@@ -520,7 +520,7 @@ static hipError_t launch_shape(const RxParams &p, const FusedArgs &fa, const Fus
     if (auto_) arith = SELENITE_ARITH_CMSIS;      // no split-precision kernel for this launch: the bit-exact one
     if constexpr (ND > 0 && M == 4) {
         static_assert(kMfmaWaves == 1, "one channel per workgroup: any channel count launches (plan.name says k_ssb_mfma)");
-        if (arith != SELENITE_ARITH_CMSIS && plan.use_mfma && whole && !fm) {
+        if (arith != SELENITE_ARITH_CMSIS && plan.use_mfma && whole) {
             if (src_q15) return launch_mfma<ND, M, NH, int16_t, int16_t>(p, fa, plan.d_btab, src, dst, st);
             return launch_mfma<ND, M, NH, float, float>(p, fa, plan.d_btab, src, dst, st);
         }
@@ -582,7 +582,10 @@ hipError_t plan_fused(const selenite_rx_config &g, bool delay_is_impulse, int de
         if (g.nd_taps) plan.name_buf = "k_ssb_split16" + shape + tail;
         else if (na == 256) plan.name_buf = "k_hilb_split16<" + std::to_string(g.nh_taps) + ">" + tail;
     }
-    if (g.mode == SELENITE_MODE_FM) plan.name_buf = "k_ssb_fused" + shape;                           // FM: the exact / fma kernel in every arithmetic mode
+    if (g.mode == SELENITE_MODE_FM) {                                                                // FM: the exact / fma kernels in every arithmetic mode
+        const bool fma = g.arith == SELENITE_ARITH_FMA || g.arith == SELENITE_ARITH_SPLIT16;
+        plan.name_buf = (fma && plan.use_mfma && g.nd_taps && g.decim == 4 ? "k_ssb_mfma" : "k_ssb_fused") + shape;
+    }
     plan.name = plan.name_buf.c_str();
     return hipSuccess;
 }
