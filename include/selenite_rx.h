@@ -226,6 +226,13 @@ int selenite_rx_guard_stats(selenite_rx_instance *S, uint64_t *guard_blocks, uin
                             uint64_t *rerun_channel_calls);
 /* per_channel[channels]: guarded DSP blocks of every channel since init / the last clear (sticky per-channel view). */
 int selenite_rx_guard_channels(selenite_rx_instance *S, uint32_t *per_channel);
+/* SELENITE_ARITH_AUTO, what the rerun cannot repair ("what the guard does not see"): guarded DSP blocks among
+ * the first ones of a call -- those inside the reach of the Hilbert-pair history, (nh_taps - 1) audio samples -- of a channel whose
+ * PREVIOUS call stayed on the matrix kernel.  Such a block is recomputed in exact arithmetic from a history of split16 precision:
+ * its distance from CMSIS is that of a guarded block of raw SELENITE_ARITH_SPLIT16 (up to ~3e-5 of the block maximum), not 0.
+ * Needs a channel whose level crosses the guard ratio downwards exactly at a call boundary; 0 on the bench workload.  Counted
+ * since init / the last selenite_rx_guard_clear; drains the stream. */
+int selenite_rx_guard_handover(selenite_rx_instance *S, uint64_t *handover_blocks);
 int selenite_rx_guard_clear(selenite_rx_instance *S);
 
 /* ---- streams, state, memory ----------------------------------------------------------- */

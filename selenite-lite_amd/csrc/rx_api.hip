@@ -138,8 +138,9 @@ static int reset_state(selenite_rx_instance *S)
     if (g.n_biquad) HIPCHK(S, hipMemsetAsync(S->d_biq_state, 0, C * 4 * g.n_biquad * sizeof(float), S->stream));
     HIPCHK(S, hipMemsetAsync(S->d_phase, 0, C * sizeof(uint32_t), S->stream));
     HIPCHK(S, hipMemsetAsync(S->d_flags, 0, kFlagWords * sizeof(uint32_t), S->stream));
-    HIPCHK(S, hipMemsetAsync(S->d_guard_ch, 0, 2 * C * sizeof(uint32_t), S->stream));
-    if (S->d_rerun_flag) HIPCHK(S, hipMemsetAsync(S->d_rerun_flag, 0, C * sizeof(uint32_t), S->stream));
+    HIPCHK(S, hipMemsetAsync(S->d_guard_ch, 0, 3 * C * sizeof(uint32_t), S->stream));
+    // (1 = "the channel's state is in exact arithmetic": what a cleared state is; k_ssb_split16 rewrites every word every call)
+    if (S->d_rerun_flag) HIPCHK(S, hipMemsetD32Async((hipDeviceptr_t)S->d_rerun_flag, 1, C, S->stream));
     std::vector<float> gi(C, g.agc_gain_init);
     HIPCHK(S, hipMemcpyAsync(S->d_gain, gi.data(), C * sizeof(float), hipMemcpyHostToDevice, S->stream));
     HIPCHK(S, hipStreamSynchronize(S->stream));
@@ -256,7 +257,7 @@ extern "C" int selenite_rx_init(selenite_rx_instance **out, const selenite_rx_co
     INITCHK(dev_alloc(&S->d_biq_state, C * 4 * cfg->n_biquad));
     INITCHK(dev_alloc(&S->d_gain, C));
     INITCHK(dev_alloc(&S->d_flags, (size_t)kFlagWords));
-    INITCHK(dev_alloc(&S->d_guard_ch, 2 * C));
+    INITCHK(dev_alloc(&S->d_guard_ch, 3 * C));
     INITCHK(dev_alloc(&S->d_rerun_flag, cfg->arith == SELENITE_ARITH_AUTO ? C : 0));
 #undef INITCHK
     classify_coeffs(S);
@@ -411,7 +412,21 @@ extern "C" int selenite_rx_guard_clear(selenite_rx_instance *S)
 {
     if (!S) return SELENITE_RX_ARGUMENT_ERROR;
     HIPCHK(S, hipSetDevice(S->device));
-    HIPCHK(S, hipMemsetAsync(S->d_guard_ch, 0, 2 * (size_t)S->cfg.channels * sizeof(uint32_t), S->stream));
+    HIPCHK(S, hipMemsetAsync(S->d_guard_ch, 0, 3 * (size_t)S->cfg.channels * sizeof(uint32_t), S->stream));
+    return SELENITE_RX_SUCCESS;
+}
+
+extern "C" int selenite_rx_guard_handover(selenite_rx_instance *S, uint64_t *handover_blocks)
+{
+    if (!S || !handover_blocks) return SELENITE_RX_ARGUMENT_ERROR;
+    HIPCHK(S, hipSetDevice(S->device));
+    HIPCHK(S, hipStreamSynchronize(S->stream));
+    const size_t C = S->cfg.channels;
+    std::vector<uint32_t> w(C);
+    HIPCHK(S, hipMemcpy(w.data(), S->d_guard_ch + 2 * C, C * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    uint64_t n = 0;
+    for (size_t c = 0; c < C; ++c) n += w[c];
+    *handover_blocks = n;
     return SELENITE_RX_SUCCESS;
 }
 
@@ -439,10 +454,11 @@ static RxParams make_params(selenite_rx_instance *S, uint32_t block_size)
     p.guard_ratio = S->guard_ratio;
     p.guard_ch = S->d_guard_ch;
     p.guard_calls = S->d_guard_ch + g.channels;
+    p.guard_hand = S->d_guard_ch + 2 * (size_t)g.channels;
     if (S->sub_count) {                                     // a contiguous channel range of the instance: every per-channel array moves with it
         const size_t c0 = S->sub_first;
         p.channels = S->sub_count;
-        p.step += c0; p.phase += c0; p.gain += c0; p.guard_ch += c0; p.guard_calls += c0;
+        p.step += c0; p.phase += c0; p.gain += c0; p.guard_ch += c0; p.guard_calls += c0; p.guard_hand += c0;
         if (p.dec_state) p.dec_state += c0 * 2 * (g.nd_taps - 1);
         if (p.fir_state) p.fir_state += c0 * 2 * (g.nh_taps - 1);
         if (p.biq_state) p.biq_state += c0 * 4 * g.n_biquad;
@@ -525,6 +541,10 @@ static int run_part(selenite_rx_instance *S, const void *src, bool src_q15, void
         if (rc) return rc;
         audio = S->d_scratch;
     }
+    // (SELENITE_ARITH_AUTO outside the SSB fused kernels -- CW, generic: every channel's state stays in exact arithmetic, and the
+    // provenance words k_ssb_split16 reads at its next call say so)
+    if (phase != kPhase2 && S->d_rerun_flag && !ssb_fused)
+        HIPCHK(S, hipMemsetD32Async((hipDeviceptr_t)(S->d_rerun_flag + (S->sub_count ? S->sub_first : 0u)), 1, p.channels, st));
     bool env_emitted = false;      // global gain: the fused kernel wrote the per-channel block maxima
     if (ssb_fused || cw_fused) {
         RxParams pf = p;
@@ -918,6 +938,7 @@ extern "C" int selenite_rx_set_state(selenite_rx_instance *S, const selenite_rx_
         for (size_t c = 1; c < C; ++c) S->phase_uniform = S->phase_uniform && v->nco_phase[c] == v->nco_phase[0];
         S->phase_host = v->nco_phase[0];
     }
+    if (S->d_rerun_flag) HIPCHK(S, hipMemsetD32Async((hipDeviceptr_t)S->d_rerun_flag, 1, C, S->stream));      // a given state counts as exact
     return SELENITE_RX_SUCCESS;
 }
 

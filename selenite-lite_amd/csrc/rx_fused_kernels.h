@@ -396,6 +396,7 @@ __global__ __launch_bounds__(64, 2) void k_ssb_fused(RxParams p, FusedArgs fa, c
     if (lane == 0) {
         if constexpr (NCO != 0) p.phase[c] = ph0 + p.block_size * step;
         if (p.agc) p.gain[c] = gain;
+        if (p.rerun_flag && !p.chan_flags) p.rerun_flag[c] = 1u;     // SELENITE_ARITH_AUTO, a call without a matrix kernel: the state is exact (read by k_ssb_split16 at its next call)
     }
     if (!p.chan_flags) break;
     wave_lds_sync();                                     // the state reads above before the next channel's prologue fills

@@ -49,6 +49,8 @@ struct RxParams {
     float guard_ratio;
     uint32_t *guard_ch;    // [channels] sticky count of guarded DSP blocks per channel, or NULL
     uint32_t *guard_calls; // [channels] sticky count of process calls in which the channel had a guarded block, or NULL
+    uint32_t *guard_hand;  // [channels] sticky count of "handover" blocks (SELENITE_ARITH_AUTO, k_ssb_split16): guarded blocks inside the
+                           // Hilbert-pair history of a call whose predecessor left the channel's state in split16 precision, or NULL
     // SELENITE_ARITH_AUTO: a channel with a guarded block in this call keeps its pre-call streaming state (the split16
     // kernel does not write it back) and raises rerun_flag[channel] (every channel's flag is rewritten every call: plain
     // stores, no atomics -- 48 k atomics on one counter cost 0.7 ms per launch when most channels were guarded); a second
@@ -145,7 +147,7 @@ struct selenite_rx_instance {
     uint32_t *d_step = nullptr, *d_phase = nullptr;
     float *d_dec_state = nullptr, *d_fir_state = nullptr, *d_biq_state = nullptr, *d_gain = nullptr;
     uint32_t *d_flags = nullptr;       // kFlagWords words
-    uint32_t *d_guard_ch = nullptr;    // [2][channels] guarded DSP blocks per channel | process calls with a guarded block (sticky)
+    uint32_t *d_guard_ch = nullptr;    // [3][channels] guarded DSP blocks per channel | process calls with a guarded block | handover blocks (sticky)
     uint32_t *d_rerun_flag = nullptr;  // [channels] SELENITE_ARITH_AUTO: 1 = recompute this channel's current call exactly
     float guard_ratio = 0.25f;         // -12 dB
     bool steps_grid256 = false;        // every NCO step is a multiple of 2^24: every channel's LO repeats every 256 samples

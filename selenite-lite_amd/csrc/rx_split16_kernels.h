@@ -73,10 +73,15 @@ __device__ __forceinline__ void lds_order()
 // envelopes broadcast by v_readlane; GROUP = 0: any power-of-two `group` (run time).
 // Parity guard: `gd.thr` = guard ratio x the largest |component| the pass's matrix product saw; every DSP block of the pass
 // whose envelope (max |audio| before the gain) is below it is counted in gd.n (gd.first: the first lane of every DSP block).
+// gd.hist / gd.nh (k_ssb_split16, SELENITE_ARITH_AUTO): the guarded blocks among the first ones of a call, those that still see the
+// Hilbert-pair history the previous call left -- a history of split16 precision when that call kept the channel on the matrix
+// kernel: the "handover" blocks of DESIGN.md section 3, which the exact rerun cannot make exact; they are counted on their own.
 struct GuardPass {
     float thr;
     uint64_t first;
     uint32_t n;
+    uint64_t hist;     // lanes of the blocks inside the Hilbert history of the call's start while pass 0 is demodulated, else 0
+    uint32_t nh;
 };
 template <int GROUP>
 __device__ __forceinline__ void agc_pass(const AgcParams &ap, uint32_t agc_on, int lane, int group, float (&au)[4], float &gain,
@@ -87,7 +92,9 @@ __device__ __forceinline__ void agc_pass(const AgcParams &ap, uint32_t agc_on, i
     auto guard = [&](float env) {                    // env: the block envelope, in (at least) the first lane of every block
         const int lanes = nvb * (GROUP ? GROUP : group);
         const uint64_t exist = lanes >= 64 ? ~0ull : ((1ull << lanes) - 1ull);
-        gd.n += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(env < gd.thr) & gd.first & exist);
+        const uint64_t hit = __builtin_amdgcn_ballot_w64(env < gd.thr) & gd.first & exist;
+        gd.n += (uint32_t)__builtin_popcountll(hit);
+        gd.nh += (uint32_t)__builtin_popcountll(hit & gd.hist);
     };
     if constexpr (GROUP == 16) {
         m = row16_fmax(m);
@@ -303,7 +310,7 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
     static_assert(GS::HS % kWave == 0 && (2 * G::HH4) % kWave == 0, "state fills are whole wave loads");
     v2f st_hv[NHI];
     float st_fv[NFI], st_gain;
-    uint32_t st_ph0, st_step;
+    uint32_t st_ph0, st_step, st_exact;
     auto load_state = [&](uint32_t ch) {
         ch = ch < p.channels ? ch : p.channels - 1;               // past the last channel: harmless reload, never installed
         const float *stI = p.dec_state + (size_t)ch * 2 * (ND - 1), *stQ = stI + (ND - 1);
@@ -324,14 +331,16 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
         st_ph0 = NCO ? p.phase[ch] : 0u;
         st_step = NCO ? p.step[ch] : 0u;
         st_gain = p.gain[ch];
+        st_exact = p.rerun_flag ? p.rerun_flag[ch] : 1u;          // AUTO: 1 = the previous call left this channel's state in exact arithmetic
     };
+    uint32_t prev_exact = 1u;
     uint32_t b_hist = 0, ph0 = 0, step = 0;                       // b_hist: bit pattern of the largest |history component|
     float gain = 1.0f;
     int s_cur = 0x7fff;                                               // sample scale exponent of the images (none yet)
     // parity guard (GuardPass): thresholds of the pass being mixed and of the pass before it (whose demodulator runs later)
     float thr_cur = 0.0f, thr_prev = 0.0f;
     GuardPass gd;
-    gd.thr = 0.0f; gd.n = 0u;
+    gd.thr = 0.0f; gd.n = 0u; gd.hist = 0ull; gd.nh = 0u;
     if constexpr (GROUP == 16) gd.first = 0x0001000100010001ull;
     else if constexpr (GROUP == 32) gd.first = 0x0000000100000001ull;
     else if constexpr (GROUP == 64) gd.first = 1ull;
@@ -339,6 +348,9 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
         gd.first = 0ull;
         for (int l = 0; l < 64; l += (int)fa.group) gd.first |= 1ull << l;
     }
+    // lanes of the DSP blocks that hold one of the first HH audio samples of a call (the reach of the Hilbert-pair history)
+    const int hist_lanes = ((G::HH + 4 * (int)fa.group - 1) / (4 * (int)fa.group)) * (int)fa.group;
+    const uint64_t hist_mask = hist_lanes >= 64 ? ~0ull : ((1ull << hist_lanes) - 1ull);
     auto install_state = [&]() {
         float mh = 0.0f;
 #pragma unroll
@@ -354,7 +366,7 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
         b_hist = wave_umax_bits(mh);
         ph0 = st_ph0; step = st_step; gain = st_gain;
         s_cur = 0x7fff;
-        gd.n = 0u;
+        gd.n = 0u; gd.nh = 0u; prev_exact = st_exact;
         if constexpr (NCO == 4) {
             // LO of samples 2 lane, 2 lane + 1 and 128 + 2 lane, 129 + 2 lane of every 256-sample period: the phases the
             // per-sample NCO (NCO == 1) would form for them in any pass, n0 * step and 256 * step being multiples of 2^32
@@ -725,6 +737,7 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
             v4f dt = { 0.0f, 0.0f, 0.0f, 0.0f };
             if constexpr (AM == 0) dt = *reinterpret_cast<const v4f *>(D + dt_off + pq);      // (the pass before this one was a full one)
             gd.thr = thr_prev;                                        // the demodulator below belongs to the pass before
+            gd.hist = pass == 1 ? hist_mask : 0ull;
             const int nvb_full = GROUP == 0 ? (int)(pq / (4u * (uint32_t)group)) : 64;
             mfma_phase([&](int kk) { demod_piece(kk, au, nvb_full); }, (NTS + TPK - 1) / TPK - 1);   // matrix pipe over the vector work of the pass before
             cb_read(cb);
@@ -738,6 +751,7 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
         store_audio(npass - 2, au);
         load_state(c + gridDim.x);                                    // the next channel's state, under this channel's last demodulator pass
         gd.thr = thr_cur;
+        gd.hist = npass == 1 ? hist_mask : 0ull;
         demod(au, (int)(tail_out / (4u * (uint32_t)group)));          // DSP blocks of the last pass that exist
         store_audio(npass - 1, au);
         STAMP(0);
@@ -747,6 +761,7 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
         const bool keep_state = gd.n != 0u && p.rerun_flag != nullptr;   // wave-uniform
         if (lane == 0) {
             if (gd.n != 0u && p.guard_ch) { p.guard_ch[c] += gd.n; p.guard_calls[c] += 1u; }
+            if (gd.nh != 0u && prev_exact == 0u && p.guard_hand) p.guard_hand[c] += gd.nh;     // handover blocks (AUTO only: prev_exact is 1 otherwise)
             if (p.rerun_flag) p.rerun_flag[c] = keep_state ? 1u : 0u;
         }
         // ---- streaming state of the channel back to HBM (exact f32) ----

@@ -63,7 +63,7 @@ ABI_SYMBOLS = [
     "selenite_rx_global_process_f32_device",
     "selenite_rx_host_alloc", "selenite_rx_host_free", "selenite_rx_host_register", "selenite_rx_host_unregister",
     "selenite_rx_time_process_each_device", "selenite_rx_device_pci_bus_id",
-    "selenite_rx_set_guard_ratio", "selenite_rx_guard_stats", "selenite_rx_guard_channels", "selenite_rx_guard_clear",
+    "selenite_rx_set_guard_ratio", "selenite_rx_guard_stats", "selenite_rx_guard_channels", "selenite_rx_guard_handover", "selenite_rx_guard_clear",
 ]
 
 class TxConfig(C.Structure):
@@ -168,6 +168,7 @@ def lib():
         L.selenite_rx_guard_stats.argtypes = [vp, u64p, u64p, u64p]
         L.selenite_rx_guard_channels.argtypes = [vp, u32p]
         L.selenite_rx_guard_clear.argtypes = [vp]
+        L.selenite_rx_guard_handover.argtypes = [vp, u64p]
         L.selenite_rx_design_lowpass.argtypes = [f32p, C.c_uint32, C.c_double]
         L.selenite_rx_design_hilbert.argtypes = [f32p, f32p, C.c_uint32]
         L.selenite_rx_design_bandpass.argtypes = [f32p, C.c_uint32, C.c_double, C.c_double]
@@ -363,12 +364,16 @@ class Rx:
             raise RxError(rc, "selenite_rx_set_guard_ratio")
 
     def guard_stats(self):
-        """dict(blocks, channel_calls, rerun_channel_calls) since init / the last guard_clear()."""
+        """dict(blocks, channel_calls, rerun_channel_calls, handover_blocks) since init / the last guard_clear()."""
         b, c, r = C.c_uint64(), C.c_uint64(), C.c_uint64()
         rc = self.L.selenite_rx_guard_stats(self.h, C.byref(b), C.byref(c), C.byref(r))
         if rc:
             raise RxError(rc, self.error())
-        return dict(blocks=int(b.value), channel_calls=int(c.value), rerun_channel_calls=int(r.value))
+        h = C.c_uint64()
+        rc = self.L.selenite_rx_guard_handover(self.h, C.byref(h))
+        if rc:
+            raise RxError(rc, self.error())
+        return dict(blocks=int(b.value), channel_calls=int(c.value), rerun_channel_calls=int(r.value), handover_blocks=int(h.value))
 
     def guard_channels(self):
         out = np.zeros(self.cfg.channels, np.uint32)

@@ -150,6 +150,45 @@ def test_guard_counts_follow_the_definition():
     g.close()
 
 
+def test_handover_blocks_are_counted():
+    """What the rerun cannot repair is at least visible ("what the guard does not see"): a guarded block inside the
+    reach of the Hilbert-pair history at the start of a call, in a channel the PREVIOUS call left on the matrix kernel, is computed in
+    exact arithmetic from a history of split16 precision.  selenite_rx_guard_handover counts those blocks.  Signal: LSB on a USB-side
+    tone, 127-tap pair, 192-frame DSP blocks -- the per-block level hovers around the guard ratio.  (a) the start-up call (every channel
+    guarded, state = cleared = exact) counts none; (b) over the run some are counted; (c) every block over the plain bar lies in a
+    channel-call that counted one; (d) reset / set_state declare the state exact again."""
+    import selenite_rx as sr
+    nch, block, na = 21, 192, 48
+    kw = dict(nco=True, nco_step_all=0x00c00000, agc=True)
+    g = sr.Rx(rc.ChainSpec(nch, block, 4, 256, 127, 0, rc.MODE_LSB, ARITH_AUTO, **kw).config())
+    o = CpuChain(rc.ChainSpec(nch, block, 4, 256, 127, 0, rc.MODE_LSB, ARITH_CMSIS, **kw), "orc")
+    pos, total, over = 0, 0, 0
+    for i, bs in enumerate([block * k for k in (1, 2, 10, 11, 1, 50, 2, 10, 3, 10)]):
+        iq = synth_iq(0, nch, pos, bs)
+        pos += bs
+        before = g.guard_stats()["handover_blocks"]
+        d, m = per_block(g.process(iq), o.process(iq), na)
+        now = g.guard_stats()["handover_blocks"] - before
+        if i == 0:
+            assert now == 0 and g.guard_stats()["blocks"] > 0          # (a)
+        bad = d > 1e-5 * m
+        if bad.any():
+            assert bad[:, 3:].sum() == 0                                # only inside the reach of the history: ceil(126 / 48) blocks
+            assert now >= bad.any(axis=1).sum()                         # (c) every such channel-call counted at least one
+            over += int(bad.sum())
+        total += now
+    assert total > 0                                                    # (b)
+    g.reset()
+    g.guard_clear()
+    g.process(synth_iq(0, nch, 0, 10 * block))
+    assert g.guard_stats()["handover_blocks"] == 0                      # (d)
+    st = g.state()
+    g.set_state(st)
+    g.process(synth_iq(0, nch, 10 * block, 10 * block))
+    assert g.guard_stats()["handover_blocks"] == 0
+    g.close()
+
+
 def test_auto_on_the_bench_workload_guards_nothing_in_the_steady_state():
     """The bench workload (cfg3, every channel one tone in band): after the start-up transient of the first call no block is
     guarded, so AUTO costs one empty rerun launch; and the plain bar holds on every block."""
@@ -163,7 +202,7 @@ def test_auto_on_the_bench_workload_guards_nothing_in_the_steady_state():
             g.guard_clear()
         d, m = per_block(g.process(iq), o.process(iq, 8), 64)
         assert (d <= 1e-5 * m).all(), (call, (d / np.maximum(m, 1e-30)).max())
-    assert g.guard_stats() == dict(blocks=0, channel_calls=0, rerun_channel_calls=0)
+    assert g.guard_stats() == dict(blocks=0, channel_calls=0, rerun_channel_calls=0, handover_blocks=0)
     g.close()
 
 

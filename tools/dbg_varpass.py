@@ -21,7 +21,7 @@ for arith in (rc.ARITH_SPLIT16, rc.ARITH_AUTO):
         d = np.abs(yg.astype(np.float64) - yo).reshape(nch, -1, na).max(axis=2)
         m = np.abs(yo).reshape(nch, -1, na).max(axis=2)
         r = d / np.maximum(m, 1e-30)
-        print(arith, bs, "worst", r.max(), "at", np.unravel_index(r.argmax(), r.shape), g.kernel_name())
+        print(arith, bs, "worst", r.max(), "at", np.unravel_index(r.argmax(), r.shape), g.kernel_name(), g.guard_stats())
         sg, so = g.state(), o.state()
         for k in sg:
             if np.asarray(sg[k]).size == 0: continue
