@@ -226,12 +226,17 @@ int selenite_rx_guard_stats(selenite_rx_instance *S, uint64_t *guard_blocks, uin
                             uint64_t *rerun_channel_calls);
 /* per_channel[channels]: guarded DSP blocks of every channel since init / the last clear (sticky per-channel view). */
 int selenite_rx_guard_channels(selenite_rx_instance *S, uint32_t *per_channel);
-/* SELENITE_ARITH_AUTO, what the rerun cannot repair ("what the guard does not see"): guarded DSP blocks among
- * the first ones of a call -- those inside the reach of the Hilbert-pair history, (nh_taps - 1) audio samples -- of a channel whose
- * PREVIOUS call stayed on the matrix kernel.  Such a block is recomputed in exact arithmetic from a history of split16 precision:
- * its distance from CMSIS is that of a guarded block of raw SELENITE_ARITH_SPLIT16 (up to ~3e-5 of the block maximum), not 0.
- * Needs a channel whose level crosses the guard ratio downwards exactly at a call boundary; 0 on the bench workload.  Counted
- * since init / the last selenite_rx_guard_clear; drains the stream. */
+/* SELENITE_ARITH_AUTO across calls ("across a call boundary").  A channel the previous call left on the
+ * matrix kernel carries a Hilbert-pair history (the last nh_taps - 1 decimated samples) of split16 precision; if THIS call has to
+ * be recomputed for it, its first blocks -- those inside the reach of that history -- would start from it.  Handover repair
+ * (default on): k_ssb_split16 also leaves the exact mixed samples in front of the decimator state behind (decim * (nh_taps - 1)
+ * samples per channel and call, rounded up to whole quads: 2 KB for the cfg3 chain), and the rerun recomputes the Hilbert-pair
+ * history from them in exact arithmetic first: the recomputed call is CMSIS bit for bit from its first sample (apart from the
+ * gain the previous call's AGC left: ~1e-6 relative).  Cost: those bytes (2.4 % of the headline at 4096 samples per call, half
+ * that at 8192).  Off: nothing is kept, and such blocks -- and, in either setting, those behind a call too short to hold the
+ * samples (under nd_taps + decim * (nh_taps - 1) per channel) -- carry the error of a guarded block of raw SELENITE_ARITH_SPLIT16
+ * (up to ~1e-3 of a block maximum that is the residue of a sideband cancellation) and are COUNTED: */
+int selenite_rx_set_handover_repair(selenite_rx_instance *S, int on);
 int selenite_rx_guard_handover(selenite_rx_instance *S, uint64_t *handover_blocks);
 int selenite_rx_guard_clear(selenite_rx_instance *S);
 

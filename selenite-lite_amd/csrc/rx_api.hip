@@ -111,7 +111,7 @@ static void classify_coeffs(selenite_rx_instance *S)
 
 static void free_device(selenite_rx_instance *S)
 {
-    void *ptrs[] = { S->d_flags, S->d_guard_ch, S->d_rerun_flag, S->d_conv_in, S->d_dec_c, S->d_hilb_c, S->d_delay_c, S->d_biq_c, S->d_sintab, S->d_step, S->d_phase,
+    void *ptrs[] = { S->d_flags, S->d_guard_ch, S->d_rerun_flag, S->d_hist_ext, S->d_conv_in, S->d_dec_c, S->d_hilb_c, S->d_delay_c, S->d_biq_c, S->d_sintab, S->d_step, S->d_phase,
                      S->d_dec_state, S->d_fir_state, S->d_biq_state, S->d_gain, S->d_scratch, S->d_env, S->d_env_part,
                      S->d_io_in, S->d_io_out, S->d_lo, S->pipe.d_in[0], S->pipe.d_in[1], S->pipe.d_out[0], S->pipe.d_out[1] };
     for (void *p : ptrs)
@@ -139,8 +139,8 @@ static int reset_state(selenite_rx_instance *S)
     HIPCHK(S, hipMemsetAsync(S->d_phase, 0, C * sizeof(uint32_t), S->stream));
     HIPCHK(S, hipMemsetAsync(S->d_flags, 0, kFlagWords * sizeof(uint32_t), S->stream));
     HIPCHK(S, hipMemsetAsync(S->d_guard_ch, 0, 3 * C * sizeof(uint32_t), S->stream));
-    // (1 = "the channel's state is in exact arithmetic": what a cleared state is; k_ssb_split16 rewrites every word every call)
-    if (S->d_rerun_flag) HIPCHK(S, hipMemsetD32Async((hipDeviceptr_t)S->d_rerun_flag, 1, C, S->stream));
+    // (0 = no rerun pending, the channel's state is in exact arithmetic (kProvExact): what a cleared state is)
+    if (S->d_rerun_flag) HIPCHK(S, hipMemsetAsync(S->d_rerun_flag, 0, C * sizeof(uint32_t), S->stream));
     std::vector<float> gi(C, g.agc_gain_init);
     HIPCHK(S, hipMemcpyAsync(S->d_gain, gi.data(), C * sizeof(float), hipMemcpyHostToDevice, S->stream));
     HIPCHK(S, hipStreamSynchronize(S->stream));
@@ -259,6 +259,14 @@ extern "C" int selenite_rx_init(selenite_rx_instance **out, const selenite_rx_co
     INITCHK(dev_alloc(&S->d_flags, (size_t)kFlagWords));
     INITCHK(dev_alloc(&S->d_guard_ch, 3 * C));
     INITCHK(dev_alloc(&S->d_rerun_flag, cfg->arith == SELENITE_ARITH_AUTO ? C : 0));
+    if (cfg->arith == SELENITE_ARITH_AUTO && cfg->nd_taps >= 2 && cfg->nh_taps >= 2 &&
+        ssb_split16_has_shape((int)cfg->nd_taps, (int)cfg->decim, (int)cfg->nh_taps) && !std::getenv("SELENITE_RX_NO_HIST_EXT")) {
+        // k_ssb_split16 leaves the mixed samples in front of the decimator state here (two buffers: the one a channel's state points
+        // at stays intact while the next call fills the other), for k_hist_exact
+        S->ext_len = cfg->decim * ((cfg->nh_taps - 1u + 3u) & ~3u);
+        INITCHK(dev_alloc(&S->d_hist_ext, 2 * C * (S->ext_len + 2)));       // (rows of ext_len + 2 samples: pair-aligned 16-byte stores)
+        INITCHK(hipMemset(S->d_hist_ext, 0, 2 * C * (S->ext_len + 2) * sizeof(float2)));
+    }
 #undef INITCHK
     classify_coeffs(S);
     if (plan_fused(S->cfg, S->delay_is_impulse, S->delay_index, S->hilb_odd_only, S->plan) != hipSuccess) {
@@ -416,6 +424,13 @@ extern "C" int selenite_rx_guard_clear(selenite_rx_instance *S)
     return SELENITE_RX_SUCCESS;
 }
 
+extern "C" int selenite_rx_set_handover_repair(selenite_rx_instance *S, int on)
+{
+    if (!S) return SELENITE_RX_ARGUMENT_ERROR;
+    S->handover_repair = on != 0;
+    return SELENITE_RX_SUCCESS;
+}
+
 extern "C" int selenite_rx_guard_handover(selenite_rx_instance *S, uint64_t *handover_blocks)
 {
     if (!S || !handover_blocks) return SELENITE_RX_ARGUMENT_ERROR;
@@ -455,10 +470,12 @@ static RxParams make_params(selenite_rx_instance *S, uint32_t block_size)
     p.guard_ch = S->d_guard_ch;
     p.guard_calls = S->d_guard_ch + g.channels;
     p.guard_hand = S->d_guard_ch + 2 * (size_t)g.channels;
+    p.hist_ext = S->handover_repair ? S->d_hist_ext : nullptr; p.ext_len = S->ext_len; p.ext_buf_stride = (size_t)g.channels * (S->ext_len + 2);
     if (S->sub_count) {                                     // a contiguous channel range of the instance: every per-channel array moves with it
         const size_t c0 = S->sub_first;
         p.channels = S->sub_count;
         p.step += c0; p.phase += c0; p.gain += c0; p.guard_ch += c0; p.guard_calls += c0; p.guard_hand += c0;
+        if (p.hist_ext) p.hist_ext += c0 * (p.ext_len + 2);
         if (p.dec_state) p.dec_state += c0 * 2 * (g.nd_taps - 1);
         if (p.fir_state) p.fir_state += c0 * 2 * (g.nh_taps - 1);
         if (p.biq_state) p.biq_state += c0 * 4 * g.n_biquad;
@@ -544,7 +561,7 @@ static int run_part(selenite_rx_instance *S, const void *src, bool src_q15, void
     // (SELENITE_ARITH_AUTO outside the SSB fused kernels -- CW, generic: every channel's state stays in exact arithmetic, and the
     // provenance words k_ssb_split16 reads at its next call say so)
     if (phase != kPhase2 && S->d_rerun_flag && !ssb_fused)
-        HIPCHK(S, hipMemsetD32Async((hipDeviceptr_t)(S->d_rerun_flag + (S->sub_count ? S->sub_first : 0u)), 1, p.channels, st));
+        HIPCHK(S, hipMemsetAsync(S->d_rerun_flag + (S->sub_count ? S->sub_first : 0u), 0, p.channels * sizeof(uint32_t), st));
     bool env_emitted = false;      // global gain: the fused kernel wrote the per-channel block maxima
     if (ssb_fused || cw_fused) {
         RxParams pf = p;
@@ -938,7 +955,7 @@ extern "C" int selenite_rx_set_state(selenite_rx_instance *S, const selenite_rx_
         for (size_t c = 1; c < C; ++c) S->phase_uniform = S->phase_uniform && v->nco_phase[c] == v->nco_phase[0];
         S->phase_host = v->nco_phase[0];
     }
-    if (S->d_rerun_flag) HIPCHK(S, hipMemsetD32Async((hipDeviceptr_t)S->d_rerun_flag, 1, C, S->stream));      // a given state counts as exact
+    if (S->d_rerun_flag) HIPCHK(S, hipMemsetAsync(S->d_rerun_flag, 0, C * sizeof(uint32_t), S->stream));      // a given state counts as exact
     return SELENITE_RX_SUCCESS;
 }
 

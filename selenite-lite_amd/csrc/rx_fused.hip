@@ -491,6 +491,8 @@ static hipError_t launch_shape(const RxParams &p, const FusedArgs &fa, const Fus
         RxParams p2 = p;
         p2.chan_flags = p.rerun_flag;
         p2.rerun_flag = nullptr; p2.guard_ch = nullptr; p2.guard_calls = nullptr;
+        // (channels the call before left on the matrix kernel: their Hilbert-pair history first, in exact arithmetic -- rx_generic.hip)
+        if (hipError_t e = launch_hist_exact(p2, st); e != hipSuccess) return e;
         return launch_exact(ND, M, NH, src_q15, p2, fa, src, dst, st);            // rx_fused_exact.hip
     };
     // what the matrix kernels take: DSP blocks that divide the 256-output pass; whole passes (k_ssb_mfma, k_hilb_split16), or a

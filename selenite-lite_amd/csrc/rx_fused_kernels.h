@@ -209,7 +209,7 @@ __global__ __launch_bounds__(64, 2) void k_ssb_fused(RxParams p, FusedArgs fa, c
             if (win >= nwin) break;
             const uint32_t ci = 16u * win + (uint32_t)(lane & 15);
             const uint32_t f = (lane < 16 && ci < p.channels) ? p.chan_flags[ci] : 0u;
-            todo = __builtin_amdgcn_ballot_w64(f != 0u);
+            todo = __builtin_amdgcn_ballot_w64((f & kFlagRerun) != 0u);
             if (todo == 0) win += gridDim.x;
         }
         if (todo == 0) break;
@@ -396,7 +396,10 @@ __global__ __launch_bounds__(64, 2) void k_ssb_fused(RxParams p, FusedArgs fa, c
     if (lane == 0) {
         if constexpr (NCO != 0) p.phase[c] = ph0 + p.block_size * step;
         if (p.agc) p.gain[c] = gain;
-        if (p.rerun_flag && !p.chan_flags) p.rerun_flag[c] = 1u;     // SELENITE_ARITH_AUTO, a call without a matrix kernel: the state is exact (read by k_ssb_split16 at its next call)
+        // SELENITE_ARITH_AUTO: the state this kernel leaves is exact (kProvExact, rerun bit down) -- as the rerun pass, and as a call
+        // without a matrix kernel; k_ssb_split16 reads the word at the channel's next call
+        if (p.chan_flags) p.chan_flags[c] = 0u;
+        else if (p.rerun_flag) p.rerun_flag[c] = 0u;
     }
     if (!p.chan_flags) break;
     wave_lds_sync();                                     // the state reads above before the next channel's prologue fills

@@ -190,6 +190,56 @@ __global__ __launch_bounds__(64) void k_front_generic(RxParams p, const TIn *__r
     if (p.nco && lane == 0) p.phase[c] = ph0 + p.block_size * step;
 }
 
+// ------------------------------------------------------------------------------------------
+// k_hist_exact -- SELENITE_ARITH_AUTO, what makes the rerun exact across a call boundary.
+// A channel the call before left on the matrix kernel carries a Hilbert-pair history (the last nh - 1 decimated samples of
+// both rails) of split16 precision.  When THIS call has to be recomputed for it (p.chan_flags: rerun bit, provenance
+// kProvSplitExt), the history is first recomputed here in the reference's arithmetic -- arm_fir_decimate_f32.c:193-284: one
+// accumulator from 0, taps ascending, product rounded, then sum rounded -- from the exact mixed samples k_ssb_split16 left behind:
+// T = hist_ext[1 .. L + 1) (positions [E - H - L, E - H)) ++ decimator state ([E - H, E)), H = nd - 1, L = ext_len = M * HH4.  History entry r
+// (r = nh - 2 the newest) is the decimator output whose newest sample sits at E - M (nh - 1 - r): T[t0 .. t0 + nd), t0 = L - M (nh - 1 - r).
+// One wavefront per flagged channel, the flag array walked in 16-channel windows (which channels, and how many, only the
+// device knows); rare by construction (a channel whose level crosses the guard ratio downwards at a call boundary).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_hist_exact(RxParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x;
+    const uint32_t nd = p.nd, M = p.decim, HH = p.nh - 1u, L = p.ext_len, H = nd - 1u;
+    float *TI = lds, *TQ = lds + (L + H);
+    const uint32_t nwin = (p.channels + 15u) / 16u;
+    for (uint32_t win = blockIdx.x; win < nwin; win += gridDim.x) {
+        const uint32_t ci = 16u * win + (uint32_t)(lane & 15);
+        const uint32_t f = (lane < 16 && ci < p.channels) ? p.chan_flags[ci] : 0u;
+        uint64_t todo = __builtin_amdgcn_ballot_w64((f & kFlagRerun) != 0u && ((f >> kProvShift) & kProvMask) == kProvSplitExt);
+        while (todo != 0) {                                           // wave-uniform
+            const uint32_t c = 16u * win + (uint32_t)__builtin_ctzll(todo);
+            todo &= todo - 1;
+            const uint32_t buf = (p.chan_flags[c] >> kExtBufShift) & 1u;
+            const float2 *ext = p.hist_ext + (size_t)buf * p.ext_buf_stride + (size_t)c * (L + 2u) + 1;      // (rows of L + 2: one spare sample at either end)
+            for (uint32_t i = lane; i < L; i += kWave) { const float2 v = ext[i]; TI[i] = v.x; TQ[i] = v.y; }
+            for (uint32_t i = lane; i < H; i += kWave) {
+                TI[L + i] = p.dec_state[((size_t)c * 2 + 0) * H + i];
+                TQ[L + i] = p.dec_state[((size_t)c * 2 + 1) * H + i];
+            }
+            __syncthreads();
+            for (uint32_t r = lane; r < HH; r += kWave) {
+                const uint32_t t0 = L - M * (HH - r);
+                float ai = 0.0f, aq = 0.0f;
+                for (uint32_t k = 0; k < nd; ++k) {
+                    const float ck = p.dec_c[k];
+                    const float pi_ = TI[t0 + k] * ck, pq_ = TQ[t0 + k] * ck;
+                    ai = ai + pi_;
+                    aq = aq + pq_;
+                }
+                p.fir_state[((size_t)c * 2 + 0) * HH + r] = ai;
+                p.fir_state[((size_t)c * 2 + 1) * HH + r] = aq;
+            }
+            __syncthreads();
+        }
+    }
+}
+
 template <int ARITH>
 __global__ __launch_bounds__(64) void k_biquad_generic(RxParams p, float *__restrict__ audio)
 {
@@ -509,6 +559,17 @@ __global__ __launch_bounds__(256) void k_q15_to_f32(const int16_t *__restrict__ 
         __builtin_nontemporal_store(a, reinterpret_cast<v4f *>(dst) + 2 * i);
         __builtin_nontemporal_store(b, reinterpret_cast<v4f *>(dst) + 2 * i + 1);
     }
+}
+
+hipError_t launch_hist_exact(const RxParams &p, hipStream_t st)
+{
+    if (!p.chan_flags || !p.hist_ext || p.nd < 2 || p.nh < 2) return hipSuccess;
+    static const bool off = std::getenv("SELENITE_RX_NO_HIST_EXACT") != nullptr;      // diagnostic: what the rerun does without it
+    if (off) return hipSuccess;
+    const uint32_t nwin = (p.channels + 15u) / 16u;
+    const size_t lds = 2 * (size_t)(p.ext_len + p.nd - 1u) * sizeof(float);
+    hipLaunchKernelGGL(k_hist_exact, dim3(nwin < 1024u ? nwin : 1024u), dim3(64), lds, st, p);
+    return hipGetLastError();
 }
 
 hipError_t launch_q15_to_f32(const int16_t *src, float *dst, size_t n, hipStream_t st)

@@ -56,13 +56,24 @@ struct RxParams {
     // stores, no atomics -- 48 k atomics on one counter cost 0.7 ms per launch when most channels were guarded); a second
     // launch of the bit-exact kernel (chan_flags = those flags) recomputes the call for the flagged channels -- audio and
     // state -- in the CMSIS arithmetic
-    uint32_t *rerun_flag;        // [channels] or NULL (plain SPLIT16: count only)
-    const uint32_t *chan_flags;  // exact kernels: process only the channels whose flag is set (16-channel windows, grid-stride)
+    uint32_t *rerun_flag;        // [channels] or NULL (plain SPLIT16: count only).  Word of a channel (SELENITE_ARITH_AUTO):
+                                 //   bit 0      recompute this channel's current call in exact arithmetic (kFlagRerun)
+                                 //   bits 1-2   provenance of the channel's streaming state (kProv*): what the call before left
+                                 //   bit 3      which of the two hist_ext buffers holds the samples in front of that state
+    // k_ssb_split16, SELENITE_ARITH_AUTO: the mixed samples in front of the decimator state, hist_ext[buf][channel][ext_len] (I, Q),
+    // positions [E - (nd - 1) - ext_len, E - (nd - 1)) of the stream that ends at E -- what it takes to recompute the Hilbert-pair
+    // history (the last HH4 decimated samples) in exact arithmetic when the NEXT call has to be rerun (k_hist_exact)
+    float2 *hist_ext;            // or NULL
+    uint32_t ext_len;            // decim * HH4
+    size_t ext_buf_stride;       // elements between the two buffers
+    uint32_t *chan_flags;  // exact kernels: process only the channels whose flag is set (16-channel windows, grid-stride)
     AgcParams agcp;
 };
 
 // words of RxParams::flags
 enum { kFlagNanInf = 0, kFlagWords = 4 };
+// RxParams::rerun_flag words
+enum : uint32_t { kFlagRerun = 1u, kProvShift = 1u, kProvMask = 3u, kProvExact = 0u, kProvSplitExt = 1u, kProvSplit = 2u, kExtBufShift = 3u };
 
 __host__ __device__ inline bool mode_is_cw(uint32_t m) { return m == SELENITE_MODE_CW || m == SELENITE_MODE_CWR; }
 __host__ __device__ inline bool mode_is_upper(uint32_t m)
@@ -77,6 +88,9 @@ hipError_t launch_front_generic(const RxParams &p, int arith, const void *src, b
 size_t front_generic_lds_bytes(const RxParams &p);
 // arm_q15_to_float over a whole buffer (SupportFunctions/arm_q15_to_float.c:87): n int16 values -> n floats
 hipError_t launch_q15_to_f32(const int16_t *src, float *dst, size_t n, hipStream_t st);
+// SELENITE_ARITH_AUTO, in front of the rerun pass: the Hilbert-pair history of every flagged channel whose state the call before left
+// on the matrix kernel (with its hist_ext) is recomputed in exact arithmetic from hist_ext + the decimator state (rx_generic.hip)
+hipError_t launch_hist_exact(const RxParams &p, hipStream_t st);
 // CW biquad cascade, in place on f32 audio
 hipError_t launch_biquad_generic(const RxParams &p, int arith, float *audio, hipStream_t st);
 // per-channel AGC (or plain copy/convert when p.agc == 0): audio -> dst
@@ -148,7 +162,10 @@ struct selenite_rx_instance {
     float *d_dec_state = nullptr, *d_fir_state = nullptr, *d_biq_state = nullptr, *d_gain = nullptr;
     uint32_t *d_flags = nullptr;       // kFlagWords words
     uint32_t *d_guard_ch = nullptr;    // [3][channels] guarded DSP blocks per channel | process calls with a guarded block | handover blocks (sticky)
-    uint32_t *d_rerun_flag = nullptr;  // [channels] SELENITE_ARITH_AUTO: 1 = recompute this channel's current call exactly
+    uint32_t *d_rerun_flag = nullptr;  // [channels] SELENITE_ARITH_AUTO: rerun bit + state provenance (RxParams::rerun_flag)
+    float2 *d_hist_ext = nullptr;      // [2][channels][ext_len] SELENITE_ARITH_AUTO with k_ssb_split16: RxParams::hist_ext
+    uint32_t ext_len = 0;
+    bool handover_repair = true;       // selenite_rx_set_handover_repair
     float guard_ratio = 0.25f;         // -12 dB
     bool steps_grid256 = false;        // every NCO step is a multiple of 2^24: every channel's LO repeats every 256 samples
     float *d_scratch = nullptr;  size_t scratch_bytes = 0;   // intermediate f32 audio

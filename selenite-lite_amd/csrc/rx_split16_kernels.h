@@ -310,7 +310,7 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
     static_assert(GS::HS % kWave == 0 && (2 * G::HH4) % kWave == 0, "state fills are whole wave loads");
     v2f st_hv[NHI];
     float st_fv[NFI], st_gain;
-    uint32_t st_ph0, st_step, st_exact;
+    uint32_t st_ph0, st_step, st_word;
     auto load_state = [&](uint32_t ch) {
         ch = ch < p.channels ? ch : p.channels - 1;               // past the last channel: harmless reload, never installed
         const float *stI = p.dec_state + (size_t)ch * 2 * (ND - 1), *stQ = stI + (ND - 1);
@@ -331,9 +331,17 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
         st_ph0 = NCO ? p.phase[ch] : 0u;
         st_step = NCO ? p.step[ch] : 0u;
         st_gain = p.gain[ch];
-        st_exact = p.rerun_flag ? p.rerun_flag[ch] : 1u;          // AUTO: 1 = the previous call left this channel's state in exact arithmetic
+        st_word = p.rerun_flag ? p.rerun_flag[ch] : 0u;           // AUTO: provenance of the channel's state, which hist_ext buffer goes with it
     };
-    uint32_t prev_exact = 1u;
+    uint32_t prev_prov = kProvExact, prev_buf = 0u;
+    // SELENITE_ARITH_AUTO: the mixed samples in front of the decimator state go to hist_ext (RxParams), so that a rerun of the NEXT
+    // call can start from a Hilbert-pair history in exact arithmetic (k_hist_exact) -- when this call is long enough to hold them
+    // (rows of ext_len + 2 samples, [E - (ND - 1) - ext_len - 1, E - (ND - 1) + 1): one more at either end makes the window start on an
+    // even sample, so the two samples of a lane leave in ONE 16-byte store that never straddles the window)
+    static_assert(ND % 2 == 0, "hist_ext rows are pair-aligned for even tap counts");
+    const int ext_start = (int)p.block_size - (ND - 1) - (int)p.ext_len - 1;  // call-relative position of hist_ext[0]
+    const bool ext_on = p.hist_ext != nullptr && ext_start >= 0;              // wave-uniform
+    __amdgpu_buffer_rsrc_t rs_ext = make_rsrc(p.hist_ext, 0u);
     uint32_t b_hist = 0, ph0 = 0, step = 0;                       // b_hist: bit pattern of the largest |history component|
     float gain = 1.0f;
     int s_cur = 0x7fff;                                               // sample scale exponent of the images (none yet)
@@ -366,7 +374,10 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
         b_hist = wave_umax_bits(mh);
         ph0 = st_ph0; step = st_step; gain = st_gain;
         s_cur = 0x7fff;
-        gd.n = 0u; gd.nh = 0u; prev_exact = st_exact;
+        gd.n = 0u; gd.nh = 0u;
+        prev_prov = (st_word >> kProvShift) & kProvMask; prev_buf = (st_word >> kExtBufShift) & 1u;
+        if (ext_on)                                                   // the buffer the state of the call before does NOT point at
+            rs_ext = make_rsrc(p.hist_ext + (size_t)(prev_buf ^ 1u) * p.ext_buf_stride + (size_t)c * (p.ext_len + 2u), (p.ext_len + 2u) * 8u);
         if constexpr (NCO == 4) {
             // LO of samples 2 lane, 2 lane + 1 and 128 + 2 lane, 129 + 2 lane of every 256-sample period: the phases the
             // per-sample NCO (NCO == 1) would form for them in any pass, n0 * step and 256 * step being multiples of 2^32
@@ -450,6 +461,16 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
             } else {
                 m[2 * i] = a;
                 m[2 * i + 1] = b;
+            }
+        }
+        if (ext_on && (int)(n0 + G::T) > ext_start) {                 // wave-uniform: the last one or two passes of the call
+#pragma unroll
+            for (int i = 0; i < NLD; ++i) {
+                const int e0 = (int)n0 + 128 * i - ext_start;         // row index of the load's first sample (even)
+                if (e0 + 128 > 0 && e0 < (int)p.ext_len + 2) {        // wave-uniform: this load meets the window (pairs outside it: out of range, dropped)
+                    const u4v pr = { __float_as_uint(m[2 * i].x), __float_as_uint(m[2 * i].y), __float_as_uint(m[2 * i + 1].x), __float_as_uint(m[2 * i + 1].y) };
+                    __builtin_amdgcn_raw_buffer_store_b128(pr, rs_ext, (e0 + 2 * lane) * 8, 0, SRX_OUT_AUX);      // (non-temporal: read back only by a rerun)
+                }
             }
         }
         float mt = 0.0f, mh = 0.0f;                                   // |.| maxima: tail (next history), head
@@ -761,8 +782,11 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
         const bool keep_state = gd.n != 0u && p.rerun_flag != nullptr;   // wave-uniform
         if (lane == 0) {
             if (gd.n != 0u && p.guard_ch) { p.guard_ch[c] += gd.n; p.guard_calls[c] += 1u; }
-            if (gd.nh != 0u && prev_exact == 0u && p.guard_hand) p.guard_hand[c] += gd.nh;     // handover blocks (AUTO only: prev_exact is 1 otherwise)
-            if (p.rerun_flag) p.rerun_flag[c] = keep_state ? 1u : 0u;
+            // handover blocks the rerun cannot repair: the call before stayed on the matrix kernel and left no hist_ext (a short call)
+            if (gd.nh != 0u && prev_prov == kProvSplit && p.guard_hand) p.guard_hand[c] += gd.nh;
+            if (p.rerun_flag)
+                p.rerun_flag[c] = keep_state ? (kFlagRerun | (prev_prov << kProvShift) | (prev_buf << kExtBufShift))
+                                             : (((ext_on ? kProvSplitExt : kProvSplit) << kProvShift) | ((prev_buf ^ 1u) << kExtBufShift));
         }
         // ---- streaming state of the channel back to HBM (exact f32) ----
         lds_order();

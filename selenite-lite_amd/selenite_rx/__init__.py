@@ -63,7 +63,7 @@ ABI_SYMBOLS = [
     "selenite_rx_global_process_f32_device",
     "selenite_rx_host_alloc", "selenite_rx_host_free", "selenite_rx_host_register", "selenite_rx_host_unregister",
     "selenite_rx_time_process_each_device", "selenite_rx_device_pci_bus_id",
-    "selenite_rx_set_guard_ratio", "selenite_rx_guard_stats", "selenite_rx_guard_channels", "selenite_rx_guard_handover", "selenite_rx_guard_clear",
+    "selenite_rx_set_guard_ratio", "selenite_rx_guard_stats", "selenite_rx_guard_channels", "selenite_rx_guard_handover", "selenite_rx_set_handover_repair", "selenite_rx_guard_clear",
 ]
 
 class TxConfig(C.Structure):
@@ -169,6 +169,7 @@ def lib():
         L.selenite_rx_guard_channels.argtypes = [vp, u32p]
         L.selenite_rx_guard_clear.argtypes = [vp]
         L.selenite_rx_guard_handover.argtypes = [vp, u64p]
+        L.selenite_rx_set_handover_repair.argtypes = [vp, C.c_int]
         L.selenite_rx_design_lowpass.argtypes = [f32p, C.c_uint32, C.c_double]
         L.selenite_rx_design_hilbert.argtypes = [f32p, f32p, C.c_uint32]
         L.selenite_rx_design_bandpass.argtypes = [f32p, C.c_uint32, C.c_double, C.c_double]
@@ -374,6 +375,9 @@ class Rx:
         if rc:
             raise RxError(rc, self.error())
         return dict(blocks=int(b.value), channel_calls=int(c.value), rerun_channel_calls=int(r.value), handover_blocks=int(h.value))
+
+    def set_handover_repair(self, on):
+        return self.L.selenite_rx_set_handover_repair(self.h, int(bool(on)))
 
     def guard_channels(self):
         out = np.zeros(self.cfg.channels, np.uint32)

@@ -150,6 +150,81 @@ def test_guard_counts_follow_the_definition():
     g.close()
 
 
+@pytest.mark.parametrize("shape,block", [((256, 4, 127), 192), ((256, 4, 63), 64), ((128, 4, 127), 256), ((256, 4, 127), 96), ((256, 2, 63), 64)])
+@pytest.mark.parametrize("q15", [False, True])
+def test_a_rerun_starts_from_an_exact_hilbert_history(shape, block, q15):
+    """The sideband flips at a call boundary (DSP_Set_Mode USB -> LSB on a signal in the upper sideband; the streaming state is
+    kept): every channel was loud and stayed on the matrix kernel, and is now the residue of a cancellation -- guarded from its
+    first block, rerun.  The rerun starts from the state the matrix kernel left; its Hilbert-pair history is recomputed first, in
+    exact arithmetic, from the mixed samples k_ssb_split16 keeps in front of the decimator state (k_hist_exact): bit-exact audio
+    from the first block on (AGC off; the gain of a kept channel is the only other split-precision state), no handover counted.
+    Without it (SELENITE_RX_NO_HIST_EXACT=1) the first blocks are ~1e-3 of their maxima off."""
+    import selenite_rx as sr
+    nd, M, nh = shape
+    nch, na = 37, block // M
+    steps = (np.arange(nch, dtype=np.uint64) * 0x9E3779B1 % (1 << 32)).astype(np.uint32) & np.uint32(0x03000000)     # in-band LOs
+    kw = dict(nco=True, nco_steps=steps, agc=False)
+    g = sr.Rx(rc.ChainSpec(nch, block, M, nd, nh, 0, rc.MODE_USB, ARITH_AUTO, **kw).config())
+    o = CpuChain(rc.ChainSpec(nch, block, M, nd, nh, 0, rc.MODE_USB, ARITH_CMSIS, **kw), "orc")
+    unit, pos = 3840, 0
+
+    def call():
+        nonlocal pos
+        iq = synth_iq(0, nch, pos, unit)
+        pos += unit
+        if q15:
+            iq16 = np.clip(np.round(iq * 20000.0), -32768, 32767).astype(np.int16)
+            return g.process_q15(iq16), o.process_q15(iq16)
+        return g.process(iq), o.process(iq)
+    for k in range(2):                                               # warm up: the start-up transient is rerun, then little is guarded
+        call()
+    g.guard_clear()
+    call()
+    kept = g.guard_channels() == 0                                   # channels the loud call left on the matrix kernel
+    assert kept.sum() >= nch // 2
+    assert g.set_mode(rc.MODE_LSB) == 0 and o.set_mode(rc.MODE_LSB) == 0
+    g.guard_clear()
+    yg, yo = call()
+    st = g.guard_stats()
+    rerun = g.guard_channels() > 0
+    assert st["handover_blocks"] == 0 and (rerun & kept).sum() >= nch // 4
+    both = rerun & kept                                              # kept on the matrix kernel, then rerun: exact from an exact history
+    assert np.array_equal(yg[both], yo[both]) if q15 else bits_equal(yg[both], yo[both]), rc.rel_err(yg[both], yo[both])
+    if not q15:
+        d, m = per_block(yg, yo, na)
+        assert (d <= 1e-5 * m).all()
+    for key in ("dec_state", "nco_phase", "fir_state"):
+        sg, so = g.state()[key], o.state()[key]
+        ok = (sg[both].view(np.uint32) == so[both].view(np.uint32)).all()
+        assert ok, key
+    g.close()
+
+
+def test_without_handover_repair_the_blocks_are_counted():
+    """selenite_rx_set_handover_repair(S, 0): nothing is kept in front of the decimator state, the sideband flip of the test above
+    leaves the first blocks of the recomputed call on a split16-precision history -- every one of them counted."""
+    import selenite_rx as sr
+    nch, block, na = 37, 64, 16
+    steps = (np.arange(nch, dtype=np.uint64) * 0x9E3779B1 % (1 << 32)).astype(np.uint32) & np.uint32(0x03000000)
+    kw = dict(nco=True, nco_steps=steps, agc=False)
+    g = sr.Rx(rc.ChainSpec(nch, block, 4, 256, 63, 0, rc.MODE_USB, ARITH_AUTO, **kw).config())
+    o = CpuChain(rc.ChainSpec(nch, block, 4, 256, 63, 0, rc.MODE_USB, ARITH_CMSIS, **kw), "orc")
+    assert g.set_handover_repair(False) == 0
+    pos = 0
+    for k in range(3):
+        iq = synth_iq(0, nch, pos, 3840); pos += 3840
+        g.process(iq); o.process(iq)
+    g.set_mode(rc.MODE_LSB); o.set_mode(rc.MODE_LSB)
+    g.guard_clear()
+    iq = synth_iq(0, nch, pos, 3840)
+    d, m = per_block(g.process(iq), o.process(iq), na)
+    st = g.guard_stats()
+    bad = d > 1e-5 * m
+    assert bad.any() and not bad[:, 4:].any()            # inside the reach of the 63-tap pair: 62 samples = 4 blocks of 16
+    assert st["handover_blocks"] >= bad.sum()
+    g.close()
+
+
 def test_handover_blocks_are_counted():
     """What the rerun cannot repair is at least visible ("what the guard does not see"): a guarded block inside the
     reach of the Hilbert-pair history at the start of a call, in a channel the PREVIOUS call left on the matrix kernel, is computed in
