@@ -417,7 +417,14 @@ def main():
                 rx_x = make_rx(ar)
                 others[nm] = leg(rx_x)
                 rx_x.close()
-            others["note"] = ("auto: split16 + bit-exact rerun of guarded channels; split16: tolerance-based, guarded blocks only counted; "
+            if arith == sr.ARITH_AUTO and "split16" in rx.kernel_name() and "hilb" not in rx.kernel_name():
+                # what the handover repair of AUTO costs ("across a call boundary"): the same mode without the
+                # mixed samples k_ssb_split16 keeps in front of the decimator state (2 KB per channel and call on this chain)
+                rx_x = make_rx(sr.ARITH_AUTO)
+                rx_x.set_handover_repair(False)
+                others["auto_without_handover_repair"] = leg(rx_x)
+                rx_x.close()
+            others["note"] = ("auto: split16 + bit-exact rerun of guarded channels (handover repair on: the library default); split16: tolerance-based, guarded blocks only counted; "
                               "fma: bit-exact vs the oracle's fmaf restatement; cmsis: bit-exact (0 ULP) vs CMSIS-DSP 1.5.3 arithmetic")
             out["other_arith_modes"] = others
             if spec.nco and cfg_name == "cfg3" and args.nco == "default":

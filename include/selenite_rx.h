@@ -230,7 +230,7 @@ int selenite_rx_guard_channels(selenite_rx_instance *S, uint32_t *per_channel);
  * matrix kernel carries a Hilbert-pair history (the last nh_taps - 1 decimated samples) of split16 precision; if THIS call has to
  * be recomputed for it, its first blocks -- those inside the reach of that history -- would start from it.  Handover repair
  * (default on): k_ssb_split16 also leaves the exact mixed samples in front of the decimator state behind (decim * (nh_taps - 1)
- * samples per channel and call, rounded up to whole quads: 2 KB for the cfg3 chain), and the rerun recomputes the Hilbert-pair
+ * samples per channel and call, rounded up to whole quads of audio samples: 2 KB for the cfg3 chain), and the rerun recomputes the Hilbert-pair
  * history from them in exact arithmetic first: the recomputed call is CMSIS bit for bit from its first sample (apart from the
  * gain the previous call's AGC left: ~1e-6 relative).  Cost: those bytes (2.4 % of the headline at 4096 samples per call, half
  * that at 8192).  Off: nothing is kept, and such blocks -- and, in either setting, those behind a call too short to hold the

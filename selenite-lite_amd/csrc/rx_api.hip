@@ -264,8 +264,8 @@ extern "C" int selenite_rx_init(selenite_rx_instance **out, const selenite_rx_co
         // k_ssb_split16 leaves the mixed samples in front of the decimator state here (two buffers: the one a channel's state points
         // at stays intact while the next call fills the other), for k_hist_exact
         S->ext_len = cfg->decim * ((cfg->nh_taps - 1u + 3u) & ~3u);
-        INITCHK(dev_alloc(&S->d_hist_ext, 2 * C * (S->ext_len + 2)));       // (rows of ext_len + 2 samples: pair-aligned 16-byte stores)
-        INITCHK(hipMemset(S->d_hist_ext, 0, 2 * C * (S->ext_len + 2) * sizeof(float2)));
+        INITCHK(dev_alloc(&S->d_hist_ext, 2 * C * S->ext_len));
+        INITCHK(hipMemset(S->d_hist_ext, 0, 2 * C * S->ext_len * sizeof(float2)));
     }
 #undef INITCHK
     classify_coeffs(S);
@@ -470,12 +470,12 @@ static RxParams make_params(selenite_rx_instance *S, uint32_t block_size)
     p.guard_ch = S->d_guard_ch;
     p.guard_calls = S->d_guard_ch + g.channels;
     p.guard_hand = S->d_guard_ch + 2 * (size_t)g.channels;
-    p.hist_ext = S->handover_repair ? S->d_hist_ext : nullptr; p.ext_len = S->ext_len; p.ext_buf_stride = (size_t)g.channels * (S->ext_len + 2);
+    p.hist_ext = S->handover_repair ? S->d_hist_ext : nullptr; p.ext_len = S->ext_len; p.ext_buf_stride = (size_t)g.channels * S->ext_len;
     if (S->sub_count) {                                     // a contiguous channel range of the instance: every per-channel array moves with it
         const size_t c0 = S->sub_first;
         p.channels = S->sub_count;
         p.step += c0; p.phase += c0; p.gain += c0; p.guard_ch += c0; p.guard_calls += c0; p.guard_hand += c0;
-        if (p.hist_ext) p.hist_ext += c0 * (p.ext_len + 2);
+        if (p.hist_ext) p.hist_ext += c0 * p.ext_len;
         if (p.dec_state) p.dec_state += c0 * 2 * (g.nd_taps - 1);
         if (p.fir_state) p.fir_state += c0 * 2 * (g.nh_taps - 1);
         if (p.biq_state) p.biq_state += c0 * 4 * g.n_biquad;

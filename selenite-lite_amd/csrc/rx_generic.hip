@@ -196,7 +196,7 @@ __global__ __launch_bounds__(64) void k_front_generic(RxParams p, const TIn *__r
 // both rails) of split16 precision.  When THIS call has to be recomputed for it (p.chan_flags: rerun bit, provenance
 // kProvSplitExt), the history is first recomputed here in the reference's arithmetic -- arm_fir_decimate_f32.c:193-284: one
 // accumulator from 0, taps ascending, product rounded, then sum rounded -- from the exact mixed samples k_ssb_split16 left behind:
-// T = hist_ext[1 .. L + 1) (positions [E - H - L, E - H)) ++ decimator state ([E - H, E)), H = nd - 1, L = ext_len = M * HH4.  History entry r
+// T = (one unused slot) ++ hist_ext[0 .. L - 1) (positions [E - H - L + 1, E - H)) ++ decimator state ([E - H, E)), H = nd - 1, L = ext_len = M * HH4.  History entry r
 // (r = nh - 2 the newest) is the decimator output whose newest sample sits at E - M (nh - 1 - r): T[t0 .. t0 + nd), t0 = L - M (nh - 1 - r).
 // One wavefront per flagged channel, the flag array walked in 16-channel windows (which channels, and how many, only the
 // device knows); rare by construction (a channel whose level crosses the guard ratio downwards at a call boundary).
@@ -216,8 +216,12 @@ __global__ __launch_bounds__(64) void k_hist_exact(RxParams p)
             const uint32_t c = 16u * win + (uint32_t)__builtin_ctzll(todo);
             todo &= todo - 1;
             const uint32_t buf = (p.chan_flags[c] >> kExtBufShift) & 1u;
-            const float2 *ext = p.hist_ext + (size_t)buf * p.ext_buf_stride + (size_t)c * (L + 2u) + 1;      // (rows of L + 2: one spare sample at either end)
-            for (uint32_t i = lane; i < L; i += kWave) { const float2 v = ext[i]; TI[i] = v.x; TQ[i] = v.y; }
+            // (the row starts one sample late -- rx_split16_kernels.h: T[0] meets no tap; its last entry repeats the state's first one)
+            const float2 *ext = p.hist_ext + (size_t)buf * p.ext_buf_stride + (size_t)c * L;
+            for (uint32_t i = lane; i < L; i += kWave) {
+                const float2 v = i ? ext[i - 1] : make_float2(0.0f, 0.0f);
+                TI[i] = v.x; TQ[i] = v.y;
+            }
             for (uint32_t i = lane; i < H; i += kWave) {
                 TI[L + i] = p.dec_state[((size_t)c * 2 + 0) * H + i];
                 TQ[L + i] = p.dec_state[((size_t)c * 2 + 1) * H + i];

@@ -336,10 +336,11 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
     uint32_t prev_prov = kProvExact, prev_buf = 0u;
     // SELENITE_ARITH_AUTO: the mixed samples in front of the decimator state go to hist_ext (RxParams), so that a rerun of the NEXT
     // call can start from a Hilbert-pair history in exact arithmetic (k_hist_exact) -- when this call is long enough to hold them
-    // (rows of ext_len + 2 samples, [E - (ND - 1) - ext_len - 1, E - (ND - 1) + 1): one more at either end makes the window start on an
-    // even sample, so the two samples of a lane leave in ONE 16-byte store that never straddles the window)
-    static_assert(ND % 2 == 0, "hist_ext rows are pair-aligned for even tap counts");
-    const int ext_start = (int)p.block_size - (ND - 1) - (int)p.ext_len - 1;  // call-relative position of hist_ext[0]
+    // (the row holds positions [E - (ND - 1) - ext_len + 1, E - (ND - 1) + 1): moved up by one sample so that it starts on an even
+    // one -- the two samples of a lane leave in ONE 16-byte store that never straddles the window, a row is ext_len * 8 bytes of
+    // whole cache lines -- which costs nothing: the oldest M (HH4 - HH) >= 2 samples of the nominal window meet no tap)
+    static_assert(ND % 2 == 0 && M * (G::HH4 - G::HH) >= 1, "hist_ext rows are pair-aligned for even tap counts");
+    const int ext_start = (int)p.block_size - (ND - 1) - (int)p.ext_len + 1;  // call-relative position of hist_ext[0]
     const bool ext_on = p.hist_ext != nullptr && ext_start >= 0;              // wave-uniform
     __amdgpu_buffer_rsrc_t rs_ext = make_rsrc(p.hist_ext, 0u);
     uint32_t b_hist = 0, ph0 = 0, step = 0;                       // b_hist: bit pattern of the largest |history component|
@@ -377,7 +378,7 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
         gd.n = 0u; gd.nh = 0u;
         prev_prov = (st_word >> kProvShift) & kProvMask; prev_buf = (st_word >> kExtBufShift) & 1u;
         if (ext_on)                                                   // the buffer the state of the call before does NOT point at
-            rs_ext = make_rsrc(p.hist_ext + (size_t)(prev_buf ^ 1u) * p.ext_buf_stride + (size_t)c * (p.ext_len + 2u), (p.ext_len + 2u) * 8u);
+            rs_ext = make_rsrc(p.hist_ext + (size_t)(prev_buf ^ 1u) * p.ext_buf_stride + (size_t)c * p.ext_len, p.ext_len * 8u);
         if constexpr (NCO == 4) {
             // LO of samples 2 lane, 2 lane + 1 and 128 + 2 lane, 129 + 2 lane of every 256-sample period: the phases the
             // per-sample NCO (NCO == 1) would form for them in any pass, n0 * step and 256 * step being multiples of 2^32
@@ -467,7 +468,7 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
 #pragma unroll
             for (int i = 0; i < NLD; ++i) {
                 const int e0 = (int)n0 + 128 * i - ext_start;         // row index of the load's first sample (even)
-                if (e0 + 128 > 0 && e0 < (int)p.ext_len + 2) {        // wave-uniform: this load meets the window (pairs outside it: out of range, dropped)
+                if (e0 + 128 > 0 && e0 < (int)p.ext_len) {        // wave-uniform: this load meets the window (pairs outside it: out of range, dropped)
                     const u4v pr = { __float_as_uint(m[2 * i].x), __float_as_uint(m[2 * i].y), __float_as_uint(m[2 * i + 1].x), __float_as_uint(m[2 * i + 1].y) };
                     __builtin_amdgcn_raw_buffer_store_b128(pr, rs_ext, (e0 + 2 * lane) * 8, 0, SRX_OUT_AUX);      // (non-temporal: read back only by a rerun)
                 }
