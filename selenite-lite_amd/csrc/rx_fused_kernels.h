@@ -398,7 +398,12 @@ __global__ __launch_bounds__(64, 2) void k_ssb_fused(RxParams p, FusedArgs fa, c
         if (p.agc) p.gain[c] = gain;
         // SELENITE_ARITH_AUTO: the state this kernel leaves is exact (kProvExact, rerun bit down) -- as the rerun pass, and as a call
         // without a matrix kernel; k_ssb_split16 reads the word at the channel's next call
-        if (p.chan_flags) p.chan_flags[c] = 0u;
+        // (AM, not FM: the Hilbert-pair history is not touched, so its provenance stays -- "with samples" degrades to "without",
+        // the decimator state having moved on without them)
+        if (AM != 0 && fa.am != 2u) {
+            uint32_t *w = p.chan_flags ? p.chan_flags + c : (p.rerun_flag ? p.rerun_flag + c : nullptr);
+            if (w) *w = ((*w >> kProvShift) & kProvMask) == kProvExact ? 0u : ((kProvSplit << kProvShift) | (*w & (1u << kExtBufShift)));
+        } else if (p.chan_flags) p.chan_flags[c] = 0u;
         else if (p.rerun_flag) p.rerun_flag[c] = 0u;
     }
     if (!p.chan_flags) break;

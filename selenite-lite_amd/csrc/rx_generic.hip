@@ -567,7 +567,7 @@ __global__ __launch_bounds__(256) void k_q15_to_f32(const int16_t *__restrict__ 
 
 hipError_t launch_hist_exact(const RxParams &p, hipStream_t st)
 {
-    if (!p.chan_flags || !p.hist_ext || p.nd < 2 || p.nh < 2) return hipSuccess;
+    if (!p.chan_flags || !p.hist_ext || p.nd < 2 || p.nh < 2 || p.mode == SELENITE_MODE_AM) return hipSuccess;      // (AM does not read the history)
     static const bool off = std::getenv("SELENITE_RX_NO_HIST_EXACT") != nullptr;      // diagnostic: what the rerun does without it
     if (off) return hipSuccess;
     const uint32_t nwin = (p.channels + 15u) / 16u;

@@ -341,7 +341,9 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
     // whole cache lines -- which costs nothing: the oldest M (HH4 - HH) >= 2 samples of the nominal window meet no tap)
     static_assert(ND % 2 == 0 && M * (G::HH4 - G::HH) >= 1, "hist_ext rows are pair-aligned for even tap counts");
     const int ext_start = (int)p.block_size - (ND - 1) - (int)p.ext_len + 1;  // call-relative position of hist_ext[0]
-    const bool ext_on = p.hist_ext != nullptr && ext_start >= 0;              // wave-uniform
+    // (AM never touches the Hilbert-pair history: it keeps no samples either, and what it hands on is the provenance it found --
+    // degraded to "matrix kernel, no samples" when it was "with samples", because the decimator state moves on without them)
+    const bool ext_on = AM == 0 && p.hist_ext != nullptr && ext_start >= 0;   // wave-uniform
     __amdgpu_buffer_rsrc_t rs_ext = make_rsrc(p.hist_ext, 0u);
     uint32_t b_hist = 0, ph0 = 0, step = 0;                       // b_hist: bit pattern of the largest |history component|
     float gain = 1.0f;
@@ -785,9 +787,11 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
             if (gd.n != 0u && p.guard_ch) { p.guard_ch[c] += gd.n; p.guard_calls[c] += 1u; }
             // handover blocks the rerun cannot repair: the call before stayed on the matrix kernel and left no hist_ext (a short call)
             if (gd.nh != 0u && prev_prov == kProvSplit && p.guard_hand) p.guard_hand[c] += gd.nh;
-            if (p.rerun_flag)
-                p.rerun_flag[c] = keep_state ? (kFlagRerun | (prev_prov << kProvShift) | (prev_buf << kExtBufShift))
-                                             : (((ext_on ? kProvSplitExt : kProvSplit) << kProvShift) | ((prev_buf ^ 1u) << kExtBufShift));
+            if (p.rerun_flag) {
+                const uint32_t kept = AM != 0 ? (((prev_prov == kProvExact ? kProvExact : kProvSplit) << kProvShift) | (prev_buf << kExtBufShift))
+                                              : (((ext_on ? kProvSplitExt : kProvSplit) << kProvShift) | ((prev_buf ^ 1u) << kExtBufShift));
+                p.rerun_flag[c] = keep_state ? (kFlagRerun | (prev_prov << kProvShift) | (prev_buf << kExtBufShift)) : kept;
+            }
         }
         // ---- streaming state of the channel back to HBM (exact f32) ----
         lds_order();

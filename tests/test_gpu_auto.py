@@ -200,6 +200,43 @@ def test_a_rerun_starts_from_an_exact_hilbert_history(shape, block, q15):
     g.close()
 
 
+def test_am_in_between_does_not_fool_the_repair():
+    """AM leaves the Hilbert-pair history alone while the decimator state moves on: the samples kept in front of the state no
+    longer belong to that history, so behind an AM call nothing may be "repaired" from them -- the provenance degrades to "matrix
+    kernel, no samples", the first blocks of a later rerun are counted as handover blocks, everything outside the reach of the
+    history holds the plain bar, and the state converges to the oracle's bits."""
+    import selenite_rx as sr
+    nch, block, na, nh = 37, 64, 16, 63
+    steps = (np.arange(nch, dtype=np.uint64) * 0x9E3779B1 % (1 << 32)).astype(np.uint32) & np.uint32(0x03000000)
+    kw = dict(nco=True, nco_steps=steps, agc=False)
+    g = sr.Rx(rc.ChainSpec(nch, block, 4, 256, nh, 0, rc.MODE_USB, ARITH_AUTO, **kw).config())
+    o = CpuChain(rc.ChainSpec(nch, block, 4, 256, nh, 0, rc.MODE_USB, ARITH_CMSIS, **kw), "orc")
+    pos = 0
+
+    def call(mode):
+        nonlocal pos
+        assert g.set_mode(mode) == 0 and o.set_mode(mode) == 0
+        iq = synth_iq(0, nch, pos, 3840)
+        pos += 3840
+        return per_block(g.process(iq), o.process(iq), na)
+    for k in range(3):
+        call(rc.MODE_USB)
+    d, m = call(rc.MODE_AM)
+    assert (d <= 1e-5 * m).all()
+    g.guard_clear()
+    d, m = call(rc.MODE_LSB)                                          # rerun on every channel; the history is the USB period's, split16 precision
+    bad = d > 1e-5 * m
+    assert not bad[:, 4:].any()                                       # 62 samples = 4 blocks of 16
+    assert g.guard_stats()["handover_blocks"] >= bad.sum() and bad.any()
+    d, m = call(rc.MODE_LSB)
+    assert (d <= 1e-5 * m).all()
+    rerun = g.guard_channels() > 0
+    for key in ("dec_state", "fir_state", "nco_phase"):
+        sg, so = g.state()[key], o.state()[key]
+        assert (sg[rerun].view(np.uint32) == so[rerun].view(np.uint32)).all(), key
+    g.close()
+
+
 def test_without_handover_repair_the_blocks_are_counted():
     """selenite_rx_set_handover_repair(S, 0): nothing is kept in front of the decimator state, the sideband flip of the test above
     leaves the first blocks of the recomputed call on a split16-precision history -- every one of them counted."""
