@@ -76,6 +76,9 @@ __device__ __forceinline__ void lds_order()
 // gd.hist / gd.nh (k_ssb_split16, SELENITE_ARITH_AUTO): the guarded blocks among the first ones of a call, those that still see the
 // Hilbert-pair history the previous call left -- a history of split16 precision when that call kept the channel on the matrix
 // kernel: the "handover" blocks of DESIGN.md section 3, which the exact rerun cannot make exact; they are counted on their own.
+#ifndef SRX_EXT_AUX
+#define SRX_EXT_AUX SRX_OUT_AUX
+#endif
 struct GuardPass {
     float thr;
     uint64_t first;
@@ -472,7 +475,7 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
                 const int e0 = (int)n0 + 128 * i - ext_start;         // row index of the load's first sample (even)
                 if (e0 + 128 > 0 && e0 < (int)p.ext_len) {        // wave-uniform: this load meets the window (pairs outside it: out of range, dropped)
                     const u4v pr = { __float_as_uint(m[2 * i].x), __float_as_uint(m[2 * i].y), __float_as_uint(m[2 * i + 1].x), __float_as_uint(m[2 * i + 1].y) };
-                    __builtin_amdgcn_raw_buffer_store_b128(pr, rs_ext, (e0 + 2 * lane) * 8, 0, SRX_OUT_AUX);      // (non-temporal: read back only by a rerun)
+                    __builtin_amdgcn_raw_buffer_store_b128(pr, rs_ext, (e0 + 2 * lane) * 8, 0, SRX_EXT_AUX);      // (non-temporal: read back only by a rerun)
                 }
             }
         }
