@@ -492,7 +492,7 @@ static hipError_t launch_shape(const RxParams &p, const FusedArgs &fa, const Fus
         p2.chan_flags = p.rerun_flag;
         p2.rerun_flag = nullptr; p2.guard_ch = nullptr; p2.guard_calls = nullptr;
         // (channels the call before left on the matrix kernel: their Hilbert-pair history first, in exact arithmetic -- rx_generic.hip)
-        if (hipError_t e = launch_hist_exact(p2, st); e != hipSuccess) return e;
+        if (hipError_t e = launch_hist_exact(p2, false, st); e != hipSuccess) return e;
         return launch_exact(ND, M, NH, src_q15, p2, fa, src, dst, st);            // rx_fused_exact.hip
     };
     // what the matrix kernels take: DSP blocks that divide the 256-output pass; whole passes (k_ssb_mfma, k_hilb_split16), or a
@@ -519,7 +519,14 @@ static hipError_t launch_shape(const RxParams &p, const FusedArgs &fa, const Fus
             return e;
         }
     }
-    if (auto_) arith = SELENITE_ARITH_CMSIS;      // no split-precision kernel for this launch: the bit-exact one
+    if (auto_) {                                  // no split-precision kernel for this launch: the bit-exact one, on every channel --
+        arith = SELENITE_ARITH_CMSIS;             // from a Hilbert-pair history in exact arithmetic where the call before left the samples for it
+        if (p.rerun_flag) {
+            RxParams p3 = p;
+            p3.chan_flags = p.rerun_flag;
+            if (hipError_t e = launch_hist_exact(p3, true, st); e != hipSuccess) return e;
+        }
+    }
     if constexpr (ND > 0 && M == 4) {
         static_assert(kMfmaWaves == 1, "one channel per workgroup: any channel count launches (plan.name says k_ssb_mfma)");
         if (arith != SELENITE_ARITH_CMSIS && plan.use_mfma && whole) {

@@ -201,7 +201,7 @@ __global__ __launch_bounds__(64) void k_front_generic(RxParams p, const TIn *__r
 // One wavefront per flagged channel, the flag array walked in 16-channel windows (which channels, and how many, only the
 // device knows); rare by construction (a channel whose level crosses the guard ratio downwards at a call boundary).
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_hist_exact(RxParams p)
+__global__ __launch_bounds__(64) void k_hist_exact(RxParams p, uint32_t all)      // all: every channel with that provenance (a call that runs the exact kernel on all channels), not only the flagged ones
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x;
@@ -211,7 +211,7 @@ __global__ __launch_bounds__(64) void k_hist_exact(RxParams p)
     for (uint32_t win = blockIdx.x; win < nwin; win += gridDim.x) {
         const uint32_t ci = 16u * win + (uint32_t)(lane & 15);
         const uint32_t f = (lane < 16 && ci < p.channels) ? p.chan_flags[ci] : 0u;
-        uint64_t todo = __builtin_amdgcn_ballot_w64((f & kFlagRerun) != 0u && ((f >> kProvShift) & kProvMask) == kProvSplitExt);
+        uint64_t todo = __builtin_amdgcn_ballot_w64(((f & kFlagRerun) != 0u || all != 0u) && ((f >> kProvShift) & kProvMask) == kProvSplitExt);
         while (todo != 0) {                                           // wave-uniform
             const uint32_t c = 16u * win + (uint32_t)__builtin_ctzll(todo);
             todo &= todo - 1;
@@ -565,14 +565,14 @@ __global__ __launch_bounds__(256) void k_q15_to_f32(const int16_t *__restrict__ 
     }
 }
 
-hipError_t launch_hist_exact(const RxParams &p, hipStream_t st)
+hipError_t launch_hist_exact(const RxParams &p, bool all, hipStream_t st)
 {
     if (!p.chan_flags || !p.hist_ext || p.nd < 2 || p.nh < 2 || p.mode == SELENITE_MODE_AM) return hipSuccess;      // (AM does not read the history)
     static const bool off = std::getenv("SELENITE_RX_NO_HIST_EXACT") != nullptr;      // diagnostic: what the rerun does without it
     if (off) return hipSuccess;
     const uint32_t nwin = (p.channels + 15u) / 16u;
     const size_t lds = 2 * (size_t)(p.ext_len + p.nd - 1u) * sizeof(float);
-    hipLaunchKernelGGL(k_hist_exact, dim3(nwin < 1024u ? nwin : 1024u), dim3(64), lds, st, p);
+    hipLaunchKernelGGL(k_hist_exact, dim3(nwin < 1024u ? nwin : 1024u), dim3(64), lds, st, p, all ? 1u : 0u);
     return hipGetLastError();
 }
 

@@ -90,7 +90,8 @@ size_t front_generic_lds_bytes(const RxParams &p);
 hipError_t launch_q15_to_f32(const int16_t *src, float *dst, size_t n, hipStream_t st);
 // SELENITE_ARITH_AUTO, in front of the rerun pass: the Hilbert-pair history of every flagged channel whose state the call before left
 // on the matrix kernel (with its hist_ext) is recomputed in exact arithmetic from hist_ext + the decimator state (rx_generic.hip)
-hipError_t launch_hist_exact(const RxParams &p, hipStream_t st);
+// (all: a call that runs the exact kernel on every channel -- FM, a shape without a matrix kernel for this call length -- repairs every such channel)
+hipError_t launch_hist_exact(const RxParams &p, bool all, hipStream_t st);
 // CW biquad cascade, in place on f32 audio
 hipError_t launch_biquad_generic(const RxParams &p, int arith, float *audio, hipStream_t st);
 // per-channel AGC (or plain copy/convert when p.agc == 0): audio -> dst

@@ -200,6 +200,52 @@ def test_a_rerun_starts_from_an_exact_hilbert_history(shape, block, q15):
     g.close()
 
 
+@pytest.mark.parametrize("seed", range(24))
+def test_random_mode_and_length_sequences(seed):
+    """SELENITE_ARITH_AUTO through random sequences of DSP_Set_Mode (every value of the firmware's enum that runs on the fused
+    kernels) and call lengths (one DSP block ... several passes): on every call every DSP block holds the plain bar against
+    the oracle -- except blocks inside the reach of the Hilbert-pair history in a call that counted a handover (behind a call
+    too short to keep the samples, or behind AM), and only those.  Exercises the provenance words, both hist_ext buffers,
+    k_hist_exact, the tail split and the one-pass short calls together."""
+    import selenite_rx as sr
+    rng = np.random.default_rng(1000 + seed)
+    shape, block = [((256, 4, 63), 64), ((256, 4, 127), 192), ((128, 4, 63), 256), ((256, 2, 63), 64), ((256, 4, 63), 96), ((128, 2, 127), 128)][seed % 6]
+    nd, M, nh = shape
+    nch, na = 19, block // M
+    nbh = -(-(nh - 1) // na)
+    steps = (rng.integers(0, 1 << 32, nch, dtype=np.uint64).astype(np.uint32)) & np.uint32(0x07000000 if seed % 2 else 0xFFFFFFFF)
+    kw = dict(nco=True, nco_steps=steps, agc=bool(seed % 3))
+    g = sr.Rx(rc.ChainSpec(nch, block, M, nd, nh, 0, rc.MODE_USB, ARITH_AUTO, **kw).config())
+    o = CpuChain(rc.ChainSpec(nch, block, M, nd, nh, 0, rc.MODE_USB, ARITH_CMSIS, **kw), "orc")
+    modes = [rc.MODE_USB, rc.MODE_LSB, rc.MODE_AM, rc.MODE_FM, rc.MODE_DIG, rc.MODE_PKT, rc.MODE_CW, rc.MODE_CWR]
+    unit = 256 // na * na * M
+    pos, mode = 0, rc.MODE_USB
+    for call in range(14):
+        if rng.random() < 0.4:
+            mode = modes[rng.integers(len(modes))]
+            assert g.set_mode(mode) == 0 and o.set_mode(mode) == 0
+        k = int(rng.choice([1, 2, 3, unit // block, 2 * unit // block + 1, 4 * unit // block, 5 * unit // block + 2]))
+        bs = k * block
+        iq = synth_iq(0, nch, pos, bs)
+        pos += bs
+        before = g.guard_stats()["handover_blocks"]
+        d, m = per_block(g.process(iq), o.process(iq), na)
+        hand = g.guard_stats()["handover_blocks"] - before
+        if mode == rc.MODE_FM:
+            # FM: the exact kernel in AUTO, from a delay line repaired like the Hilbert-pair history (k_hist_exact on every channel);
+            # behind a call that kept no samples its very first output sees z[-1] at split16 precision: <= 1e-6 rad
+            gain = np.asarray(o.state()["agc_gain"], np.float64).reshape(nch) if kw["agc"] else np.ones(nch)
+            assert (d[:, 1:] <= 1e-5 * m[:, 1:]).all() and (d[:, 0] <= 1e-5 * m[:, 0] + 1e-6 * gain).all(), (call, mode)
+            continue
+        bad = d > 1e-5 * m
+        if bad.any():
+            assert not bad[:, nbh:].any(), (call, mode, bs, (d / np.maximum(m, 1e-30)).max())
+            assert hand >= bad.any(axis=1).sum(), (call, mode, bs, hand)
+    sg, so = g.state(), o.state()
+    assert bits_equal(sg["dec_state"], so["dec_state"]) and np.array_equal(sg["nco_phase"], so["nco_phase"])
+    g.close()
+
+
 def test_am_in_between_does_not_fool_the_repair():
     """AM leaves the Hilbert-pair history alone while the decimator state moves on: the samples kept in front of the state no
     longer belong to that history, so behind an AM call nothing may be "repaired" from them -- the provenance degrades to "matrix
