@@ -215,12 +215,28 @@ __global__ __launch_bounds__(64) void k_hist_exact(RxParams p, uint32_t all)    
         while (todo != 0) {                                           // wave-uniform
             const uint32_t c = 16u * win + (uint32_t)__builtin_ctzll(todo);
             todo &= todo - 1;
-            const uint32_t buf = (p.chan_flags[c] >> kExtBufShift) & 1u;
+            const uint32_t word = p.chan_flags[c], buf = (word >> kExtBufShift) & 1u;
             // (the row starts one sample late -- rx_split16_kernels.h: T[0] meets no tap; its last entry repeats the state's first one)
             const float2 *ext = p.hist_ext + (size_t)buf * p.ext_buf_stride + (size_t)c * L;
-            for (uint32_t i = lane; i < L; i += kWave) {
-                const float2 v = i ? ext[i - 1] : make_float2(0.0f, 0.0f);
-                TI[i] = v.x; TQ[i] = v.y;
+            if (word & kExtQ15) {
+                // an int16-slot call left its RAW samples: arm_q15_to_float and the NCO mix again, sample by sample, with the arithmetic
+                // of the chain (same phases: T[i] sits H + L - i samples in front of the channel's current phase)
+                const short2 *raw = reinterpret_cast<const short2 *>(ext);
+                const uint32_t ph_e = p.nco ? p.phase[c] : 0u, step = p.nco ? p.step[c] : 0u;
+                for (uint32_t i = lane; i < L; i += kWave) {
+                    float2 v = make_float2(0.0f, 0.0f);
+                    if (i) {
+                        const short2 q = raw[i - 1];
+                        v = make_float2(q15_to_float(q.x), q15_to_float(q.y));
+                        if (p.nco) v = cmul<0>(v, nco_lo<0>(p.sintab, ph_e - (H + L - i) * step));
+                    }
+                    TI[i] = v.x; TQ[i] = v.y;
+                }
+            } else {
+                for (uint32_t i = lane; i < L; i += kWave) {
+                    const float2 v = i ? ext[i - 1] : make_float2(0.0f, 0.0f);
+                    TI[i] = v.x; TQ[i] = v.y;
+                }
             }
             for (uint32_t i = lane; i < H; i += kWave) {
                 TI[L + i] = p.dec_state[((size_t)c * 2 + 0) * H + i];

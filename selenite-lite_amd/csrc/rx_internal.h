@@ -73,7 +73,8 @@ struct RxParams {
 // words of RxParams::flags
 enum { kFlagNanInf = 0, kFlagWords = 4 };
 // RxParams::rerun_flag words
-enum : uint32_t { kFlagRerun = 1u, kProvShift = 1u, kProvMask = 3u, kProvExact = 0u, kProvSplitExt = 1u, kProvSplit = 2u, kExtBufShift = 3u };
+enum : uint32_t { kFlagRerun = 1u, kProvShift = 1u, kProvMask = 3u, kProvExact = 0u, kProvSplitExt = 1u, kProvSplit = 2u, kExtBufShift = 3u,
+                  kExtQ15 = 16u };     // bit 4: the hist_ext row holds the RAW int16 samples of an int16-slot call (half the bytes; k_hist_exact mixes them again)
 
 __host__ __device__ inline bool mode_is_cw(uint32_t m) { return m == SELENITE_MODE_CW || m == SELENITE_MODE_CWR; }
 __host__ __device__ inline bool mode_is_upper(uint32_t m)

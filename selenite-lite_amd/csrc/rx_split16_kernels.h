@@ -336,7 +336,7 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
         st_gain = p.gain[ch];
         st_word = p.rerun_flag ? p.rerun_flag[ch] : 0u;           // AUTO: provenance of the channel's state, which hist_ext buffer goes with it
     };
-    uint32_t prev_prov = kProvExact, prev_buf = 0u;
+    uint32_t prev_prov = kProvExact, prev_buf = 0u, st_word_cur = 0u;
     // SELENITE_ARITH_AUTO: the mixed samples in front of the decimator state go to hist_ext (RxParams), so that a rerun of the NEXT
     // call can start from a Hilbert-pair history in exact arithmetic (k_hist_exact) -- when this call is long enough to hold them
     // (the row holds positions [E - (ND - 1) - ext_len + 1, E - (ND - 1) + 1): moved up by one sample so that it starts on an even
@@ -381,9 +381,9 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
         ph0 = st_ph0; step = st_step; gain = st_gain;
         s_cur = 0x7fff;
         gd.n = 0u; gd.nh = 0u;
-        prev_prov = (st_word >> kProvShift) & kProvMask; prev_buf = (st_word >> kExtBufShift) & 1u;
+        prev_prov = (st_word >> kProvShift) & kProvMask; prev_buf = (st_word >> kExtBufShift) & 1u; st_word_cur = st_word;
         if (ext_on)                                                   // the buffer the state of the call before does NOT point at
-            rs_ext = make_rsrc(p.hist_ext + (size_t)(prev_buf ^ 1u) * p.ext_buf_stride + (size_t)c * p.ext_len, p.ext_len * 8u);
+            rs_ext = make_rsrc(p.hist_ext + (size_t)(prev_buf ^ 1u) * p.ext_buf_stride + (size_t)c * p.ext_len, p.ext_len * (sizeof(TIn) == 2 ? 4u : 8u));
         if constexpr (NCO == 4) {
             // LO of samples 2 lane, 2 lane + 1 and 128 + 2 lane, 129 + 2 lane of every 256-sample period: the phases the
             // per-sample NCO (NCO == 1) would form for them in any pass, n0 * step and 256 * step being multiples of 2^32
@@ -474,8 +474,12 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
             for (int i = 0; i < NLD; ++i) {
                 const int e0 = (int)n0 + 128 * i - ext_start;         // row index of the load's first sample (even)
                 if (e0 + 128 > 0 && e0 < (int)p.ext_len) {        // wave-uniform: this load meets the window (pairs outside it: out of range, dropped)
-                    const u4v pr = { __float_as_uint(m[2 * i].x), __float_as_uint(m[2 * i].y), __float_as_uint(m[2 * i + 1].x), __float_as_uint(m[2 * i + 1].y) };
-                    __builtin_amdgcn_raw_buffer_store_b128(pr, rs_ext, (e0 + 2 * lane) * 8, 0, SRX_EXT_AUX);      // (non-temporal: read back only by a rerun)
+                    if constexpr (sizeof(TIn) == 2) {                 // int16 slots: the raw samples as they came (half the bytes; the NCO phase of every one is known)
+                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2v, raw[i]), rs_ext, (e0 + 2 * lane) * 4, 0, SRX_EXT_AUX);
+                    } else {
+                        const u4v pr = { __float_as_uint(m[2 * i].x), __float_as_uint(m[2 * i].y), __float_as_uint(m[2 * i + 1].x), __float_as_uint(m[2 * i + 1].y) };
+                        __builtin_amdgcn_raw_buffer_store_b128(pr, rs_ext, (e0 + 2 * lane) * 8, 0, SRX_EXT_AUX);      // (non-temporal: read back only by a rerun)
+                    }
                 }
             }
         }
@@ -791,9 +795,10 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
             // handover blocks the rerun cannot repair: the call before stayed on the matrix kernel and left no hist_ext (a short call)
             if (gd.nh != 0u && prev_prov == kProvSplit && p.guard_hand) p.guard_hand[c] += gd.nh;
             if (p.rerun_flag) {
-                const uint32_t kept = AM != 0 ? (((prev_prov == kProvExact ? kProvExact : kProvSplit) << kProvShift) | (prev_buf << kExtBufShift))
-                                              : (((ext_on ? kProvSplitExt : kProvSplit) << kProvShift) | ((prev_buf ^ 1u) << kExtBufShift));
-                p.rerun_flag[c] = keep_state ? (kFlagRerun | (prev_prov << kProvShift) | (prev_buf << kExtBufShift)) : kept;
+                const uint32_t kept = AM != 0 ? (((prev_prov == kProvExact ? kProvExact : kProvSplit) << kProvShift) | (prev_buf << kExtBufShift))      // (no samples: the format bit is void)
+                                              : (((ext_on ? kProvSplitExt : kProvSplit) << kProvShift) | ((prev_buf ^ 1u) << kExtBufShift) |
+                                                 (ext_on && sizeof(TIn) == 2 ? kExtQ15 : 0u));
+                p.rerun_flag[c] = keep_state ? (kFlagRerun | (st_word_cur & (kExtQ15 | (kProvMask << kProvShift) | (1u << kExtBufShift)))) : kept;
             }
         }
         // ---- streaming state of the channel back to HBM (exact f32) ----

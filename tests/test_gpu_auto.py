@@ -246,6 +246,45 @@ def test_random_mode_and_length_sequences(seed):
     g.close()
 
 
+@pytest.mark.parametrize("kept_q15", [False, True])
+def test_the_repair_knows_the_slot_format_of_the_call_that_kept_the_samples(kept_q15):
+    """f32 and int16-slot calls may alternate on one instance: an int16-slot call keeps its RAW samples in front of the decimator state
+    (half the bytes; k_hist_exact converts and mixes them again), an f32 call the mixed ones -- the provenance word says which.  Sideband
+    flip behind a call of one format, recomputed in a call of the other: the rerun channels are the oracle bit for bit."""
+    import selenite_rx as sr
+    nch, block, na = 37, 64, 16
+    steps = (np.arange(nch, dtype=np.uint64) * 0x9E3779B1 % (1 << 32)).astype(np.uint32) & np.uint32(0x03000000)
+    kw = dict(nco=True, nco_steps=steps, agc=False)
+    g = sr.Rx(rc.ChainSpec(nch, block, 4, 256, 63, 0, rc.MODE_USB, ARITH_AUTO, **kw).config())
+    o = CpuChain(rc.ChainSpec(nch, block, 4, 256, 63, 0, rc.MODE_USB, ARITH_CMSIS, **kw), "orc")
+    pos = 0
+
+    def call(q15):
+        nonlocal pos
+        iq = synth_iq(0, nch, pos, 3840)
+        pos += 3840
+        if q15:
+            iq16 = np.clip(np.round(iq * 20000.0), -32768, 32767).astype(np.int16)
+            return g.process_q15(iq16), o.process_q15(iq16)
+        return g.process(iq), o.process(iq)
+    for k in range(3):
+        call(kept_q15)
+    kept_before = g.guard_channels().copy()
+    g.guard_clear()
+    call(kept_q15)
+    kept = g.guard_channels() == 0
+    assert g.set_mode(rc.MODE_LSB) == 0 and o.set_mode(rc.MODE_LSB) == 0
+    g.guard_clear()
+    yg, yo = call(not kept_q15)
+    both = (g.guard_channels() > 0) & kept
+    assert both.sum() >= nch // 4 and g.guard_stats()["handover_blocks"] == 0
+    assert np.array_equal(yg[both], yo[both])
+    for key in ("dec_state", "fir_state"):
+        sg, so = g.state()[key], o.state()[key]
+        assert (sg[both].view(np.uint32) == so[both].view(np.uint32)).all(), key
+    g.close()
+
+
 def test_am_in_between_does_not_fool_the_repair():
     """AM leaves the Hilbert-pair history alone while the decimator state moves on: the samples kept in front of the state no
     longer belong to that history, so behind an AM call nothing may be "repaired" from them -- the provenance degrades to "matrix
