@@ -82,3 +82,11 @@ cpu_ns = (time.perf_counter() - t) / 5000 * 1e9
 print("\n# BASELINE cfg1 (C = 1, one 256-sample block, USB, 63-tap Hilbert pair + AGC), ns per block:")
 print("  GPU %s: back-to-back device calls %.0f ns/block (median of 500), call + sync %.0f ns/block; one host core, %s (ctypes call included): %.0f ns/block"
       % (rx.kernel_name(), ms[250] * 1e6, np.median(sync) * 1e9, "CMSIS-DSP 1.5.3 (oracle/_ref)" if which == "ref" else "oracle restatement", cpu_ns))
+
+# the same block in the other arithmetic contracts (one kernel launch per call instead of AUTO's two)
+for nm, ar in (("split16", rc.ARITH_SPLIT16), ("fma", rc.ARITH_FMA), ("cmsis (bit-exact)", rc.ARITH_CMSIS)):
+    rx2 = sr.Rx(rc.baseline_spec("cfg1", 1, ar).config())
+    spin(rx2, d_in, d_out, 256, 60.0)
+    ms2 = np.sort(rx2.time_process_each(d_in.ptr, d_out.ptr, 256, 500))
+    print("  GPU %-18s %s: back-to-back device calls %.0f ns/block" % (nm, rx2.kernel_name(), ms2[250] * 1e6))
+    rx2.close()
