@@ -676,6 +676,24 @@ def test_host_pointer_calls_are_pipelined_in_channel_chunks_and_bit_identical(ar
             out = sr.pinned_array((nch, bs // 4), np.float32)
             got_pinned = c.process(pin, out)
             assert rc.bits_equal(got_pageable, want) and rc.bits_equal(got_pinned, want), call
+        if arith == rc.ARITH_AUTO:      # a sideband flip: channels the last call kept on the matrix kernel are rerun from a repaired history
+            # (hist_ext rows and provenance words of a channel sub-range: DESIGN.md section 3, "across a call boundary")
+            for g in (a, b, c):
+                assert g.set_mode(rc.MODE_LSB) == 0
+            iq = rc.synth_iq(0, nch, 3 * bs, bs)
+            d_in.upload(iq); a.process_device(d_in.ptr, d_out.ptr, bs); a.sync()
+            want = d_out.download((nch, bs // 4), np.float32)
+            assert rc.bits_equal(b.process(iq), want)
+            pin = sr.pinned_array(iq.shape, np.float32); pin[...] = iq
+            assert rc.bits_equal(c.process(pin, sr.pinned_array((nch, bs // 4), np.float32)), want)
+            o = rc.CpuChain(rc.baseline_spec("cfg3", nch, rc.ARITH_CMSIS, nco_steps=spec.nco_steps), "orc")
+            for call in range(3):
+                o.process(rc.synth_iq(0, nch, call * bs, bs))
+            o.set_mode(rc.MODE_LSB)
+            yo = o.process(iq)
+            d = np.abs(want.astype(np.float64) - yo).reshape(nch, -1, 64).max(axis=2); m = np.abs(yo).reshape(nch, -1, 64).max(axis=2)
+            assert (d <= 1e-5 * m).all(), (d / np.maximum(m, 1e-30)).max()
+            assert a.guard_stats()["handover_blocks"] == 0 and b.guard_stats()["handover_blocks"] == 0
         sa, sb, sc = a.state(), b.state(), c.state()
         for k in sa:
             assert np.array_equal(sa[k].view(np.uint32), sb[k].view(np.uint32)) and np.array_equal(sa[k].view(np.uint32), sc[k].view(np.uint32)), k
