@@ -391,6 +391,9 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": traffic,
                          "traffic_source": None if traffic is None else os.path.relpath(TRAFFIC_JSON, ROOT) + " (committed rocprofv3 --pmc passes of this kernel and shape; not measured in this run)",
+                         "traffic_note": ("SELENITE_ARITH_AUTO: includes the handover-repair rows k_ssb_split16 writes in front of the decimator state "
+                                          "(2 KB per channel and call for f32 slots, 1 KB for int16 slots -- DESIGN.md section 3); the algorithmic figure of SURVEY 8d "
+                                          "does not count them") if (arith == sr.ARITH_AUTO and "k_ssb_split16" in rx.kernel_name()) else None,
                          "algorithmic_bytes_per_launch": alg_bytes, "read_bytes_per_launch": rd_bytes,
                          "read_frac": round(rd_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                          "launch_ms_hip_events": round(k_ms, 4),
