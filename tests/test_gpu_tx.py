@@ -222,6 +222,29 @@ def test_tx_split16_interpolator_on_the_matrix_pipe(variant):
     assert rel_err(sg["interp_state"], so["interp_state"]) <= TOL
 
 
+@pytest.mark.parametrize("alc", [False, True])
+@pytest.mark.parametrize("drop", [1e-1, 1e-2, 1e-3, 1e-4])
+def test_tx_split16_holds_the_plain_bar_through_level_steps(alc, drop):
+    """Why TX has no parity guard (the RX kernels do): its interpolator's output sits at the level of its input by
+    construction and the block exponent follows the data pass by pass, so a level step inside a call -- the audio drops by 20 ... 80 dB
+    after 300 samples, stays there, comes back -- leaves every ALC block of 256 output samples within the plain 1e-5 of the CMSIS
+    arithmetic (measured <= 1e-6)."""
+    g = gpu_tx(rc.TxSpec(16, arith=rc.ARITH_SPLIT16, alc=alc))
+    o = rc.TxCpuChain(rc.TxSpec(16, arith=ARITH_CMSIS, alc=alc), "orc")
+    for k in range(4):
+        a = rc.synth_audio(0, 16, 1024 * k, 1024).copy()
+        if k == 1:
+            a[:, 300:] *= drop
+        if k == 2:
+            a *= drop
+        yg, yo = g.process(a), o.process(a)
+        nb = yo.shape[1] // 256
+        d = np.abs(yg.astype(np.float64) - yo).reshape(16, nb, -1).max(axis=2)
+        m = np.abs(yo).reshape(16, nb, -1).max(axis=2)
+        assert (d <= TOL * m).all(), (k, (d / np.maximum(m, 1e-30)).max())
+    g.close()
+
+
 def test_tx_split16_q15_silence_and_full_scale():
     g = gpu_tx(rc.TxSpec(9, arith=rc.ARITH_SPLIT16))
     o = rc.TxCpuChain(rc.TxSpec(9), "orc")
