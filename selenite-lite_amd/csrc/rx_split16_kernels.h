@@ -793,7 +793,8 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
         if (lane == 0) {
             if (gd.n != 0u && p.guard_ch) { p.guard_ch[c] += gd.n; p.guard_calls[c] += 1u; }
             // handover blocks the rerun cannot repair: the call before stayed on the matrix kernel and left no hist_ext (a short call)
-            if (gd.nh != 0u && prev_prov == kProvSplit && p.guard_hand) p.guard_hand[c] += gd.nh;
+            // (or left them but the repair has been switched off since)
+            if (AM == 0 && gd.nh != 0u && (prev_prov == kProvSplit || (prev_prov == kProvSplitExt && !p.hist_ext)) && p.guard_hand) p.guard_hand[c] += gd.nh;      // (AM reads no history)
             if (p.rerun_flag) {
                 const uint32_t kept = AM != 0 ? (((prev_prov == kProvExact ? kProvExact : kProvSplit) << kProvShift) | (prev_buf << kExtBufShift))      // (no samples: the format bit is void)
                                               : (((ext_on ? kProvSplitExt : kProvSplit) << kProvShift) | ((prev_buf ^ 1u) << kExtBufShift) |
