@@ -226,6 +226,10 @@ int selenite_rx_guard_stats(selenite_rx_instance *S, uint64_t *guard_blocks, uin
                             uint64_t *rerun_channel_calls);
 /* per_channel[channels]: guarded DSP blocks of every channel since init / the last clear (sticky per-channel view). */
 int selenite_rx_guard_channels(selenite_rx_instance *S, uint32_t *per_channel);
+/* Diagnostic: per_channel[channels] = the word SELENITE_ARITH_AUTO keeps per channel (bit 0: recompute pending; bits 1-2: what the
+ * call before left the streaming state as -- 0 exact, 1 matrix kernel with the samples for the repair, 2 without; bit 5: the channel is
+ * HELD by the bit-exact kernel, bit 6: its last call there was clean; bits 8-31: level of the last pass).  Zeros in the other modes. */
+int selenite_rx_auto_words(selenite_rx_instance *S, uint32_t *per_channel);
 /* SELENITE_ARITH_AUTO across calls ("across a call boundary").  A channel the previous call left on the
  * matrix kernel carries a Hilbert-pair history (the last nh_taps - 1 decimated samples) of split16 precision; if THIS call has to
  * be recomputed for it, its first blocks -- those inside the reach of that history -- would start from it.  Handover repair
@@ -285,6 +289,13 @@ int  selenite_rx_time_process_q15_device(selenite_rx_instance *S, const int16_t 
  * overlap between consecutive launches; bench.py reports both this median and the plain mean above. */
 int  selenite_rx_time_process_each_device(selenite_rx_instance *S, const void *dSrcIQ, void *dDstAudio, uint32_t blockSize,
                                           uint32_t iters, float *ms_each, int q15);
+/* The streaming roof of THIS instance's call, measured: `iters` launches of a kernel that moves exactly the algorithmic bytes of one
+ * process call of blockSize samples (input in, audio out, per-channel state in and out -- a scratch copy, the instance's
+ * state is not touched) with the access pattern of the fused kernels (persistent single-wave workgroups, 1 KB non-temporal wave loads,
+ * next pass prefetched) and NO arithmetic; ms_each[iters] receives the per-launch durations.  dDstAudio is overwritten with junk.
+ * bench.py reports the DSP kernels as a fraction of this floor beside the fraction of the nominal 8 TB/s. */
+int  selenite_rx_time_streaming_roof_device(selenite_rx_instance *S, const void *dSrcIQ, void *dDstAudio, uint32_t blockSize,
+                                            uint32_t iters, float *ms_each, int q15);
 /* PCI bus id ("0000:05:00.0") of HIP device `ordinal` into buf; bench.py lists the devices of the ranks with it. */
 int  selenite_rx_device_pci_bus_id(int ordinal, char *buf, size_t len);
 

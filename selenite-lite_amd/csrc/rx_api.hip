@@ -111,7 +111,7 @@ static void classify_coeffs(selenite_rx_instance *S)
 
 static void free_device(selenite_rx_instance *S)
 {
-    void *ptrs[] = { S->d_flags, S->d_guard_ch, S->d_rerun_flag, S->d_hist_ext, S->d_conv_in, S->d_dec_c, S->d_hilb_c, S->d_delay_c, S->d_biq_c, S->d_sintab, S->d_step, S->d_phase,
+    void *ptrs[] = { S->d_flags, S->d_guard_ch, S->d_rerun_flag, S->d_rerun_list, S->d_hist_ext, S->d_conv_in, S->d_dec_c, S->d_hilb_c, S->d_delay_c, S->d_biq_c, S->d_sintab, S->d_step, S->d_phase,
                      S->d_dec_state, S->d_fir_state, S->d_biq_state, S->d_gain, S->d_scratch, S->d_env, S->d_env_part,
                      S->d_io_in, S->d_io_out, S->d_lo, S->pipe.d_in[0], S->pipe.d_in[1], S->pipe.d_out[0], S->pipe.d_out[1] };
     for (void *p : ptrs)
@@ -141,6 +141,8 @@ static int reset_state(selenite_rx_instance *S)
     HIPCHK(S, hipMemsetAsync(S->d_guard_ch, 0, 3 * C * sizeof(uint32_t), S->stream));
     // (0 = no rerun pending, the channel's state is in exact arithmetic (kProvExact): what a cleared state is)
     if (S->d_rerun_flag) HIPCHK(S, hipMemsetAsync(S->d_rerun_flag, 0, C * sizeof(uint32_t), S->stream));
+    if (S->d_rerun_list) HIPCHK(S, hipMemsetAsync(S->d_rerun_list, 0, 2 * sizeof(uint32_t), S->stream));      // both counters
+    S->rerun_par = 0;
     std::vector<float> gi(C, g.agc_gain_init);
     HIPCHK(S, hipMemcpyAsync(S->d_gain, gi.data(), C * sizeof(float), hipMemcpyHostToDevice, S->stream));
     HIPCHK(S, hipStreamSynchronize(S->stream));
@@ -259,13 +261,14 @@ extern "C" int selenite_rx_init(selenite_rx_instance **out, const selenite_rx_co
     INITCHK(dev_alloc(&S->d_flags, (size_t)kFlagWords));
     INITCHK(dev_alloc(&S->d_guard_ch, 3 * C));
     INITCHK(dev_alloc(&S->d_rerun_flag, cfg->arith == SELENITE_ARITH_AUTO ? C : 0));
+    INITCHK(dev_alloc(&S->d_rerun_list, cfg->arith == SELENITE_ARITH_AUTO ? C + 2 : 0));
     if (cfg->arith == SELENITE_ARITH_AUTO && cfg->nd_taps >= 2 && cfg->nh_taps >= 2 &&
         ssb_split16_has_shape((int)cfg->nd_taps, (int)cfg->decim, (int)cfg->nh_taps) && !std::getenv("SELENITE_RX_NO_HIST_EXT")) {
         // k_ssb_split16 leaves the mixed samples in front of the decimator state here (two buffers: the one a channel's state points
         // at stays intact while the next call fills the other), for k_hist_exact
+        // (round 4: allocated by the first call that needs it -- 2 x channels x ext_len x 8 bytes, 4 KB per channel for the cfg3 chain --
+        // and released when the repair is switched off: ensure_hist_ext / selenite_rx_set_handover_repair)
         S->ext_len = cfg->decim * ((cfg->nh_taps - 1u + 3u) & ~3u);
-        INITCHK(dev_alloc(&S->d_hist_ext, 2 * C * S->ext_len));
-        INITCHK(hipMemset(S->d_hist_ext, 0, 2 * C * S->ext_len * sizeof(float2)));
     }
 #undef INITCHK
     classify_coeffs(S);
@@ -416,6 +419,17 @@ extern "C" int selenite_rx_guard_channels(selenite_rx_instance *S, uint32_t *per
     return SELENITE_RX_SUCCESS;
 }
 
+// diagnostic (tests, tools): the per-channel words of SELENITE_ARITH_AUTO (rx_internal.h: rerun / provenance / hold bits, level)
+extern "C" int selenite_rx_auto_words(selenite_rx_instance *S, uint32_t *per_channel)
+{
+    if (!S || !per_channel) return SELENITE_RX_ARGUMENT_ERROR;
+    HIPCHK(S, hipSetDevice(S->device));
+    HIPCHK(S, hipStreamSynchronize(S->stream));
+    if (!S->d_rerun_flag) { std::memset(per_channel, 0, (size_t)S->cfg.channels * sizeof(uint32_t)); return SELENITE_RX_SUCCESS; }
+    HIPCHK(S, hipMemcpy(per_channel, S->d_rerun_flag, (size_t)S->cfg.channels * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return SELENITE_RX_SUCCESS;
+}
+
 extern "C" int selenite_rx_guard_clear(selenite_rx_instance *S)
 {
     if (!S) return SELENITE_RX_ARGUMENT_ERROR;
@@ -428,6 +442,31 @@ extern "C" int selenite_rx_set_handover_repair(selenite_rx_instance *S, int on)
 {
     if (!S) return SELENITE_RX_ARGUMENT_ERROR;
     S->handover_repair = on != 0;
+    if (!S->handover_repair && S->d_hist_ext) {
+        // the rows go (0.27 GB at 65 536 channels of the cfg3 chain); a state that pointed at them is "matrix kernel, no samples" from now on
+        HIPCHK(S, hipSetDevice(S->device));
+        HIPCHK(S, hipStreamSynchronize(S->stream));
+        const size_t C = S->cfg.channels;
+        std::vector<uint32_t> w(C);
+        HIPCHK(S, hipMemcpy(w.data(), S->d_rerun_flag, C * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        for (size_t c = 0; c < C; ++c)
+            if (((w[c] >> kProvShift) & kProvMask) == kProvSplitExt)
+                w[c] = (w[c] & ~((kProvMask << kProvShift) | kExtQ15)) | (kProvSplit << kProvShift);
+        HIPCHK(S, hipMemcpy(S->d_rerun_flag, w.data(), C * sizeof(uint32_t), hipMemcpyHostToDevice));
+        HIPCHK(S, hipFree(S->d_hist_ext));
+        S->d_hist_ext = nullptr;
+    }
+    return SELENITE_RX_SUCCESS;
+}
+
+// SELENITE_ARITH_AUTO on a shape with a split-precision decimator: the rows k_ssb_split16 leaves for k_hist_exact, allocated by the
+// first call that can use them
+static int ensure_hist_ext(selenite_rx_instance *S)
+{
+    if (S->d_hist_ext || !S->ext_len || !S->handover_repair || !S->d_rerun_flag) return SELENITE_RX_SUCCESS;
+    const size_t n = 2 * (size_t)S->cfg.channels * S->ext_len;
+    HIPCHK(S, hipMalloc((void **)&S->d_hist_ext, n * sizeof(float2)));
+    HIPCHK(S, hipMemsetAsync(S->d_hist_ext, 0, n * sizeof(float2), S->stream));
     return SELENITE_RX_SUCCESS;
 }
 
@@ -517,6 +556,8 @@ static int run_part(selenite_rx_instance *S, const void *src, bool src_q15, void
 {
     const selenite_rx_config &g = S->cfg;
     HIPCHK(S, hipSetDevice(S->device));
+    if (phase != kPhase2 && S->plan.kind != 0 && S->plan.d_btab16 && !S->force_generic)
+        if (int rc = ensure_hist_ext(S)) return rc;
     RxParams p = make_params(S, block_size);
     p.in_stride = in_stride; p.out_stride = out_stride;
     if (front_generic_lds_bytes(p) > 64 * 1024 && (S->force_generic || S->plan.kind == 0))
@@ -560,8 +601,17 @@ static int run_part(selenite_rx_instance *S, const void *src, bool src_q15, void
     }
     // (SELENITE_ARITH_AUTO outside the SSB fused kernels -- CW, generic: every channel's state stays in exact arithmetic, and the
     // provenance words k_ssb_split16 reads at its next call say so)
-    if (phase != kPhase2 && S->d_rerun_flag && !ssb_fused)
-        HIPCHK(S, hipMemsetAsync(S->d_rerun_flag + (S->sub_count ? S->sub_first : 0u), 0, p.channels * sizeof(uint32_t), st));
+    // (a channel the matrix kernel left with its samples gets its Hilbert-pair history recomputed in exact arithmetic first: the
+    // generic / CW kernels read it -- advisor finding, round 3)
+    if (phase != kPhase2 && S->d_rerun_flag && !ssb_fused) {
+        uint32_t *words = S->d_rerun_flag + (S->sub_count ? S->sub_first : 0u);
+        if (p.hist_ext) {
+            RxParams ph = p;
+            ph.chan_flags = words;
+            HIPCHK(S, launch_hist_exact(ph, true, st));
+        }
+        HIPCHK(S, hipMemsetAsync(words, 0, p.channels * sizeof(uint32_t), st));
+    }
     bool env_emitted = false;      // global gain: the fused kernel wrote the per-channel block maxima
     if (ssb_fused || cw_fused) {
         RxParams pf = p;
@@ -591,6 +641,9 @@ static int run_part(selenite_rx_instance *S, const void *src, bool src_q15, void
             // the split16 kernel raises the rerun flag of the channels it guards and leaves their state alone; the bit-exact
             // kernel then recomputes the flagged channels (launch_fused)
             pf.rerun_flag = S->d_rerun_flag + (S->sub_count ? S->sub_first : 0u);
+            pf.chan_list = S->d_rerun_list + 2;
+            pf.chan_count = S->d_rerun_list;              // the two counters; launch_shape picks by *rerun_par_host where it launches the prepare kernel
+            pf.rerun_par_host = &S->rerun_par;
         }
         void *fdst = dst;
         bool fq15 = dst_q15;
@@ -1050,6 +1103,40 @@ extern "C" int selenite_rx_time_process_each_device(selenite_rx_instance *S, con
     }
     HIPCHK(S, hipEventSynchronize(ev.e[iters]));
     for (uint32_t i = 0; i < iters; ++i) HIPCHK(S, hipEventElapsedTime(&ms_each[i], ev.e[i], ev.e[i + 1]));
+    return SELENITE_RX_SUCCESS;
+}
+
+extern "C" int selenite_rx_time_streaming_roof_device(selenite_rx_instance *S, const void *dSrcIQ, void *dDstAudio, uint32_t blockSize,
+                                                      uint32_t iters, float *ms_each, int q15)
+{
+    if (!S || !ms_each || iters == 0 || !dSrcIQ || !dDstAudio) return SELENITE_RX_ARGUMENT_ERROR;
+    if (!block_size_ok(S, blockSize, "selenite_rx_time_streaming_roof_device")) return S->status;
+    const selenite_rx_config &g = S->cfg;
+    HIPCHK(S, hipSetDevice(S->device));
+    // the per-channel state of SURVEY.md 8d (what selenite_rx_algorithmic_bytes counts), in a scratch buffer: the instance's own stays untouched
+    uint32_t words = 0;
+    if (g.nd_taps > 1) words += 2 * (g.nd_taps - 1);
+    if (g.nh_taps > 1) words += 2 * (g.nh_taps - 1);
+    words += 4 * g.n_biquad + (g.agc_enable ? 1 : 0) + (g.nco_enable ? 1 : 0);
+    if (words > 1024) return fail(S, SELENITE_RX_LENGTH_ERROR, "selenite_rx_time_streaming_roof_device: state larger than the roof kernel handles");
+    struct Scratch {
+        float *p = nullptr; std::vector<hipEvent_t> e;
+        ~Scratch() { if (p) (void)hipFree(p); for (hipEvent_t x : e) if (x) (void)hipEventDestroy(x); }
+    } sc;
+    const size_t nst = (size_t)g.channels * (words ? words : 1);
+    HIPCHK(S, hipMalloc((void **)&sc.p, nst * sizeof(float)));
+    HIPCHK(S, hipMemsetAsync(sc.p, 0, nst * sizeof(float), S->stream));
+    sc.e.assign((size_t)iters + 1, nullptr);
+    for (auto &x : sc.e) HIPCHK(S, hipEventCreate(&x));
+    const uint32_t in_bytes = blockSize * (q15 ? 4u : 8u), out_bytes = (blockSize / g.decim) * (q15 ? 2u : 4u);
+    for (int w = 0; w < 3; ++w) HIPCHK(S, launch_stream_roof(dSrcIQ, dDstAudio, sc.p, g.channels, in_bytes, out_bytes, words, S->stream));
+    HIPCHK(S, hipEventRecord(sc.e[0], S->stream));
+    for (uint32_t i = 0; i < iters; ++i) {
+        HIPCHK(S, launch_stream_roof(dSrcIQ, dDstAudio, sc.p, g.channels, in_bytes, out_bytes, words, S->stream));
+        HIPCHK(S, hipEventRecord(sc.e[i + 1], S->stream));
+    }
+    HIPCHK(S, hipEventSynchronize(sc.e[iters]));
+    for (uint32_t i = 0; i < iters; ++i) HIPCHK(S, hipEventElapsedTime(&ms_each[i], sc.e[i], sc.e[i + 1]));
     return SELENITE_RX_SUCCESS;
 }
 

@@ -490,7 +490,13 @@ static hipError_t launch_shape(const RxParams &p, const FusedArgs &fa, const Fus
     auto rerun = [&]() -> hipError_t {
         RxParams p2 = p;
         p2.chan_flags = p.rerun_flag;
-        p2.rerun_flag = nullptr; p2.guard_ch = nullptr; p2.guard_calls = nullptr;
+        p2.rerun_flag = nullptr;                      // (guard_ch / guard_calls stay: the rerun pass counts for the channels it HOLDS, which the matrix kernel skipped)
+        if (p.rerun_par_host) {                       // the dense list of this call: counted in one of two alternating counters (rx_internal.h)
+            const uint32_t par = *p.rerun_par_host & 1u;
+            p2.chan_count = p.chan_count + par;
+            p2.chan_count_next = p.chan_count + (par ^ 1u);
+            *p.rerun_par_host = par ^ 1u;
+        }
         // (channels the call before left on the matrix kernel: their Hilbert-pair history first, in exact arithmetic -- rx_generic.hip)
         if (hipError_t e = launch_hist_exact(p2, false, st); e != hipSuccess) return e;
         return launch_exact(ND, M, NH, src_q15, p2, fa, src, dst, st);            // rx_fused_exact.hip
@@ -505,8 +511,22 @@ static hipError_t launch_shape(const RxParams &p, const FusedArgs &fa, const Fus
     const uint32_t tq = fa.pass_out * M;
     // (a last pass shorter than the decimator history: only as a call of its own -- fused_tail_split cuts it off)
     const bool split_ok = split16_pass_ok(fa.pass_out) && (p.block_size % tq == 0 || p.block_size % tq >= kHS || p.block_size < tq);
+    // SELENITE_ARITH_AUTO (round 4: "handover_blocks == 0 by construction"): the matrix kernel only takes calls long enough to leave the
+    // mixed samples in front of the decimator state behind (hist_ext: nd - 1 + M HH4 - 1 samples) -- every state it leaves can then be
+    // repaired by k_hist_exact.  Shorter calls (the firmware's literal one-slot callback, a tail cut off by fused_tail_split) run on the
+    // bit-exact kernel, from a history repaired first (below): they are state-traffic bound either way.  With the repair switched
+    // off (a diagnostic: selenite_rx_set_handover_repair) nothing is kept and such calls stay on the matrix kernel, counted.
+    const bool auto_ok = !auto_ || p.hist_ext == nullptr || p.block_size + 1u >= (uint32_t)(ND > 0 ? ND - 1 : 0) + p.ext_len;
     if constexpr (ND > 0 && (M == 4 || M == 2) && NH > 0) {
-        if (split && plan.d_btab16 && split_ok) {
+        if (split && plan.d_btab16 && split_ok && auto_ok) {
+            if (auto_ && fa.am == 1u && p.rerun_flag) {
+                // AM neither reads nor moves the Hilbert-pair history while the decimator state moves on: the samples kept in front of
+                // that state belong to the history for the last time NOW -- repair every channel that has them, before the AM call
+                RxParams p3 = p;
+                p3.chan_flags = p.rerun_flag;
+                p3.chan_list = nullptr; p3.chan_count_next = nullptr;
+                if (hipError_t e = launch_hist_exact(p3, true, st); e != hipSuccess) return e;
+            }
             hipError_t e = launch_ssb_split16(ND, M, NH, p, fa, src, src_q15, dst, st);      // rx_split16.hip
             if (e == hipSuccess && auto_ && p.rerun_flag) e = rerun();
             return e;
@@ -524,6 +544,7 @@ static hipError_t launch_shape(const RxParams &p, const FusedArgs &fa, const Fus
         if (p.rerun_flag) {
             RxParams p3 = p;
             p3.chan_flags = p.rerun_flag;
+            p3.chan_list = nullptr; p3.chan_count_next = nullptr;
             if (hipError_t e = launch_hist_exact(p3, true, st); e != hipSuccess) return e;
         }
     }

@@ -55,15 +55,26 @@ __device__ __forceinline__ void decim_quad(const float *S, int lane, const float
 // GROUP = lanes per DSP block as a compile-time constant (16: 64-sample blocks, 64: 256-sample blocks;
 // 0 = runtime `group`): constant lane indices turn the block-envelope broadcasts into v_readlane and
 // the lane reductions into DPP instead of ds_bpermute round trips.
+// The exact kernel as the rerun pass of SELENITE_ARITH_AUTO evaluates the parity guard itself (round 4, hysteresis): a channel it
+// recomputes stays with it (kFlagHold: the matrix kernel skips the channel in the next calls) until TWO calls in a row show no DSP
+// block under 1.25 x the guard ratio (2 dB), so a level hovering at the ratio does not bounce between the kernels -- a bounce costs
+// the matrix pass AND the exact pass of a call; a wide margin would keep quiet-but-clean channels (the survey of
+// profiles/r3/guard_ratio_survey.txt has a third of its in-band blocks between 0.25 and 0.5) on the slow kernel for good.
+struct GuardEx {
+    float thr, thr2;    // guard ratio x / 1.25 x guard ratio x the largest |component| of the mixed samples the pass and the pass before it hold
+    uint32_t n, n2;     // DSP blocks of the call under thr / thr2
+};
+
 template <int ARITH, int GROUP, int ND, int M, int NH, typename TOut, int AM = 0>
 __device__ __forceinline__ void demod_agc_store(const RxParams &p, const FusedArgs &fa, const float *dI,
                                                 const float *dQ, int lane, int group,
                                                 const float (&hreg)[(NH + 63) / 64 ? (NH + 63) / 64 : 1], float &gain,
                                                 TOut *__restrict__ dst, size_t out_index, bool &nonfinite,
                                                 int nvb = 64,        // DSP blocks of this pass that exist (whole passes: all of them)
-                                                float *env_row = nullptr)   // global gain, phase 1, as the rerun pass of SELENITE_ARITH_AUTO:
+                                                float *env_row = nullptr,   // global gain, phase 1, as the rerun pass of SELENITE_ARITH_AUTO:
                                                                             // max |audio| of the pass's DSP blocks goes here (what the split16 kernel left
                                                                             // for this channel came from the arithmetic being replaced)
+                                                GuardEx *gx = nullptr)      // rerun pass of SELENITE_ARITH_AUTO: count the blocks under the guard thresholds
 {
     using G = Geo<ND, M, NH>;
     float au[4];
@@ -94,7 +105,7 @@ __device__ __forceinline__ void demod_agc_store(const RxParams &p, const FusedAr
         const float4 v = lds_ld4f(dI + 4 * lane);
         au[0] = v.x; au[1] = v.y; au[2] = v.z; au[3] = v.w;
     }
-    if (env_row) {                                                // (wave-uniform; the AGC is off in this launch)
+    if (env_row || gx) {                                          // (wave-uniform; env_row: the AGC is off in this launch)
         const int gl = GROUP ? GROUP : group;
         float m = fmaxf(fmaxf(fabsf(au[0]), fabsf(au[1])), fmaxf(fabsf(au[2]), fabsf(au[3])));
         if ((gl & (gl - 1)) == 0) {
@@ -106,7 +117,12 @@ __device__ __forceinline__ void demod_agc_store(const RxParams &p, const FusedAr
             for (int j = 0; j < gl; ++j) mm = fmaxf(mm, __shfl(m, ((lane / gl) * gl + j) & 63, 64));
             m = mm;
         }
-        if (lane % gl == 0 && lane / gl < nvb) env_row[lane / gl] = m;
+        const bool first = lane % gl == 0 && lane / gl < nvb;     // the first lane of every DSP block that exists
+        if (env_row && first) env_row[lane / gl] = m;
+        if (gx) {
+            gx->n += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(first && m < gx->thr));
+            gx->n2 += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(first && m < gx->thr2));
+        }
     }
     // AGC: arm_abs + arm_max per DSP block (group lanes), gain law, arm_scale
     if (p.agc) {
@@ -195,31 +211,29 @@ __global__ __launch_bounds__(64, 2) void k_ssb_fused(RxParams p, FusedArgs fa, c
     float *dI = D, *dQ = D + G::DLEN;
     constexpr int NLD = G::T / 128;                      // raw loads per lane per pass
     bool nonfinite = false;                              // any audio sample of this workgroup NaN / Inf
-    // One channel per workgroup, c = blockIdx.x -- or, as the rerun pass of SELENITE_ARITH_AUTO (p.chan_flags: one word per
-    // channel, raised by the split16 kernel of the same call for the channels whose result fell under the parity guard), the
-    // flagged channels of the 16-channel windows blockIdx.x, blockIdx.x + gridDim.x, ...: which channels, and how many,
-    // is only known on the device.
-    uint32_t win = blockIdx.x;                           // current window
-    uint64_t todo = 0;                                   // flagged channels of the window still to do (bit = channel - 16 win)
+    // One channel per workgroup, c = blockIdx.x -- or, as the rerun pass of SELENITE_ARITH_AUTO (p.chan_flags: the channel words, whose
+    // rerun bit the split16 kernel of the same call raised for the channels under the parity guard and the exact kernel keeps up for
+    // the channels it holds), entries blockIdx.x, blockIdx.x + gridDim.x, ... of the dense list k_hist_exact made of them: which
+    // channels, and how many, is only known on the device; every workgroup gets an even share.
+    uint32_t li = blockIdx.x;
+    const uint32_t ln = p.chan_flags ? *p.chan_count : 0u;
   for (;;) {
     uint32_t c = blockIdx.x;
     if (p.chan_flags) {
-        const uint32_t nwin = (p.channels + 15u) / 16u;
-        while (todo == 0) {                              // wave-uniform
-            if (win >= nwin) break;
-            const uint32_t ci = 16u * win + (uint32_t)(lane & 15);
-            const uint32_t f = (lane < 16 && ci < p.channels) ? p.chan_flags[ci] : 0u;
-            todo = __builtin_amdgcn_ballot_w64((f & kFlagRerun) != 0u);
-            if (todo == 0) win += gridDim.x;
-        }
-        if (todo == 0) break;
-        c = 16u * win + (uint32_t)__builtin_ctzll(todo);
-        todo &= todo - 1;
-        if (todo == 0) win += gridDim.x;
+        if (li >= ln) break;
+        c = p.chan_list[li];
+        li += gridDim.x;
     }
 
     const size_t out_base = (size_t)c * p.out_stride;
     const uint32_t npass = (p.nout + pq - 1) / pq;
+    // rerun pass of SELENITE_ARITH_AUTO: the parity guard is evaluated here too (GuardEx); a channel that came in HELD (not raised by
+    // the matrix kernel of this call, which skipped it) gets its guard counters from this kernel
+    const bool rerun_pass = p.chan_flags != nullptr;                 // wave-uniform
+    const uint32_t word_in = rerun_pass ? p.chan_flags[c] : 0u;
+    const bool held_in = (word_in & kFlagHold) != 0u;
+    GuardEx gx{ 0.0f, 0.0f, 0u, 0u };
+    float hmax = 0.0f;                                               // largest |component| of the FIR history the channel came in with
     const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(src + (size_t)c * p.in_stride * 2, p.block_size * (R::kBytes / 2));
     const __amdgpu_buffer_rsrc_t rs_lo = make_rsrc(p.lo, NCO == 2 ? p.block_size * 8u : 0u);
     typename R::type raw[NLD];
@@ -243,6 +257,7 @@ __global__ __launch_bounds__(64, 2) void k_ssb_fused(RxParams p, FusedArgs fa, c
             [&](int i, float v) {
                 const int rail = i / (M * G::HQ4), rem = i % (M * G::HQ4);
                 S[(rem % M) * G::PSF + G::elem(rem / M) + rail] = v;
+                hmax = fmaxf(hmax, fabsf(v));
             });
     }
     if constexpr (NH > 0) {
@@ -251,8 +266,9 @@ __global__ __launch_bounds__(64, 2) void k_ssb_fused(RxParams p, FusedArgs fa, c
                 const int rail = i / G::HH4, sidx = i % G::HH4 - G::FH;
                 return sidx >= 0 ? rail * G::HH + sidx : -1;
             },
-            [&](int i, float v) { D[(i / G::HH4) * G::DLEN + i % G::HH4] = v; });
+            [&](int i, float v) { D[(i / G::HH4) * G::DLEN + i % G::HH4] = v; if (ND == 0) hmax = fmaxf(hmax, fabsf(v)); });
     }
+    float pm_prev = rerun_pass ? __uint_as_float(wave_umax_bits(hmax)) : 0.0f;   // what "the pass before" pass 0 held: the history
     float hreg[(NH + 63) / 64 ? (NH + 63) / 64 : 1];
 #pragma unroll
     for (int v = 0; v < (NH + 63) / 64; ++v) hreg[v] = (64 * v + lane < NH) ? p.hilb_c[64 * v + lane] : 0.0f;
@@ -277,6 +293,7 @@ __global__ __launch_bounds__(64, 2) void k_ssb_fused(RxParams p, FusedArgs fa, c
         const uint32_t cur = (pass + 1 == npass) ? p.nout - pass * pq : pq;      // audio samples of this pass (whole DSP blocks)
         // ---- 1. NCO mix of the prefetched samples, scatter into the LDS image ----
         u4v lo4[NLD];
+        float mx = 0.0f;                                              // rerun pass: largest |component| of this pass's mixed samples
         if constexpr (NCO == 2) {                                     // shared LO table (L2 resident):
 #pragma unroll
             for (int i = 0; i < NLD; ++i)                             // all loads of the pass in flight at once
@@ -307,6 +324,7 @@ __global__ __launch_bounds__(64, 2) void k_ssb_fused(RxParams p, FusedArgs fa, c
                 a = cmul<0>(a, make_float2(la.x, la.y));
                 b = cmul<0>(b, make_float2(lb.x, lb.y));
             }
+            if (rerun_pass) mx = fmaxf(fmaxf(mx, fmaxf(fabsf(a.x), fabsf(a.y))), fmaxf(fabsf(b.x), fabsf(b.y)));
             if constexpr (ND > 0) {
                 const int m = G::HQ4 + (int)(n / M), pp = (int)(n % M);   // n even: pp in {0,2}
                 float *d = S + pp * G::PSF + G::elem(m);
@@ -316,6 +334,15 @@ __global__ __launch_bounds__(64, 2) void k_ssb_fused(RxParams p, FusedArgs fa, c
                 *reinterpret_cast<float2 *>(dI + G::HH4 + n) = make_float2(a.x, b.x);
                 *reinterpret_cast<float2 *>(dQ + G::HH4 + n) = make_float2(a.y, b.y);
             }
+        }
+        if (rerun_pass) {
+            // the matrix kernel's guard compares a block's envelope with the largest sample its pass's product saw (new samples and
+            // the decimator history) and, for the first blocks, the pass before; here: this pass and the one before it, for every block
+            const float pm = __uint_as_float(wave_umax_bits(mx));
+            const float lvl = fmaxf(pm, pm_prev);
+            gx.thr = lvl * p.guard_ratio;
+            gx.thr2 = gx.thr * 1.25f;
+            pm_prev = pm;
         }
         wave_lds_sync();
         // ---- prefetch the next pass while this one computes (beyond the call: zeros, no traffic) ----
@@ -334,11 +361,11 @@ __global__ __launch_bounds__(64, 2) void k_ssb_fused(RxParams p, FusedArgs fa, c
         // (rerun pass of AUTO inside a global-gain call whose split16 kernel emitted block maxima: refresh this channel's row)
         float *env_row = (p.chan_flags && p.env_part) ? p.env_part + (size_t)c * (p.block_size / p.block) + (size_t)pass * (pq / (4u * (uint32_t)group)) : nullptr;
         if (group == 16)
-            demod_agc_store<ARITH, 16, ND, M, NH, TOut, AM>(p, fa, dI, dQ, lane, group, hreg, gain, dst, out_base + (size_t)pass * pq, nonfinite, nvb, env_row);
+            demod_agc_store<ARITH, 16, ND, M, NH, TOut, AM>(p, fa, dI, dQ, lane, group, hreg, gain, dst, out_base + (size_t)pass * pq, nonfinite, nvb, env_row, rerun_pass ? &gx : nullptr);
         else if (group == 64)
-            demod_agc_store<ARITH, 64, ND, M, NH, TOut, AM>(p, fa, dI, dQ, lane, group, hreg, gain, dst, out_base + (size_t)pass * pq, nonfinite, nvb, env_row);
+            demod_agc_store<ARITH, 64, ND, M, NH, TOut, AM>(p, fa, dI, dQ, lane, group, hreg, gain, dst, out_base + (size_t)pass * pq, nonfinite, nvb, env_row, rerun_pass ? &gx : nullptr);
         else
-            demod_agc_store<ARITH, 0, ND, M, NH, TOut, AM>(p, fa, dI, dQ, lane, group, hreg, gain, dst, out_base + (size_t)pass * pq, nonfinite, nvb, env_row);
+            demod_agc_store<ARITH, 0, ND, M, NH, TOut, AM>(p, fa, dI, dQ, lane, group, hreg, gain, dst, out_base + (size_t)pass * pq, nonfinite, nvb, env_row, rerun_pass ? &gx : nullptr);
         wave_lds_sync();
         // ---- 6. history copy-back (arm_fir_decimate_f32.c:396-426, arm_fir_f32.c:947-978) ----
         if constexpr (ND > 0) {
@@ -396,15 +423,29 @@ __global__ __launch_bounds__(64, 2) void k_ssb_fused(RxParams p, FusedArgs fa, c
     if (lane == 0) {
         if constexpr (NCO != 0) p.phase[c] = ph0 + p.block_size * step;
         if (p.agc) p.gain[c] = gain;
-        // SELENITE_ARITH_AUTO: the state this kernel leaves is exact (kProvExact, rerun bit down) -- as the rerun pass, and as a call
-        // without a matrix kernel; k_ssb_split16 reads the word at the channel's next call
-        // (AM, not FM: the Hilbert-pair history is not touched, so its provenance stays -- "with samples" degrades to "without",
-        // the decimator state having moved on without them)
-        if (AM != 0 && fa.am != 2u) {
-            uint32_t *w = p.chan_flags ? p.chan_flags + c : (p.rerun_flag ? p.rerun_flag + c : nullptr);
-            if (w) *w = ((*w >> kProvShift) & kProvMask) == kProvExact ? 0u : ((kProvSplit << kProvShift) | (*w & (1u << kExtBufShift)));
-        } else if (p.chan_flags) p.chan_flags[c] = 0u;
-        else if (p.rerun_flag) p.rerun_flag[c] = 0u;
+        // SELENITE_ARITH_AUTO: the state this kernel leaves is exact (kProvExact) -- as the rerun pass, and as a call without a matrix
+        // kernel; k_ssb_split16 reads the word at the channel's next call.  (AM, not FM, leaves the Hilbert-pair history alone: its
+        // provenance stays what it was -- exact in practice, k_hist_exact having run in front of the AM call; "with samples" would
+        // degrade to "without", the decimator state having moved on without them.)
+        // Rerun pass (round 4): the channel is HELD on this kernel (kFlagRerun | kFlagHold: the matrix kernel skips it from the next
+        // call on) while any block of the call sits under 1.25 x the guard ratio; the second call in a row without one hands it back (word 0).
+        uint32_t *w = p.chan_flags ? p.chan_flags + c : (p.rerun_flag ? p.rerun_flag + c : nullptr);
+        if (w) {
+            uint32_t nw = 0u;
+            if (AM != 0 && fa.am != 2u) {
+                const uint32_t prov = (*w >> kProvShift) & kProvMask;
+                nw = prov == kProvExact ? 0u : ((kProvSplit << kProvShift) | (*w & (1u << kExtBufShift)));
+            }
+            if (rerun_pass && (nw >> kProvShift) == 0u) {
+                if (gx.n2 != 0u) nw = kFlagRerun | kFlagHold;
+                else if (!(held_in && (word_in & kFlagClean1) != 0u)) nw = kFlagRerun | kFlagHold | kFlagClean1;
+            }
+            *w = nw;
+        }
+        if (held_in && p.guard_ch) {                                  // (a channel the matrix kernel raised in this call was counted there)
+            if (gx.n) p.guard_ch[c] = p.guard_ch[c] > 0xFFFFFFFFu - gx.n ? 0xFFFFFFFFu : p.guard_ch[c] + gx.n;
+            if (p.guard_calls[c] != 0xFFFFFFFFu) p.guard_calls[c] += 1u;
+        }
     }
     if (!p.chan_flags) break;
     wave_lds_sync();                                     // the state reads above before the next channel's prologue fills
@@ -433,8 +474,8 @@ static hipError_t launch_one(const RxParams &p, const FusedArgs &fa, const void 
     }
     // (rerun pass of SELENITE_ARITH_AUTO: which channels are flagged is only known on the device -- a resident-sized grid strides
     // over the 16-channel windows of the flag array)
-    const uint32_t nwin = (p.channels + 15u) / 16u;
-    const uint32_t grid = p.chan_flags ? (nwin < 2048u ? nwin : 2048u) : p.channels;
+    static const uint32_t rerun_grid = [] { const char *e = std::getenv("SELENITE_RX_RERUN_GRID"); return e && std::atoi(e) > 0 ? (uint32_t)std::atoi(e) : 2048u; }();
+    const uint32_t grid = p.chan_flags ? (p.channels < rerun_grid ? p.channels : rerun_grid) : p.channels;
     hipLaunchKernelGGL(k, dim3(grid), dim3(64), lds, st, p, fa, static_cast<const TIn *>(src),
                        static_cast<TOut *>(dst));
     return hipGetLastError();

@@ -201,13 +201,45 @@ __global__ __launch_bounds__(64) void k_front_generic(RxParams p, const TIn *__r
 // One wavefront per flagged channel, the flag array walked in 16-channel windows (which channels, and how many, only the
 // device knows); rare by construction (a channel whose level crosses the guard ratio downwards at a call boundary).
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_hist_exact(RxParams p, uint32_t all)      // all: every channel with that provenance (a call that runs the exact kernel on all channels), not only the flagged ones
+__global__ __launch_bounds__(64) void k_hist_exact(RxParams p, uint32_t all, uint32_t repair)     // all: every channel with that provenance (a call that runs the exact kernel on all channels), not only the flagged ones
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x;
     const uint32_t nd = p.nd, M = p.decim, HH = p.nh - 1u, L = p.ext_len, H = nd - 1u;
     float *TI = lds, *TQ = lds + (L + H);
     const uint32_t nwin = (p.channels + 15u) / 16u;
+    if (blockIdx.x == 0 && lane == 0 && p.chan_count_next) *p.chan_count_next = 0u;      // the counter the NEXT call's launch counts in
+    if (p.chan_list) {
+        // round 4: the channels to recompute as a dense list for the rerun pass.  A workgroup takes 1024 channels at a time: 16 words
+        // per lane, a wave prefix sum of the per-lane counts, ONE atomic on the list's counter (64 atomics for 65 536 channels: one per
+        // 16-channel window cost 50 us of serialised atomics when most windows had a flagged channel).  The order of the chunks in the
+        // list varies from run to run, the results do not: every channel is computed on its own.
+        const uint32_t nchunk = (p.channels + 1023u) / 1024u;
+        for (uint32_t ch = blockIdx.x; ch < nchunk; ch += gridDim.x) {
+            const uint32_t c0 = 1024u * ch + 16u * (uint32_t)lane;
+            uint32_t bits = 0u;                                           // bit k: channel c0 + k has its rerun bit up
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const uint32_t ci = c0 + (uint32_t)k;
+                const uint32_t w = ci < p.channels ? p.chan_flags[ci] : 0u;
+                bits |= (w & kFlagRerun) << k;
+            }
+            const uint32_t n = (uint32_t)__builtin_popcount(bits);
+            uint32_t incl = n;                                            // inclusive prefix sum over the wave
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t v = (uint32_t)__shfl_up((int)incl, off, 64);
+                if (lane >= off) incl += v;
+            }
+            const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            if (total == 0u) continue;                                    // wave-uniform
+            uint32_t base = 0u;
+            if (lane == 0) base = atomicAdd(p.chan_count, total);
+            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base) + incl - n;
+            for (uint32_t b2 = bits; b2 != 0u; b2 &= b2 - 1u) p.chan_list[base++] = c0 + (uint32_t)__builtin_ctz(b2);
+        }
+    }
+    if (!repair) return;
     for (uint32_t win = blockIdx.x; win < nwin; win += gridDim.x) {
         const uint32_t ci = 16u * win + (uint32_t)(lane & 15);
         const uint32_t f = (lane < 16 && ci < p.channels) ? p.chan_flags[ci] : 0u;
@@ -255,6 +287,9 @@ __global__ __launch_bounds__(64) void k_hist_exact(RxParams p, uint32_t all)    
                 p.fir_state[((size_t)c * 2 + 0) * HH + r] = ai;
                 p.fir_state[((size_t)c * 2 + 1) * HH + r] = aq;
             }
+            // the channel's Hilbert-pair history is exact now: say so (what follows may be a kernel that hands the provenance on as it
+            // finds it -- AM, which neither reads nor writes that history; everything else rewrites the word anyway)
+            if (lane == 0) p.chan_flags[c] = word & ~(kProvMask << kProvShift);
             __syncthreads();
         }
     }
@@ -583,12 +618,15 @@ __global__ __launch_bounds__(256) void k_q15_to_f32(const int16_t *__restrict__ 
 
 hipError_t launch_hist_exact(const RxParams &p, bool all, hipStream_t st)
 {
-    if (!p.chan_flags || !p.hist_ext || p.nd < 2 || p.nh < 2 || p.mode == SELENITE_MODE_AM) return hipSuccess;      // (AM does not read the history)
+    if (!p.chan_flags) return hipSuccess;
+    // (in front of an AM call too, round 4: AM neither reads nor moves the Hilbert-pair history, but the decimator state moves on under it --
+    // the last moment the samples kept in front of that state still belong to the history is now)
     static const bool off = std::getenv("SELENITE_RX_NO_HIST_EXACT") != nullptr;      // diagnostic: what the rerun does without it
-    if (off) return hipSuccess;
+    const bool repair = p.hist_ext && p.nd >= 2 && p.nh >= 2 && !off;
+    if (!repair && !p.chan_list) return hipSuccess;
     const uint32_t nwin = (p.channels + 15u) / 16u;
-    const size_t lds = 2 * (size_t)(p.ext_len + p.nd - 1u) * sizeof(float);
-    hipLaunchKernelGGL(k_hist_exact, dim3(nwin < 1024u ? nwin : 1024u), dim3(64), lds, st, p, all ? 1u : 0u);
+    const size_t lds = repair ? 2 * (size_t)(p.ext_len + p.nd - 1u) * sizeof(float) : 0;
+    hipLaunchKernelGGL(k_hist_exact, dim3(nwin < 1024u ? nwin : 1024u), dim3(64), lds, st, p, all ? 1u : 0u, repair ? 1u : 0u);
     return hipGetLastError();
 }
 

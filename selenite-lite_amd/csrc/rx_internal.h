@@ -60,13 +60,30 @@ struct RxParams {
                                  //   bit 0      recompute this channel's current call in exact arithmetic (kFlagRerun)
                                  //   bits 1-2   provenance of the channel's streaming state (kProv*): what the call before left
                                  //   bit 3      which of the two hist_ext buffers holds the samples in front of that state
+                                 //   bit 4      that row holds raw int16 samples (kExtQ15)
+                                 //   bit 5      hysteresis (kFlagHold): the exact kernel serves this channel DIRECTLY -- the matrix kernel skips
+                                 //              it -- until two calls in a row show no block near the guard ratio (bit 6: one has) (round 4)
+                                 //   bits 8-31  the largest |component| the LAST pass of the call before held in its images (the upper 24 bits
+                                 //              of the float's bit pattern, rounded up): the first blocks of this call still see Hilbert-pair
+                                 //              history computed from those samples, so their guard threshold covers them too (kLvlMask)
     // k_ssb_split16, SELENITE_ARITH_AUTO: the mixed samples in front of the decimator state, hist_ext[buf][channel][ext_len] (I, Q),
     // positions [E - (nd - 1) - ext_len, E - (nd - 1)) of the stream that ends at E -- what it takes to recompute the Hilbert-pair
     // history (the last HH4 decimated samples) in exact arithmetic when the NEXT call has to be rerun (k_hist_exact)
     float2 *hist_ext;            // or NULL
     uint32_t ext_len;            // decim * HH4
     size_t ext_buf_stride;       // elements between the two buffers
-    uint32_t *chan_flags;  // exact kernels: process only the channels whose flag is set (16-channel windows, grid-stride)
+    uint32_t *chan_flags;  // exact kernels as the rerun pass of SELENITE_ARITH_AUTO: the channel words (= rerun_flag of the matrix kernel's launch)
+    // ... and the channels to recompute as a DENSE list (round 4): k_hist_exact, in front of the rerun pass, appends every channel whose
+    // rerun bit is up (one atomic per 16-channel window that has any) -- workgroup b of the rerun pass then takes entries b, b + grid, ...:
+    // an even share whatever the pattern of flagged channels (walking the words in windows gave the slowest workgroup ~32 channels when
+    // 80 % were flagged: as long as recomputing everything).  Two counters alternate between calls: a call's prepare kernel zeroes
+    // the one the NEXT call will count in.
+    uint32_t *chan_list;         // [channels]
+    uint32_t *chan_count;        // entries in chan_list (device)
+    uint32_t *chan_count_next;   // zeroed by this call's prepare kernel
+    uint32_t *rerun_par_host;    // HOST word (the instance's): which of the two counters the next prepare kernel counts in -- read and
+                                 // flipped where that kernel is launched (rx_fused.hip: launch_shape), so a call that never launches it
+                                 // (a short call on the bit-exact kernel) leaves the pair in step
     AgcParams agcp;
 };
 
@@ -74,7 +91,10 @@ struct RxParams {
 enum { kFlagNanInf = 0, kFlagWords = 4 };
 // RxParams::rerun_flag words
 enum : uint32_t { kFlagRerun = 1u, kProvShift = 1u, kProvMask = 3u, kProvExact = 0u, kProvSplitExt = 1u, kProvSplit = 2u, kExtBufShift = 3u,
-                  kExtQ15 = 16u };     // bit 4: the hist_ext row holds the RAW int16 samples of an int16-slot call (half the bytes; k_hist_exact mixes them again)
+                  kExtQ15 = 16u,       // bit 4: the hist_ext row holds the RAW int16 samples of an int16-slot call (half the bytes; k_hist_exact mixes them again)
+                  kFlagHold = 32u,     // bit 5: held on the exact kernel (hysteresis of SELENITE_ARITH_AUTO)
+                  kFlagClean1 = 64u,   // bit 6: ... and its last call there had no block near the guard ratio (the second such call in a row hands it back)
+                  kLvlMask = 0xFFFFFF00u };
 
 __host__ __device__ inline bool mode_is_cw(uint32_t m) { return m == SELENITE_MODE_CW || m == SELENITE_MODE_CWR; }
 __host__ __device__ inline bool mode_is_upper(uint32_t m)
@@ -148,6 +168,10 @@ hipError_t launch_synth(float *dIQ, const float *sintab, uint32_t first_channel,
 void synth_host(float *iq, const float *sintab, uint32_t first_channel, uint32_t nch,
                 uint64_t first_sample, uint32_t nsamp, uint64_t seed);
 
+// no-arithmetic streaming kernel with the traffic of one process call (rx_synth.hip; bench.py `streaming_roof`)
+hipError_t launch_stream_roof(const void *in, void *out, float *state, uint32_t channels, uint32_t in_bytes, uint32_t out_bytes,
+                              uint32_t state_words, hipStream_t st);
+
 // host copy of sinTable_f32 regenerated from its documented generator (rx_api.hip)
 const float *host_sin_table();
 
@@ -165,6 +189,8 @@ struct selenite_rx_instance {
     uint32_t *d_flags = nullptr;       // kFlagWords words
     uint32_t *d_guard_ch = nullptr;    // [3][channels] guarded DSP blocks per channel | process calls with a guarded block | handover blocks (sticky)
     uint32_t *d_rerun_flag = nullptr;  // [channels] SELENITE_ARITH_AUTO: rerun bit + state provenance (RxParams::rerun_flag)
+    uint32_t *d_rerun_list = nullptr;  // [channels + 2] dense list of the channels to recompute, behind its two alternating counters (RxParams::chan_list)
+    uint32_t rerun_par = 0;            // which counter the next call counts in
     float2 *d_hist_ext = nullptr;      // [2][channels][ext_len] SELENITE_ARITH_AUTO with k_ssb_split16: RxParams::hist_ext
     uint32_t ext_len = 0;
     bool handover_repair = true;       // selenite_rx_set_handover_repair

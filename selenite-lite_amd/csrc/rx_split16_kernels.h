@@ -56,6 +56,9 @@ __device__ __forceinline__ void st_st(float *p, float v)
 #endif
 }
 
+// sticky per-channel counters do not wrap (advisor, round 3: a uint32 of guarded blocks wraps after days at firmware slot rates)
+__device__ __forceinline__ uint32_t sat_add_u32(uint32_t a, uint32_t b) { return a > 0xFFFFFFFFu - b ? 0xFFFFFFFFu : a + b; }
+
 __device__ __forceinline__ float amax2(v2f x, float m) { return fmaxf(fmaxf(fabsf(x.x), fabsf(x.y)), m); }
 
 // memory-order point for the single-wave workgroups of this file: LDS operations of a wave execute in
@@ -85,6 +88,12 @@ struct GuardPass {
     uint32_t n;
     uint64_t hist;     // lanes of the blocks inside the Hilbert history of the call's start while pass 0 is demodulated, else 0
     uint32_t nh;
+    // round 4 (advisor finding): the first blocks of a pass -- those inside the reach of the Hilbert-pair history, lanes `hm` -- also read
+    // decimated samples the PASS BEFORE produced, whose split-precision error scales with the largest sample THAT pass's product saw:
+    // their threshold thr_h = ratio x max(this pass's maximum, the previous pass's) (at a call's start: the level the call before left
+    // in the channel's word).  A loud signal that ends up to nd + M (nh - 1) samples in front of a pass is then still guarded.
+    float thr_h;
+    uint64_t hm;
 };
 template <int GROUP>
 __device__ __forceinline__ void agc_pass(const AgcParams &ap, uint32_t agc_on, int lane, int group, float (&au)[4], float &gain,
@@ -95,7 +104,7 @@ __device__ __forceinline__ void agc_pass(const AgcParams &ap, uint32_t agc_on, i
     auto guard = [&](float env) {                    // env: the block envelope, in (at least) the first lane of every block
         const int lanes = nvb * (GROUP ? GROUP : group);
         const uint64_t exist = lanes >= 64 ? ~0ull : ((1ull << lanes) - 1ull);
-        const uint64_t hit = __builtin_amdgcn_ballot_w64(env < gd.thr) & gd.first & exist;
+        const uint64_t hit = (__builtin_amdgcn_ballot_w64(env < gd.thr) | (__builtin_amdgcn_ballot_w64(env < gd.thr_h) & gd.hm)) & gd.first & exist;
         gd.n += (uint32_t)__builtin_popcountll(hit);
         gd.nh += (uint32_t)__builtin_popcountll(hit & gd.hist);
     };
@@ -193,7 +202,54 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
     static_assert(ND > 0 && (M == 4 || M == 2) && NH > 0 && G::T % 128 == 0 && GS::HS % 128 == 0, "split16 decimator: /4 or /2, + Hilbert");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x;
-    uint32_t c = blockIdx.x;                                      // persistent: this workgroup runs channels c, c + gridDim.x, ...
+    // persistent: this workgroup runs channels blockIdx.x, blockIdx.x + gridDim.x, ... -- in SELENITE_ARITH_AUTO minus the channels the
+    // exact kernel HOLDS (kFlagHold, round 4: a channel that was recomputed stays with the exact kernel until a call of it shows no
+    // block near the guard ratio; the matrix kernel does not touch it -- no loads, no passes, its word stays).  The words of the next
+    // 64 candidates are read with one wave load and kept as a scalar bit mask (bit k: channel ch_lo + k gridDim.x is ours).
+    uint64_t ch_mask = 0ull, ch_hi = blockIdx.x;
+    uint32_t ch_lo = 0u;
+    auto ch_scan = [&](uint32_t &w, bool &mine) {                 // issue: the words of the 64 candidates from ch_hi on
+        const uint64_t ci = ch_hi + (uint64_t)lane * gridDim.x;
+        mine = ci < (uint64_t)p.channels;
+        w = p.rerun_flag != nullptr ? p.rerun_flag[mine ? ci : 0] : 0u;
+    };
+    auto ch_take = [&](uint32_t w, bool mine) {                   // consume
+        ch_mask = __builtin_amdgcn_ballot_w64(mine && (w & kFlagHold) == 0u);
+        ch_lo = (uint32_t)ch_hi;
+        ch_hi += 64ull * gridDim.x;
+    };
+    auto ch_next = [&]() -> uint32_t {                            // the next channel of this workgroup, or p.channels when there is none
+        while (ch_mask == 0ull) {                                 // wave-uniform; the first mask is taken below, a reload happens after 64 candidates
+            if (ch_hi >= (uint64_t)p.channels) return p.channels;
+            uint32_t w; bool mine;
+            ch_scan(w, mine);
+            ch_take(w, mine);
+        }
+        const uint32_t k = (uint32_t)__builtin_ctzll(ch_mask);
+        ch_mask &= ch_mask - 1ull;
+        return ch_lo + k * gridDim.x;
+    };
+    uint32_t w_first; bool mine_first;
+    ch_scan(w_first, mine_first);                                 // (in flight under the fragment loads below)
+    // Toeplitz B fragments (8 halfs per lane): [kk][hi/lo]
+    h8 Bh[GS::KS], Bl[GS::KS];
+    {
+        const h8 *bt = static_cast<const h8 *>(fa.btab16);
+#pragma unroll
+        for (int kk = 0; kk < GS::KS; ++kk) {
+            Bh[kk] = bt[(2 * kk + 0) * 64 + lane];
+            Bl[kk] = bt[(2 * kk + 1) * 64 + lane];
+        }
+    }
+    // Hilbert taps: wave-uniform values held in scalar registers for the whole kernel (only the structurally
+    // non-zero ones are ever referenced: (NH + 1) / 2 SGPRs), so a tap costs no v_readlane per pass
+    float hreg[(NH + 63) / 64];
+#pragma unroll
+    for (int v = 0; v < (NH + 63) / 64; ++v) hreg[v] = (64 * v + lane < NH) ? p.hilb_c[64 * v + lane] : 0.0f;
+    ch_take(w_first, mine_first);
+    uint32_t c = ch_next();
+    if (c >= p.channels) return;                                  // (every channel of this workgroup is held)
+    uint32_t c_nx = ch_next();
 #ifdef SRX_STAMP       // diagnostics build (make STAMP=1): s_memtime stamps of one wave in 1024 (tools/stamp_split16.py)
     unsigned long long *stamp_p = (fa.dbg && (c & 1023u) == 511u) ? fa.dbg + (c >> 10) * 64 : nullptr;
     int stamp_i = 0;
@@ -230,7 +286,7 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
     auto in_rsrc = [&](uint32_t ch) {                             // a channel past the last one: empty range, loads return zeros
         return make_rsrc(src + (size_t)ch * p.in_stride * 2, ch < p.channels ? p.block_size * (R::kBytes / 2) : 0u);
     };
-    __amdgpu_buffer_rsrc_t rs_in = in_rsrc(c), rs_in_next = in_rsrc(c + gridDim.x);
+    __amdgpu_buffer_rsrc_t rs_in = in_rsrc(c), rs_in_next = in_rsrc(c_nx);
     __amdgpu_buffer_rsrc_t rs_out = make_rsrc(dst + (size_t)c * p.out_stride, p.nout * (W::kBytes / 4));
     // global gain, phase 1: the kernel runs with its own AGC off and leaves max |audio| of every DSP block of every channel
     // behind, so the envelope reduction does not have to read the audio again (GROUP == 16 launches with whole passes only)
@@ -279,21 +335,6 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
     };
     prefetch(0);
 
-    // Toeplitz B fragments (8 halfs per lane): [kk][hi/lo]
-    h8 Bh[GS::KS], Bl[GS::KS];
-    {
-        const h8 *bt = static_cast<const h8 *>(fa.btab16);
-#pragma unroll
-        for (int kk = 0; kk < GS::KS; ++kk) {
-            Bh[kk] = bt[(2 * kk + 0) * 64 + lane];
-            Bl[kk] = bt[(2 * kk + 1) * 64 + lane];
-        }
-    }
-    // Hilbert taps: wave-uniform values held in scalar registers for the whole kernel (only the structurally
-    // non-zero ones are ever referenced: (NH + 1) / 2 SGPRs), so a tap costs no v_readlane per pass
-    float hreg[(NH + 63) / 64];
-#pragma unroll
-    for (int v = 0; v < (NH + 63) / 64; ++v) hreg[v] = (64 * v + lane < NH) ? p.hilb_c[64 * v + lane] : 0.0f;
 #if SRX_HS_SGPR
     float hs[NH];
 #pragma unroll
@@ -352,9 +393,10 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
     float gain = 1.0f;
     int s_cur = 0x7fff;                                               // sample scale exponent of the images (none yet)
     // parity guard (GuardPass): thresholds of the pass being mixed and of the pass before it (whose demodulator runs later)
-    float thr_cur = 0.0f, thr_prev = 0.0f;
+    float thr_cur = 0.0f, thr_prev = 0.0f, thrh_cur = 0.0f, thrh_prev = 0.0f;
+    uint32_t b_prev = 0u;                                             // what the pass before this one held (bit pattern); at a call's start: from the channel's word
     GuardPass gd;
-    gd.thr = 0.0f; gd.n = 0u; gd.hist = 0ull; gd.nh = 0u;
+    gd.thr = 0.0f; gd.n = 0u; gd.hist = 0ull; gd.nh = 0u; gd.thr_h = 0.0f;
     if constexpr (GROUP == 16) gd.first = 0x0001000100010001ull;
     else if constexpr (GROUP == 32) gd.first = 0x0000000100000001ull;
     else if constexpr (GROUP == 64) gd.first = 1ull;
@@ -365,6 +407,7 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
     // lanes of the DSP blocks that hold one of the first HH audio samples of a call (the reach of the Hilbert-pair history)
     const int hist_lanes = ((G::HH + 4 * (int)fa.group - 1) / (4 * (int)fa.group)) * (int)fa.group;
     const uint64_t hist_mask = hist_lanes >= 64 ? ~0ull : ((1ull << hist_lanes) - 1ull);
+    gd.hm = AM != 0 ? 0ull : hist_mask;                               // (AM reads no Hilbert history)
     auto install_state = [&]() {
         float mh = 0.0f;
 #pragma unroll
@@ -381,6 +424,7 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
         ph0 = st_ph0; step = st_step; gain = st_gain;
         s_cur = 0x7fff;
         gd.n = 0u; gd.nh = 0u;
+        b_prev = st_word & kLvlMask;
         prev_prov = (st_word >> kProvShift) & kProvMask; prev_buf = (st_word >> kExtBufShift) & 1u; st_word_cur = st_word;
         if (ext_on)                                                   // the buffer the state of the call before does NOT point at
             rs_ext = make_rsrc(p.hist_ext + (size_t)(prev_buf ^ 1u) * p.ext_buf_stride + (size_t)c * p.ext_len, p.ext_len * (sizeof(TIn) == 2 ? 4u : 8u));
@@ -493,8 +537,10 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
         const uint32_t b_tail = wave_umax_bits(mt);
         const uint32_t b_need = max(max(wave_umax_bits(mh), b_tail), b_hist);       // the largest |component| the pass's images hold
         const uint32_t e_need = b_need >> 23;
-        thr_prev = thr_cur;
+        thr_prev = thr_cur; thrh_prev = thrh_cur;
         thr_cur = __uint_as_float(b_need) * p.guard_ratio;
+        thrh_cur = __uint_as_float(max(b_need, b_prev)) * p.guard_ratio;
+        b_prev = b_need;
         // largest |component| * 2^s in [2^14, 2^15):  s = 14 - (E - 127); 2^s must itself be a normal float
         int s_new = 141 - (int)e_need;
         s_new = s_new > 127 ? 127 : (s_new < -126 ? -126 : s_new);
@@ -767,7 +813,7 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
             u4v cb[NCB];
             v4f dt = { 0.0f, 0.0f, 0.0f, 0.0f };
             if constexpr (AM == 0) dt = *reinterpret_cast<const v4f *>(D + dt_off + pq);      // (the pass before this one was a full one)
-            gd.thr = thr_prev;                                        // the demodulator below belongs to the pass before
+            gd.thr = thr_prev; gd.thr_h = thrh_prev;                  // the demodulator below belongs to the pass before
             gd.hist = pass == 1 ? hist_mask : 0ull;
             const int nvb_full = GROUP == 0 ? (int)(pq / (4u * (uint32_t)group)) : 64;
             mfma_phase([&](int kk) { demod_piece(kk, au, nvb_full); }, (NTS + TPK - 1) / TPK - 1);   // matrix pipe over the vector work of the pass before
@@ -780,8 +826,8 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
             STAMP(0);
         }
         store_audio(npass - 2, au);
-        load_state(c + gridDim.x);                                    // the next channel's state, under this channel's last demodulator pass
-        gd.thr = thr_cur;
+        load_state(c_nx);                                             // the next channel's state, under this channel's last demodulator pass
+        gd.thr = thr_cur; gd.thr_h = thrh_cur;
         gd.hist = npass == 1 ? hist_mask : 0ull;
         demod(au, (int)(tail_out / (4u * (uint32_t)group)));          // DSP blocks of the last pass that exist
         store_audio(npass - 1, au);
@@ -791,15 +837,18 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
         // state and raises its rerun flag (the flag of every channel is rewritten every call) ----
         const bool keep_state = gd.n != 0u && p.rerun_flag != nullptr;   // wave-uniform
         if (lane == 0) {
-            if (gd.n != 0u && p.guard_ch) { p.guard_ch[c] += gd.n; p.guard_calls[c] += 1u; }
+            if (gd.n != 0u && p.guard_ch) { p.guard_ch[c] = sat_add_u32(p.guard_ch[c], gd.n); p.guard_calls[c] = sat_add_u32(p.guard_calls[c], 1u); }
             // handover blocks the rerun cannot repair: the call before stayed on the matrix kernel and left no hist_ext (a short call)
             // (or left them but the repair has been switched off since)
-            if (AM == 0 && gd.nh != 0u && (prev_prov == kProvSplit || (prev_prov == kProvSplitExt && !p.hist_ext)) && p.guard_hand) p.guard_hand[c] += gd.nh;      // (AM reads no history)
+            if (AM == 0 && gd.nh != 0u && (prev_prov == kProvSplit || (prev_prov == kProvSplitExt && !p.hist_ext)) && p.guard_hand) p.guard_hand[c] = sat_add_u32(p.guard_hand[c], gd.nh);      // (AM reads no history)
             if (p.rerun_flag) {
                 const uint32_t kept = AM != 0 ? (((prev_prov == kProvExact ? kProvExact : kProvSplit) << kProvShift) | (prev_buf << kExtBufShift))      // (no samples: the format bit is void)
                                               : (((ext_on ? kProvSplitExt : kProvSplit) << kProvShift) | ((prev_buf ^ 1u) << kExtBufShift) |
                                                  (ext_on && sizeof(TIn) == 2 ? kExtQ15 : 0u));
-                p.rerun_flag[c] = keep_state ? (kFlagRerun | (st_word_cur & (kExtQ15 | (kProvMask << kProvShift) | (1u << kExtBufShift)))) : kept;
+                // (kept on the matrix kernel: the level of the last pass goes with the state -- the first blocks of the next call read
+                // Hilbert-pair history computed from those samples; rounded up to the 24 bits the word has room for)
+                p.rerun_flag[c] = keep_state ? (kFlagRerun | (st_word_cur & (kExtQ15 | (kProvMask << kProvShift) | (1u << kExtBufShift))))
+                                             : (kept | ((b_prev + 0xFFu) & kLvlMask));
             }
         }
         // ---- streaming state of the channel back to HBM (exact f32) ----
@@ -824,11 +873,12 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
             if constexpr (NCO != 0) p.phase[c] = ph0 + p.block_size * step;
             if (p.agc) p.gain[c] = gain;
         }
-        c += gridDim.x;
+        c = c_nx;
         if (c >= p.channels) break;
+        c_nx = ch_next();
         lds_order();                                                  // the state reads above before the next channel's installs
         rs_in = rs_in_next;
-        rs_in_next = in_rsrc(c + gridDim.x);
+        rs_in_next = in_rsrc(c_nx);
         rs_out = make_rsrc(dst + (size_t)c * p.out_stride, p.nout * (W::kBytes / 4));
         if constexpr (ENV != 0) rs_env = env_rsrc(c);
     }
@@ -1198,6 +1248,8 @@ __global__ __launch_bounds__(64, 2) void k_hilb_split16(RxParams p, FusedArgs fa
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x;
     const uint32_t c = blockIdx.x;
+    // SELENITE_ARITH_AUTO, hysteresis (round 4): a channel the exact kernel holds is its alone -- the rerun pass of this call serves it
+    if (p.rerun_flag != nullptr && (p.rerun_flag[c] & kFlagHold) != 0u) return;
     float *tab = lds + GH::oTab;
     _Float16 *Xh = reinterpret_cast<_Float16 *>(lds + GH::oX), *Xl = Xh + GH::IMG;
     float *dI = lds + GH::oDI, *dQ = lds + GH::oDQ, *O = lds + GH::oO;      // f32 rails [HH history | 256 new]
@@ -1372,7 +1424,7 @@ __global__ __launch_bounds__(64, 2) void k_hilb_split16(RxParams p, FusedArgs fa
     {
         const bool keep_state = gd.n != 0u && p.rerun_flag != nullptr;   // wave-uniform
         if (lane == 0) {
-            if (gd.n != 0u && p.guard_ch) { p.guard_ch[c] += gd.n; p.guard_calls[c] += 1u; }
+            if (gd.n != 0u && p.guard_ch) { p.guard_ch[c] = sat_add_u32(p.guard_ch[c], gd.n); p.guard_calls[c] = sat_add_u32(p.guard_calls[c], 1u); }
             if (p.rerun_flag) p.rerun_flag[c] = keep_state ? 1u : 0u;
         }
         if (keep_state) {

@@ -103,4 +103,81 @@ void synth_host(float *iq, const float *sintab, uint32_t first_channel, uint32_t
     }
 }
 
+
+
+// ------------------------------------------------------------------------------------------
+// k_stream_roof -- measurement support (bench.py `streaming_roof`, SURVEY.md 8d "practical HBM ceiling"): the traffic of one
+// process call with NO arithmetic.  Launched the way the fused kernels are: a persistent grid of single-wave workgroups, workgroup
+// b streams channels b, b + G, ...; per channel `in_bytes` of input in 1 KB non-temporal buffer loads (eight in flight, the next
+// eight always prefetched, across the channel boundary too), `state_bytes` of state read and written back, `out_bytes` of
+// audio written as 1 KB non-temporal stores spread evenly over the passes.  One integer add per loaded register keeps the loads
+// alive.  What this kernel takes is the floor for ANY kernel that moves the algorithmic bytes of the call with this access
+// pattern; the DSP kernels are reported as a fraction of it next to the fraction of the nominal 8 TB/s.
+// ------------------------------------------------------------------------------------------
+typedef unsigned int u4s __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t roof_rsrc(const void *p, uint32_t bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, (int)bytes, 0x00020000);
+}
+
+__global__ __launch_bounds__(64, 2) void k_stream_roof(const char *__restrict__ in, char *__restrict__ out, float *__restrict__ state,
+                                                       uint32_t channels, uint32_t in_bytes, uint32_t out_bytes, uint32_t state_words,
+                                                       size_t in_stride, size_t out_stride)
+{
+    const int lane = threadIdx.x;
+    constexpr int NL = 8;                                         // 1 KB wave loads per pass
+    const uint32_t npass = (in_bytes + NL * 1024u - 1u) / (NL * 1024u);
+    const uint32_t out_per_pass = ((out_bytes + npass - 1u) / npass + 1023u) & ~1023u;    // whole 1 KB stores; the range check drops the surplus
+    u4s raw[NL];
+    uint32_t c = blockIdx.x;
+    if (c >= channels) return;
+    __amdgpu_buffer_rsrc_t rs = roof_rsrc(in + (size_t)c * in_stride, in_bytes);
+#pragma unroll
+    for (int i = 0; i < NL; ++i) raw[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, lane * 16 + i * 1024, 0, 2);
+    for (; c < channels; c += gridDim.x) {
+        float *st = state + (size_t)c * state_words;
+        float sv[16];
+        const uint32_t nsv = (state_words + 63u) / 64u;           // <= 16 (asserted on the host)
+        for (uint32_t j = 0; j < nsv; ++j) sv[j] = (j * 64u + lane < state_words) ? st[j * 64u + lane] : 0.0f;
+        const uint32_t cn = c + gridDim.x;
+        const __amdgpu_buffer_rsrc_t rn = roof_rsrc(in + (size_t)cn * in_stride, cn < channels ? in_bytes : 0u);
+        const __amdgpu_buffer_rsrc_t ro = roof_rsrc(out + (size_t)c * out_stride, out_bytes);
+        u4s acc = { 0u, 0u, 0u, 0u };
+        for (uint32_t pass = 0; pass < npass; ++pass) {
+#pragma unroll
+            for (int i = 0; i < NL; ++i) acc += raw[i];
+            const bool last = pass + 1 == npass;
+            const __amdgpu_buffer_rsrc_t r = last ? rn : rs;
+            const int so = last ? 0 : (int)((pass + 1) * NL * 1024u);
+#pragma unroll
+            for (int i = 0; i < NL; ++i) raw[i] = __builtin_amdgcn_raw_buffer_load_b128(r, lane * 16 + i * 1024, so, 2);
+            for (uint32_t o = 0; o < out_per_pass; o += 1024u)
+                __builtin_amdgcn_raw_buffer_store_b128(acc, ro, lane * 16, (int)(pass * out_per_pass + o), 2);
+        }
+        for (uint32_t j = 0; j < nsv; ++j)
+            if (j * 64u + lane < state_words) st[j * 64u + lane] = sv[j] + __uint_as_float(acc.x & 1u);
+        rs = rn;
+    }
+}
+
+hipError_t launch_stream_roof(const void *in, void *out, float *state, uint32_t channels, uint32_t in_bytes, uint32_t out_bytes,
+                              uint32_t state_words, hipStream_t st)
+{
+    if (state_words > 16u * 64u) return hipErrorInvalidValue;
+    static int resident = 0;
+    if (resident == 0) {
+        int per_cu = 0, dev = 0;
+        hipDeviceProp_t prop;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_stream_roof, 64, 0) == hipSuccess && per_cu > 0 &&
+            hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+            resident = (per_cu < 8 ? per_cu : 8) * prop.multiProcessorCount;     // 8 single-wave workgroups per CU: the launch shape of k_ssb_split16
+        else
+            resident = 2048;
+    }
+    const uint32_t grid = (uint32_t)resident < channels ? (uint32_t)resident : channels;
+    hipLaunchKernelGGL(k_stream_roof, dim3(grid), dim3(64), 0, st, static_cast<const char *>(in), static_cast<char *>(out), state,
+                       channels, in_bytes, out_bytes, state_words, (size_t)in_bytes, (size_t)out_bytes);
+    return hipGetLastError();
+}
+
 }  // namespace srx

@@ -62,8 +62,8 @@ ABI_SYMBOLS = [
     "selenite_rx_abi_version",
     "selenite_rx_global_process_f32_device",
     "selenite_rx_host_alloc", "selenite_rx_host_free", "selenite_rx_host_register", "selenite_rx_host_unregister",
-    "selenite_rx_time_process_each_device", "selenite_rx_device_pci_bus_id",
-    "selenite_rx_set_guard_ratio", "selenite_rx_guard_stats", "selenite_rx_guard_channels", "selenite_rx_guard_handover", "selenite_rx_set_handover_repair", "selenite_rx_guard_clear",
+    "selenite_rx_time_process_each_device", "selenite_rx_time_streaming_roof_device", "selenite_rx_device_pci_bus_id",
+    "selenite_rx_set_guard_ratio", "selenite_rx_guard_stats", "selenite_rx_guard_channels", "selenite_rx_auto_words", "selenite_rx_guard_handover", "selenite_rx_set_handover_repair", "selenite_rx_guard_clear",
 ]
 
 class TxConfig(C.Structure):
@@ -163,10 +163,12 @@ def lib():
         L.selenite_rx_algorithmic_bytes.restype = C.c_uint64
         u64p = C.POINTER(C.c_uint64)
         L.selenite_rx_time_process_each_device.argtypes = [vp, vp, vp, C.c_uint32, C.c_uint32, f32p, C.c_int]
+        L.selenite_rx_time_streaming_roof_device.argtypes = [vp, vp, vp, C.c_uint32, C.c_uint32, f32p, C.c_int]
         L.selenite_rx_device_pci_bus_id.argtypes = [C.c_int, C.c_char_p, C.c_size_t]
         L.selenite_rx_set_guard_ratio.argtypes = [vp, C.c_float]
         L.selenite_rx_guard_stats.argtypes = [vp, u64p, u64p, u64p]
         L.selenite_rx_guard_channels.argtypes = [vp, u32p]
+        L.selenite_rx_auto_words.argtypes = [vp, u32p]
         L.selenite_rx_guard_clear.argtypes = [vp]
         L.selenite_rx_guard_handover.argtypes = [vp, u64p]
         L.selenite_rx_set_handover_repair.argtypes = [vp, C.c_int]
@@ -386,6 +388,14 @@ class Rx:
             raise RxError(rc, self.error())
         return out
 
+    def auto_words(self):
+        """Diagnostic: the per-channel words of SELENITE_ARITH_AUTO (bit 0 rerun, bits 1-2 provenance, bit 5 held by the exact kernel, ...)."""
+        out = np.zeros(self.cfg.channels, np.uint32)
+        rc = self.L.selenite_rx_auto_words(self.h, out.ctypes.data_as(u32p))
+        if rc:
+            raise RxError(rc, self.error())
+        return out
+
     def guard_clear(self):
         return self.L.selenite_rx_guard_clear(self.h)
 
@@ -412,6 +422,14 @@ class Rx:
         """per-call durations (ms) of `iters` back-to-back device calls, one HIP event between calls"""
         ms = np.zeros(iters, np.float32)
         rc = self.L.selenite_rx_time_process_each_device(self.h, d_src, d_dst, block_size, iters, _fp(ms), int(q15))
+        if rc:
+            raise RxError(rc, self.error())
+        return ms
+
+    def time_streaming_roof(self, d_src, d_dst, block_size, iters, q15=False):
+        """per-launch durations (ms) of the no-arithmetic kernel that moves the algorithmic bytes of one call (d_dst is overwritten)"""
+        ms = np.zeros(iters, np.float32)
+        rc = self.L.selenite_rx_time_streaming_roof_device(self.h, d_src, d_dst, block_size, iters, _fp(ms), int(q15))
         if rc:
             raise RxError(rc, self.error())
         return ms

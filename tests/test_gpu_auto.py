@@ -104,7 +104,8 @@ def test_auto_holds_the_plain_bar_where_split16_alone_does_not_have_to(shape, mo
 def test_guard_counts_follow_the_definition():
     """selenite_rx_guard_channels against the definition evaluated on the oracle's audio: a DSP block is guarded when its
     envelope (before the AGC) is under 0.25 x the largest |component| of the mixed samples of its pass and of the decimator
-    history in front of it.  Blocks well inside / outside the zone must agree (the GPU decides on its own audio, which
+    history in front of it -- for the blocks inside the reach of the Hilbert-pair history (the first block of a pass here) also of
+    the pass before (round 4).  Blocks well inside / outside the zone must agree (the GPU decides on its own audio, which
     differs from the oracle's in the 7th digit, so a +-10 % band around the threshold is left open)."""
     import selenite_rx as sr
     nch, bs = 128, 4096
@@ -116,28 +117,31 @@ def test_guard_counts_follow_the_definition():
     iq = synth_iq(0, nch, 0, 2 * bs)
     o.process(iq[:, :bs]); g.process(iq[:, :bs])          # second call: the history is live
     g.guard_clear()
-    hist = o.state()["dec_state"]                         # [nch][2][255] mixed samples in front of the call
     yo = o.process(iq[:, bs:])
     g.process(iq[:, bs:])
     mixed_tail = o.state()["dec_state"]
-    # mixed samples of the call: |component| maxima per pass of 1024 need the mixed signal; the decimator state gives the
-    # last 255 of them, the rest comes from the NCO model of test_gpu_truth (oracle's LO + f32 complex multiply)
+    # mixed samples of both calls from the NCO model of test_gpu_truth (oracle's LO + f32 complex multiply); the decimator state
+    # the oracle ends with pins the model bit for bit
     L = rc.oracle_lib()
     L.orc_nco_lo.argtypes = [rc.C.c_void_p, rc.C.c_uint32, rc.C.c_void_p]
     L.orc_nco_lo.restype = None
-    mixed = np.empty((nch, bs, 2), np.float32)
+    mixed = np.empty((nch, 2 * bs, 2), np.float32)
     for c in range(nch):
-        ph = ((np.arange(bs, dtype=np.uint64) + bs) * int(steps[c])).astype(np.uint32)
-        lo = np.empty((bs, 2), np.float32)
-        L.orc_nco_lo(ph.ctypes.data, bs, lo.ctypes.data)
-        a, b, lc, ls = iq[c, bs:, 0], iq[c, bs:, 1], lo[:, 0], lo[:, 1]
+        ph = (np.arange(2 * bs, dtype=np.uint64) * int(steps[c])).astype(np.uint32)
+        lo = np.empty((2 * bs, 2), np.float32)
+        L.orc_nco_lo(ph.ctypes.data, 2 * bs, lo.ctypes.data)
+        a, b, lc, ls = iq[c, :, 0], iq[c, :, 1], lo[:, 0], lo[:, 1]
         mixed[c, :, 0] = a * lc - b * ls
         mixed[c, :, 1] = a * ls + b * lc
     assert np.array_equal(mixed[:, -255:, 0], mixed_tail[:, 0])
-    full = np.concatenate([np.stack([hist[:, 0], hist[:, 1]], axis=2), mixed], axis=1)        # [nch][255 + bs][2]
     env = np.abs(yo).reshape(nch, -1, 64).max(axis=2)                                         # 16 DSP blocks per channel, 4 per pass
-    pm = np.stack([np.abs(full[:, 1024 * p: 1024 * p + 1024 + 255]).reshape(nch, -1).max(axis=1) for p in range(bs // 1024)], axis=1)
-    ratio = env / np.repeat(pm, 4, axis=1)
+    # what a pass's matrix product holds: its 1024 samples and the 255 in front of them; pass -1 = the last pass of the call before
+    pmax = lambda p: np.abs(mixed[:, bs + 1024 * p - 255: bs + 1024 * (p + 1)]).reshape(nch, -1).max(axis=1)
+    pm = np.stack([pmax(p) for p in range(bs // 1024)], axis=1)
+    pm_h = np.stack([np.maximum(pmax(p), pmax(p - 1)) for p in range(bs // 1024)], axis=1)
+    ref = np.repeat(pm, 4, axis=1)
+    ref[:, ::4] = pm_h                  # (round 4) the first block of a pass still sees Hilbert-pair history from the pass before: the larger of the two
+    ratio = env / ref
     sure, never = (ratio < 0.225).sum(axis=1), (ratio < 0.275).sum(axis=1)
     cnt = g.guard_channels()
     assert (cnt >= sure).all() and (cnt <= never).all()
@@ -176,7 +180,7 @@ def test_a_rerun_starts_from_an_exact_hilbert_history(shape, block, q15):
             iq16 = np.clip(np.round(iq * 20000.0), -32768, 32767).astype(np.int16)
             return g.process_q15(iq16), o.process_q15(iq16)
         return g.process(iq), o.process(iq)
-    for k in range(2):                                               # warm up: the start-up transient is rerun, then little is guarded
+    for k in range(4):                                               # warm up: the start-up transient is rerun and held for two clean calls, then little is guarded
         call()
     g.guard_clear()
     call()
@@ -204,15 +208,13 @@ def test_a_rerun_starts_from_an_exact_hilbert_history(shape, block, q15):
 def test_random_mode_and_length_sequences(seed):
     """SELENITE_ARITH_AUTO through random sequences of DSP_Set_Mode (every value of the firmware's enum that runs on the fused
     kernels) and call lengths (one DSP block ... several passes): on every call every DSP block holds the plain bar against
-    the oracle -- except blocks inside the reach of the Hilbert-pair history in a call that counted a handover (behind a call
-    too short to keep the samples, or behind AM), and only those.  Exercises the provenance words, both hist_ext buffers,
-    k_hist_exact, the tail split and the one-pass short calls together."""
+    the oracle, and no handover block is ever counted.  Exercises the provenance words, both hist_ext buffers, k_hist_exact, the
+    tail split, the short calls on the bit-exact kernel and the hold bit together."""
     import selenite_rx as sr
     rng = np.random.default_rng(1000 + seed)
     shape, block = [((256, 4, 63), 64), ((256, 4, 127), 192), ((128, 4, 63), 256), ((256, 2, 63), 64), ((256, 4, 63), 96), ((128, 2, 127), 128)][seed % 6]
     nd, M, nh = shape
     nch, na = 19, block // M
-    nbh = -(-(nh - 1) // na)
     steps = (rng.integers(0, 1 << 32, nch, dtype=np.uint64).astype(np.uint32)) & np.uint32(0x07000000 if seed % 2 else 0xFFFFFFFF)
     kw = dict(nco=True, nco_steps=steps, agc=bool(seed % 3))
     g = sr.Rx(rc.ChainSpec(nch, block, M, nd, nh, 0, rc.MODE_USB, ARITH_AUTO, **kw).config())
@@ -228,19 +230,12 @@ def test_random_mode_and_length_sequences(seed):
         bs = k * block
         iq = synth_iq(0, nch, pos, bs)
         pos += bs
-        before = g.guard_stats()["handover_blocks"]
         d, m = per_block(g.process(iq), o.process(iq), na)
-        hand = g.guard_stats()["handover_blocks"] - before
-        if mode == rc.MODE_FM:
-            # FM: the exact kernel in AUTO, from a delay line repaired like the Hilbert-pair history (k_hist_exact on every channel);
-            # behind a call that kept no samples its very first output sees z[-1] at split16 precision: <= 1e-6 rad
-            gain = np.asarray(o.state()["agc_gain"], np.float64).reshape(nch) if kw["agc"] else np.ones(nch)
-            assert (d[:, 1:] <= 1e-5 * m[:, 1:]).all() and (d[:, 0] <= 1e-5 * m[:, 0] + 1e-6 * gain).all(), (call, mode)
-            continue
-        bad = d > 1e-5 * m
-        if bad.any():
-            assert not bad[:, nbh:].any(), (call, mode, bs, (d / np.maximum(m, 1e-30)).max())
-            assert hand >= bad.any(axis=1).sum(), (call, mode, bs, hand)
+        # round 4: the PLAIN bar on every block of every call, FM's first output included -- a call too short to keep the samples in
+        # front of the decimator state runs on the bit-exact kernel, AM has the history repaired in front of it, so nothing ever starts
+        # from a Hilbert-pair history (or an FM z[-1]) of split16 precision -- and the counter of such blocks stays at zero
+        assert (d <= 1e-5 * m).all(), (call, mode, bs, (d / np.maximum(m, 1e-30)).max())
+    assert g.guard_stats()["handover_blocks"] == 0
     sg, so = g.state(), o.state()
     assert bits_equal(sg["dec_state"], so["dec_state"]) and np.array_equal(sg["nco_phase"], so["nco_phase"])
     g.close()
@@ -267,7 +262,7 @@ def test_the_repair_knows_the_slot_format_of_the_call_that_kept_the_samples(kept
             iq16 = np.clip(np.round(iq * 20000.0), -32768, 32767).astype(np.int16)
             return g.process_q15(iq16), o.process_q15(iq16)
         return g.process(iq), o.process(iq)
-    for k in range(3):
+    for k in range(4):
         call(kept_q15)
     kept_before = g.guard_channels().copy()
     g.guard_clear()
@@ -285,11 +280,12 @@ def test_the_repair_knows_the_slot_format_of_the_call_that_kept_the_samples(kept
     g.close()
 
 
-def test_am_in_between_does_not_fool_the_repair():
-    """AM leaves the Hilbert-pair history alone while the decimator state moves on: the samples kept in front of the state no
-    longer belong to that history, so behind an AM call nothing may be "repaired" from them -- the provenance degrades to "matrix
-    kernel, no samples", the first blocks of a later rerun are counted as handover blocks, everything outside the reach of the
-    history holds the plain bar, and the state converges to the oracle's bits."""
+def test_am_in_between_is_repaired_in_front_of_the_am_call():
+    """AM leaves the Hilbert-pair history alone while the decimator state moves on: the samples kept in front of the state belong to
+    that history for the last time when the AM call starts.  Round 4: k_hist_exact runs over every channel that has them in front
+    of an AM call (round 3 let the provenance degrade and counted the blocks of a later rerun).  USB x3, AM, LSB (every channel
+    guarded: the residue of a sideband cancellation on a history from the USB period): bit-exact audio from the first block, no
+    handover block, state = the oracle's bits."""
     import selenite_rx as sr
     nch, block, na, nh = 37, 64, 16, 63
     steps = (np.arange(nch, dtype=np.uint64) * 0x9E3779B1 % (1 << 32)).astype(np.uint32) & np.uint32(0x03000000)
@@ -298,24 +294,30 @@ def test_am_in_between_does_not_fool_the_repair():
     o = CpuChain(rc.ChainSpec(nch, block, 4, 256, nh, 0, rc.MODE_USB, ARITH_CMSIS, **kw), "orc")
     pos = 0
 
-    def call(mode):
+    def call(mode, bs=3840):
         nonlocal pos
         assert g.set_mode(mode) == 0 and o.set_mode(mode) == 0
-        iq = synth_iq(0, nch, pos, 3840)
-        pos += 3840
-        return per_block(g.process(iq), o.process(iq), na)
-    for k in range(3):
+        iq = synth_iq(0, nch, pos, bs)
+        pos += bs
+        yg, yo = g.process(iq), o.process(iq)
+        return yg, yo, per_block(yg, yo, na)
+    for k in range(4):
         call(rc.MODE_USB)
-    d, m = call(rc.MODE_AM)
-    assert (d <= 1e-5 * m).all()
     g.guard_clear()
-    d, m = call(rc.MODE_LSB)                                          # rerun on every channel; the history is the USB period's, split16 precision
-    bad = d > 1e-5 * m
-    assert not bad[:, 4:].any()                                       # 62 samples = 4 blocks of 16
-    assert g.guard_stats()["handover_blocks"] >= bad.sum() and bad.any()
-    d, m = call(rc.MODE_LSB)
-    assert (d <= 1e-5 * m).all()
+    call(rc.MODE_USB)
+    kept = g.guard_channels() == 0                                    # on the matrix kernel going into AM
+    assert kept.sum() >= nch // 2
+    for bs in (3840, 64, 1024):                                       # AM calls of several lengths (a one-block call: the bit-exact kernel)
+        _, _, (d, m) = call(rc.MODE_AM, bs)
+        assert (d <= 1e-5 * m).all()
+    g.guard_clear()
+    yg, yo, (d, m) = call(rc.MODE_LSB)
+    st = g.guard_stats()
+    assert st["handover_blocks"] == 0 and st["rerun_channel_calls"] >= kept.sum()
     rerun = g.guard_channels() > 0
+    assert (rerun & kept).sum() >= nch // 4
+    assert bits_equal(yg[rerun], yo[rerun]), rc.rel_err(yg[rerun], yo[rerun])
+    assert (d <= 1e-5 * m).all()
     for key in ("dec_state", "fir_state", "nco_phase"):
         sg, so = g.state()[key], o.state()[key]
         assert (sg[rerun].view(np.uint32) == so[rerun].view(np.uint32)).all(), key
@@ -333,7 +335,7 @@ def test_without_handover_repair_the_blocks_are_counted():
     o = CpuChain(rc.ChainSpec(nch, block, 4, 256, 63, 0, rc.MODE_USB, ARITH_CMSIS, **kw), "orc")
     assert g.set_handover_repair(False) == 0
     pos = 0
-    for k in range(3):
+    for k in range(5):
         iq = synth_iq(0, nch, pos, 3840); pos += 3840
         g.process(iq); o.process(iq)
     g.set_mode(rc.MODE_LSB); o.set_mode(rc.MODE_LSB)
@@ -347,38 +349,26 @@ def test_without_handover_repair_the_blocks_are_counted():
     g.close()
 
 
-def test_handover_blocks_are_counted():
-    """What the rerun cannot repair is at least visible ("what the guard does not see"): a guarded block inside the
-    reach of the Hilbert-pair history at the start of a call, in a channel the PREVIOUS call left on the matrix kernel, is computed in
-    exact arithmetic from a history of split16 precision.  selenite_rx_guard_handover counts those blocks.  Signal: LSB on a USB-side
-    tone, 127-tap pair, 192-frame DSP blocks -- the per-block level hovers around the guard ratio.  (a) the start-up call (every channel
-    guarded, state = cleared = exact) counts none; (b) over the run some are counted; (c) every block over the plain bar lies in a
-    channel-call that counted one; (d) reset / set_state declare the state exact again."""
+def test_a_level_hovering_at_the_guard_ratio_through_calls_of_every_length():
+    """Round 3 counted "handover" blocks here (LSB on a USB-side tone, 127-tap pair, 192-frame DSP blocks: the per-block level hovers
+    around the guard ratio; calls of 1, 2, 10, 11, 50 blocks -- some too short to keep the samples in front of the decimator state)
+    and the test relaxed the bar for them.  Round 4: such calls run on the bit-exact kernel, a recomputed channel stays with it while
+    its level is within 6 dB of the ratio, and every block of every call holds the PLAIN bar with the counter at zero."""
     import selenite_rx as sr
     nch, block, na = 21, 192, 48
     kw = dict(nco=True, nco_step_all=0x00c00000, agc=True)
     g = sr.Rx(rc.ChainSpec(nch, block, 4, 256, 127, 0, rc.MODE_LSB, ARITH_AUTO, **kw).config())
     o = CpuChain(rc.ChainSpec(nch, block, 4, 256, 127, 0, rc.MODE_LSB, ARITH_CMSIS, **kw), "orc")
-    pos, total, over = 0, 0, 0
+    pos = 0
     for i, bs in enumerate([block * k for k in (1, 2, 10, 11, 1, 50, 2, 10, 3, 10)]):
         iq = synth_iq(0, nch, pos, bs)
         pos += bs
-        before = g.guard_stats()["handover_blocks"]
         d, m = per_block(g.process(iq), o.process(iq), na)
-        now = g.guard_stats()["handover_blocks"] - before
-        if i == 0:
-            assert now == 0 and g.guard_stats()["blocks"] > 0          # (a)
-        bad = d > 1e-5 * m
-        if bad.any():
-            assert bad[:, 3:].sum() == 0                                # only inside the reach of the history: ceil(126 / 48) blocks
-            assert now >= bad.any(axis=1).sum()                         # (c) every such channel-call counted at least one
-            over += int(bad.sum())
-        total += now
-    assert total > 0                                                    # (b)
+        assert (d <= 1e-5 * m).all(), (i, bs, (d / np.maximum(m, 1e-30)).max())
+    assert g.guard_stats()["handover_blocks"] == 0
     g.reset()
     g.guard_clear()
     g.process(synth_iq(0, nch, 0, 10 * block))
-    assert g.guard_stats()["handover_blocks"] == 0                      # (d)
     st = g.state()
     g.set_state(st)
     g.process(synth_iq(0, nch, 10 * block, 10 * block))
@@ -386,16 +376,158 @@ def test_handover_blocks_are_counted():
     g.close()
 
 
+@pytest.mark.parametrize("q15", [False, True])
+@pytest.mark.parametrize("shape,block", [((256, 4, 63), 96), ((256, 4, 127), 192), ((128, 2, 63), 96)])
+def test_sideband_flip_with_one_firmware_slot_per_call(shape, block, q15):
+    """The firmware's literal callback (dsp_if.c:50-67: one 96-frame slot per call, dsp_if.h:69-73) in SELENITE_ARITH_AUTO, with a
+    DSP_Set_Mode USB -> LSB on an upper-sideband signal in the middle: long calls (matrix kernel) and one-slot calls (shorter than
+    nd - 1 + M (nh - 1): the bit-exact kernel, its Hilbert-pair history repaired from the samples the long call kept) alternate;
+    every DSP block of every call holds the plain bar, handover counter 0 (arm_fir_f32.c:947-978 is the state being handed over)."""
+    import selenite_rx as sr
+    nd, M, nh = shape
+    nch, na = 23, block // M
+    steps = (np.arange(nch, dtype=np.uint64) * 0x9E3779B1 % (1 << 32)).astype(np.uint32) & np.uint32(0x03000000)     # in-band LOs
+    kw = dict(nco=True, nco_steps=steps, agc=not q15)
+    g = sr.Rx(rc.ChainSpec(nch, block, M, nd, nh, 0, rc.MODE_USB, ARITH_AUTO, **kw).config())
+    o = CpuChain(rc.ChainSpec(nch, block, M, nd, nh, 0, rc.MODE_USB, ARITH_CMSIS, **kw), "orc")
+    pos = 0
+
+    def call(nblk):
+        nonlocal pos
+        iq = synth_iq(0, nch, pos, nblk * block)
+        pos += nblk * block
+        if q15:
+            iq16 = np.clip(np.round(iq * 20000.0), -32768, 32767).astype(np.int16)
+            assert np.abs(g.process_q15(iq16).astype(np.int32) - o.process_q15(iq16)).max() <= 1
+            return
+        d, m = per_block(g.process(iq), o.process(iq), na)
+        assert (d <= 1e-5 * m).all(), (nblk, (d / np.maximum(m, 1e-30)).max())
+    for nblk in (40, 40, 1, 1, 40, 1):
+        call(nblk)
+    assert g.set_mode(rc.MODE_LSB) == 0 and o.set_mode(rc.MODE_LSB) == 0
+    for nblk in (1, 1, 1, 40, 1, 2, 40):
+        call(nblk)
+    assert g.set_mode(rc.MODE_USB) == 0 and o.set_mode(rc.MODE_USB) == 0
+    for nblk in (1, 40, 1):
+        call(nblk)
+    st = g.guard_stats()
+    assert st["handover_blocks"] == 0 and st["rerun_channel_calls"] > 0
+    sg, so = g.state(), o.state()
+    assert bits_equal(sg["dec_state"], so["dec_state"]) and np.array_equal(sg["nco_phase"], so["nco_phase"])
+    g.close()
+
+
+def test_a_recomputed_channel_stays_on_the_exact_kernel_and_comes_back():
+    """Hysteresis of SELENITE_ARITH_AUTO (round 4).  Channels whose tone sits in the decimator's stop band are guarded in every
+    call: after the first rerun the exact kernel HOLDS them -- the matrix kernel skips them (no guarded block is counted by it any
+    more, the channel-calls keep counting as exact ones) and their audio is the oracle's bit for bit, call after call (AGC off).
+    When the signal comes back into the pass band (the input of those channels is rotated so that their LO lands it there) the
+    exact kernel sees two calls in a row without a block within 2 dB of the guard ratio and hands the channel back: the next call
+    runs it on the matrix kernel again (no longer bit-identical, still inside the plain bar, nothing recomputed)."""
+    import selenite_rx as sr
+    nch, block, na = 64, 64, 16
+    # LO steps that leave the synthetic tone of a channel in band (even channels) or move it far out of band (odd channels)
+    steps = np.where(np.arange(nch) % 2 == 0, 0x01000000, 0x40000000).astype(np.uint32)
+    kw = dict(nco=True, nco_steps=steps, agc=False)
+    g = sr.Rx(rc.ChainSpec(nch, block, 4, 256, 63, 0, rc.MODE_USB, ARITH_AUTO, **kw).config())
+    o = CpuChain(rc.ChainSpec(nch, block, 4, 256, 63, 0, rc.MODE_USB, ARITH_CMSIS, **kw), "orc")
+    pos = 0
+    held = np.zeros(nch, bool)
+
+    def call(back=False, bs=4096):
+        nonlocal pos
+        iq = synth_iq(0, nch, pos, bs)
+        if back:                                                      # the held channels: rotated by (0x40000000 - 0x01000000) / 2^32 cycles per sample
+            rot = np.exp(2j * np.pi * (0.25 - 1.0 / 256.0) * (np.arange(bs) + pos))
+            z = (iq[held, :, 0] + 1j * iq[held, :, 1]) * rot
+            iq[held, :, 0], iq[held, :, 1] = z.real.astype(np.float32), z.imag.astype(np.float32)
+        pos += bs
+        yg, yo = g.process(iq), o.process(iq)
+        d, m = per_block(yg, yo, na)
+        assert (d <= 1e-5 * m).all(), (d / np.maximum(m, 1e-30)).max()
+        return yg, yo
+    call(); call(); call()                                            # start-up: everything recomputed, then held for two clean calls
+    HOLD = 32                                                         # kFlagHold of the channel words (selenite_rx_auto_words)
+    sets = []
+    for k in range(3):
+        g.guard_clear()
+        call()
+        sets.append(g.guard_channels() > 0)
+    held[:] = sets[0] & sets[1] & sets[2]                             # guarded in every call: never handed back
+    assert held[1::2].sum() >= nch // 4 and not held[::2].any(), held        # (some of the shifted channels have another tone land in band)
+    assert ((g.auto_words()[held] & HOLD) != 0).all() and ((g.auto_words()[::2] & HOLD) == 0).all()
+    for k in range(3):
+        g.guard_clear()
+        yg, yo = call()
+        st = g.guard_stats()
+        assert (g.guard_channels()[held] > 0).all()
+        assert st["rerun_channel_calls"] >= held.sum() and st["handover_blocks"] == 0
+        assert bits_equal(yg[held], yo[held])                         # the exact kernel, from an exact state: the oracle's bits
+        assert not bits_equal(yg[::2], yo[::2])                       # the in-band channels: the matrix kernel
+    for key in ("dec_state", "fir_state", "nco_phase"):
+        sg, so = g.state()[key], o.state()[key]
+        assert (sg[held].view(np.uint32) == so[held].view(np.uint32)).all(), key
+    call(back=True)                                                   # the filters fill with the in-band signal
+    call(back=True); call(back=True)                                  # two clean calls on the exact kernel ...
+    assert ((g.auto_words()[held] & HOLD) == 0).all()
+    g.guard_clear()
+    yg, yo = call(back=True)                                          # ... and the channels are back on the matrix kernel
+    assert (g.guard_channels()[held] == 0).all() and ((g.auto_words()[held] & HOLD) == 0).all()
+    assert not bits_equal(yg[held], yo[held])
+    g.close()
+
+
+@pytest.mark.parametrize("shape,block", [((256, 4, 63), 1024), ((256, 4, 127), 1024), ((128, 2, 63), 512), ((256, 4, 63), 64)])
+def test_a_level_step_anywhere_in_front_of_a_pass_is_still_guarded(shape, block):
+    """Advisor finding (round 3): the first outputs of a pass read Hilbert-pair history the PASS BEFORE computed, whose split-precision
+    error scales with the largest sample THAT pass saw.  An in-band signal that drops by 50 dB between nd + M (nh - 1) and nd samples
+    in front of a pass boundary leaves that history loud and the new pass quiet; with DSP blocks of a whole pass (256 audio samples)
+    no block of the loud pass is quiet enough to be guarded itself, so the threshold of the first blocks of a pass has to cover the
+    pass before too -- and, at a call's start, the level the call before left in the channel's word.  Level step swept over the
+    critical window in steps of 32 samples, one channel per position, in the middle of a call and across a call boundary: the plain
+    bar on every block (arm_fir_f32.c:573-577, 947-978: the history the FIR pair keeps)."""
+    import selenite_rx as sr
+    nd, M, nh = shape
+    T, na = 256 * M, block // M
+    ends = list(range(2 * T - nd - M * nh - 96, 2 * T + 64, 32))
+    nch = len(ends)
+    kw = dict(nco=True, nco_steps=np.full(nch, 0x01000000, np.uint32), agc=True)
+    for split_at in (None, 2 * T):                                       # one call of 4 passes | pass 1 / pass 2 meet at a call boundary
+        g = sr.Rx(rc.ChainSpec(nch, block, M, nd, nh, 0, rc.MODE_USB, ARITH_AUTO, **kw).config())
+        o = CpuChain(rc.ChainSpec(nch, block, M, nd, nh, 0, rc.MODE_USB, ARITH_CMSIS, **kw), "orc")
+        pos = 0
+        for k in range(4):                                               # start-up: recomputed, held for two clean calls, then the matrix kernel
+            warm = synth_iq(0, nch, pos, 4 * T); pos += 4 * T
+            g.process(warm); o.process(warm)
+        g.guard_clear()
+        iq = synth_iq(0, nch, pos, 4 * T)
+        for c, e in enumerate(ends):
+            iq[c, e:] *= np.float32(0.003)                               # the level drops by 50 dB at sample e
+        parts = [iq] if split_at is None else [iq[:, :split_at], iq[:, split_at:]]
+        for part in parts:
+            part = np.ascontiguousarray(part)
+            d, m = per_block(g.process(part), o.process(part), na)
+            assert (d <= 1e-5 * m).all(), (shape, split_at, (d / np.maximum(m, 1e-30)).max(), np.argwhere(d > 1e-5 * m)[:4])
+        assert g.guard_stats()["handover_blocks"] == 0 and g.guard_stats()["rerun_channel_calls"] > 0
+        g.close()
+
+
 def test_auto_on_the_bench_workload_guards_nothing_in_the_steady_state():
-    """The bench workload (cfg3, every channel one tone in band): after the start-up transient of the first call no block is
-    guarded, so AUTO costs one empty rerun launch; and the plain bar holds on every block."""
+    """The bench workload (cfg3, every channel one tone in band): after the start-up transient (first call: recomputed; second and
+    third call: still held by the exact kernel, which finds nothing near the guard ratio twice in a row and hands every channel
+    back) no block is guarded, so AUTO costs one empty rerun launch; and the plain bar holds on every block."""
     import selenite_rx as sr
     nch, bs = 1024, 4096
     g = sr.Rx(rc.baseline_spec("cfg3", nch, ARITH_AUTO).config())
     o = CpuChain(rc.baseline_spec("cfg3", nch, ARITH_CMSIS), "orc")
     iq = synth_iq(0, nch, 0, bs)
-    for call in range(3):
+    n0 = 0
+    for call in range(5):
         if call == 1:
+            n0 = g.guard_stats()["rerun_channel_calls"]                 # the channels whose first block ramps up under the guard ratio
+            assert 0 < n0 <= nch
+        if call == 3:
+            assert g.guard_stats()["rerun_channel_calls"] == 3 * n0     # recomputed once, then held for two clean calls
             g.guard_clear()
         d, m = per_block(g.process(iq), o.process(iq, 8), 64)
         assert (d <= 1e-5 * m).all(), (call, (d / np.maximum(m, 1e-30)).max())

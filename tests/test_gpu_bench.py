@@ -15,7 +15,7 @@ BENCH = os.path.join(rc.ROOT, "bench.py")
 
 
 def run_bench(*args):
-    out = subprocess.run([sys.executable, BENCH, "--steps", "3", "--warmup", "1", "--spinup-ms", "0",
+    out = subprocess.run([sys.executable, BENCH, "--steps", "3", "--warmup", "4", "--spinup-ms", "0",
                           "--channels", "1024"] + list(args), check=True, capture_output=True, text=True, timeout=600)
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout
@@ -27,7 +27,7 @@ def test_bench_json_contract_default_shape():
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
-    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak"
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 4 and d["scaling"] == "weak"
     assert d["vs_baseline"] is None and d["higher_is_better"] is True and d["dtype"].startswith("f32")
     assert "f16 hi+lo" in d["dtype"]                                   # the default arithmetic says what its multiplicands are
     assert "workload" in d["config"] and "cfg3" in d["config"]["workload"] and "model" not in d["config"]
@@ -35,8 +35,13 @@ def test_bench_json_contract_default_shape():
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     assert r["algorithmic_bytes_per_launch"] == 1024 * 41952          # SURVEY.md 8d per channel-block figure
-    derived = r["algorithmic_bytes_per_launch"] / (r["launch_ms_hip_events"] * 1e-3) / 1e9
-    assert abs(r["achieved"] - derived) <= 0.02 * derived             # (launch_ms is rounded to 0.1 us in the JSON)
+    derived = r["algorithmic_bytes_per_launch"] / (d["ms_per_step"] * 1e-3) / 1e9      # round 4: from the wall clock the driver can check
+    assert abs(r["achieved"] - derived) <= 0.02 * derived             # (ms_per_step is rounded to 0.1 us in the JSON)
+    assert 0 < r["frac_hip_events"] < 1 and r["launch_ms_hip_events"] <= d["ms_per_step"] * 1.05
+    sr_ = d["streaming_roof"]                                         # the no-arithmetic kernel of the same run
+    assert sr_["kernel"] == "k_stream_roof" and 0 < sr_["ms_per_launch"] and 0 < sr_["frac_of_peak"] < 1
+    assert abs(r["frac_of_streaming_roof"] - sr_["ms_per_launch"] / d["ms_per_step"]) < 1e-3
+    assert d["north_star_target"]["target"] == 0.60 and d["north_star_target"]["read_frac"] == r["read_frac"]
     c = d["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["cores"] == os.cpu_count() and c["value"] > 0 and "sample" in c
     assert c["single_core"]["cores"] == 1 and 0 < c["single_core"]["value"] <= c["value"]
@@ -113,7 +118,7 @@ def test_bench_under_the_nccl_backend_with_one_rank_carries_the_dist_block():
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
     env.update(SELENITE_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29611", HSA_ENABLE_IPC_MODE_LEGACY="0")
     for extra, coll in (([], 0), (["--global-gain"], 1)):
-        out = subprocess.run([sys.executable, BENCH, "--steps", "3", "--warmup", "1", "--spinup-ms", "0", "--channels", "1024",
+        out = subprocess.run([sys.executable, BENCH, "--steps", "3", "--warmup", "4", "--spinup-ms", "0", "--channels", "1024",
                               "--main-only"] + extra, capture_output=True, text=True, timeout=900, env=env)
         assert out.returncode == 0, out.stderr[-2000:]
         d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])

@@ -103,7 +103,7 @@ def test_full_size_sampled_channels_match_oracle(name, arith):
 
 
 def test_full_size_sideband_flip_is_repaired_on_every_channel():
-    """cfg3 at full size (65 536 channels x 4096) in SELENITE_ARITH_AUTO: two calls in USB (every channel ends on the matrix kernel),
+    """cfg3 at full size (65 536 channels x 4096) in SELENITE_ARITH_AUTO: four calls in USB (every channel ends on the matrix kernel),
     DSP_Set_Mode(LSB), one call -- most of the 65 536 channels (82 %) guarded and rerun from a Hilbert-pair history k_hist_exact recomputes from the
     samples kept in front of the decimator state (1024 workgroups over 4096 flag windows, the rerun over 2048).  Sampled channels
     are the oracle bit for bit, audio and state; no handover block is counted; then a call back in USB holds the plain bar."""
@@ -111,13 +111,13 @@ def test_full_size_sideband_flip_is_repaired_on_every_channel():
     chans = sample_channels(run.nch)
     o = CpuChain(baseline_spec(run.chain, len(chans), ARITH_CMSIS), "orc")
     na = run.spec.block // run.spec.decim
-    for k in range(2):
+    for k in range(4):                  # (start-up: recomputed, then held by the exact kernel for two clean calls; the fourth call is the matrix kernel's)
         y = run.call(k)
         o.process(np.concatenate([synth_iq(c, 1, k * run.bs, run.bs) for c in chans], axis=0))
     run.rx.guard_clear()
     assert run.rx.set_mode(rc.MODE_LSB) == 0 and o.set_mode(rc.MODE_LSB) == 0
-    y = run.call(2)
-    yo = o.process(np.concatenate([synth_iq(c, 1, 2 * run.bs, run.bs) for c in chans], axis=0))
+    y = run.call(4)
+    yo = o.process(np.concatenate([synth_iq(c, 1, 4 * run.bs, run.bs) for c in chans], axis=0))
     st = run.rx.guard_stats()
     assert st["handover_blocks"] == 0 and st["rerun_channel_calls"] >= run.nch // 2
     d = np.abs(y[chans].astype(np.float64) - yo).reshape(len(chans), -1, na).max(axis=2)
@@ -131,8 +131,8 @@ def test_full_size_sideband_flip_is_repaired_on_every_channel():
         assert (bits_equal(a, b) if a.dtype == np.float32 else np.array_equal(a, b)), key
     assert bits_equal(y[chans][rer], yo[rer]) or run.spec.agc                # (bit for bit without the AGC; with it the kept gain is ~1e-6 off)
     assert run.rx.set_mode(rc.MODE_USB) == 0 and o.set_mode(rc.MODE_USB) == 0
-    y = run.call(3)
-    yo = o.process(np.concatenate([synth_iq(c, 1, 3 * run.bs, run.bs) for c in chans], axis=0))
+    y = run.call(5)
+    yo = o.process(np.concatenate([synth_iq(c, 1, 5 * run.bs, run.bs) for c in chans], axis=0))
     d = np.abs(y[chans].astype(np.float64) - yo).reshape(len(chans), -1, na).max(axis=2)
     m = np.abs(yo).reshape(len(chans), -1, na).max(axis=2)
     assert (d <= TOL * m).all()
@@ -176,6 +176,16 @@ def test_every_channel_of_the_bench_workload_split16_within_the_north_star_toler
     na = run.spec.block // run.spec.decim
     worst = 0.0
     for k in range(2):
+        if k == 1 and arith == rc.ARITH_AUTO:
+            # (round 4: a recomputed channel stays with the bit-exact kernel until two calls in a row show nothing near the guard ratio --
+            # the start-up call recomputes everybody, so the matrix kernel is back from the fourth call on: that is the call to check)
+            for extra in (1, 2):
+                run.call(extra)
+                o.process(run.d_in.download((run.nch, run.bs, 2), np.float32), nthreads=os.cpu_count() or 8)
+            st = run.rx.guard_stats()
+            assert st["rerun_channel_calls"] == 2 * run.nch and st["blocks"] == 0, st
+            run.rx.guard_clear()
+            k = 3
         y = run.call(k)
         iq = run.d_in.download((run.nch, run.bs, 2), np.float32)     # device generator == oracle generator (test_device_synth_matches_host)
         yo = o.process(iq, nthreads=os.cpu_count() or 8)
@@ -189,6 +199,7 @@ def test_every_channel_of_the_bench_workload_split16_within_the_north_star_toler
         if arith == rc.ARITH_AUTO:
             st = run.rx.guard_stats()
             assert st["rerun_channel_calls"] == st["channel_calls"] and (k == 0 or st["channel_calls"] == 0), (k, st)
+            assert st["handover_blocks"] == 0
             run.rx.guard_clear()
     print("bench workload, arith %d, all %d blocks: worst per-block relative error %.3g" % (arith, 2 * run.nch * run.nout // na, worst))
     sg, so = run.rx.state(), o.state()
