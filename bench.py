@@ -152,24 +152,49 @@ def parity_check(name, workloads, arith, q15, nch=64, calls=2):
             "rerun_channel_calls": st["rerun_channel_calls"]}
 
 
-def dist_block(env, devices, collectives_per_step, per_rank_ms):
-    """What lets the driver verify the ranks of an N > 1 line: backend, world, one device per rank, collectives per step."""
-    return {"backend": env.backend or "none", "world": env.world, "devices": devices,
+def dist_block(env, devices, collectives_per_step, per_rank_ms, comm_count=None):
+    """What lets the driver verify the ranks of an N > 1 line: backend, world, the communicator's size as the backend counted it
+    (one all-reduce of ones before anything is timed), one device per rank, collectives per step."""
+    return {"backend": env.backend or "none", "world": env.world, "comm_count": comm_count, "devices": devices,
             "collectives_per_step": collectives_per_step, "per_rank_ms_per_step": per_rank_ms}
+
+
+def check_ranks(env, devices, comm_count, share_gpu):
+    """Before anything is timed: the communicator holds WORLD_SIZE ranks and every rank sits on its own GPU.  Every rank holds the
+    same gathered values, so every rank takes the same decision: nobody is left waiting in a collective."""
+    problems = []
+    if comm_count != env.world:
+        problems.append("the communicator counts %d rank(s), WORLD_SIZE is %d" % (comm_count, env.world))
+    if not share_gpu and len(set(devices)) != len(devices):
+        problems.append("ranks share a device: %s" % devices)
+    if problems:
+        if env.rank == 0:
+            sys.stderr.write("bench.py: refusing to time this job -- %s\n" % "; ".join(problems))
+        env.close()
+        sys.exit(4)
 
 
 def selftest_launch(env, args):
     """--selftest-launch: the launcher / rendezvous / collective plumbing of the N > 1 path without a GPU
     (CPU tests): no library call, gloo only.  Emits the same `dist` block as a real line."""
     env.init_process_group("gloo", use_gpu=False)
+    comm = env.comm_count()
+    hang = os.environ.get("SELENITE_SELFTEST_HANG_RANK")
+    if hang is not None and int(hang) == env.rank:       # test hook: a rank that never reaches the next collective
+        env.stage("hung on purpose (selftest)")
+        time.sleep(3600)
+    if os.environ.get("SELENITE_SELFTEST_FAIL_RANK") == str(env.rank):      # test hook: a rank that dies
+        env.stage("failing on purpose (selftest)")
+        os._exit(7)
     env.barrier()
     mine = 0.001 * (env.rank + 1)
     worst = env.max_over_ranks(mine)
     devices = env.gather_objects("cpu:%d" % env.local_rank)
+    check_ranks(env, devices, comm, False)
     per_rank = env.gather_objects(round(mine * 1e3, 4))
     if env.rank == 0:
         print(json.dumps({"selftest": "launch", "n_gpus": args.gpus, "world": env.world, "max_over_ranks_s": worst,
-                          "dist": dist_block(env, devices, 1 if args.global_gain else 0, per_rank),
+                          "dist": dist_block(env, devices, 1 if args.global_gain else 0, per_rank, comm),
                           "config": {"parallelism": "channels sharded x%d, no data-path collective" % env.world}}), flush=True)
     env.close()
 
@@ -220,9 +245,12 @@ def main():
         return selftest_launch(env, args)
     rank, world = env.rank, env.world
     local_rank = 0 if os.environ.get("SELENITE_BENCH_SHARE_GPU") == "1" else env.local_rank   # test rig: ranks share device 0 (gloo)
+    comm = 1
+    share_gpu = os.environ.get("SELENITE_BENCH_SHARE_GPU") == "1"
     if world > 1 or os.environ.get("SELENITE_BENCH_FORCE_DIST") == "1":      # (the env var lets a 1-GPU box exercise this path)
         env.local_rank = local_rank
         env.init_process_group(args.dist_backend)
+        comm = env.comm_count()
     elif args.global_gain:
         import torch
         env.torch = torch
@@ -236,6 +264,10 @@ def main():
     channels = args.channels or channels
     bs = args.block_size or bs
     sr.lib().selenite_rx_set_device(local_rank)
+    if env.dist is not None:
+        # every rank on its own GPU, the communicator complete: checked on every rank BEFORE the timed region
+        check_ranks(env, env.gather_objects(sr.device_pci_bus_id(local_rank)), comm, share_gpu)
+        env.stage("setting up the instance")
     def nco_steps(kind):
         """per-channel NCO steps of the side legs / --nco: (steps or None, environment for the instance's construction)"""
         if kind == "per_channel":
@@ -318,9 +350,11 @@ def main():
                 "ms_mean": round(float(ms.mean()), 4), "ms_min": round(float(ms[0]), 4), "ms_p90": round(float(ms[int(0.9 * len(ms))]), 4),
                 "launches": int(iters), "kernel": rx_x.kernel_name(), "nco": rx_x.nco_path()}
 
+    env.stage("spin-up and warm-up")
     spin(step, rx.sync, args.spinup_ms)
     for _ in range(args.warmup):
         step()
+    env.stage("timed steps")
     rx.guard_clear()
     sync_all()
     t0 = time.perf_counter()
@@ -335,6 +369,7 @@ def main():
     sync_all()
     t1 = time.perf_counter()
     rx.check()
+    env.stage("after the timed steps")
     guard = rx.guard_stats()
     elapsed = env.max_over_ranks(t1 - t0)
     per_rank_ms = env.gather_objects(round((t1 - t0) * 1e3 / args.steps, 4))
@@ -439,7 +474,7 @@ def main():
                 "note": "read_frac counts READ bytes only (SURVEY.md 8d: 8 B per input sample + the state read) over ms_per_step against 8 TB/s; "
                         "the no-arithmetic streaming kernel of the same run sets what that figure can be at most for this traffic shape"}
         if world > 1 or env.dist is not None:
-            out["dist"] = dist_block(env, devices, 1 if args.global_gain else 0, per_rank_ms)
+            out["dist"] = dist_block(env, devices, 1 if args.global_gain else 0, per_rank_ms, comm)
         if world == 1 and not args.global_gain and not args.main_only:
             # the same workload in the other arithmetic contracts and with the general NCO flavours, outside the timed
             # region; every leg: own spin-up, >= 100 launches, median of per-launch HIP-event durations

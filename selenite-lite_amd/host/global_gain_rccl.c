@@ -15,10 +15,12 @@
  * Build: gcc -O2 -I../../include -I/opt/rocm/include global_gain_rccl.c -L.. -lselenite_rx -L/opt/rocm/lib -lrccl ...
  * Usage: global_gain_rccl [ngpus (default: all)] [channels_total] [samples_per_call] [calls]
  */
+#include <pthread.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <unistd.h>
 
 #include <hip/hip_runtime_api.h>
 #include <rccl/rccl.h>
@@ -27,10 +29,33 @@
 
 #define MAXDEV 8
 
+/* Watchdog (the first multi-GPU run must not sit in a hung RCCL bootstrap until somebody's outer limit): a thread
+ * that, GLOBAL_GAIN_TIMEOUT_S seconds (default 300) after start, names the stage the host has reached and leaves with _exit(3). */
+static const char *volatile g_stage = "start";
+static volatile int g_done = 0;
+static void *watchdog(void *arg)
+{
+    const long limit = (long)(intptr_t)arg;
+    for (long t = 0; t < limit * 10 && !g_done; ++t) usleep(100000);
+    if (!g_done) {
+        fprintf(stderr, "global_gain_rccl: still at '%s' after %ld s -- giving up (exit 3)\n", g_stage, limit);
+        fflush(stderr);
+        _exit(3);
+    }
+    return NULL;
+}
+
 static int fail(const char *what) { fprintf(stderr, "global_gain_rccl: %s: %s\n", what, selenite_rx_error_string(NULL)); return 1; }
 
 int main(int argc, char **argv)
 {
+    {
+        const char *e = getenv("GLOBAL_GAIN_TIMEOUT_S");
+        const long limit = e && atol(e) > 0 ? atol(e) : 300;
+        pthread_t th;
+        if (pthread_create(&th, NULL, watchdog, (void *)(intptr_t)limit) == 0) pthread_detach(th);
+        if (getenv("GLOBAL_GAIN_SELFTEST_HANG")) { g_stage = "hung on purpose (selftest)"; for (;;) sleep(1); }
+    }
     int ndev = selenite_rx_device_count();
     if (ndev < 1) { fprintf(stderr, "global_gain_rccl: no HIP device (there is no CPU fallback)\n"); return 2; }
     if (argc > 1 && atoi(argv[1]) > 0 && atoi(argv[1]) < ndev) ndev = atoi(argv[1]);
@@ -60,8 +85,21 @@ int main(int argc, char **argv)
 
     for (int r = 0; r <= ndev; ++r) first[r] = (uint32_t)((uint64_t)total * r / ndev);   /* contiguous channel ranges */
     for (int r = 0; r < ndev; ++r) devs[r] = r;
+    g_stage = "ncclCommInitAll";
     if (ncclCommInitAll(comm, ndev, devs) != ncclSuccess) { fprintf(stderr, "global_gain_rccl: ncclCommInitAll failed\n"); return 1; }
 
+    /* the communicators as RCCL counts them, and one distinct GPU per rank, before any work is queued */
+    for (int r = 0; r < ndev; ++r) {
+        int nr = -1;
+        if (ncclCommCount(comm[r], &nr) != ncclSuccess || nr != ndev) { fprintf(stderr, "global_gain_rccl: communicator of rank %d counts %d ranks, expected %d\n", r, nr, ndev); return 4; }
+        char a[32] = "", b[32] = "";
+        (void)selenite_rx_device_pci_bus_id(r, a, sizeof a);
+        for (int q = 0; q < r; ++q) {
+            (void)selenite_rx_device_pci_bus_id(q, b, sizeof b);
+            if (strcmp(a, b) == 0) { fprintf(stderr, "global_gain_rccl: ranks %d and %d share device %s\n", q, r, a); return 4; }
+        }
+    }
+    g_stage = "instances";
     for (int r = 0; r < ndev; ++r) {
         const uint32_t n = first[r + 1] - first[r];
         if (selenite_rx_set_device(r)) return fail("set_device");
@@ -84,6 +122,7 @@ int main(int argc, char **argv)
     if (!w_in || !w_out || !h_ref || !h_got) return fail("alloc");
 
     int bad = 0;
+    g_stage = "process calls (phase 1, grouped ncclAllReduce, phase 2)";
     for (int call = 0; call < calls && !bad; ++call) {
         /* the reference: all channels in one instance */
         if (selenite_rx_set_device(0)) return fail("set_device");
@@ -129,7 +168,9 @@ int main(int argc, char **argv)
     }
     printf("], \"channels\": %u, \"samples_per_call\": %u, \"calls\": %d, \"collective\": \"ncclAllReduce(ncclMax), %u floats per call\", "
            "\"collectives_per_call\": 1, \"sharded_equals_unsharded\": %s}\n", total, bs, calls, bs / 256, bad ? "false" : "true");
+    g_stage = "teardown";
     for (int r = 0; r < ndev; ++r) { selenite_rx_free(rx[r]); ncclCommDestroy(comm[r]); }
     selenite_rx_free(whole);
+    g_done = 1;
     return bad;
 }

@@ -13,9 +13,16 @@ This module holds the multi-GPU host logic that bench.py and the tests share:
   GlobalGainStepper   one global-gain process call: phase 1 -> all-reduce(MAX) -> phase 2, ordered on ONE stream
 """
 import os
+import signal
 import socket
 import subprocess
 import sys
+import tempfile
+import threading
+import time
+
+LAUNCH_TIMEOUT_S = 900.0        # launch_ranks: wall-clock limit of the whole N-rank run (the driver's own limit is 1800 s)
+RANK_TIMEOUT_S = 600.0          # RankEnv watchdog: a rank that has not finished by then reports where it sits and exits 3
 
 
 def channel_range(total_channels, rank, world):
@@ -42,16 +49,84 @@ def free_port():
     return port
 
 
-def launch_ranks(nproc, script, argv, env=None):
-    """Run `script argv` as `nproc` ranks of one node under torch.distributed.run (rendezvous on 127.0.0.1) and
-    return the launcher's exit code.  Called by a process that has NOT touched the GPU: the ranks are fresh child
-    processes (never an exec of a process that initialised HIP)."""
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
-           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), script] + list(argv)
-    e = dict(os.environ if env is None else env)
-    e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on this driver (RCCL, tensor sharing)
-    e.setdefault("OMP_NUM_THREADS", "1")
-    return subprocess.run(cmd, env=e).returncode
+def _stage_file(directory, rank):
+    return os.path.join(directory, "rank_%d.stage" % rank)
+
+
+def launch_ranks(nproc, script, argv, env=None, timeout=None):
+    """Run `script argv` as `nproc` ranks of one node -- RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set as
+    torch.distributed.run sets them, rendezvous on 127.0.0.1 -- and return an exit code.  Called by a process that has NOT
+    touched the GPU: the ranks are fresh child processes (never an exec of a process that initialised HIP).
+
+    Self-defending (the first real N > 1 run must not sit in a hung RCCL init until the driver's limit): every
+    rank is a child of THIS process in its own process group and writes the stage it has reached (RankEnv.stage) into a file;
+    when a rank fails, or the run exceeds `timeout` seconds (SELENITE_LAUNCH_TIMEOUT_S, default 900), every rank still alive is
+    killed with its group, the stuck ranks and the stages they reached are named on stderr, and the result is non-zero
+    (124 for a timeout, else the failing rank's code)."""
+    if timeout is None:
+        timeout = float(os.environ.get("SELENITE_LAUNCH_TIMEOUT_S", LAUNCH_TIMEOUT_S))
+    base = dict(os.environ if env is None else env)
+    base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on this driver (RCCL, tensor sharing)
+    base.setdefault("OMP_NUM_THREADS", "1")
+    port = str(free_port())
+    stage_dir = tempfile.mkdtemp(prefix="selenite_ranks_")
+    procs = []
+    for r in range(nproc):
+        e = dict(base, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(nproc), LOCAL_WORLD_SIZE=str(nproc),
+                 MASTER_ADDR="127.0.0.1", MASTER_PORT=port, SELENITE_RANK_STAGE_DIR=stage_dir)
+        procs.append(subprocess.Popen([sys.executable, script] + list(argv), env=e, start_new_session=True))
+
+    def stage(r):
+        try:
+            return open(_stage_file(stage_dir, r)).read().strip() or "started"
+        except OSError:
+            return "started (no stage reported)"
+
+    def kill_all():
+        for q in procs:
+            if q.poll() is None:
+                try:
+                    os.killpg(q.pid, signal.SIGKILL)          # the rank and whatever it started: its own session, nobody else's
+                except OSError:
+                    pass
+        for q in procs:
+            try:
+                q.wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                pass
+
+    t0, rc = time.monotonic(), 0
+    try:
+        while True:
+            codes = [q.poll() for q in procs]
+            bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+            if bad:
+                r, c = bad[0]
+                sys.stderr.write("launch_ranks: rank %d exited with %d (stage: %s); stopping the other ranks: %s\n"
+                                 % (r, c, stage(r), ", ".join("rank %d at '%s'" % (k, stage(k)) for k, x in enumerate(codes) if x is None) or "none left"))
+                rc = c if c > 0 else 1
+                break
+            if all(c == 0 for c in codes):
+                break
+            if time.monotonic() - t0 > timeout:
+                stuck = [k for k, x in enumerate(codes) if x is None]
+                sys.stderr.write("launch_ranks: no result after %.0f s -- stuck: %s; killing the ranks\n"
+                                 % (timeout, ", ".join("rank %d at '%s'" % (k, stage(k)) for k in stuck)))
+                rc = 124
+                break
+            time.sleep(0.05)
+    finally:
+        kill_all()
+        for r in range(nproc):
+            try:
+                os.unlink(_stage_file(stage_dir, r))
+            except OSError:
+                pass
+        try:
+            os.rmdir(stage_dir)
+        except OSError:
+            pass
+    return rc
 
 
 class RankEnv:
@@ -66,6 +141,31 @@ class RankEnv:
         self.dist = None
         self.torch = None
         self.backend = None
+        self._stage_dir = environ.get("SELENITE_RANK_STAGE_DIR")
+        self._stage = "started"
+        self._done = threading.Event()
+        self.stage("started")
+        # a rank of an N > 1 job never waits for ever (a peer that died before the rendezvous, a hung RCCL bootstrap): past the limit it
+        # says where it sits and leaves with code 3 -- under torch.distributed.run that takes the other ranks down too
+        limit = float(environ.get("SELENITE_RANK_TIMEOUT_S", RANK_TIMEOUT_S))
+        if self.world > 1 and limit > 0:
+            threading.Thread(target=self._watchdog, args=(limit,), daemon=True).start()
+
+    def stage(self, name):
+        """Where this rank is (launch_ranks and the watchdog name it when the rank is stuck)."""
+        self._stage = name
+        if self._stage_dir:
+            try:
+                with open(_stage_file(self._stage_dir, self.rank), "w") as f:
+                    f.write(name)
+            except OSError:
+                pass
+
+    def _watchdog(self, limit):
+        if not self._done.wait(limit):
+            sys.stderr.write("RankEnv: rank %d of %d still at '%s' after %.0f s -- giving up (exit 3)\n" % (self.rank, self.world, self._stage, limit))
+            sys.stderr.flush()
+            os._exit(3)
 
     def init_process_group(self, backend, use_gpu=True):
         """torch FIRST: its bundled libamdhip64 (same soname) then serves libselenite_rx.so too, so the process
@@ -77,7 +177,22 @@ class RankEnv:
             torch.cuda.set_device(self.local_rank)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
+        self.stage("init_process_group(%s)" % backend)
         dist.init_process_group(backend=backend, rank=self.rank, world_size=self.world)
+        self.stage("process group up")
+
+    def comm_count(self):
+        """The size of the communicator as the BACKEND sees it: every rank adds 1 through an all-reduce (the first collective of the job:
+        RCCL builds its rings here).  Rank 0 checks it against WORLD_SIZE before anything is timed."""
+        if self.dist is None:
+            return 1
+        self.stage("first collective (communicator check)")
+        dev = ("cuda:%d" % self.local_rank) if self.backend == "nccl" else "cpu"
+        t = self.torch.ones(1, dtype=self.torch.int32, device=dev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        n = int(t.item())
+        self.stage("communicator checked")
+        return n
 
     def barrier(self):
         if self.dist is not None:
@@ -98,18 +213,19 @@ class RankEnv:
         if self.dist is None:
             return [obj]
         out = [None] * self.world
-        try:
-            self.dist.all_gather_object(out, obj)
-        except Exception as e:                      # diagnostics must never cost the measurement
-            sys.stderr.write("RankEnv.gather_objects: %s\n" % e)
-            return [obj if r == self.rank else None for r in range(self.world)]
+        # (no try / except: a collective that fails on SOME ranks leaves the group out of step for everything behind it -- outside the
+        # timed region a failure must fail the run, not print a line with holes in it; advisor finding, round 3)
+        self.dist.all_gather_object(out, obj)
         return out
 
     def close(self):
         if self.dist is not None:
+            self.stage("closing")
             self.dist.barrier()
             self.dist.destroy_process_group()
             self.dist = None
+        self.stage("done")
+        self._done.set()
 
 
 class GlobalGainStepper:
