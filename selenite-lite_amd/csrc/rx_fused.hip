@@ -483,8 +483,11 @@ static hipError_t launch_shape(const RxParams &p, const FusedArgs &fa, const Fus
 {
     if (src_q15 != dst_q15) return hipErrorNotSupported;
     const bool auto_ = arith == SELENITE_ARITH_AUTO;
-    const bool fm = fa.am == 2u;                  // the discriminator divides by |z|: no parity bar holds on a split product -- exact / fma kernels only (k_ssb_fused, k_ssb_mfma)
-    const bool split = (arith == SELENITE_ARITH_SPLIT16 || auto_) && !fm;
+    // FM: the discriminator divides by |z|, so no parity bar holds on a raw split product (SPLIT16 runs FM as FMA).  AUTO (round 4) has
+    // the guard for it: a block is guarded when min|z| x max|audio| < ratio x pass maximum, its channel recomputed by the bit-exact kernel
+    // -- on the decimating shapes (k_ssb_split16); the no-decimator shapes keep the bit-exact kernel (their FIR pair is not on the matrix pipe in FM)
+    const bool fm = fa.am == 2u;
+    const bool split = (arith == SELENITE_ARITH_SPLIT16 || auto_) && !(fm && !(auto_ && ND > 0));
     // SELENITE_ARITH_AUTO, second launch: the bit-exact kernel over the channels whose rerun flag the split16 kernel raised
     // (their streaming state is still the pre-call state; audio and state are recomputed in the CMSIS arithmetic)
     auto rerun = [&]() -> hipError_t {
@@ -612,7 +615,8 @@ hipError_t plan_fused(const selenite_rx_config &g, bool delay_is_impulse, int de
         if (g.nd_taps) plan.name_buf = "k_ssb_split16" + shape + tail;
         else if (na == 256) plan.name_buf = "k_hilb_split16<" + std::to_string(g.nh_taps) + ">" + tail;
     }
-    if (g.mode == SELENITE_MODE_FM) {                                                                // FM: the exact / fma kernels in every arithmetic mode
+    if (g.mode == SELENITE_MODE_FM && !(g.arith == SELENITE_ARITH_AUTO && g.nd_taps && plan.name_buf.rfind("k_ssb_split16", 0) == 0)) {
+        // FM: the exact / fma kernels (AUTO on a decimating shape with a matrix kernel keeps it: guarded on min|z|, round 4)
         const bool fma = g.arith == SELENITE_ARITH_FMA || g.arith == SELENITE_ARITH_SPLIT16;
         plan.name_buf = (fma && plan.use_mfma && g.nd_taps && g.decim == 4 ? "k_ssb_mfma" : "k_ssb_fused") + shape;
     }

@@ -88,6 +88,13 @@ __device__ __forceinline__ void demod_agc_store(const RxParams &p, const FusedAr
             const float pi0 = dI[G::HH4 + 4 * lane - 1], pq0 = dQ[G::HH4 + 4 * lane - 1];
             au[0] = fm_disc(vi.x, vq.x, pi0, pq0);  au[1] = fm_disc(vi.y, vq.y, vi.x, vq.x);
             au[2] = fm_disc(vi.z, vq.z, vi.y, vq.y); au[3] = fm_disc(vi.w, vq.w, vi.z, vq.z);
+            if (gx) {                                             // the matrix kernel's FM guard (rx_split16_kernels.h): thresholds over min|z| of the pass
+                float zz = fminf(fminf(vi.x * vi.x + vq.x * vq.x, vi.y * vi.y + vq.y * vq.y), fminf(vi.z * vi.z + vq.z * vq.z, vi.w * vi.w + vq.w * vq.w));
+                zz = fminf(zz, pi0 * pi0 + pq0 * pq0);
+                const float zmin = __builtin_sqrtf(__uint_as_float(~wave_umax_bits(__uint_as_float(~__float_as_uint(zz)))));
+                gx->thr = gx->thr / zmin;
+                gx->thr2 = gx->thr2 / zmin;
+            }
         } else {
             au[0] = cmag<0>(vi.x, vq.x); au[1] = cmag<0>(vi.y, vq.y);
             au[2] = cmag<0>(vi.z, vq.z); au[3] = cmag<0>(vi.w, vq.w);

@@ -202,6 +202,11 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
     static_assert(ND > 0 && (M == 4 || M == 2) && NH > 0 && G::T % 128 == 0 && GS::HS % 128 == 0, "split16 decimator: /4 or /2, + Hilbert");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x;
+    // FM (round 4; SELENITE_ARITH_AUTO only): a run-time flavour of the AM instantiations, as in k_ssb_fused -- the discriminator
+    // z[n] conj(z[n-1]) on the decimated rails, z[-1] of a pass = the newest entry of the FIR pair's delay lines, which FM keeps running
+    // (history moves, state write-back and the samples for k_hist_exact as in the SSB modes).  `keeps` = the FIR-pair history moves.
+    const bool fm = AM != 0 && fa.am == 2u;                       // wave-uniform
+    const bool keeps = AM == 0 || fm;
     // persistent: this workgroup runs channels blockIdx.x, blockIdx.x + gridDim.x, ... -- in SELENITE_ARITH_AUTO minus the channels the
     // exact kernel HOLDS (kFlagHold, round 4: a channel that was recomputed stays with the exact kernel until a call of it shows no
     // block near the guard ratio; the matrix kernel does not touch it -- no loads, no passes, its word stays).  The words of the next
@@ -387,7 +392,7 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
     const int ext_start = (int)p.block_size - (ND - 1) - (int)p.ext_len + 1;  // call-relative position of hist_ext[0]
     // (AM never touches the Hilbert-pair history: it keeps no samples either, and what it hands on is the provenance it found --
     // degraded to "matrix kernel, no samples" when it was "with samples", because the decimator state moves on without them)
-    const bool ext_on = AM == 0 && p.hist_ext != nullptr && ext_start >= 0;   // wave-uniform
+    const bool ext_on = keeps && p.hist_ext != nullptr && ext_start >= 0;     // wave-uniform
     __amdgpu_buffer_rsrc_t rs_ext = make_rsrc(p.hist_ext, 0u);
     uint32_t b_hist = 0, ph0 = 0, step = 0;                       // b_hist: bit pattern of the largest |history component|
     float gain = 1.0f;
@@ -407,7 +412,8 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
     // lanes of the DSP blocks that hold one of the first HH audio samples of a call (the reach of the Hilbert-pair history)
     const int hist_lanes = ((G::HH + 4 * (int)fa.group - 1) / (4 * (int)fa.group)) * (int)fa.group;
     const uint64_t hist_mask = hist_lanes >= 64 ? ~0ull : ((1ull << hist_lanes) - 1ull);
-    gd.hm = AM != 0 ? 0ull : hist_mask;                               // (AM reads no Hilbert history)
+    // (AM reads no history at all; FM one sample of it, z[-1]: the first DSP block of a pass)
+    gd.hm = AM == 0 ? hist_mask : (fm ? ((GROUP ? GROUP : (int)fa.group) >= 64 ? ~0ull : ((1ull << (GROUP ? GROUP : (int)fa.group)) - 1ull)) : 0ull);
     auto install_state = [&]() {
         float mh = 0.0f;
 #pragma unroll
@@ -720,8 +726,23 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
             if (kk == 0) {
                 const float4 vi = lds_ld4f(dI + G::HH4 + 4 * lane);
                 const float4 vq = lds_ld4f(dQ + G::HH4 + 4 * lane);
-                au[0] = cmag<0>(vi.x, vq.x); au[1] = cmag<0>(vi.y, vq.y);
-                au[2] = cmag<0>(vi.z, vq.z); au[3] = cmag<0>(vi.w, vq.w);
+                if (fm) {
+                    const float pi0 = dI[G::HH4 + 4 * lane - 1], pq0 = dQ[G::HH4 + 4 * lane - 1];
+                    au[0] = fm_disc(vi.x, vq.x, pi0, pq0);  au[1] = fm_disc(vi.y, vq.y, vi.x, vq.x);
+                    au[2] = fm_disc(vi.z, vq.z, vi.y, vq.y); au[3] = fm_disc(vi.w, vq.w, vi.z, vq.z);
+                    // parity guard of the discriminator: its error is |dz| / (pi |z|) per sample of the pair, |dz| ~ 1e-6 of the pass
+                    // maximum (the split product), against a bar of 1e-5 of the block's max |audio|: a block is guarded when
+                    // min|z| x max|audio| < ratio x pass maximum (min|z| over the pass and the sample in front of it): the thresholds of
+                    // this pass divided by min|z| (a pass that touches zero guards everything)
+                    float zz = fminf(fminf(vi.x * vi.x + vq.x * vq.x, vi.y * vi.y + vq.y * vq.y), fminf(vi.z * vi.z + vq.z * vq.z, vi.w * vi.w + vq.w * vq.w));
+                    zz = fminf(zz, pi0 * pi0 + pq0 * pq0);
+                    const float zmin = __builtin_sqrtf(__uint_as_float(~wave_umax_bits(__uint_as_float(~__float_as_uint(zz)))));
+                    gd.thr = gd.thr / zmin;
+                    gd.thr_h = gd.thr_h / zmin;
+                } else {
+                    au[0] = cmag<0>(vi.x, vq.x); au[1] = cmag<0>(vi.y, vq.y);
+                    au[2] = cmag<0>(vi.z, vq.z); au[3] = cmag<0>(vi.w, vq.w);
+                }
 #ifndef SRX_X_NOAGC
                 agc_pass<GROUP>(p.agcp, p.agc, lane, group, au, gain, nvb, gd);
 #endif
@@ -812,7 +833,7 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
             lds_order();
             u4v cb[NCB];
             v4f dt = { 0.0f, 0.0f, 0.0f, 0.0f };
-            if constexpr (AM == 0) dt = *reinterpret_cast<const v4f *>(D + dt_off + pq);      // (the pass before this one was a full one)
+            if (keeps) dt = *reinterpret_cast<const v4f *>(D + dt_off + pq);      // (the pass before this one was a full one)
             gd.thr = thr_prev; gd.thr_h = thrh_prev;                  // the demodulator below belongs to the pass before
             gd.hist = pass == 1 ? hist_mask : 0ull;
             const int nvb_full = GROUP == 0 ? (int)(pq / (4u * (uint32_t)group)) : 64;
@@ -820,7 +841,7 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
             cb_read(cb);
             lds_order();
             cb_write(cb);
-            if constexpr (AM == 0) *reinterpret_cast<v4f *>(D + dt_off) = dt;
+            if (keeps) *reinterpret_cast<v4f *>(D + dt_off) = dt;
             dwrite();
             lds_order();
             STAMP(0);
@@ -840,9 +861,9 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
             if (gd.n != 0u && p.guard_ch) { p.guard_ch[c] = sat_add_u32(p.guard_ch[c], gd.n); p.guard_calls[c] = sat_add_u32(p.guard_calls[c], 1u); }
             // handover blocks the rerun cannot repair: the call before stayed on the matrix kernel and left no hist_ext (a short call)
             // (or left them but the repair has been switched off since)
-            if (AM == 0 && gd.nh != 0u && (prev_prov == kProvSplit || (prev_prov == kProvSplitExt && !p.hist_ext)) && p.guard_hand) p.guard_hand[c] = sat_add_u32(p.guard_hand[c], gd.nh);      // (AM reads no history)
+            if (keeps && gd.nh != 0u && (prev_prov == kProvSplit || (prev_prov == kProvSplitExt && !p.hist_ext)) && p.guard_hand) p.guard_hand[c] = sat_add_u32(p.guard_hand[c], gd.nh);      // (AM reads no history)
             if (p.rerun_flag) {
-                const uint32_t kept = AM != 0 ? (((prev_prov == kProvExact ? kProvExact : kProvSplit) << kProvShift) | (prev_buf << kExtBufShift))      // (no samples: the format bit is void)
+                const uint32_t kept = !keeps ? (((prev_prov == kProvExact ? kProvExact : kProvSplit) << kProvShift) | (prev_buf << kExtBufShift))      // (no samples: the format bit is void)
                                               : (((ext_on ? kProvSplitExt : kProvSplit) << kProvShift) | ((prev_buf ^ 1u) << kExtBufShift) |
                                                  (ext_on && sizeof(TIn) == 2 ? kExtQ15 : 0u));
                 // (kept on the matrix kernel: the level of the last pass goes with the state -- the first blocks of the next call read
@@ -862,7 +883,7 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
                 if (s >= 0) { st_st(stI + s, h.x); st_st(stQ + s, h.y); }
             }
         }
-        if constexpr (AM == 0) {                                      // AM never ran the Hilbert pair: its state stays
+        if (keeps) {                                                  // AM never ran the Hilbert pair: its state stays (FM keeps the delay lines running)
             if (!keep_state)
                 for (int i = lane; i < 2 * G::HH4; i += kWave) {
                     const int rail = i / G::HH4, mi = i % G::HH4, s = mi - G::FH;
