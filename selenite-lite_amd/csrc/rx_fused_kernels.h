@@ -112,18 +112,24 @@ __device__ __forceinline__ void demod_agc_store(const RxParams &p, const FusedAr
         const float4 v = lds_ld4f(dI + 4 * lane);
         au[0] = v.x; au[1] = v.y; au[2] = v.z; au[3] = v.w;
     }
-    if (env_row || gx) {                                          // (wave-uniform; env_row: the AGC is off in this launch)
-        const int gl = GROUP ? GROUP : group;
-        float m = fmaxf(fmaxf(fabsf(au[0]), fabsf(au[1])), fmaxf(fabsf(au[2]), fabsf(au[3])));
-        if ((gl & (gl - 1)) == 0) {
+    // arm_abs + arm_max per DSP block (group lanes): the block maximum in every lane of the block -- for the AGC, for the block maxima a
+    // global-gain call wants (env_row) and for the guard evaluation of the rerun pass (gx); computed once, and unconditionally: a
+    // wave-uniform branch around it cost the rerun pass a fifth of its time (it split the pass into small basic blocks)
+    float m = fmaxf(fmaxf(fabsf(au[0]), fabsf(au[1])), fmaxf(fabsf(au[2]), fabsf(au[3])));
+    const int gl = GROUP ? GROUP : group;
+    if constexpr (GROUP > 0) {
 #pragma unroll
-            for (int off = 1; off < 64; off <<= 1)
-                if (off < gl) m = fmaxf(m, __shfl_xor(m, off, 64));
-        } else {
-            float mm = 0.0f;
-            for (int j = 0; j < gl; ++j) mm = fmaxf(mm, __shfl(m, ((lane / gl) * gl + j) & 63, 64));
-            m = mm;
-        }
+        for (int off = 1; off < GROUP; off <<= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    } else if ((group & (group - 1)) == 0) {                  // power of two: butterfly
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1)
+            if (off < group) m = fmaxf(m, __shfl_xor(m, off, 64));
+    } else {                                                  // e.g. 6 lanes: the firmware's 96-frame blocks by 4 (dsp_if.h:69-73)
+        float mm = 0.0f;
+        for (int j = 0; j < group; ++j) mm = fmaxf(mm, __shfl(m, ((lane / group) * group + j) & 63, 64));
+        m = mm;
+    }
+    {
         const bool first = lane % gl == 0 && lane / gl < nvb;     // the first lane of every DSP block that exists
         if (env_row && first) env_row[lane / gl] = m;
         if (gx) {
@@ -131,13 +137,10 @@ __device__ __forceinline__ void demod_agc_store(const RxParams &p, const FusedAr
             gx->n2 += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(first && m < gx->thr2));
         }
     }
-    // AGC: arm_abs + arm_max per DSP block (group lanes), gain law, arm_scale
+    // AGC: gain law on the block maxima, arm_scale
     if (p.agc) {
-        float m = fmaxf(fmaxf(fabsf(au[0]), fabsf(au[1])), fmaxf(fabsf(au[2]), fabsf(au[3])));
         float g = gain, mine = gain;
         if constexpr (GROUP > 0) {
-#pragma unroll
-            for (int off = 1; off < GROUP; off <<= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
             const int myblk = lane / GROUP;
             // the divisions target/env of the blocks of this pass are independent of the gain
             // recurrence: issue them together, then run the (cheap) recurrence
@@ -156,15 +159,6 @@ __device__ __forceinline__ void demod_agc_store(const RxParams &p, const FusedAr
             }
         } else {
             const int myblk = lane / group;
-            if ((group & (group - 1)) == 0) {                     // power of two: butterfly
-#pragma unroll
-                for (int off = 1; off < 64; off <<= 1)
-                    if (off < group) m = fmaxf(m, __shfl_xor(m, off, 64));
-            } else {                                              // e.g. 6 lanes: the firmware's 96-frame blocks by 4 (dsp_if.h:69-73)
-                float mm = 0.0f;
-                for (int j = 0; j < group; ++j) mm = fmaxf(mm, __shfl(m, (myblk * group + j) & 63, 64));
-                m = mm;
-            }
             const int nblk = min(64 / group, nvb);
             for (int b = 0; b < nblk; ++b) {
                 const float env = __shfl(m, b * group, 64);
@@ -224,12 +218,37 @@ __global__ __launch_bounds__(64, 2) void k_ssb_fused(RxParams p, FusedArgs fa, c
     // channels, and how many, is only known on the device; every workgroup gets an even share.
     uint32_t li = blockIdx.x;
     const uint32_t ln = p.chan_flags ? *p.chan_count : 0u;
+    // what does not depend on the channel, once per workgroup: sine table, decimator taps (lane-distributed), Hilbert taps
+    if constexpr (NCO == 1 || NCO == 4)
+        for (int i = lane; i < 513; i += kWave) tab[i] = p.sintab[i];
+    float creg[G::NCR > 0 ? G::NCR : 1];
+    if constexpr (ND > 0) {
+#pragma unroll
+        for (int v = 0; v < G::NCR; ++v) creg[v] = fa.cq[64 * v + lane];
+    }
+    float hreg[(NH + 63) / 64 ? (NH + 63) / 64 : 1];
+#pragma unroll
+    for (int v = 0; v < (NH + 63) / 64; ++v) hreg[v] = (64 * v + lane < NH) ? p.hilb_c[64 * v + lane] : 0.0f;
+    auto in_rsrc = [&](uint32_t ch, bool valid) { return make_rsrc(src + (size_t)ch * p.in_stride * 2, valid ? p.block_size * (R::kBytes / 2) : 0u); };
+    // the first pass of a channel is in flight before the channel starts: loaded here for the first one, under the last pass of the
+    // channel before it for the others (rerun pass: the list says which channel comes next)
+    uint32_t c_cur = blockIdx.x;
+    if (p.chan_flags) c_cur = li < ln ? p.chan_list[li] : 0u;
+    typename R::type raw[NLD];
+    {
+        const __amdgpu_buffer_rsrc_t rs0 = in_rsrc(c_cur, !p.chan_flags || li < ln);
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) raw[i] = R::load(rs0, lane * R::kBytes + i * 64 * R::kBytes, 0);
+    }
   for (;;) {
-    uint32_t c = blockIdx.x;
+    const uint32_t c = c_cur;
+    uint32_t c_nxt = 0u;
+    bool has_nxt = false;
     if (p.chan_flags) {
         if (li >= ln) break;
-        c = p.chan_list[li];
         li += gridDim.x;
+        has_nxt = li < ln;
+        c_nxt = has_nxt ? p.chan_list[li] : 0u;
     }
 
     const size_t out_base = (size_t)c * p.out_stride;
@@ -241,19 +260,12 @@ __global__ __launch_bounds__(64, 2) void k_ssb_fused(RxParams p, FusedArgs fa, c
     const bool held_in = (word_in & kFlagHold) != 0u;
     GuardEx gx{ 0.0f, 0.0f, 0u, 0u };
     float hmax = 0.0f;                                               // largest |component| of the FIR history the channel came in with
-    const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(src + (size_t)c * p.in_stride * 2, p.block_size * (R::kBytes / 2));
+    const __amdgpu_buffer_rsrc_t rs_in = in_rsrc(c, true);
+    const __amdgpu_buffer_rsrc_t rs_next = in_rsrc(c_nxt, has_nxt);      // (no next channel: an empty range -- zeros, no traffic)
     const __amdgpu_buffer_rsrc_t rs_lo = make_rsrc(p.lo, NCO == 2 ? p.block_size * 8u : 0u);
-    typename R::type raw[NLD];
-#pragma unroll
-    for (int i = 0; i < NLD; ++i) raw[i] = R::load(rs_in, lane * R::kBytes + i * 64 * R::kBytes, 0);
 
-    // ---- prologue: tables and streaming state into LDS / registers ----
-    if constexpr (NCO == 1 || NCO == 4)
-        for (int i = lane; i < 513; i += kWave) tab[i] = p.sintab[i];
-    float creg[G::NCR > 0 ? G::NCR : 1];
+    // ---- prologue: streaming state into LDS / registers ----
     if constexpr (ND > 0) {
-#pragma unroll
-        for (int v = 0; v < G::NCR; ++v) creg[v] = fa.cq[64 * v + lane];
         // history element (phase pp, index m) holds sample s = (m*M + pp) - F of the CMSIS state
         // (oldest first); slots before the state (s < 0) only ever meet zero-padded taps
         batched_fill<2 * M * G::HQ4>(lane, p.dec_state + (size_t)c * 2 * (ND - 1),
@@ -275,10 +287,7 @@ __global__ __launch_bounds__(64, 2) void k_ssb_fused(RxParams p, FusedArgs fa, c
             },
             [&](int i, float v) { D[(i / G::HH4) * G::DLEN + i % G::HH4] = v; if (ND == 0) hmax = fmaxf(hmax, fabsf(v)); });
     }
-    float pm_prev = rerun_pass ? __uint_as_float(wave_umax_bits(hmax)) : 0.0f;   // what "the pass before" pass 0 held: the history
-    float hreg[(NH + 63) / 64 ? (NH + 63) / 64 : 1];
-#pragma unroll
-    for (int v = 0; v < (NH + 63) / 64; ++v) hreg[v] = (64 * v + lane < NH) ? p.hilb_c[64 * v + lane] : 0.0f;
+    float pm_prev = __uint_as_float(wave_umax_bits(hmax));           // what "the pass before" pass 0 held: the history
     const uint32_t ph0 = NCO ? p.phase[c] : 0u;
     const uint32_t step = NCO ? p.step[c] : 0u;
     float gain = p.agc ? p.gain[c] : 1.0f;
@@ -331,7 +340,7 @@ __global__ __launch_bounds__(64, 2) void k_ssb_fused(RxParams p, FusedArgs fa, c
                 a = cmul<0>(a, make_float2(la.x, la.y));
                 b = cmul<0>(b, make_float2(lb.x, lb.y));
             }
-            if (rerun_pass) mx = fmaxf(fmaxf(mx, fmaxf(fabsf(a.x), fabsf(a.y))), fmaxf(fabsf(b.x), fabsf(b.y)));
+            mx = fmaxf(fmaxf(mx, fmaxf(fabsf(a.x), fabsf(a.y))), fmaxf(fabsf(b.x), fabsf(b.y)));      // (unconditional: no branch in the mix stage)
             if constexpr (ND > 0) {
                 const int m = G::HQ4 + (int)(n / M), pp = (int)(n % M);   // n even: pp in {0,2}
                 float *d = S + pp * G::PSF + G::elem(m);
@@ -342,9 +351,10 @@ __global__ __launch_bounds__(64, 2) void k_ssb_fused(RxParams p, FusedArgs fa, c
                 *reinterpret_cast<float2 *>(dQ + G::HH4 + n) = make_float2(a.y, b.y);
             }
         }
-        if (rerun_pass) {
+        {
             // the matrix kernel's guard compares a block's envelope with the largest sample its pass's product saw (new samples and
             // the decimator history) and, for the first blocks, the pass before; here: this pass and the one before it, for every block
+            // (evaluated in every launch -- a dozen instructions per pass --, used by the rerun pass only)
             const float pm = __uint_as_float(wave_umax_bits(mx));
             const float lvl = fmaxf(pm, pm_prev);
             gx.thr = lvl * p.guard_ratio;
@@ -352,9 +362,14 @@ __global__ __launch_bounds__(64, 2) void k_ssb_fused(RxParams p, FusedArgs fa, c
             pm_prev = pm;
         }
         wave_lds_sync();
-        // ---- prefetch the next pass while this one computes (beyond the call: zeros, no traffic) ----
+        // ---- prefetch the next pass while this one computes (the last pass: the first pass of the workgroup's next channel) ----
+        {
+            const bool last = pass + 1 == npass;                      // wave-uniform
+            const __amdgpu_buffer_rsrc_t rs_pf = last ? rs_next : rs_in;
+            const int so = last ? 0 : (int)((n0 + tq) * (R::kBytes / 2));
 #pragma unroll
-        for (int i = 0; i < NLD; ++i) raw[i] = R::load(rs_in, lane * R::kBytes + i * 64 * R::kBytes, (int)((n0 + tq) * (R::kBytes / 2)));
+            for (int i = 0; i < NLD; ++i) raw[i] = R::load(rs_pf, lane * R::kBytes + i * 64 * R::kBytes, so);
+        }
         // ---- 2. arm_fir_decimate_f32 on both rails, 4 adjacent outputs per lane ----
         if constexpr (ND > 0) {
             v2f acc[4] = { { 0.0f, 0.0f }, { 0.0f, 0.0f }, { 0.0f, 0.0f }, { 0.0f, 0.0f } };
@@ -368,11 +383,11 @@ __global__ __launch_bounds__(64, 2) void k_ssb_fused(RxParams p, FusedArgs fa, c
         // (rerun pass of AUTO inside a global-gain call whose split16 kernel emitted block maxima: refresh this channel's row)
         float *env_row = (p.chan_flags && p.env_part) ? p.env_part + (size_t)c * (p.block_size / p.block) + (size_t)pass * (pq / (4u * (uint32_t)group)) : nullptr;
         if (group == 16)
-            demod_agc_store<ARITH, 16, ND, M, NH, TOut, AM>(p, fa, dI, dQ, lane, group, hreg, gain, dst, out_base + (size_t)pass * pq, nonfinite, nvb, env_row, rerun_pass ? &gx : nullptr);
+            demod_agc_store<ARITH, 16, ND, M, NH, TOut, AM>(p, fa, dI, dQ, lane, group, hreg, gain, dst, out_base + (size_t)pass * pq, nonfinite, nvb, env_row, &gx);
         else if (group == 64)
-            demod_agc_store<ARITH, 64, ND, M, NH, TOut, AM>(p, fa, dI, dQ, lane, group, hreg, gain, dst, out_base + (size_t)pass * pq, nonfinite, nvb, env_row, rerun_pass ? &gx : nullptr);
+            demod_agc_store<ARITH, 64, ND, M, NH, TOut, AM>(p, fa, dI, dQ, lane, group, hreg, gain, dst, out_base + (size_t)pass * pq, nonfinite, nvb, env_row, &gx);
         else
-            demod_agc_store<ARITH, 0, ND, M, NH, TOut, AM>(p, fa, dI, dQ, lane, group, hreg, gain, dst, out_base + (size_t)pass * pq, nonfinite, nvb, env_row, rerun_pass ? &gx : nullptr);
+            demod_agc_store<ARITH, 0, ND, M, NH, TOut, AM>(p, fa, dI, dQ, lane, group, hreg, gain, dst, out_base + (size_t)pass * pq, nonfinite, nvb, env_row, &gx);
         wave_lds_sync();
         // ---- 6. history copy-back (arm_fir_decimate_f32.c:396-426, arm_fir_f32.c:947-978) ----
         if constexpr (ND > 0) {
@@ -455,6 +470,7 @@ __global__ __launch_bounds__(64, 2) void k_ssb_fused(RxParams p, FusedArgs fa, c
         }
     }
     if (!p.chan_flags) break;
+    c_cur = c_nxt;
     wave_lds_sync();                                     // the state reads above before the next channel's prologue fills
   }
     if (nonfinite) p.flags[kFlagNanInf] = 1u;            // ARM_MATH_NANINF, read by selenite_rx_sync

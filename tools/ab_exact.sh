@@ -6,5 +6,5 @@ for rep in 1 2 3; do
 for v in "$@"; do
   lib=$GRAFT_REPO_ROOT/selenite-lite_amd/variants/lib_$v.so
   [ "$v" = main ] && lib=$GRAFT_REPO_ROOT/selenite-lite_amd/libselenite_rx.so
-  echo "$v: $(SELENITE_RX_LIB=$lib python bench.py --main-only --arith cmsis --steps 100 ${AB_ARGS:-} | python -c 'import json,sys; d=json.loads(sys.stdin.read()); print(d["ms_per_step"], d["value"], d["roofline"]["launch_ms_median"])')"
+  echo "$v: $(SELENITE_RX_LIB=$lib python bench.py --main-only ${AB_ARGS:---arith cmsis} --steps 100 | python -c 'import json,sys; d=json.loads(sys.stdin.read()); print(d["ms_per_step"], d["value"], d["roofline"]["launch_ms_median"])')"
 done; done
