@@ -536,7 +536,10 @@ static hipError_t launch_shape(const RxParams &p, const FusedArgs &fa, const Fus
         }
     }
     if constexpr (ND == 0 && M == 1 && NH > 0) {
-        if (split && plan.d_btab16 && fa.group == 64 && whole) {
+        // k_hilb_split16: whole passes of the largest whole number of DSP blocks in 256 (256 itself, or e.g. 192: BASELINE cfg2's
+        // literal 48 000 samples are 250 blocks of 192); whole 4-sample lanes per block
+        const bool hilb_ok = fa.pass_out != 0 && p.nout % fa.pass_out == 0;
+        if (split && plan.d_btab16 && hilb_ok) {
             hipError_t e = launch_hilb_split16(NH, p, fa, src, src_q15, dst, st);            // rx_split16.hip
             if (e == hipSuccess && auto_ && p.rerun_flag) e = rerun();
             return e;
@@ -608,12 +611,12 @@ hipError_t plan_fused(const selenite_rx_config &g, bool delay_is_impulse, int de
     (void)name;
     if (plan.use_mfma && g.arith != SELENITE_ARITH_CMSIS) plan.name_buf = "k_ssb_mfma" + shape;     // split16 without a matrix kernel of its own runs as fma
     if (g.arith == SELENITE_ARITH_AUTO) plan.name_buf = "k_ssb_fused" + shape;                      // without a matrix kernel of its own: bit-exact
-    const bool split_pass = g.nd_taps ? split16_pass_ok(256u / na * na) : 256 % na == 0;
+    const bool split_pass = g.nd_taps ? split16_pass_ok(256u / na * na) : true;      // (k_hilb_split16 takes any pass of whole 4-sample lanes)
     if (256 % na != 0) plan.name_buf = "k_ssb_fused" + shape;                                        // DSP blocks that do not divide a pass: variable-length passes
     if (split_pass && plan.d_btab16 && (g.arith == SELENITE_ARITH_SPLIT16 || g.arith == SELENITE_ARITH_AUTO)) {
         const char *tail = g.arith == SELENITE_ARITH_AUTO ? "+exact rerun of guarded channels" : "";
         if (g.nd_taps) plan.name_buf = "k_ssb_split16" + shape + tail;
-        else if (na == 256) plan.name_buf = "k_hilb_split16<" + std::to_string(g.nh_taps) + ">" + tail;
+        else plan.name_buf = "k_hilb_split16<" + std::to_string(g.nh_taps) + ">" + tail;
     }
     if (g.mode == SELENITE_MODE_FM && !(g.arith == SELENITE_ARITH_AUTO && g.nd_taps && plan.name_buf.rfind("k_ssb_split16", 0) == 0)) {
         // FM: the exact / fma kernels (AUTO on a decimating shape with a matrix kernel keeps it: guarded on min|z|, round 4)

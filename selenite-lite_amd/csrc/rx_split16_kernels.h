@@ -1274,21 +1274,28 @@ __global__ __launch_bounds__(64, 2) void k_hilb_split16(RxParams p, FusedArgs fa
     float *tab = lds + GH::oTab;
     _Float16 *Xh = reinterpret_cast<_Float16 *>(lds + GH::oX), *Xl = Xh + GH::IMG;
     float *dI = lds + GH::oDI, *dQ = lds + GH::oDQ, *O = lds + GH::oO;      // f32 rails [HH history | 256 new]
-    const uint32_t npass = p.nout / 256;
+    // a pass produces pq audio samples: 256, or (round 4) the largest whole number of DSP blocks in 256 when the block does not divide
+    // it -- 192 for DSP blocks of 192 frames, BASELINE cfg2's literal 48 000 samples = 250 of them.  The 256-sample
+    // tile is always mixed and multiplied in full (input beyond the call reads as zeros); with pq < 256 its last outputs belong to
+    // the next pass and are dropped by the store's lane mask, and the histories take the samples in front of pq.
+    const uint32_t pq = fa.pass_out;
+    const uint32_t npass = p.nout / pq;
     const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(src + (size_t)c * p.in_stride * 2, p.block_size * (R::kBytes / 2));
     const __amdgpu_buffer_rsrc_t rs_out = make_rsrc(dst + (size_t)c * p.out_stride, p.nout * (W::kBytes / 4));
     const __amdgpu_buffer_rsrc_t rs_lo = make_rsrc(p.lo, NCO == 2 ? p.block_size * 8u : 0u);
-    constexpr int kInPass = 256 * (R::kBytes / 2);
+    const int kInPass = (int)pq * (R::kBytes / 2);
     typename R::type raw[2];
     u4v lo4[2];
     auto prefetch = [&](uint32_t pass) {                              // pass == npass: out of range, zeros, no traffic
         const int so = pass < npass ? (int)pass * kInPass : (int)(p.block_size * (R::kBytes / 2));
+        // (pq < 256: the samples behind pq feed only outputs that are dropped -- not loaded: out of range, zeros, no traffic; they are
+        // the next pass's to load)
 #pragma unroll
-        for (int i = 0; i < 2; ++i) raw[i] = R::load(rs_in, lane * R::kBytes + i * 64 * R::kBytes, so);
+        for (int i = 0; i < 2; ++i) raw[i] = R::load(rs_in, (uint32_t)(128 * i + 2 * lane) < pq ? lane * R::kBytes + i * 64 * R::kBytes : 0x40000000, so);
         if constexpr (NCO == 2) {
-            const int sl = pass < npass ? (int)pass * 256 * 8 : (int)p.block_size * 8;
+            const int sl = pass < npass ? (int)(pass * pq) * 8 : (int)p.block_size * 8;
 #pragma unroll
-            for (int i = 0; i < 2; ++i) lo4[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_lo, lane * 16 + i * 1024, sl, 0);
+            for (int i = 0; i < 2; ++i) lo4[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_lo, (uint32_t)(128 * i + 2 * lane) < pq ? lane * 16 + i * 1024 : 0x40000000, sl, 0);
         }
     };
     prefetch(0);
@@ -1325,7 +1332,13 @@ __global__ __launch_bounds__(64, 2) void k_hilb_split16(RxParams p, FusedArgs fa
         *reinterpret_cast<float2 *>(dQ + hv) = make_float2(q0, q1);
         b_hist = wave_umax_bits(fmaxf(fabsf(q0), fabsf(q1)));
     }
-    GuardPass gd{ 0.0f, 1ull, 0u };                                   // parity guard: one DSP block per pass
+    GuardPass gd{ 0.0f, 1ull, 0u };                                   // parity guard: one DSP block per pass ...
+    const int group = (int)fa.group;
+    if (pq != 256u || group != 64) {                                  // ... or pq / (4 group) of them (run-time geometry)
+        gd.first = 0ull;
+        for (int l = 0; l < 64; l += group) gd.first |= 1ull << l;
+    }
+    const int nvb = (int)(pq / (4u * (uint32_t)group));
     const uint32_t ph0 = NCO ? p.phase[c] : 0u, step = NCO ? p.step[c] : 0u;
     float gain = p.gain[c];
     const int mcol = lane & 15, rg = lane >> 4;
@@ -1334,7 +1347,7 @@ __global__ __launch_bounds__(64, 2) void k_hilb_split16(RxParams p, FusedArgs fa
     lds_order();
 
     for (uint32_t pass = 0; pass < npass; ++pass) {
-        const uint32_t n0 = pass * 256u;
+        const uint32_t n0 = pass * pq;
         // ---- 1. NCO mix; both rails f32 into LDS; Q rail split into the f16 images at the block scale ----
         v2f ma[2], mb[2];
 #pragma unroll
@@ -1370,7 +1383,7 @@ __global__ __launch_bounds__(64, 2) void k_hilb_split16(RxParams p, FusedArgs fa
                 const int n = 128 * i + 2 * lane;
                 const float m2 = fmaxf(fabsf(ma[i].y), fabsf(mb[i].y));
                 mq = fmaxf(mq, m2);
-                mt = fmaxf(mt, n >= 256 - GH::HH ? m2 : 0.0f);          // HH is even: a pair is inside or outside as a whole
+                mt = fmaxf(mt, (n >= (int)pq - GH::HH || pq != 256u) ? m2 : 0.0f);   // HH is even: a pair is inside or outside as a whole (pq < 256: the whole tile, a safe bound)
             }
             const uint32_t b_tail = wave_umax_bits(mt);
             const uint32_t b_need = max(max(wave_umax_bits(mq), b_tail), b_hist);      // the largest |Q| the matrix product sees
@@ -1420,18 +1433,19 @@ __global__ __launch_bounds__(64, 2) void k_hilb_split16(RxParams p, FusedArgs fa
             const float4 o4 = lds_ld4f(O + 4 * lane);
             au[0] = o4.x; au[1] = o4.y; au[2] = o4.z; au[3] = o4.w;
         }
-        agc_pass<64>(p.agcp, p.agc, lane, 64, au, gain, 1, gd);   // (AM: exact arithmetic, thr stays 0: never guarded)
+        if (pq == 256u && group == 64) agc_pass<64>(p.agcp, p.agc, lane, 64, au, gain, 1, gd);   // (AM: exact arithmetic, thr stays 0: never guarded)
+        else agc_pass<0>(p.agcp, p.agc, lane, group, au, gain, nvb, gd);
         {
             const float z = __builtin_fmaf(au[3], 0.0f, __builtin_fmaf(au[2], 0.0f, __builtin_fmaf(au[1], 0.0f, au[0] * 0.0f)));
             nonfinite = nonfinite || (z != z);
         }
-        W::store(rs_out, lane * W::kBytes, (int)pass * (256 * (W::kBytes / 4)), au);
+        W::store(rs_out, (uint32_t)lane < pq / 4u ? lane * W::kBytes : 0x40000000, (int)(pass * pq) * (W::kBytes / 4), au);
         // ---- 6. history: last NH-1 samples of both f32 rails and of both images to the front ----
         if constexpr (AM == 0) {
-            const float2 ti = *reinterpret_cast<const float2 *>(dI + 256 + hv);
-            const float2 tq = *reinterpret_cast<const float2 *>(dQ + 256 + hv);
-            const uint32_t th = *reinterpret_cast<const uint32_t *>(Xh + GH::phys(256 + hv));
-            const uint32_t tl = *reinterpret_cast<const uint32_t *>(Xl + GH::phys(256 + hv));
+            const float2 ti = *reinterpret_cast<const float2 *>(dI + pq + hv);
+            const float2 tq = *reinterpret_cast<const float2 *>(dQ + pq + hv);
+            const uint32_t th = *reinterpret_cast<const uint32_t *>(Xh + GH::phys((int)pq + hv));
+            const uint32_t tl = *reinterpret_cast<const uint32_t *>(Xl + GH::phys((int)pq + hv));
             lds_order();
             *reinterpret_cast<float2 *>(dI + hv) = ti;
             *reinterpret_cast<float2 *>(dQ + hv) = tq;

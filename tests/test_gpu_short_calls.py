@@ -67,17 +67,17 @@ def test_any_call_length_on_the_exact_fused_kernels(shape, arith, nco):
 @pytest.mark.parametrize("q15", [False, True])
 def test_the_firmware_block_geometry_runs_on_the_fused_kernel(shape, block, arith, q15):
     """DSP blocks of 96 (192, 48) frames: AGC groups of 6 (12, 24, 48) lanes, passes of 240 (192) audio samples.  Calls of one
-    slot (96 frames, dsp_if.c:50-67), two, ten, eleven, fifty.  Exact / fma arithmetic: bit-exact on k_ssb_fused.  AUTO: the
-    decimating shapes run whole 240-output passes on the matrix kernel (plain bar), the rest bit-exact."""
+    slot (96 frames, dsp_if.c:50-67), two, ten, eleven, fifty.  Exact / fma arithmetic: bit-exact on k_ssb_fused.  AUTO: whole
+    240- / 192-output passes on the matrix kernels (k_ssb_split16; round 4: k_hilb_split16 for the no-decimator shapes), plain bar."""
     nd, M, nh = shape
     nch = 21
     kw = dict(nco=True, nco_step_all=0x00c00000, agc=True)
     ref = ARITH_CMSIS if arith == ARITH_AUTO else arith
-    matrix = arith == ARITH_AUTO and nd != 0
+    matrix = arith == ARITH_AUTO
     name = run_pair(rc.ChainSpec(nch, block, M, nd, nh, 0, rc.MODE_LSB, arith, **kw),
                     rc.ChainSpec(nch, block, M, nd, nh, 0, rc.MODE_LSB, ref, **kw),
                     [block, 2 * block, 10 * block, 11 * block, block, 50 * block], q15=q15, exact=not matrix, na=block // M)
-    assert name.startswith(("k_ssb_split16<%d,%d,%d>" if matrix else "k_ssb_fused<%d,%d,%d>") % shape)
+    assert name.startswith(("k_hilb_split16<%d>" % nh) if matrix and nd == 0 else ("k_ssb_split16<%d,%d,%d>" if matrix else "k_ssb_fused<%d,%d,%d>") % shape)
 
 
 @pytest.mark.parametrize("shape,block", [((256, 4, 63), 96), ((256, 4, 63), 192), ((256, 4, 63), 384), ((128, 2, 63), 96),
@@ -180,3 +180,34 @@ def test_cw_kernel_for_other_dsp_blocks(stages, block, q15):
     spec = rc.ChainSpec(nch, block, 1, 0, 0, stages, rc.MODE_CW, ARITH_CMSIS, **kw)
     name = run_pair(spec, spec, [block, 3 * block, 2 * block, 7 * block], q15=q15)
     assert name == "k_cw_fused<%d,%d>" % (stages, block)
+
+
+@pytest.mark.parametrize("nh,block", [(127, 192), (63, 192), (127, 96), (31, 160), (127, 128)])
+@pytest.mark.parametrize("arith", [rc.ARITH_SPLIT16, ARITH_AUTO])
+@pytest.mark.parametrize("nco", ["shared", "per_channel", "off"])
+def test_the_hilbert_matrix_kernel_with_passes_of_fewer_than_256_outputs(nh, block, arith, nco):
+    """k_hilb_split16 (no decimator) with DSP blocks that do not divide the 256-sample tile: passes of the largest whole number of
+    blocks in it (192 for blocks of 192 frames -- BASELINE cfg2's literal 48 000 samples are 250 of them --, 192 = two blocks of 96,
+    160, 256 = two of 128); calls of whole passes stay on the matrix kernel, anything else runs bit-exactly on k_ssb_fused in AUTO.
+    Raw split16: input-referred bar; AUTO: plain bar.  The FIR pair's state (the mixed samples) bit-exact after every call."""
+    import selenite_rx as sr
+    nch, na = 27, block
+    pq = 256 // na * na
+    steps = (np.arange(nch, dtype=np.uint64) * 0x9E3779B1 % (1 << 32)).astype(np.uint32)
+    kw = {"shared": dict(nco=True, nco_step_all=0x00c00000), "per_channel": dict(nco=True, nco_steps=steps), "off": dict()}[nco]
+    kw["agc"] = True
+    g = sr.Rx(rc.ChainSpec(nch, block, 1, 0, nh, 0, rc.MODE_USB, arith, **kw).config())
+    o = CpuChain(rc.ChainSpec(nch, block, 1, 0, nh, 0, rc.MODE_USB, ARITH_CMSIS, **kw), "orc")
+    assert g.kernel_name().startswith("k_hilb_split16<%d>" % nh), g.kernel_name()
+    pos = 0
+    for bs in (pq, 5 * pq, block, 3 * pq, 2 * pq + block if pq != block else 2 * pq, 25 * pq):
+        iq = synth_iq(0, nch, pos, bs)
+        pos += bs
+        yg, yo = g.process(iq), o.process(iq)
+        d = np.abs(yg.astype(np.float64) - yo).reshape(nch, -1, na).max(axis=2)
+        m = np.abs(yo).reshape(nch, -1, na).max(axis=2)
+        bar = 1e-5 * m if arith == ARITH_AUTO else 1e-5 * m + 1e-6 * np.abs(iq).max()
+        assert (d <= bar).all(), (bs, (d / np.maximum(m, 1e-30)).max())
+        assert bits_equal(g.state()["fir_state"], o.state()["fir_state"]), bs
+        assert np.array_equal(g.state()["nco_phase"], o.state()["nco_phase"]), bs
+    g.close()
