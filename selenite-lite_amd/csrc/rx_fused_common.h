@@ -41,6 +41,8 @@ struct FusedArgs {
     uint32_t upper;         // 1: audio = I' - Q'   0: audio = I' + Q'
     uint32_t am;            // 1: audio = |I + jQ| (arm_cmplx_mag_f32); the Hilbert pair and its state are untouched
                             // 2: FM -- angle of z[n] conj(z[n-1]) in half turns; the pair's delay lines keep running (k_ssb_fused only)
+    uint32_t nco;           // k_ssb_fused: NCO flavour of the launch (0 off, 1 per channel per sample, 2 shared table, 4 per-channel periodic LO
+                            // in registers) -- a run-time switch since round 4 (launch_one sets it)
     uint32_t group;         // lanes per DSP block = (block / M) / 4
     uint32_t pass_out;      // k_ssb_fused: audio samples a full pass produces = the largest whole number of DSP blocks in 256 (256 when
                             // block / M divides 256; 240 for the firmware's 96-frame blocks by 4, 192 for 96 frames without decimator)

@@ -65,6 +65,8 @@ struct GuardEx {
     uint32_t n, n2;     // DSP blocks of the call under thr / thr2
 };
 
+// AM: 0 = SSB combine, 1 = AM / FM (fa.am says which), 2 = decided at run time by fa.am (k_ssb_fused, round 4: one kernel per shape
+// and slot format instead of one per NCO flavour and demodulator -- the binary was 35 MB)
 template <int ARITH, int GROUP, int ND, int M, int NH, typename TOut, int AM = 0>
 __device__ __forceinline__ void demod_agc_store(const RxParams &p, const FusedArgs &fa, const float *dI,
                                                 const float *dQ, int lane, int group,
@@ -78,7 +80,8 @@ __device__ __forceinline__ void demod_agc_store(const RxParams &p, const FusedAr
 {
     using G = Geo<ND, M, NH>;
     float au[4];
-    if constexpr (NH > 0 && AM != 0) {
+    const bool am_on = AM == 2 ? fa.am != 0u : AM != 0;               // (wave-uniform; a compile-time constant for AM = 0 / 1)
+    if (NH > 0 && am_on) {
         // AM: envelope of the decimated rails; new sample n of a pass sits at HH4 + n
         const float4 vi = lds_ld4f(dI + G::HH4 + 4 * lane);
         const float4 vq = lds_ld4f(dQ + G::HH4 + 4 * lane);
@@ -99,7 +102,7 @@ __device__ __forceinline__ void demod_agc_store(const RxParams &p, const FusedAr
             au[0] = cmag<0>(vi.x, vq.x); au[1] = cmag<0>(vi.y, vq.y);
             au[2] = cmag<0>(vi.z, vq.z); au[3] = cmag<0>(vi.w, vq.w);
         }
-    } else if constexpr (NH > 0) {
+    } else if (NH > 0) {
         float q2[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
         hilbert_quad<ARITH, ND, M, NH>(dQ, lane, hreg, q2);
         const float *di = dI + G::FH + fa.delay_idx + 4 * lane;   // unit-impulse delay FIR
@@ -190,11 +193,16 @@ __device__ __forceinline__ void demod_agc_store(const RxParams &p, const FusedAr
     }
 }
 
-template <int ARITH, int NCO, int ND, int M, int NH, typename TIn, typename TOut, int AM = 0>
+// NCO flavour (fa.nco: 0 off, 1 per-channel per sample, 2 shared table, 4 per-channel periodic) and demodulator (fa.am) are RUN-TIME
+// switches, wave-uniform, outside the hot loops (round 4): one kernel per arithmetic, shape and slot format -- the sixteen
+// instantiations per shape this replaced were most of a 35 MB library and of its four-minute build.
+template <int ARITH, int ND, int M, int NH, typename TIn, typename TOut>
 __global__ __launch_bounds__(64, 2) void k_ssb_fused(RxParams p, FusedArgs fa, const TIn *__restrict__ src,
                                                      TOut *__restrict__ dst)
 {
     using G = Geo<ND, M, NH>;
+    const uint32_t NCO = fa.nco;                         // wave-uniform
+    constexpr int AM = 2;                                // demod_agc_store: look at fa.am
     using R = BRaw<TIn>;
     static_assert(ND == 0 ? M == 1 : (M == 2 || M == 4 || M == 8), "fused kernel: no decimator, or decimate by 2, 4 or 8");
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -219,7 +227,7 @@ __global__ __launch_bounds__(64, 2) void k_ssb_fused(RxParams p, FusedArgs fa, c
     uint32_t li = blockIdx.x;
     const uint32_t ln = p.chan_flags ? *p.chan_count : 0u;
     // what does not depend on the channel, once per workgroup: sine table, decimator taps (lane-distributed), Hilbert taps
-    if constexpr (NCO == 1 || NCO == 4)
+    if (NCO == 1u || NCO == 4u)
         for (int i = lane; i < 513; i += kWave) tab[i] = p.sintab[i];
     float creg[G::NCR > 0 ? G::NCR : 1];
     if constexpr (ND > 0) {
@@ -262,7 +270,7 @@ __global__ __launch_bounds__(64, 2) void k_ssb_fused(RxParams p, FusedArgs fa, c
     float hmax = 0.0f;                                               // largest |component| of the FIR history the channel came in with
     const __amdgpu_buffer_rsrc_t rs_in = in_rsrc(c, true);
     const __amdgpu_buffer_rsrc_t rs_next = in_rsrc(c_nxt, has_nxt);      // (no next channel: an empty range -- zeros, no traffic)
-    const __amdgpu_buffer_rsrc_t rs_lo = make_rsrc(p.lo, NCO == 2 ? p.block_size * 8u : 0u);
+    const __amdgpu_buffer_rsrc_t rs_lo = make_rsrc(p.lo, NCO == 2u ? p.block_size * 8u : 0u);
 
     // ---- prologue: streaming state into LDS / registers ----
     if constexpr (ND > 0) {
@@ -297,8 +305,8 @@ __global__ __launch_bounds__(64, 2) void k_ssb_fused(RxParams p, FusedArgs fa, c
     // whatever its phase, and a pass (256 M inputs: the host selects this flavour only with 256-output passes) is a whole number
     // of periods: load i of any pass multiplies by LO[(128 i + 2 lane, + 1) mod 256] -- two register quads, computed once per
     // channel and call with the arithmetic of the per-sample flavour (same phases modulo 2^32: same bits)
-    lo_v2f lo_per[4];
-    if constexpr (NCO == 4) {
+    lo_v2f lo_per[4] = { { 1.0f, 0.0f }, { 1.0f, 0.0f }, { 1.0f, 0.0f }, { 1.0f, 0.0f } };
+    if (NCO == 4u) {
         const uint32_t pe = ph0 + 2u * lane * step;
         nco_lo_pair(tab, pe, pe + step, lo_per[0], lo_per[1]);
         nco_lo_pair(tab, pe + 128u * step, pe + 129u * step, lo_per[2], lo_per[3]);
@@ -308,16 +316,41 @@ __global__ __launch_bounds__(64, 2) void k_ssb_fused(RxParams p, FusedArgs fa, c
         const uint32_t n0 = pass * tq;
         const uint32_t cur = (pass + 1 == npass) ? p.nout - pass * pq : pq;      // audio samples of this pass (whole DSP blocks)
         // ---- 1. NCO mix of the prefetched samples, scatter into the LDS image ----
-        u4v lo4[NLD];
+        // the LO of a chunk of loads first -- one wave-uniform branch per flavour, outside the loop that mixes and scatters --, then one
+        // branch-free loop (a branch inside it splits the pass into small basic blocks: measured 20 % on the rerun pass)
         float mx = 0.0f;                                              // rerun pass: largest |component| of this pass's mixed samples
-        if constexpr (NCO == 2) {                                     // shared LO table (L2 resident):
+        constexpr int CH = NLD < 8 ? NLD : 8;                         // loads per chunk (decimation by 8: two chunks -- 16 LO pairs at once spilled)
+        static_assert(NLD % CH == 0, "whole chunks");
+        const bool mixing = NCO != 0u;                                // wave-uniform: two copies of the mix loop, one without the multiply
 #pragma unroll
-            for (int i = 0; i < NLD; ++i)                             // all loads of the pass in flight at once
-                lo4[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_lo, lane * 16 + i * 1024, (int)(n0 * 8u), 0);
+        for (int ch = 0; ch < NLD / CH; ++ch) {
+        lo_v2f la[CH], lb[CH];
+        if (NCO == 2u) {                                              // shared LO table (L2 resident): all loads of the chunk in flight at once
+            u4v lo4[CH];
+#pragma unroll
+            for (int j = 0; j < CH; ++j)
+                lo4[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_lo, lane * 16 + (ch * CH + j) * 1024, (int)(n0 * 8u), 0);
             __builtin_amdgcn_sched_barrier(0);
-        }
 #pragma unroll
-        for (int i = 0; i < NLD; ++i) {
+            for (int j = 0; j < CH; ++j) {
+                la[j] = lo_v2f{ __uint_as_float(lo4[j].x), __uint_as_float(lo4[j].y) };
+                lb[j] = lo_v2f{ __uint_as_float(lo4[j].z), __uint_as_float(lo4[j].w) };
+            }
+        } else if (NCO == 1u) {                                       // arm_sin/cos_f32 restated for the vector ALU: same bits (rx_device.h)
+#pragma unroll
+            for (int j = 0; j < CH; ++j) {
+                const uint32_t pe = ph0 + (n0 + 128u * (ch * CH + j) + 2u * lane) * step;
+                nco_lo_pair(tab, pe, pe + step, la[j], lb[j]);
+            }
+        } else {                                                      // per-channel periodic LO (registers); NCO off: not used
+#pragma unroll
+            for (int j = 0; j < CH; ++j) { la[j] = lo_per[2 * (j & 1)]; lb[j] = lo_per[2 * (j & 1) + 1]; }
+        }
+        auto mix_scatter = [&](auto mixc) {
+            constexpr bool MIX = decltype(mixc)::value;
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+            const int i = ch * CH + j;
             const uint32_t n = 128u * i + 2u * lane;                  // even sample index in the pass
             float2 a, b;
             {
@@ -325,20 +358,9 @@ __global__ __launch_bounds__(64, 2) void k_ssb_fused(RxParams p, FusedArgs fa, c
                 R::unpack(raw[i], va, vb);
                 a = make_float2(va.x, va.y); b = make_float2(vb.x, vb.y);
             }
-            if constexpr (NCO == 2) {
-                const u4v l2 = lo4[i];
-                a = cmul<0>(a, make_float2(__uint_as_float(l2.x), __uint_as_float(l2.y)));
-                b = cmul<0>(b, make_float2(__uint_as_float(l2.z), __uint_as_float(l2.w)));
-            } else if constexpr (NCO == 1) {
-                lo_v2f la, lb;                                            // arm_sin/cos_f32 restated for the vector ALU: same bits (rx_device.h)
-                const uint32_t pe = ph0 + (n0 + n) * step;
-                nco_lo_pair(tab, pe, pe + step, la, lb);
-                a = cmul<0>(a, make_float2(la.x, la.y));
-                b = cmul<0>(b, make_float2(lb.x, lb.y));
-            } else if constexpr (NCO == 4) {
-                const lo_v2f la = lo_per[2 * (i & 1)], lb = lo_per[2 * (i & 1) + 1];
-                a = cmul<0>(a, make_float2(la.x, la.y));
-                b = cmul<0>(b, make_float2(lb.x, lb.y));
+            if constexpr (MIX) {
+                a = cmul<0>(a, make_float2(la[j].x, la[j].y));
+                b = cmul<0>(b, make_float2(lb[j].x, lb[j].y));
             }
             mx = fmaxf(fmaxf(mx, fmaxf(fabsf(a.x), fabsf(a.y))), fmaxf(fabsf(b.x), fabsf(b.y)));      // (unconditional: no branch in the mix stage)
             if constexpr (ND > 0) {
@@ -350,6 +372,10 @@ __global__ __launch_bounds__(64, 2) void k_ssb_fused(RxParams p, FusedArgs fa, c
                 *reinterpret_cast<float2 *>(dI + G::HH4 + n) = make_float2(a.x, b.x);
                 *reinterpret_cast<float2 *>(dQ + G::HH4 + n) = make_float2(a.y, b.y);
             }
+        }
+        };
+        if (mixing) mix_scatter(std::true_type{});
+        else mix_scatter(std::false_type{});
         }
         {
             // the matrix kernel's guard compares a block's envelope with the largest sample its pass's product saw (new samples and
@@ -435,7 +461,7 @@ __global__ __launch_bounds__(64, 2) void k_ssb_fused(RxParams p, FusedArgs fa, c
         }
     }
     if constexpr (NH > 0) {
-        if (AM == 0 || fa.am == 2u) {                                 // AM never ran the Hilbert pair: its state stays (FM keeps the delay lines running)
+        if (fa.am != 1u) {                                            // AM never ran the Hilbert pair: its state stays (FM keeps the delay lines running)
             for (int i = lane; i < 2 * G::HH4; i += kWave) {
                 const int rail = i / G::HH4, m = i % G::HH4, s = m - G::FH;
                 if (s >= 0) p.fir_state[((size_t)c * 2 + rail) * G::HH + s] = D[rail * G::DLEN + m];
@@ -443,7 +469,7 @@ __global__ __launch_bounds__(64, 2) void k_ssb_fused(RxParams p, FusedArgs fa, c
         }
     }
     if (lane == 0) {
-        if constexpr (NCO != 0) p.phase[c] = ph0 + p.block_size * step;
+        if (NCO != 0u) p.phase[c] = ph0 + p.block_size * step;
         if (p.agc) p.gain[c] = gain;
         // SELENITE_ARITH_AUTO: the state this kernel leaves is exact (kProvExact) -- as the rerun pass, and as a call without a matrix
         // kernel; k_ssb_split16 reads the word at the channel's next call.  (AM, not FM, leaves the Hilbert-pair history alone: its
@@ -454,7 +480,7 @@ __global__ __launch_bounds__(64, 2) void k_ssb_fused(RxParams p, FusedArgs fa, c
         uint32_t *w = p.chan_flags ? p.chan_flags + c : (p.rerun_flag ? p.rerun_flag + c : nullptr);
         if (w) {
             uint32_t nw = 0u;
-            if (AM != 0 && fa.am != 2u) {
+            if (fa.am == 1u) {
                 const uint32_t prov = (*w >> kProvShift) & kProvMask;
                 nw = prov == kProvExact ? 0u : ((kProvSplit << kProvShift) | (*w & (1u << kExtBufShift)));
             }
@@ -478,25 +504,22 @@ __global__ __launch_bounds__(64, 2) void k_ssb_fused(RxParams p, FusedArgs fa, c
 
 
 template <int ARITH, int ND, int M, int NH, typename TIn, typename TOut>
-static hipError_t launch_one(const RxParams &p, const FusedArgs &fa, const void *src, void *dst, hipStream_t st)
+static hipError_t launch_one(const RxParams &p, const FusedArgs &fa_in, const void *src, void *dst, hipStream_t st)
 {
     using G = Geo<ND, M, NH>;
     constexpr size_t lds = (size_t)G::total * sizeof(float);
-    // per-channel LO with a period of 256 samples (every step a multiple of 2^24) and 256-output passes: one period per channel in registers
-    const bool per4 = p.nco == 1 && p.lo_period == 256 && fa.pass_out == 256;
-    auto k = fa.am ? (p.nco == 2 ? k_ssb_fused<ARITH, 2, ND, M, NH, TIn, TOut, 1>
-                         : (per4 ? k_ssb_fused<ARITH, 4, ND, M, NH, TIn, TOut, 1>
-                         : (p.nco == 1 ? k_ssb_fused<ARITH, 1, ND, M, NH, TIn, TOut, 1> : k_ssb_fused<ARITH, 0, ND, M, NH, TIn, TOut, 1>)))
-                   : (p.nco == 2 ? k_ssb_fused<ARITH, 2, ND, M, NH, TIn, TOut, 0>
-                         : (per4 ? k_ssb_fused<ARITH, 4, ND, M, NH, TIn, TOut, 0>
-                         : (p.nco == 1 ? k_ssb_fused<ARITH, 1, ND, M, NH, TIn, TOut, 0> : k_ssb_fused<ARITH, 0, ND, M, NH, TIn, TOut, 0>)));
+    FusedArgs fa = fa_in;
+    // NCO flavour of the launch: shared table (2); per-channel LO with a period of 256 samples (every step a multiple of 2^24) and
+    // 256-output passes: one period per channel in registers (4); per channel per sample (1); off (0)
+    fa.nco = p.nco == 2 ? 2u : (p.nco == 1 ? ((p.lo_period == 256 && fa.pass_out == 256) ? 4u : 1u) : 0u);
+    auto k = k_ssb_fused<ARITH, ND, M, NH, TIn, TOut>;
     if constexpr (lds > 48 * 1024) {                      // per device and per kernel: set on every launch (cheap)
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
     // (rerun pass of SELENITE_ARITH_AUTO: which channels are flagged is only known on the device -- a resident-sized grid strides
-    // over the 16-channel windows of the flag array)
+    // over the dense list of them)
     static const uint32_t rerun_grid = [] { const char *e = std::getenv("SELENITE_RX_RERUN_GRID"); return e && std::atoi(e) > 0 ? (uint32_t)std::atoi(e) : 2048u; }();
     const uint32_t grid = p.chan_flags ? (p.channels < rerun_grid ? p.channels : rerun_grid) : p.channels;
     hipLaunchKernelGGL(k, dim3(grid), dim3(64), lds, st, p, fa, static_cast<const TIn *>(src),

@@ -40,7 +40,7 @@ def test_bench_json_contract_default_shape():
     assert 0 < r["frac_hip_events"] < 1 and r["launch_ms_hip_events"] <= d["ms_per_step"] * 1.05
     sr_ = d["streaming_roof"]                                         # the no-arithmetic kernel of the same run
     assert sr_["kernel"] == "k_stream_roof" and 0 < sr_["ms_per_launch"] and 0 < sr_["frac_of_peak"] < 1
-    assert abs(r["frac_of_streaming_roof"] - sr_["ms_per_launch"] / d["ms_per_step"]) < 1e-3
+    assert abs(r["frac_of_streaming_roof"] - sr_["ms_per_launch"] / d["ms_per_step"]) < 5e-3      # (both rounded to 0.1 us in the JSON)
     assert d["north_star_target"]["target"] == 0.60 and d["north_star_target"]["read_frac"] == r["read_frac"]
     c = d["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["cores"] == os.cpu_count() and c["value"] > 0 and "sample" in c
