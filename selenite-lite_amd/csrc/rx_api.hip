@@ -263,7 +263,7 @@ extern "C" int selenite_rx_init(selenite_rx_instance **out, const selenite_rx_co
     INITCHK(dev_alloc(&S->d_rerun_flag, cfg->arith == SELENITE_ARITH_AUTO ? C : 0));
     INITCHK(dev_alloc(&S->d_rerun_list, cfg->arith == SELENITE_ARITH_AUTO ? C + 2 : 0));
     if (cfg->arith == SELENITE_ARITH_AUTO && cfg->nd_taps >= 2 && cfg->nh_taps >= 2 &&
-        ssb_split16_has_shape((int)cfg->nd_taps, (int)cfg->decim, (int)cfg->nh_taps) && !std::getenv("SELENITE_RX_NO_HIST_EXT")) {
+        split16_template_nd((int)cfg->nd_taps, (int)cfg->decim, (int)cfg->nh_taps) > 0 && !std::getenv("SELENITE_RX_NO_HIST_EXT")) {
         // k_ssb_split16 leaves the mixed samples in front of the decimator state here (two buffers: the one a channel's state points
         // at stays intact while the next call fills the other), for k_hist_exact
         // (round 4: allocated by the first call that needs it -- 2 x channels x ext_len x 8 bytes, 4 KB per channel for the cfg3 chain --
@@ -329,7 +329,7 @@ static bool periodic_lo(const selenite_rx_instance *S)
     const selenite_rx_config &g = S->cfg;
     if (!(g.nco_enable && S->steps_uniform && (S->h_step[0] & 0x00FFFFFFu) == 0 && !S->no_periodic_lo)) return false;
     if ((g.arith == SELENITE_ARITH_SPLIT16 || g.arith == SELENITE_ARITH_AUTO) && S->plan.d_btab16 && g.nd_taps)
-        return 256u % (g.block / g.decim) == 0 && ssb_split16_periodic_lo((int)g.nd_taps, (int)g.decim, (int)g.nh_taps);
+        return 256u % (g.block / g.decim) == 0 && ssb_split16_periodic_lo(split16_template_nd((int)g.nd_taps, (int)g.decim, (int)g.nh_taps), (int)g.decim, (int)g.nh_taps);
     if (g.arith == SELENITE_ARITH_AUTO) return false;      // (runs the bit-exact k_ssb_fused)
     // k_ssb_mfma (fma arithmetic, and split16 shapes without a matrix kernel of their own): decimation by 4, 1024-sample passes
     return g.arith != SELENITE_ARITH_CMSIS && S->plan.use_mfma && g.nd_taps && g.decim == 4;
@@ -344,7 +344,7 @@ static bool periodic_lo_per_channel(const selenite_rx_instance *S)
     if (!(g.nco_enable && S->steps_grid256 && !S->no_periodic_lo && S->plan.kind != 0)) return false;
     if (256u % (g.block / g.decim) != 0) return false;                       // passes of 256 outputs only
     const bool split = (g.arith == SELENITE_ARITH_SPLIT16 || g.arith == SELENITE_ARITH_AUTO) && S->plan.d_btab16;
-    if (split && g.nd_taps) return ssb_split16_periodic_lo((int)g.nd_taps, (int)g.decim, (int)g.nh_taps);
+    if (split && g.nd_taps) return ssb_split16_periodic_lo(split16_template_nd((int)g.nd_taps, (int)g.decim, (int)g.nh_taps), (int)g.decim, (int)g.nh_taps);
     if (split) return false;                                                 // k_hilb_split16: per-sample NCO (and its AUTO rerun with it)
     const bool exact = g.arith == SELENITE_ARITH_CMSIS || g.arith == SELENITE_ARITH_AUTO;
     return exact || !(S->plan.use_mfma && g.decim == 4);                     // k_ssb_fused; the fma arithmetic by 4 runs k_ssb_mfma

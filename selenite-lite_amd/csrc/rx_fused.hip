@@ -125,11 +125,12 @@ __global__ __launch_bounds__(64 * kMfmaWaves, 2) void k_ssb_mfma(RxParams p, Fus
     // History: flat sample f in [0, HS) is CMSIS state sample s = f - F (older slots meet zero taps)
     float st_x[(2 * GM::HS + 63) / 64], st_d[NH > 0 ? (2 * G::HH4 + 63) / 64 : 1], st_gain;
     uint32_t st_ph0, st_step;
+    const int ndr = (int)p.nd, Fr = G::HQ4 * M + 1 - ndr;             // the instance's decimator may be shorter than the kernel's (k_ssb_fused)
     auto load_state = [&](uint32_t ch) {
-        batched_load<2 * GM::HS>(lane, p.dec_state + (size_t)ch * 2 * (ND - 1),
+        batched_load<2 * GM::HS>(lane, p.dec_state + (size_t)ch * 2 * (ndr - 1),
             [&](int i) {
-                const int rail = i / GM::HS, sidx = i % GM::HS - G::F;
-                return sidx >= 0 ? rail * (ND - 1) + sidx : -1;
+                const int rail = i / GM::HS, sidx = i % GM::HS - Fr;
+                return sidx >= 0 ? rail * (ndr - 1) + sidx : -1;
             }, st_x);
         if constexpr (NH > 0)
             batched_load<2 * G::HH4>(lane, p.fir_state + (size_t)ch * 2 * G::HH,
@@ -308,8 +309,8 @@ __global__ __launch_bounds__(64 * kMfmaWaves, 2) void k_ssb_mfma(RxParams p, Fus
     }
 
     for (int i = lane; i < 2 * GM::HS; i += kWave) {
-        const int rail = i / GM::HS, f = i % GM::HS, s = f - G::F;
-        if (s >= 0) p.dec_state[((size_t)c * 2 + rail) * (ND - 1) + s] = (rail ? XQ : XI)[GM::phys(f)];
+        const int rail = i / GM::HS, f = i % GM::HS, s = f - Fr;
+        if (s >= 0) p.dec_state[((size_t)c * 2 + rail) * (ndr - 1) + s] = (rail ? XQ : XI)[GM::phys(f)];
     }
     if constexpr (NH > 0) {
         if (AM == 0 || fa.am == 2u) {                                 // AM never ran the Hilbert pair: its state stays (FM keeps the delay lines running)
@@ -350,10 +351,67 @@ hipError_t launch_lo_table(float2 *lo, const float *sintab, uint32_t phase0, uin
 // ------------------------------------------------------------------------------------------
 // host side: plan + dispatch
 // ------------------------------------------------------------------------------------------
+// the instantiated shape that serves a configuration: the same decimation ratio and FIR pair, and the SHORTEST decimator that holds the
+// instance's (round 4: any 2 <= nd <= 256 runs on the fused kernels with its taps zero-padded in front; nd = 0 needs nd = 0)
+int fused_template_nd(int nd, int m, int nh)
+{
+    int best = -1;
+#define X(ND_, M_, NH_, ID_) \
+    if (m == M_ && nh == NH_ && (nd == 0 ? ND_ == 0 : (ND_ >= nd && nd >= 2)) && (best < 0 || ND_ < best)) best = ND_;
+    SRX_SHAPES(X)
+#undef X
+    return best;
+}
+// ... and the shortest split-precision decimator (k_ssb_split16 wants an even tap count: its rows for k_hist_exact are pair-aligned)
+int split16_template_nd(int nd, int m, int nh)
+{
+    int best = -1;
+    if (nd < 2 || (nd & 1)) return -1;
+#define X(ND_, M_, NH_) if (m == M_ && nh == NH_ && ND_ >= nd && (best < 0 || ND_ < best)) best = ND_;
+    SRX_SPLIT16_SHAPES(X)
+#undef X
+    return best;
+}
 template <int ND, int M, int NH>
 static bool shape_is(const selenite_rx_config &g)
 {
-    return (int)g.nd_taps == ND && (int)g.decim == M && (int)g.nh_taps == NH;
+    return fused_template_nd((int)g.nd_taps, (int)g.decim, (int)g.nh_taps) == ND && (int)g.decim == M && (int)g.nh_taps == NH;
+}
+
+// SELENITE_ARITH_SPLIT16: the Toeplitz operand of k_ssb_split16<ND, M, NH> -- ND the kernel's decimator length, which may exceed the
+// instance's (split16_template_nd): taps zero-padded in front, scaled by 2^SC (largest |tap| lands in [2^14, 2^15)), split into f16
+// hi + lo; fragment of lane l at k-step kk: 8 halfs B[k = 32kk + 8(l>>4) + j][n = l&15]
+template <int ND, int M, int NH>
+static hipError_t build_split16_table(const selenite_rx_config &g, FusedPlan &plan)
+{
+    using G = Geo<ND, M, NH>;
+    using GS = GeoS<2, ND, M, NH>;
+    const int ndr = (int)g.nd_taps, Fr = G::HQ4 * M + 1 - ndr;
+    std::vector<float> cq((size_t)G::NCQ, 0.0f);
+    for (int k = 0; k < ndr; ++k) cq[(size_t)k + Fr] = g.dec_coeffs[k];
+    float cmax = 0.0f;
+    for (int k = 0; k < ndr; ++k) cmax = std::fmax(cmax, std::fabs(g.dec_coeffs[k]));
+    int ex = 0;
+    if (cmax > 0.0f) std::frexp(cmax, &ex);                       // cmax = m * 2^ex, m in [0.5, 1)
+    const int SC = 15 - ex;                                         // largest |tap| * 2^SC in [2^14, 2^15)
+    std::vector<_Float16> b16((size_t)GS::KS * 2 * 64 * 8, (_Float16)0.0f);
+    for (int kk = 0; kk < GS::KS; ++kk)
+        for (int l = 0; l < 64; ++l)
+            for (int j = 0; j < 8; ++j) {
+                const int idx = 32 * kk + 8 * (l >> 4) + j - M * (l & 15);      // B[k][n] = cq[k - M n]
+                float cv = 0.0f;
+                if (idx >= 0 && idx < G::NCQ) cv = std::ldexp(cq[idx], SC);
+                const _Float16 hi = (_Float16)cv;
+                const _Float16 lo = (_Float16)(cv - (float)hi);
+                b16[(((size_t)2 * kk + 0) * 64 + l) * 8 + j] = hi;
+                b16[(((size_t)2 * kk + 1) * 64 + l) * 8 + j] = lo;
+            }
+    hipError_t e = hipMalloc(&plan.d_btab16, b16.size() * sizeof(_Float16));
+    if (e != hipSuccess) return e;
+    e = hipMemcpy(plan.d_btab16, b16.data(), b16.size() * sizeof(_Float16), hipMemcpyHostToDevice);
+    if (e != hipSuccess) return e;
+    plan.split_sc = SC;
+    return hipSuccess;
 }
 
 template <int ND, int M, int NH>
@@ -362,7 +420,8 @@ static hipError_t build_tables(const selenite_rx_config &g, FusedPlan &plan)
     using G = Geo<ND, M, NH>;
     if constexpr (ND > 0) {
         std::vector<float> cq((size_t)64 * G::NCR, 0.0f);
-        for (int k = 0; k < ND; ++k) cq[(size_t)k + G::F] = g.dec_coeffs[k];
+        const int ndr = (int)g.nd_taps, Fr = G::HQ4 * M + 1 - ndr;      // the instance's taps, zero-padded in front up to the kernel's length
+        for (int k = 0; k < ndr; ++k) cq[(size_t)k + Fr] = g.dec_coeffs[k];
         hipError_t e = hipMalloc((void **)&plan.d_cq, cq.size() * sizeof(float));
         if (e != hipSuccess) return e;
         e = hipMemcpy(plan.d_cq, cq.data(), cq.size() * sizeof(float), hipMemcpyHostToDevice);
@@ -374,41 +433,18 @@ static hipError_t build_tables(const selenite_rx_config &g, FusedPlan &plan)
             for (int ks = 0; ks < GM::KS; ++ks)
                 for (int l = 0; l < 64; ++l) {
                     const int idx = 4 * ks + (l >> 4) - 4 * (l & 15);
-                    if (idx >= 0 && idx <= ND) bt[(size_t)64 * ks + l] = cq[idx];
+                    if (idx >= 0 && idx < G::NCQ) bt[(size_t)64 * ks + l] = cq[idx];
                 }
             e = hipMalloc((void **)&plan.d_btab, bt.size() * sizeof(float));
             if (e != hipSuccess) return e;
             e = hipMemcpy(plan.d_btab, bt.data(), bt.size() * sizeof(float), hipMemcpyHostToDevice);
             if (e != hipSuccess) return e;
         }
-        if constexpr (M == 4 || M == 2) {
-            if (NH > 0 && ssb_split16_has_shape(ND, M, NH)) {
-                // SELENITE_ARITH_SPLIT16: taps scaled by 2^SC (largest |tap| lands in [2^14, 2^15)), split into
-                // f16 hi + lo; fragment of lane l at k-step kk: 8 halfs B[k = 32kk + 8(l>>4) + j][n = l&15]
-                using GS = GeoS<2, ND, M, NH>;
-                float cmax = 0.0f;
-                for (int k = 0; k < ND; ++k) cmax = std::fmax(cmax, std::fabs(g.dec_coeffs[k]));
-                int ex = 0;
-                if (cmax > 0.0f) std::frexp(cmax, &ex);                       // cmax = m * 2^ex, m in [0.5, 1)
-                const int SC = 15 - ex;                                         // largest |tap| * 2^SC in [2^14, 2^15)
-                std::vector<_Float16> b16((size_t)GS::KS * 2 * 64 * 8, (_Float16)0.0f);
-                for (int kk = 0; kk < GS::KS; ++kk)
-                    for (int l = 0; l < 64; ++l)
-                        for (int j = 0; j < 8; ++j) {
-                            const int idx = 32 * kk + 8 * (l >> 4) + j - M * (l & 15);      // B[k][n] = cq[k - M n]
-                            float cv = 0.0f;
-                            if (idx >= 0 && idx < G::NCQ) cv = std::ldexp(cq[idx], SC);
-                            const _Float16 hi = (_Float16)cv;
-                            const _Float16 lo = (_Float16)(cv - (float)hi);
-                            b16[(((size_t)2 * kk + 0) * 64 + l) * 8 + j] = hi;
-                            b16[(((size_t)2 * kk + 1) * 64 + l) * 8 + j] = lo;
-                        }
-                e = hipMalloc(&plan.d_btab16, b16.size() * sizeof(_Float16));
-                if (e != hipSuccess) return e;
-                e = hipMemcpy(plan.d_btab16, b16.data(), b16.size() * sizeof(_Float16), hipMemcpyHostToDevice);
-                if (e != hipSuccess) return e;
-                plan.split_sc = SC;
-            }
+        if (NH > 0) {                                                 // the split-precision decimator's operand, for ITS shape
+            const int nds = split16_template_nd(ndr, M, NH);
+#define X(ND_, M_, NH_) if (nds == ND_ && M == M_ && NH == NH_) return build_split16_table<ND_, M_, NH_>(g, plan);
+            SRX_SPLIT16_SHAPES(X)
+#undef X
         }
         return hipSuccess;
     }
@@ -508,7 +544,8 @@ static hipError_t launch_shape(const RxParams &p, const FusedArgs &fa, const Fus
     // partial last pass that holds a whole decimator history (k_ssb_split16).  Everything else -- short calls, the firmware's
     // 96-frame blocks -- runs on k_ssb_fused, whose passes have variable length.
     const bool whole = fa.pass_out == 256 && p.nout % 256 == 0;
-    constexpr uint32_t kHS = ND ? (uint32_t)(((((ND - 1 + M - 1) / M) + 3) & ~3) * M) : 0u;      // GeoS::HS: decimator history in the image
+    const int nds = ND > 0 ? split16_template_nd((int)p.nd, M, NH) : -1;               // the split-precision kernel's decimator length (>= the instance's), or -1
+    const uint32_t kHS = nds > 0 ? (uint32_t)(((((nds - 1 + M - 1) / M) + 3) & ~3) * M) : 0u;      // GeoS::HS: decimator history in the image
     // k_ssb_split16 also takes passes of fewer than 256 outputs when they are whole 16-output tiles (240 for the firmware's
     // 96-frame blocks by 4, 192 for its 96-sample audio blocks): its run-time DSP-block flavour advances by pass_out * M samples
     const uint32_t tq = fa.pass_out * M;
@@ -519,7 +556,7 @@ static hipError_t launch_shape(const RxParams &p, const FusedArgs &fa, const Fus
     // repaired by k_hist_exact.  Shorter calls (the firmware's literal one-slot callback, a tail cut off by fused_tail_split) run on the
     // bit-exact kernel, from a history repaired first (below): they are state-traffic bound either way.  With the repair switched
     // off (a diagnostic: selenite_rx_set_handover_repair) nothing is kept and such calls stay on the matrix kernel, counted.
-    const bool auto_ok = !auto_ || p.hist_ext == nullptr || p.block_size + 1u >= (uint32_t)(ND > 0 ? ND - 1 : 0) + p.ext_len;
+    const bool auto_ok = !auto_ || p.hist_ext == nullptr || p.block_size + 1u >= (uint32_t)(ND > 0 ? p.nd - 1 : 0) + p.ext_len;
     if constexpr (ND > 0 && (M == 4 || M == 2) && NH > 0) {
         if (split && plan.d_btab16 && split_ok && auto_ok) {
             if (auto_ && fa.am == 1u && p.rerun_flag) {
@@ -530,7 +567,7 @@ static hipError_t launch_shape(const RxParams &p, const FusedArgs &fa, const Fus
                 p3.chan_list = nullptr; p3.chan_count_next = nullptr;
                 if (hipError_t e = launch_hist_exact(p3, true, st); e != hipSuccess) return e;
             }
-            hipError_t e = launch_ssb_split16(ND, M, NH, p, fa, src, src_q15, dst, st);      // rx_split16.hip
+            hipError_t e = launch_ssb_split16(nds, M, NH, p, fa, src, src_q15, dst, st);     // rx_split16.hip
             if (e == hipSuccess && auto_ && p.rerun_flag) e = rerun();
             return e;
         }
@@ -648,7 +685,9 @@ bool fused_tail_split(const FusedPlan &plan, const selenite_rx_config &g, uint32
     if (!(g.arith == SELENITE_ARITH_SPLIT16 || g.arith == SELENITE_ARITH_AUTO) || !plan.d_btab16 || !g.nd_taps) return false;
     const uint32_t na = g.block / g.decim, pq = 256u / na * na, unit = pq * g.decim;
     if (!split16_pass_ok(pq) || block_size % unit == 0 || block_size < unit) return false;
-    const uint32_t hq = (g.nd_taps - 1 + g.decim - 1) / g.decim, hs = ((hq + 3) & ~3u) * g.decim;    // GeoS::HS
+    const int nds = split16_template_nd((int)g.nd_taps, (int)g.decim, (int)g.nh_taps);
+    if (nds < 0) return false;
+    const uint32_t hq = ((uint32_t)nds - 1 + g.decim - 1) / g.decim, hs = ((hq + 3) & ~3u) * g.decim;    // GeoS::HS
     return block_size % unit < hs;
 }
 

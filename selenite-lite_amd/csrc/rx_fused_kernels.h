@@ -203,6 +203,11 @@ __global__ __launch_bounds__(64, 2) void k_ssb_fused(RxParams p, FusedArgs fa, c
     using G = Geo<ND, M, NH>;
     const uint32_t NCO = fa.nco;                         // wave-uniform
     constexpr int AM = 2;                                // demod_agc_store: look at fa.am
+    // Round 4: the decimator of the INSTANCE may be shorter than the kernel's (p.nd <= ND: the host picks the smallest instantiated
+    // shape that holds it and pads the taps with zeros in front -- older samples times +0.0f leave a finite accumulator alone, the
+    // structural-zero argument of DESIGN.md section 3).  What changes is the state: p.nd - 1 samples per rail, sitting Fr slots into the
+    // kernel's history.
+    const int ndr = ND > 0 ? (int)p.nd : 0, Fr = ND > 0 ? G::HQ4 * M + 1 - ndr : 0;
     using R = BRaw<TIn>;
     static_assert(ND == 0 ? M == 1 : (M == 2 || M == 4 || M == 8), "fused kernel: no decimator, or decimate by 2, 4 or 8");
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -276,10 +281,10 @@ __global__ __launch_bounds__(64, 2) void k_ssb_fused(RxParams p, FusedArgs fa, c
     if constexpr (ND > 0) {
         // history element (phase pp, index m) holds sample s = (m*M + pp) - F of the CMSIS state
         // (oldest first); slots before the state (s < 0) only ever meet zero-padded taps
-        batched_fill<2 * M * G::HQ4>(lane, p.dec_state + (size_t)c * 2 * (ND - 1),
+        batched_fill<2 * M * G::HQ4>(lane, p.dec_state + (size_t)c * 2 * (ndr - 1),
             [&](int i) {
-                const int rail = i / (M * G::HQ4), sidx = i % (M * G::HQ4) - G::F;
-                return sidx >= 0 ? rail * (ND - 1) + sidx : -1;
+                const int rail = i / (M * G::HQ4), sidx = i % (M * G::HQ4) - Fr;
+                return sidx >= 0 ? rail * (ndr - 1) + sidx : -1;
             },
             [&](int i, float v) {
                 const int rail = i / (M * G::HQ4), rem = i % (M * G::HQ4);
@@ -456,8 +461,8 @@ __global__ __launch_bounds__(64, 2) void k_ssb_fused(RxParams p, FusedArgs fa, c
     if constexpr (ND > 0) {
         for (int i = lane; i < 2 * M * G::HQ4; i += kWave) {
             const int rail = i / (M * G::HQ4), rem = i % (M * G::HQ4);
-            const int s = rem - G::F, pp = rem % M, m = rem / M;
-            if (s >= 0) p.dec_state[((size_t)c * 2 + rail) * (ND - 1) + s] = S[pp * G::PSF + G::elem(m) + rail];
+            const int s = rem - Fr, pp = rem % M, m = rem / M;
+            if (s >= 0) p.dec_state[((size_t)c * 2 + rail) * (ndr - 1) + s] = S[pp * G::PSF + G::elem(m) + rail];
         }
     }
     if constexpr (NH > 0) {

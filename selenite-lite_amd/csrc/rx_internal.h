@@ -149,6 +149,9 @@ bool fused_tail_split(const FusedPlan &plan, const selenite_rx_config &cfg, uint
 hipError_t launch_fused(const FusedPlan &plan, const RxParams &p, int arith, const void *src,
                         bool src_q15, void *dst, bool dst_q15, int delay_index, hipStream_t st);
 
+// the instantiated decimator length that serves an instance of nd taps (its taps zero-padded in front): fused kernels / k_ssb_split16; -1: none
+int fused_template_nd(int nd, int m, int nh);
+int split16_template_nd(int nd, int m, int nh);
 // true when k_ssb_split16 of this shape has the periodic-LO flavour (a pass is a whole number of 256-sample periods)
 bool ssb_split16_periodic_lo(int nd, int m, int nh);
 // true when rx_split16.hip instantiates k_ssb_split16 for this shape

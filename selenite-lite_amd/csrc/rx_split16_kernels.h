@@ -206,6 +206,9 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
     // z[n] conj(z[n-1]) on the decimated rails, z[-1] of a pass = the newest entry of the FIR pair's delay lines, which FM keeps running
     // (history moves, state write-back and the samples for k_hist_exact as in the SSB modes).  `keeps` = the FIR-pair history moves.
     const bool fm = AM != 0 && fa.am == 2u;                       // wave-uniform
+    // (round 4) the instance's decimator may be shorter than the kernel's: p.nd <= ND taps, zero-padded in front (rx_fused.hip:
+    // split16_template_nd); the state holds p.nd - 1 samples per rail, Fr slots into the kernel's history
+    const int ndr = (int)p.nd, Fr = G::HQ4 * M + 1 - ndr;
     const bool keeps = AM == 0 || fm;
     // persistent: this workgroup runs channels blockIdx.x, blockIdx.x + gridDim.x, ... -- in SELENITE_ARITH_AUTO minus the channels the
     // exact kernel HOLDS (kFlagHold, round 4: a channel that was recomputed stays with the exact kernel until a call of it shows no
@@ -362,11 +365,11 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
     uint32_t st_ph0, st_step, st_word;
     auto load_state = [&](uint32_t ch) {
         ch = ch < p.channels ? ch : p.channels - 1;               // past the last channel: harmless reload, never installed
-        const float *stI = p.dec_state + (size_t)ch * 2 * (ND - 1), *stQ = stI + (ND - 1);
+        const float *stI = p.dec_state + (size_t)ch * 2 * (ndr - 1), *stQ = stI + (ndr - 1);
         const float *stF = p.fir_state + (size_t)ch * 2 * G::HH;
 #pragma unroll
         for (int j = 0; j < NHI; ++j) {
-            const int s = j * kWave + lane - G::F, sc = s < 0 ? 0 : s;
+            const int s = j * kWave + lane - Fr, sc = s < 0 ? 0 : s;
             const float xi = st_ld(stI + sc), xq = st_ld(stQ + sc);
             st_hv[j] = s < 0 ? v2f{ 0.0f, 0.0f } : v2f{ xi, xq };
         }
@@ -389,7 +392,7 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
     // one -- the two samples of a lane leave in ONE 16-byte store that never straddles the window, a row is ext_len * 8 bytes of
     // whole cache lines -- which costs nothing: the oldest M (HH4 - HH) >= 2 samples of the nominal window meet no tap)
     static_assert(ND % 2 == 0 && M * (G::HH4 - G::HH) >= 1, "hist_ext rows are pair-aligned for even tap counts");
-    const int ext_start = (int)p.block_size - (ND - 1) - (int)p.ext_len + 1;  // call-relative position of hist_ext[0]
+    const int ext_start = (int)p.block_size - (ndr - 1) - (int)p.ext_len + 1; // call-relative position of hist_ext[0] (even: p.nd is)
     // (AM never touches the Hilbert-pair history: it keeps no samples either, and what it hands on is the provenance it found --
     // degraded to "matrix kernel, no samples" when it was "with samples", because the decimator state moves on without them)
     const bool ext_on = keeps && p.hist_ext != nullptr && ext_start >= 0;     // wave-uniform
@@ -875,10 +878,10 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
         // ---- streaming state of the channel back to HBM (exact f32) ----
         lds_order();
         if (!keep_state) {
-            float *stI = p.dec_state + (size_t)c * 2 * (ND - 1), *stQ = stI + (ND - 1);
+            float *stI = p.dec_state + (size_t)c * 2 * (ndr - 1), *stQ = stI + (ndr - 1);
 #pragma unroll
             for (int j = 0; j < GS::HS / kWave; ++j) {
-                const int s = j * kWave + lane - G::F;
+                const int s = j * kWave + lane - Fr;
                 const v2f h = Hf[j * kWave + lane];
                 if (s >= 0) { st_st(stI + s, h.x); st_st(stQ + s, h.y); }
             }
