@@ -104,7 +104,11 @@ __device__ __forceinline__ void agc_pass(const AgcParams &ap, uint32_t agc_on, i
     auto guard = [&](float env) {                    // env: the block envelope, in (at least) the first lane of every block
         const int lanes = nvb * (GROUP ? GROUP : group);
         const uint64_t exist = lanes >= 64 ? ~0ull : ((1ull << lanes) - 1ull);
+#ifdef SRX_X_GUARD1      // timing experiment: the round-3 guard (one threshold)
+        const uint64_t hit = __builtin_amdgcn_ballot_w64(env < gd.thr) & gd.first & exist;
+#else
         const uint64_t hit = (__builtin_amdgcn_ballot_w64(env < gd.thr) | (__builtin_amdgcn_ballot_w64(env < gd.thr_h) & gd.hm)) & gd.first & exist;
+#endif
         gd.n += (uint32_t)__builtin_popcountll(hit);
         gd.nh += (uint32_t)__builtin_popcountll(hit & gd.hist);
     };
@@ -207,28 +211,28 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
     // (history moves, state write-back and the samples for k_hist_exact as in the SSB modes).  `keeps` = the FIR-pair history moves.
     const bool fm = AM != 0 && fa.am == 2u;                       // wave-uniform
     // (round 4) the instance's decimator may be shorter than the kernel's: p.nd <= ND taps, zero-padded in front (rx_fused.hip:
-    // split16_template_nd); the state holds p.nd - 1 samples per rail, Fr slots into the kernel's history
-    const int ndr = (int)p.nd, Fr = G::HQ4 * M + 1 - ndr;
+    // split16_template_nd); the state holds p.nd - 1 samples per rail, Fr = HQ4 M + 1 - p.nd slots into the kernel's history
     const bool keeps = AM == 0 || fm;
     // persistent: this workgroup runs channels blockIdx.x, blockIdx.x + gridDim.x, ... -- in SELENITE_ARITH_AUTO minus the channels the
     // exact kernel HOLDS (kFlagHold, round 4: a channel that was recomputed stays with the exact kernel until a call of it shows no
     // block near the guard ratio; the matrix kernel does not touch it -- no loads, no passes, its word stays).  The words of the next
     // 64 candidates are read with one wave load and kept as a scalar bit mask (bit k: channel ch_lo + k gridDim.x is ours).
-    uint64_t ch_mask = 0ull, ch_hi = blockIdx.x;
-    uint32_t ch_lo = 0u;
-    auto ch_scan = [&](uint32_t &w, bool &mine) {                 // issue: the words of the 64 candidates from ch_hi on
-        const uint64_t ci = ch_hi + (uint64_t)lane * gridDim.x;
+    // (ch_lo: channel of the mask's bit 0; the next scan starts 64 candidates on -- saturating at the channel count, which fits 32 bits)
+    uint64_t ch_mask = 0ull;
+    uint32_t ch_lo = blockIdx.x;
+    auto ch_scan = [&](uint32_t &w, bool &mine) {                 // issue: the words of the 64 candidates from ch_lo on
+        const uint64_t ci = (uint64_t)ch_lo + (uint64_t)lane * gridDim.x;
         mine = ci < (uint64_t)p.channels;
         w = p.rerun_flag != nullptr ? p.rerun_flag[mine ? ci : 0] : 0u;
     };
     auto ch_take = [&](uint32_t w, bool mine) {                   // consume
         ch_mask = __builtin_amdgcn_ballot_w64(mine && (w & kFlagHold) == 0u);
-        ch_lo = (uint32_t)ch_hi;
-        ch_hi += 64ull * gridDim.x;
     };
     auto ch_next = [&]() -> uint32_t {                            // the next channel of this workgroup, or p.channels when there is none
         while (ch_mask == 0ull) {                                 // wave-uniform; the first mask is taken below, a reload happens after 64 candidates
-            if (ch_hi >= (uint64_t)p.channels) return p.channels;
+            const uint64_t nx = (uint64_t)ch_lo + 64ull * gridDim.x;
+            if (nx >= (uint64_t)p.channels) return p.channels;
+            ch_lo = (uint32_t)nx;
             uint32_t w; bool mine;
             ch_scan(w, mine);
             ch_take(w, mine);
@@ -239,25 +243,9 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
     };
     uint32_t w_first; bool mine_first;
     ch_scan(w_first, mine_first);                                 // (in flight under the fragment loads below)
-    // Toeplitz B fragments (8 halfs per lane): [kk][hi/lo]
-    h8 Bh[GS::KS], Bl[GS::KS];
-    {
-        const h8 *bt = static_cast<const h8 *>(fa.btab16);
-#pragma unroll
-        for (int kk = 0; kk < GS::KS; ++kk) {
-            Bh[kk] = bt[(2 * kk + 0) * 64 + lane];
-            Bl[kk] = bt[(2 * kk + 1) * 64 + lane];
-        }
-    }
-    // Hilbert taps: wave-uniform values held in scalar registers for the whole kernel (only the structurally
-    // non-zero ones are ever referenced: (NH + 1) / 2 SGPRs), so a tap costs no v_readlane per pass
-    float hreg[(NH + 63) / 64];
-#pragma unroll
-    for (int v = 0; v < (NH + 63) / 64; ++v) hreg[v] = (64 * v + lane < NH) ? p.hilb_c[64 * v + lane] : 0.0f;
-    ch_take(w_first, mine_first);
-    uint32_t c = ch_next();
-    if (c >= p.channels) return;                                  // (every channel of this workgroup is held)
-    uint32_t c_nx = ch_next();
+    // (the first channel of the sequence is blockIdx.x unless the exact kernel holds it: its first pass is prefetched at once, as in round 3,
+    // and prefetched again for the right channel in that rare case -- waiting for the words first cost 1 % of the headline)
+    uint32_t c = blockIdx.x, c_nx = 0u;
 #ifdef SRX_STAMP       // diagnostics build (make STAMP=1): s_memtime stamps of one wave in 1024 (tools/stamp_split16.py)
     unsigned long long *stamp_p = (fa.dbg && (c & 1023u) == 511u) ? fa.dbg + (c >> 10) * 64 : nullptr;
     int stamp_i = 0;
@@ -294,7 +282,7 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
     auto in_rsrc = [&](uint32_t ch) {                             // a channel past the last one: empty range, loads return zeros
         return make_rsrc(src + (size_t)ch * p.in_stride * 2, ch < p.channels ? p.block_size * (R::kBytes / 2) : 0u);
     };
-    __amdgpu_buffer_rsrc_t rs_in = in_rsrc(c), rs_in_next = in_rsrc(c_nx);
+    __amdgpu_buffer_rsrc_t rs_in = in_rsrc(c), rs_in_next = in_rsrc(c);      // (rs_in_next: set once the channel sequence is known)
     __amdgpu_buffer_rsrc_t rs_out = make_rsrc(dst + (size_t)c * p.out_stride, p.nout * (W::kBytes / 4));
     // global gain, phase 1: the kernel runs with its own AGC off and leaves max |audio| of every DSP block of every channel
     // behind, so the envelope reduction does not have to read the audio again (GROUP == 16 launches with whole passes only)
@@ -342,6 +330,39 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
 #endif
     };
     prefetch(0);
+    // Toeplitz B fragments (8 halfs per lane): [kk][hi/lo]
+    h8 Bh[GS::KS], Bl[GS::KS];
+    {
+        const h8 *bt = static_cast<const h8 *>(fa.btab16);
+#pragma unroll
+        for (int kk = 0; kk < GS::KS; ++kk) {
+            Bh[kk] = bt[(2 * kk + 0) * 64 + lane];
+            Bl[kk] = bt[(2 * kk + 1) * 64 + lane];
+        }
+    }
+    // Hilbert taps: wave-uniform values held in scalar registers for the whole kernel (only the structurally
+    // non-zero ones are ever referenced: (NH + 1) / 2 SGPRs), so a tap costs no v_readlane per pass
+    float hreg[(NH + 63) / 64];
+#pragma unroll
+    for (int v = 0; v < (NH + 63) / 64; ++v) hreg[v] = (64 * v + lane < NH) ? p.hilb_c[64 * v + lane] : 0.0f;
+    ch_take(w_first, mine_first);
+#ifdef SRX_X_STRIDE      // timing experiment: the round-3 channel sequence (no hold bits)
+    c_nx = blockIdx.x + gridDim.x;
+#else
+    {
+        const uint32_t c_real = ch_next();
+        if (c_real >= p.channels) return;                         // (every channel of this workgroup is held)
+        if (c_real != c) {                                        // wave-uniform, rare
+            c = c_real;
+            rs_in = in_rsrc(c);
+            rs_out = make_rsrc(dst + (size_t)c * p.out_stride, p.nout * (W::kBytes / 4));
+            if constexpr (ENV != 0) rs_env = env_rsrc(c);
+            prefetch(0);
+        }
+        c_nx = ch_next();
+    }
+#endif
+    rs_in_next = in_rsrc(c_nx);
 
 #if SRX_HS_SGPR
     float hs[NH];
@@ -364,6 +385,7 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
     float st_fv[NFI], st_gain;
     uint32_t st_ph0, st_step, st_word;
     auto load_state = [&](uint32_t ch) {
+        const int ndr = (int)p.nd, Fr = G::HQ4 * M + 1 - ndr;
         ch = ch < p.channels ? ch : p.channels - 1;               // past the last channel: harmless reload, never installed
         const float *stI = p.dec_state + (size_t)ch * 2 * (ndr - 1), *stQ = stI + (ndr - 1);
         const float *stF = p.fir_state + (size_t)ch * 2 * G::HH;
@@ -392,7 +414,7 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
     // one -- the two samples of a lane leave in ONE 16-byte store that never straddles the window, a row is ext_len * 8 bytes of
     // whole cache lines -- which costs nothing: the oldest M (HH4 - HH) >= 2 samples of the nominal window meet no tap)
     static_assert(ND % 2 == 0 && M * (G::HH4 - G::HH) >= 1, "hist_ext rows are pair-aligned for even tap counts");
-    const int ext_start = (int)p.block_size - (ndr - 1) - (int)p.ext_len + 1; // call-relative position of hist_ext[0] (even: p.nd is)
+    const int ext_start = (int)p.block_size - ((int)p.nd - 1) - (int)p.ext_len + 1; // call-relative position of hist_ext[0] (even: p.nd is)
     // (AM never touches the Hilbert-pair history: it keeps no samples either, and what it hands on is the provenance it found --
     // degraded to "matrix kernel, no samples" when it was "with samples", because the decimator state moves on without them)
     const bool ext_on = keeps && p.hist_ext != nullptr && ext_start >= 0;     // wave-uniform
@@ -401,8 +423,11 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
     float gain = 1.0f;
     int s_cur = 0x7fff;                                               // sample scale exponent of the images (none yet)
     // parity guard (GuardPass): thresholds of the pass being mixed and of the pass before it (whose demodulator runs later)
-    float thr_cur = 0.0f, thr_prev = 0.0f, thrh_cur = 0.0f, thrh_prev = 0.0f;
-    uint32_t b_prev = 0u;                                             // what the pass before this one held (bit pattern); at a call's start: from the channel's word
+    // thresholds (guard ratio x pass maximum) of the pass being mixed, of the one before it (whose demodulator runs under this pass's
+    // matrix stage) and of the one before that (its first blocks read Hilbert-pair history from there); at a call's start thr_prev
+    // comes from the level in the channel's word.  b_last: bit pattern of the last pass's maximum, for that word.
+    float thr_cur = 0.0f, thr_prev = 0.0f, thr_pp = 0.0f;
+    uint32_t b_last = 0u;
     GuardPass gd;
     gd.thr = 0.0f; gd.n = 0u; gd.hist = 0ull; gd.nh = 0u; gd.thr_h = 0.0f;
     if constexpr (GROUP == 16) gd.first = 0x0001000100010001ull;
@@ -417,6 +442,10 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
     const uint64_t hist_mask = hist_lanes >= 64 ? ~0ull : ((1ull << hist_lanes) - 1ull);
     // (AM reads no history at all; FM one sample of it, z[-1]: the first DSP block of a pass)
     gd.hm = AM == 0 ? hist_mask : (fm ? ((GROUP ? GROUP : (int)fa.group) >= 64 ? ~0ull : ((1ull << (GROUP ? GROUP : (int)fa.group)) - 1ull)) : 0ull);
+    if constexpr (GROUP != 0 && AM == 0) {                            // a compile-time constant where the DSP-block geometry is one (no scalar registers)
+        constexpr int hl = ((G::HH + 4 * GROUP - 1) / (4 * GROUP)) * GROUP;
+        gd.hm = hl >= 64 ? ~0ull : ((1ull << hl) - 1ull);
+    }
     auto install_state = [&]() {
         float mh = 0.0f;
 #pragma unroll
@@ -433,7 +462,8 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
         ph0 = st_ph0; step = st_step; gain = st_gain;
         s_cur = 0x7fff;
         gd.n = 0u; gd.nh = 0u;
-        b_prev = st_word & kLvlMask;
+        thr_cur = __uint_as_float(st_word & kLvlMask) * p.guard_ratio;     // ("the pass before pass 0": shifted into thr_prev by mix(0))
+        thr_prev = 0.0f;
         prev_prov = (st_word >> kProvShift) & kProvMask; prev_buf = (st_word >> kExtBufShift) & 1u; st_word_cur = st_word;
         if (ext_on)                                                   // the buffer the state of the call before does NOT point at
             rs_ext = make_rsrc(p.hist_ext + (size_t)(prev_buf ^ 1u) * p.ext_buf_stride + (size_t)c * p.ext_len, p.ext_len * (sizeof(TIn) == 2 ? 4u : 8u));
@@ -525,7 +555,10 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
         if (ext_on && (int)(n0 + G::T) > ext_start) {                 // wave-uniform: the last one or two passes of the call
 #pragma unroll
             for (int i = 0; i < NLD; ++i) {
-                const int e0 = (int)n0 + 128 * i - ext_start;         // row index of the load's first sample (even)
+                int e0 = (int)n0 + 128 * i - ext_start;               // row index of the load's first sample (even)
+                // (opaque to the optimizer: the passes that meet the window are the same for every channel, and the eight lane offsets below,
+                // hoisted out of the channel loop, cost the kernel its last free registers -- 40 bytes of scratch in a kernel that had none)
+                asm volatile("" : "+s"(e0));
                 if (e0 + 128 > 0 && e0 < (int)p.ext_len) {        // wave-uniform: this load meets the window (pairs outside it: out of range, dropped)
                     if constexpr (sizeof(TIn) == 2) {                 // int16 slots: the raw samples as they came (half the bytes; the NCO phase of every one is known)
                         __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2v, raw[i]), rs_ext, (e0 + 2 * lane) * 4, 0, SRX_EXT_AUX);
@@ -546,10 +579,9 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
         const uint32_t b_tail = wave_umax_bits(mt);
         const uint32_t b_need = max(max(wave_umax_bits(mh), b_tail), b_hist);       // the largest |component| the pass's images hold
         const uint32_t e_need = b_need >> 23;
-        thr_prev = thr_cur; thrh_prev = thrh_cur;
+        thr_pp = thr_prev; thr_prev = thr_cur;
         thr_cur = __uint_as_float(b_need) * p.guard_ratio;
-        thrh_cur = __uint_as_float(max(b_need, b_prev)) * p.guard_ratio;
-        b_prev = b_need;
+        b_last = b_need;
         // largest |component| * 2^s in [2^14, 2^15):  s = 14 - (E - 127); 2^s must itself be a normal float
         int s_new = 141 - (int)e_need;
         s_new = s_new > 127 ? 127 : (s_new < -126 ? -126 : s_new);
@@ -837,7 +869,7 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
             u4v cb[NCB];
             v4f dt = { 0.0f, 0.0f, 0.0f, 0.0f };
             if (keeps) dt = *reinterpret_cast<const v4f *>(D + dt_off + pq);      // (the pass before this one was a full one)
-            gd.thr = thr_prev; gd.thr_h = thrh_prev;                  // the demodulator below belongs to the pass before
+            gd.thr = thr_prev; gd.thr_h = fmaxf(thr_prev, thr_pp);    // the demodulator below belongs to the pass before
             gd.hist = pass == 1 ? hist_mask : 0ull;
             const int nvb_full = GROUP == 0 ? (int)(pq / (4u * (uint32_t)group)) : 64;
             mfma_phase([&](int kk) { demod_piece(kk, au, nvb_full); }, (NTS + TPK - 1) / TPK - 1);   // matrix pipe over the vector work of the pass before
@@ -851,7 +883,7 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
         }
         store_audio(npass - 2, au);
         load_state(c_nx);                                             // the next channel's state, under this channel's last demodulator pass
-        gd.thr = thr_cur; gd.thr_h = thrh_cur;
+        gd.thr = thr_cur; gd.thr_h = fmaxf(thr_cur, thr_prev);
         gd.hist = npass == 1 ? hist_mask : 0ull;
         demod(au, (int)(tail_out / (4u * (uint32_t)group)));          // DSP blocks of the last pass that exist
         store_audio(npass - 1, au);
@@ -872,12 +904,13 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
                 // (kept on the matrix kernel: the level of the last pass goes with the state -- the first blocks of the next call read
                 // Hilbert-pair history computed from those samples; rounded up to the 24 bits the word has room for)
                 p.rerun_flag[c] = keep_state ? (kFlagRerun | (st_word_cur & (kExtQ15 | (kProvMask << kProvShift) | (1u << kExtBufShift))))
-                                             : (kept | ((b_prev + 0xFFu) & kLvlMask));
+                                             : (kept | ((b_last + 0xFFu) & kLvlMask));
             }
         }
         // ---- streaming state of the channel back to HBM (exact f32) ----
         lds_order();
         if (!keep_state) {
+            const int ndr = (int)p.nd, Fr = G::HQ4 * M + 1 - ndr;
             float *stI = p.dec_state + (size_t)c * 2 * (ndr - 1), *stQ = stI + (ndr - 1);
 #pragma unroll
             for (int j = 0; j < GS::HS / kWave; ++j) {
@@ -887,8 +920,10 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
             }
         }
         if (keeps) {                                                  // AM never ran the Hilbert pair: its state stays (FM keeps the delay lines running)
+            int lane_o = lane;                                        // (opaque: the per-lane 64-bit offsets of this loop, hoisted out of the channel
+            asm volatile("" : "+v"(lane_o));                          // loop, were the kernel's only scratch -- and a kernel with scratch pays ~12 us per launch)
             if (!keep_state)
-                for (int i = lane; i < 2 * G::HH4; i += kWave) {
+                for (int i = lane_o; i < 2 * G::HH4; i += kWave) {
                     const int rail = i / G::HH4, mi = i % G::HH4, s = mi - G::FH;
                     if (s >= 0) st_st(p.fir_state + ((size_t)c * 2 + rail) * G::HH + s, D[rail * G::DLEN + tail_out + mi]);
                 }
@@ -899,7 +934,11 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
         }
         c = c_nx;
         if (c >= p.channels) break;
+#ifdef SRX_X_STRIDE
+        c_nx = c + gridDim.x;
+#else
         c_nx = ch_next();
+#endif
         lds_order();                                                  // the state reads above before the next channel's installs
         rs_in = rs_in_next;
         rs_in_next = in_rsrc(c_nx);
