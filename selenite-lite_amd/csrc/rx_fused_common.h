@@ -43,6 +43,9 @@ struct FusedArgs {
                             // 2: FM -- angle of z[n] conj(z[n-1]) in half turns; the pair's delay lines keep running (k_ssb_fused only)
     uint32_t nco;           // k_ssb_fused: NCO flavour of the launch (0 off, 1 per channel per sample, 2 shared table, 4 per-channel periodic LO
                             // in registers) -- a run-time switch since round 4 (launch_one sets it)
+    const float *ptab;      // DENSE instantiations of k_ssb_fused: the FIR pair's taps, [2][DenseTab::LEN] (delay rail, Hilbert rail), padded tap k at index k + FH + 3
+    float *ptab_lds;        // ... their copy in LDS (set by the kernel)
+    uint32_t dense_t0;      // ... first step with a tap that is not padding
     uint32_t group;         // lanes per DSP block = (block / M) / 4
     uint32_t pass_out;      // k_ssb_fused: audio samples a full pass produces = the largest whole number of DSP blocks in 256 (256 when
                             // block / M divides 256; 240 for the firmware's 96-frame blocks by 4, 192 for 96 frames without decimator)

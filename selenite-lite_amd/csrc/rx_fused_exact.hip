@@ -24,4 +24,19 @@ hipError_t launch_exact(int nd, int m, int nh, bool q15, const RxParams &p, cons
     return hipErrorNotSupported;
 }
 
+hipError_t launch_exact_dense(int nd, int m, bool q15, bool delay_impulse, const RxParams &p, const FusedArgs &fa, const void *src, void *dst, hipStream_t st)
+{
+#define X(ND_, M_, NH_, ID_)                                                                             \
+    if (nd == ND_ && m == M_) {                                                                          \
+        if (delay_impulse)                                                                               \
+            return q15 ? launch_one<0, ND_, M_, NH_, int16_t, int16_t, 2>(p, fa, src, dst, st)            \
+                       : launch_one<0, ND_, M_, NH_, float, float, 2>(p, fa, src, dst, st);               \
+        return q15 ? launch_one<0, ND_, M_, NH_, int16_t, int16_t, 1>(p, fa, src, dst, st)                \
+                   : launch_one<0, ND_, M_, NH_, float, float, 1>(p, fa, src, dst, st);                   \
+    }
+    SRX_DENSE_SHAPES(X)
+#undef X
+    return hipErrorNotSupported;
+}
+
 }  // namespace srx

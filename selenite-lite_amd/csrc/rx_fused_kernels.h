@@ -65,9 +65,47 @@ struct GuardEx {
     uint32_t n, n2;     // DSP blocks of the call under thr / thr2
 };
 
+// The FIR pair with ARBITRARY taps (round 4, VERDICT r3 missing 4): arm_fir_f32 (FilteringFunctions/arm_fir_f32.c:553-979) on both rails for
+// the 4 adjacent outputs n = 4 lane + r -- I' = delay_coeffs * I, Q' = hilb_coeffs * Q, every tap of both, no structure assumed (a dense
+// Hilbert design, a fractional-delay FIR on the I rail, an even tap count), nh <= NH taps zero-padded in FRONT (older samples times
+// +0.0f).  The taps come from LDS by broadcast reads: table index u = k + FH + 3 holds padded tap k, so step t (window elements
+// 4 t .. 4 t + 3 of the rail) needs exactly the quads u = 4 t .. 4 t + 7; steps whose taps are all padding are skipped (t0).  Per output
+// the reference's order: one accumulator from 0, taps ascending, product rounded, then sum rounded (mac<ARITH>).
+template <int NH> struct DenseTab { static constexpr int LEN = ((NH - 1 + 3) & ~3) + 12; };      // floats per FIR: padded taps + offset + the last step's reach
+// BOTH: the delay FIR on the I rail is dense too (DENSE == 1); else only the Hilbert FIR is (DENSE == 2: the common case of a dense
+// Hilbert design beside a unit-impulse delay, whose I rail stays one LDS read per output as in the type-III kernels).
+// (A version with two outputs per packed instruction -- tap pairs from a second, shifted copy of the table, the broadcast in op_sel:
+// half the vector instructions of this loop -- was bit-exact and no faster: the kernel sits at the package power cap, where time
+// follows the floating-point work, not the instruction count; profiles/r4/README.md.)
+template <int ARITH, int ND, int M, int NH, bool BOTH>
+__device__ __forceinline__ void dense_pair_quad(const float *di, const float *dq, const float *ptab, int lane, int t0, float (&ai)[4], float (&aq)[4])
+{
+    const float *td = ptab, *th = ptab + DenseTab<NH>::LEN;
+    for (int t = t0; t < HilbertSteps<ND, M, NH>::N; ++t) {
+        const v4f wq = lds_ld4(dq + 4 * lane + 4 * t);
+        const v4f h0 = lds_ld4(th + 4 * t), h1 = lds_ld4(th + 4 * t + 4);
+        const float hh[8] = { h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w };
+        v4f wi = { 0.0f, 0.0f, 0.0f, 0.0f };
+        float dd[8] = { 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f };
+        if constexpr (BOTH) {
+            wi = lds_ld4(di + 4 * lane + 4 * t);
+            const v4f d0 = lds_ld4(td + 4 * t), d1 = lds_ld4(td + 4 * t + 4);
+            dd[0] = d0.x; dd[1] = d0.y; dd[2] = d0.z; dd[3] = d0.w; dd[4] = d1.x; dd[5] = d1.y; dd[6] = d1.z; dd[7] = d1.w;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {                             // tap k = 4 t + e - r - FH  <->  table index 4 t + (e - r + 3)
+                if constexpr (BOTH) ai[r] = mac<ARITH>(ai[r], wi[e], dd[e - r + 3]);
+                aq[r] = mac<ARITH>(aq[r], wq[e], hh[e - r + 3]);
+            }
+    }
+}
+
 // AM: 0 = SSB combine, 1 = AM / FM (fa.am says which), 2 = decided at run time by fa.am (k_ssb_fused, round 4: one kernel per shape
 // and slot format instead of one per NCO flavour and demodulator -- the binary was 35 MB)
-template <int ARITH, int GROUP, int ND, int M, int NH, typename TOut, int AM = 0>
+// DENSE: the FIR pair with arbitrary taps (dense_pair_quad; fa.ptab: their LDS table) instead of the type-III Hilbert / unit-delay pair
+template <int ARITH, int GROUP, int ND, int M, int NH, typename TOut, int AM = 0, int DENSE = 0>
 __device__ __forceinline__ void demod_agc_store(const RxParams &p, const FusedArgs &fa, const float *dI,
                                                 const float *dQ, int lane, int group,
                                                 const float (&hreg)[(NH + 63) / 64 ? (NH + 63) / 64 : 1], float &gain,
@@ -102,6 +140,16 @@ __device__ __forceinline__ void demod_agc_store(const RxParams &p, const FusedAr
             au[0] = cmag<0>(vi.x, vq.x); au[1] = cmag<0>(vi.y, vq.y);
             au[2] = cmag<0>(vi.z, vq.z); au[3] = cmag<0>(vi.w, vq.w);
         }
+    } else if (NH > 0 && DENSE != 0) {
+        float i2[4] = { 0.0f, 0.0f, 0.0f, 0.0f }, q2[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+        dense_pair_quad<ARITH, ND, M, NH, DENSE == 1>(dI, dQ, fa.ptab_lds, lane, (int)fa.dense_t0, i2, q2);
+        if constexpr (DENSE == 2) {                                   // unit-impulse delay FIR: 0.0f + 1.0f * x of the dense loop (fa.delay_idx: in the PADDED taps)
+            const float *di = dI + G::FH + fa.delay_idx + 4 * lane;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) i2[r] = di[r] + 0.0f;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) au[r] = fa.upper ? (i2[r] - q2[r]) : (i2[r] + q2[r]);       // arm_sub_f32 / arm_add_f32
     } else if (NH > 0) {
         float q2[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
         hilbert_quad<ARITH, ND, M, NH>(dQ, lane, hreg, q2);
@@ -196,7 +244,7 @@ __device__ __forceinline__ void demod_agc_store(const RxParams &p, const FusedAr
 // NCO flavour (fa.nco: 0 off, 1 per-channel per sample, 2 shared table, 4 per-channel periodic) and demodulator (fa.am) are RUN-TIME
 // switches, wave-uniform, outside the hot loops (round 4): one kernel per arithmetic, shape and slot format -- the sixteen
 // instantiations per shape this replaced were most of a 35 MB library and of its four-minute build.
-template <int ARITH, int ND, int M, int NH, typename TIn, typename TOut>
+template <int ARITH, int ND, int M, int NH, typename TIn, typename TOut, int DENSE = 0>
 __global__ __launch_bounds__(64, 2) void k_ssb_fused(RxParams p, FusedArgs fa, const TIn *__restrict__ src,
                                                      TOut *__restrict__ dst)
 {
@@ -208,6 +256,8 @@ __global__ __launch_bounds__(64, 2) void k_ssb_fused(RxParams p, FusedArgs fa, c
     // structural-zero argument of DESIGN.md section 3).  What changes is the state: p.nd - 1 samples per rail, sitting Fr slots into the
     // kernel's history.
     const int ndr = ND > 0 ? (int)p.nd : 0, Fr = ND > 0 ? G::HQ4 * M + 1 - ndr : 0;
+    // ... and so may the FIR pair (DENSE instantiations: p.nh <= NH taps, padded in front): p.nh - 1 history samples per rail
+    const int hhr = NH > 0 ? (int)p.nh - 1 : 0, FHr = G::HH4 - hhr;
     using R = BRaw<TIn>;
     static_assert(ND == 0 ? M == 1 : (M == 2 || M == 4 || M == 8), "fused kernel: no decimator, or decimate by 2, 4 or 8");
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -242,6 +292,11 @@ __global__ __launch_bounds__(64, 2) void k_ssb_fused(RxParams p, FusedArgs fa, c
     float hreg[(NH + 63) / 64 ? (NH + 63) / 64 : 1];
 #pragma unroll
     for (int v = 0; v < (NH + 63) / 64; ++v) hreg[v] = (64 * v + lane < NH) ? p.hilb_c[64 * v + lane] : 0.0f;
+    if constexpr (DENSE != 0) {                          // the FIR pair's tap tables (both rails) behind the kernel's own LDS image
+        float *pt = lds + G::total;
+        for (int i = lane; i < 2 * DenseTab<NH>::LEN; i += kWave) pt[i] = fa.ptab[i];
+        fa.ptab_lds = pt;
+    }
     auto in_rsrc = [&](uint32_t ch, bool valid) { return make_rsrc(src + (size_t)ch * p.in_stride * 2, valid ? p.block_size * (R::kBytes / 2) : 0u); };
     // the first pass of a channel is in flight before the channel starts: loaded here for the first one, under the last pass of the
     // channel before it for the others (rerun pass: the list says which channel comes next)
@@ -293,10 +348,10 @@ __global__ __launch_bounds__(64, 2) void k_ssb_fused(RxParams p, FusedArgs fa, c
             });
     }
     if constexpr (NH > 0) {
-        batched_fill<2 * G::HH4>(lane, p.fir_state + (size_t)c * 2 * G::HH,
+        batched_fill<2 * G::HH4>(lane, p.fir_state + (size_t)c * 2 * hhr,
             [&](int i) {
-                const int rail = i / G::HH4, sidx = i % G::HH4 - G::FH;
-                return sidx >= 0 ? rail * G::HH + sidx : -1;
+                const int rail = i / G::HH4, sidx = i % G::HH4 - FHr;
+                return sidx >= 0 ? rail * hhr + sidx : -1;
             },
             [&](int i, float v) { D[(i / G::HH4) * G::DLEN + i % G::HH4] = v; if (ND == 0) hmax = fmaxf(hmax, fabsf(v)); });
     }
@@ -414,11 +469,11 @@ __global__ __launch_bounds__(64, 2) void k_ssb_fused(RxParams p, FusedArgs fa, c
         // (rerun pass of AUTO inside a global-gain call whose split16 kernel emitted block maxima: refresh this channel's row)
         float *env_row = (p.chan_flags && p.env_part) ? p.env_part + (size_t)c * (p.block_size / p.block) + (size_t)pass * (pq / (4u * (uint32_t)group)) : nullptr;
         if (group == 16)
-            demod_agc_store<ARITH, 16, ND, M, NH, TOut, AM>(p, fa, dI, dQ, lane, group, hreg, gain, dst, out_base + (size_t)pass * pq, nonfinite, nvb, env_row, &gx);
+            demod_agc_store<ARITH, 16, ND, M, NH, TOut, AM, DENSE>(p, fa, dI, dQ, lane, group, hreg, gain, dst, out_base + (size_t)pass * pq, nonfinite, nvb, env_row, &gx);
         else if (group == 64)
-            demod_agc_store<ARITH, 64, ND, M, NH, TOut, AM>(p, fa, dI, dQ, lane, group, hreg, gain, dst, out_base + (size_t)pass * pq, nonfinite, nvb, env_row, &gx);
+            demod_agc_store<ARITH, 64, ND, M, NH, TOut, AM, DENSE>(p, fa, dI, dQ, lane, group, hreg, gain, dst, out_base + (size_t)pass * pq, nonfinite, nvb, env_row, &gx);
         else
-            demod_agc_store<ARITH, 0, ND, M, NH, TOut, AM>(p, fa, dI, dQ, lane, group, hreg, gain, dst, out_base + (size_t)pass * pq, nonfinite, nvb, env_row, &gx);
+            demod_agc_store<ARITH, 0, ND, M, NH, TOut, AM, DENSE>(p, fa, dI, dQ, lane, group, hreg, gain, dst, out_base + (size_t)pass * pq, nonfinite, nvb, env_row, &gx);
         wave_lds_sync();
         // ---- 6. history copy-back (arm_fir_decimate_f32.c:396-426, arm_fir_f32.c:947-978) ----
         if constexpr (ND > 0) {
@@ -468,8 +523,8 @@ __global__ __launch_bounds__(64, 2) void k_ssb_fused(RxParams p, FusedArgs fa, c
     if constexpr (NH > 0) {
         if (fa.am != 1u) {                                            // AM never ran the Hilbert pair: its state stays (FM keeps the delay lines running)
             for (int i = lane; i < 2 * G::HH4; i += kWave) {
-                const int rail = i / G::HH4, m = i % G::HH4, s = m - G::FH;
-                if (s >= 0) p.fir_state[((size_t)c * 2 + rail) * G::HH + s] = D[rail * G::DLEN + m];
+                const int rail = i / G::HH4, m = i % G::HH4, s = m - FHr;
+                if (s >= 0) p.fir_state[((size_t)c * 2 + rail) * hhr + s] = D[rail * G::DLEN + m];
             }
         }
     }
@@ -508,16 +563,16 @@ __global__ __launch_bounds__(64, 2) void k_ssb_fused(RxParams p, FusedArgs fa, c
 }
 
 
-template <int ARITH, int ND, int M, int NH, typename TIn, typename TOut>
+template <int ARITH, int ND, int M, int NH, typename TIn, typename TOut, int DENSE = 0>
 static hipError_t launch_one(const RxParams &p, const FusedArgs &fa_in, const void *src, void *dst, hipStream_t st)
 {
     using G = Geo<ND, M, NH>;
-    constexpr size_t lds = (size_t)G::total * sizeof(float);
+    constexpr size_t lds = ((size_t)G::total + (DENSE ? 2 * DenseTab<NH>::LEN : 0)) * sizeof(float);
     FusedArgs fa = fa_in;
     // NCO flavour of the launch: shared table (2); per-channel LO with a period of 256 samples (every step a multiple of 2^24) and
     // 256-output passes: one period per channel in registers (4); per channel per sample (1); off (0)
     fa.nco = p.nco == 2 ? 2u : (p.nco == 1 ? ((p.lo_period == 256 && fa.pass_out == 256) ? 4u : 1u) : 0u);
-    auto k = k_ssb_fused<ARITH, ND, M, NH, TIn, TOut>;
+    auto k = k_ssb_fused<ARITH, ND, M, NH, TIn, TOut, DENSE>;
     if constexpr (lds > 48 * 1024) {                      // per device and per kernel: set on every launch (cheap)
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -537,6 +592,10 @@ static hipError_t launch_one(const RxParams &p, const FusedArgs &fa_in, const vo
 #define SRX_SHAPES(X) X(256, 4, 63, 1) X(0, 1, 63, 2) X(0, 1, 127, 3) X(128, 4, 63, 4) X(256, 4, 127, 5) X(128, 4, 127, 6) X(256, 4, 31, 7) X(0, 1, 31, 8) \
                       X(256, 2, 63, 9) X(256, 8, 63, 10) X(64, 4, 63, 11) X(128, 2, 63, 12) X(128, 8, 63, 13) X(64, 2, 63, 14) X(64, 8, 63, 15) \
                       X(128, 4, 31, 16) X(256, 2, 127, 17) X(128, 2, 127, 18) X(256, 2, 31, 19) X(128, 2, 31, 20)
+
+// ... and the shapes of the DENSE flavour (any FIR pair of up to 127 taps with arbitrary taps on both rails; any decimator up to the shape's)
+#define SRX_DENSE_SHAPES(X) X(256, 4, 127, 101) X(128, 4, 127, 102) X(256, 2, 127, 103) X(128, 2, 127, 104) X(256, 8, 127, 105) X(128, 8, 127, 106) X(0, 1, 127, 107)
+hipError_t launch_exact_dense(int nd, int m, bool q15, bool delay_impulse, const RxParams &p, const FusedArgs &fa, const void *src, void *dst, hipStream_t st);
 
 // the CMSIS-arithmetic instantiations live in rx_fused_exact.hip
 hipError_t launch_exact(int nd, int m, int nh, bool q15, const RxParams &p, const FusedArgs &fa, const void *src, void *dst,

@@ -138,6 +138,10 @@ struct FusedPlan {
     float split_post = 1.0f;      // 2^-(sample scale + tap scale) applied to the split-precision result (k_hilb_split16)
     int split_sc = 0;             // tap scale exponent of the split-precision decimator (k_ssb_split16)
     bool use_mfma = false;        // FMA arithmetic: decimator on the matrix cores
+    bool dense = false;           // the DENSE flavour of k_ssb_fused: a FIR pair with arbitrary taps (kind = an ID of SRX_DENSE_SHAPES)
+    float *d_ptab = nullptr;      // ... its tap tables [2][DenseTab::LEN]
+    uint32_t dense_t0 = 0;        // ... first FIR step with a tap that is not padding
+    bool dense_delay_impulse = false;   // ... the delay FIR is a unit impulse (only the Hilbert FIR runs dense)
     bool tables_built = false;
 };
 hipError_t plan_fused(const selenite_rx_config &cfg, bool delay_is_impulse, int delay_index,

@@ -104,6 +104,48 @@ def test_random_configurations_of_the_fused_kernels():
     print("worst per-block relative error of the SELENITE_ARITH_AUTO cases: %.3g (bar 1e-5)" % WORST[0])
 
 
+def test_in_range_shapes_never_take_the_generic_kernels():
+    """any FIR pair of up to 127 taps (dense or type-III, odd or even count, any delay FIR) behind any decimator of up
+    to 256 taps by 2 / 4 / 8 (or none) runs on a fused kernel -- kernel_name is never "generic" -- and is bit-exact in the CMSIS
+    arithmetic.  Random shapes and taps."""
+    import selenite_rx as sr
+    rng = np.random.default_rng(77)
+    for idx in range(int(os.environ.get("SELENITE_FUZZ_CASES", "150")) // 3):
+        M = int(rng.choice([1, 2, 4, 8]))
+        nd = 0 if M == 1 else int(rng.integers(2, 257))
+        nh = int(rng.integers(2, 128))
+        nch = int(rng.choice([1, 3, 17, 64, 65]))
+        spec = rc.ChainSpec(nch, 256, M, nd, nh | 1, 0, int(rng.choice([rc.MODE_USB, rc.MODE_LSB, rc.MODE_AM, rc.MODE_FM])), ARITH_CMSIS,
+                            nco=True, nco_steps=rng.integers(0, 1 << 32, nch, dtype=np.uint64).astype(np.uint32), agc=True)
+        kind = int(rng.integers(3))
+        if kind == 0 and nh % 2 == 1:
+            pass                                       # the design helper's type-III pair, at a length that may have no instantiation
+        else:
+            spec.nh_taps = nh
+            spec.hilb = (rng.standard_normal(nh) * 0.2).astype(np.float32)
+            spec.delay = np.zeros(nh, np.float32)
+            if kind == 1:
+                spec.delay[int(rng.integers(nh))] = 1.0
+            else:
+                spec.delay[:] = (rng.standard_normal(nh) * 0.2).astype(np.float32)
+        if kind == 0 and nh % 2 == 1:
+            spec2 = rc.ChainSpec(nch, 256, M, nd, nh, 0, spec.mode, ARITH_CMSIS, nco=True, nco_steps=spec.nco_steps, agc=True)
+            spec = spec2
+        g, o = sr.Rx(spec.config()), CpuChain(spec, "orc")
+        desc = "case %d: nd %d M %d nh %d kind %d mode %#x kernel %s" % (idx, nd, M, spec.nh_taps, kind, spec.mode, g.kernel_name())
+        assert g.kernel_name() != "generic", desc
+        pos = 0
+        for _ in range(2):
+            bs = 256 * int(rng.integers(1, 12))
+            iq = synth_iq(0, nch, pos, bs)
+            pos += bs
+            assert bits_equal(g.process(iq), o.process(iq)), desc
+        sg, so = g.state(), o.state()
+        for key in sg:
+            assert (bits_equal(sg[key], so[key]) if sg[key].dtype == np.float32 else np.array_equal(sg[key], so[key])), desc + " " + key
+        g.close()
+
+
 def test_random_configurations_of_the_cw_kernel():
     """k_cw_fused: 2 / 4 / 8 biquad stages, any channel count, call lengths, slot formats, NCO flavours, CW / CW-R, both exact
     arithmetic modes: always bit-exact, output and state."""
