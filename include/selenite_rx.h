@@ -62,7 +62,8 @@ extern "C" {
                                   * arm_cmplx_mult_cmplx_f32, a stated arctangent, arm_scale_f32.  The
                                   * sample in front of a block comes from the delay lines of the FIR pair, which this mode keeps
                                   * running without evaluating the taps: needs nh_taps >= 2 (ARGUMENT_ERROR otherwise).  Exact /
-                                  * fma kernels in every arithmetic mode (SPLIT16 runs as FMA, AUTO as CMSIS). */
+                                  * fma kernels (SPLIT16 runs as FMA); round 4: AUTO runs the split-precision decimator guarded on
+                                  * min|z| x max|audio| (the discriminator's error is |dz| / (pi |z|)) with the bit-exact rerun. */
 #define SELENITE_MODE_DIG 0x0A   /* = USB */
 #define SELENITE_MODE_PKT 0x0C   /* = LSB */
 
@@ -92,7 +93,12 @@ extern "C" {
                                     inside the same process call.  <=1e-5 relative vs CMSIS per DSP block on EVERY
                                     block: unguarded blocks by the split product's accuracy (~1e-6 of the input level,
                                     so <=1e-5 of a block maximum within 12 dB of it), guarded channels with 0 ULP.
-                                    Configurations without a split-precision kernel run as SELENITE_ARITH_CMSIS. */
+                                    Round 4: on every block of every call, whatever the call lengths and mode switches
+                                    (selenite_rx_set_handover_repair); a recomputed channel stays with the bit-exact
+                                    kernel until its level is back (selenite_rx_set_guard_ratio).  Split-precision
+                                    kernels exist for every decimator of 2 .. 256 taps (even count) by 2 or by 4 in
+                                    front of a 31- / 63- / 127-tap type-III pair, and for those pairs alone;
+                                    other configurations run as SELENITE_ARITH_CMSIS. */
 
 typedef struct selenite_rx_config {
     uint32_t struct_size;     /* = sizeof(selenite_rx_config) */
@@ -213,15 +219,22 @@ int selenite_rx_global_process_f32_device(selenite_rx_instance *S, const float *
 /* ---- parity guard of the split-precision arithmetic (SELENITE_ARITH_SPLIT16 / _AUTO) -------------------------- */
 
 /* A DSP block is GUARDED when max |audio| of the block (before the AGC) is below `ratio` x the largest |component| of the
- * mixed samples its pass of the matrix product held (new samples and FIR history): there the 1e-5-of-the-block-maximum
- * figure against CMSIS is not guaranteed for the split product.  Default ratio 0.25 (-12 dB);
+ * mixed samples its pass of the matrix product held (new samples and FIR history) -- for the blocks that still read Hilbert-pair
+ * history the pass before computed (the first nh_taps - 1 audio samples of a pass) also of that pass, and at a call's start of the
+ * level the call before left (round 4): there the 1e-5-of-the-block-maximum figure against CMSIS is not guaranteed for the split
+ * product.  FM (SELENITE_ARITH_AUTO on the decimating shapes, round 4): guarded when min|z| x max|audio| is
+ * below `ratio` x that maximum (the discriminator's error is |dz| / (pi |z|)).  Default ratio 0.25 (-12 dB);
  * 0 disables the guard, +inf guards every block with non-zero input (SELENITE_ARITH_AUTO then recomputes every channel
- * bit-exactly: a test hook).  Takes effect with the next process call. */
+ * bit-exactly: a test hook).  Takes effect with the next process call.
+ * SELENITE_ARITH_AUTO recomputes a channel that owns a guarded block with the bit-exact kernel, inside the same call, and then
+ * HOLDS it there (round 4): the matrix kernel skips the channel in the following calls -- a channel whose pass band is empty call
+ * after call costs the bit-exact kernel's time, not both kernels' -- until two calls in a row show no block under 1.25 x ratio. */
 int selenite_rx_set_guard_ratio(selenite_rx_instance *S, float ratio);
 /* Counters since init / the last selenite_rx_guard_clear (any pointer may be NULL); drains the instance's stream:
  *   guard_blocks         DSP blocks guarded
  *   guard_channel_calls  (channel, process call) pairs with at least one guarded block
- *   rerun_channel_calls  of those, how many SELENITE_ARITH_AUTO recomputed with the bit-exact kernel (0 for _SPLIT16) */
+ *                        (SELENITE_ARITH_AUTO: plus every call of a channel the bit-exact kernel holds)
+ *   rerun_channel_calls  (channel, call) pairs SELENITE_ARITH_AUTO computed with the bit-exact kernel (0 for _SPLIT16) */
 int selenite_rx_guard_stats(selenite_rx_instance *S, uint64_t *guard_blocks, uint64_t *guard_channel_calls,
                             uint64_t *rerun_channel_calls);
 /* per_channel[channels]: guarded DSP blocks of every channel since init / the last clear (sticky per-channel view). */
@@ -231,15 +244,22 @@ int selenite_rx_guard_channels(selenite_rx_instance *S, uint32_t *per_channel);
  * HELD by the bit-exact kernel, bit 6: its last call there was clean; bits 8-31: level of the last pass).  Zeros in the other modes. */
 int selenite_rx_auto_words(selenite_rx_instance *S, uint32_t *per_channel);
 /* SELENITE_ARITH_AUTO across calls ("across a call boundary").  A channel the previous call left on the
- * matrix kernel carries a Hilbert-pair history (the last nh_taps - 1 decimated samples) of split16 precision; if THIS call has to
- * be recomputed for it, its first blocks -- those inside the reach of that history -- would start from it.  Handover repair
- * (default on): k_ssb_split16 also leaves the exact mixed samples in front of the decimator state behind (decim * (nh_taps - 1)
- * samples per channel and call, rounded up to whole quads of audio samples: 2 KB for the cfg3 chain), and the rerun recomputes the Hilbert-pair
- * history from them in exact arithmetic first: the recomputed call is CMSIS bit for bit from its first sample (apart from the
- * gain the previous call's AGC left: ~1e-6 relative).  Cost: those bytes (2.4 % of the headline at 4096 samples per call, half
- * that at 8192).  Off: nothing is kept, and such blocks -- and, in either setting, those behind a call too short to hold the
- * samples (under nd_taps + decim * (nh_taps - 1) per channel) -- carry the error of a guarded block of raw SELENITE_ARITH_SPLIT16
- * (up to ~1e-3 of a block maximum that is the residue of a sideband cancellation) and are COUNTED: */
+ * matrix kernel carries a Hilbert-pair history (the last nh_taps - 1 decimated samples) of split16 precision; if THIS call has to be
+ * recomputed for it, its first blocks -- those inside the reach of that history -- would start from it.  Handover repair (default on):
+ * k_ssb_split16 also leaves the exact mixed samples in front of the decimator state behind (decim * (nh_taps - 1) samples per channel
+ * and call, rounded up to whole quads of audio samples: 2 KB for the cfg3 chain; two buffers -- 4 KB of device memory per channel,
+ * 0.27 GB at 65 536 channels, allocated by the first call that needs them and released when the repair is switched off), and the
+ * rerun recomputes the Hilbert-pair history from them in exact arithmetic first: the recomputed call is CMSIS bit for bit from its
+ * first sample (apart from the gain the previous call's AGC left: ~1e-6 relative).  Cost: those bytes (2.4 % of the headline at 4096
+ * samples per call, half that at 8192).
+ * Round 4: with the repair ON there is no exception left.  A call too short to hold those samples (under nd_taps + decim *
+ * (nh_taps - 1) per channel: the firmware's literal one-slot callback) runs on the bit-exact kernel in AUTO, the history is repaired
+ * in front of an AM call (which neither reads nor moves it) and in front of the CW / generic kernels, so no block ever starts from
+ * a history of split16 precision: selenite_rx_guard_handover stays 0 by construction and every DSP block of every call holds
+ * max|out - ref| <= 1e-5 max|ref|.
+ * OFF (a diagnostic: what the repair is worth): nothing is kept; guarded blocks inside the reach of the history behind a call that
+ * stayed on the matrix kernel carry the error of a guarded block of raw SELENITE_ARITH_SPLIT16 (up to ~1e-3 of a block maximum that
+ * is the residue of a sideband cancellation) and are COUNTED: */
 int selenite_rx_set_handover_repair(selenite_rx_instance *S, int on);
 int selenite_rx_guard_handover(selenite_rx_instance *S, uint64_t *handover_blocks);
 int selenite_rx_guard_clear(selenite_rx_instance *S);
