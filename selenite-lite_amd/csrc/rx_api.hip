@@ -700,7 +700,8 @@ static int run_part(selenite_rx_instance *S, const void *src, bool src_q15, void
 
 // Entry of every process call.  Any call length (a whole number of DSP blocks) runs on the fused kernels; a
 // split-precision call that ends in a partial pass too short for the matrix kernel is cut in two launches on the same
-// streaming state (fused_tail_split; both parts address the caller's buffers with the full per-channel stride).
+// streaming state (fused_tail_split; both parts address the caller's buffers with the full per-channel stride; in
+// SELENITE_ARITH_AUTO the tail runs in the bit-exact arithmetic, rx_fused.hip launch_shape).
 static int run_chain(selenite_rx_instance *S, const void *src, bool src_q15, void *dst, bool dst_q15,
                      uint32_t block_size, Phase phase, float *ext_env)
 {

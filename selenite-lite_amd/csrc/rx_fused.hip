@@ -729,7 +729,9 @@ bool fused_tail_split(const FusedPlan &plan, const selenite_rx_config &g, uint32
     // Every call length (a whole number of DSP blocks) runs on the fused kernels since round 3 (k_ssb_fused: variable-length
     // passes).  One case is better served in two launches: a split-precision instance whose call ends in a partial pass too
     // short for k_ssb_split16 (it wants a whole decimator history in it; only DSP blocks shorter than that history get there):
-    // the whole passes stay on the matrix kernel, the tail goes to k_ssb_fused -- true when the call should be cut that way.
+    // the whole passes stay on the matrix kernel, the tail goes to k_ssb_fused (SELENITE_ARITH_SPLIT16: its fma arithmetic;
+    // SELENITE_ARITH_AUTO: the bit-exact arithmetic, from a history k_hist_exact repairs first -- launch_shape's auto_ok, the tail
+    // being too short to leave the mixed samples behind) -- true when the call should be cut that way.
     if (!(g.arith == SELENITE_ARITH_SPLIT16 || g.arith == SELENITE_ARITH_AUTO) || !plan.d_btab16 || !g.nd_taps) return false;
     const uint32_t na = g.block / g.decim, pq = 256u / na * na, unit = pq * g.decim;
     if (!split16_pass_ok(pq) || block_size % unit == 0 || block_size < unit) return false;
