@@ -116,6 +116,8 @@ static void free_device(selenite_rx_instance *S)
                      S->d_io_in, S->d_io_out, S->d_lo, S->pipe.d_in[0], S->pipe.d_in[1], S->pipe.d_out[0], S->pipe.d_out[1] };
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
+    if (S->h_rerun_seen) (void)hipHostFree(S->h_rerun_seen);
+    S->h_rerun_seen = nullptr;
     for (int i = 0; i < 2; ++i) {
         if (S->pipe.h_in[i]) (void)hipHostFree(S->pipe.h_in[i]);
         if (S->pipe.h_out[i]) (void)hipHostFree(S->pipe.h_out[i]);
@@ -262,6 +264,10 @@ extern "C" int selenite_rx_init(selenite_rx_instance **out, const selenite_rx_co
     INITCHK(dev_alloc(&S->d_guard_ch, 3 * C));
     INITCHK(dev_alloc(&S->d_rerun_flag, cfg->arith == SELENITE_ARITH_AUTO ? C : 0));
     INITCHK(dev_alloc(&S->d_rerun_list, cfg->arith == SELENITE_ARITH_AUTO ? C + 2 : 0));
+    if (cfg->arith == SELENITE_ARITH_AUTO) {
+        INITCHK(hipHostMalloc(reinterpret_cast<void **>(&S->h_rerun_seen), sizeof(uint32_t), hipHostMallocMapped));
+        *S->h_rerun_seen = 0u;
+    }
     if (cfg->arith == SELENITE_ARITH_AUTO && cfg->nd_taps >= 2 && cfg->nh_taps >= 2 &&
         split16_template_nd((int)cfg->nd_taps, (int)cfg->decim, (int)cfg->nh_taps) > 0 && !std::getenv("SELENITE_RX_NO_HIST_EXT")) {
         // k_ssb_split16 leaves the mixed samples in front of the decimator state here (two buffers: the one a channel's state points
@@ -644,6 +650,7 @@ static int run_part(selenite_rx_instance *S, const void *src, bool src_q15, void
             pf.chan_list = S->d_rerun_list + 2;
             pf.chan_count = S->d_rerun_list;              // the two counters; launch_shape picks by *rerun_par_host where it launches the prepare kernel
             pf.rerun_par_host = &S->rerun_par;
+            pf.rerun_seen = S->h_rerun_seen;
         }
         void *fdst = dst;
         bool fq15 = dst_q15;

@@ -281,6 +281,7 @@ __global__ __launch_bounds__(64, 2) void k_ssb_fused(RxParams p, FusedArgs fa, c
     // channels, and how many, is only known on the device; every workgroup gets an even share.
     uint32_t li = blockIdx.x;
     const uint32_t ln = p.chan_flags ? *p.chan_count : 0u;
+    if (p.chan_flags && p.rerun_seen && blockIdx.x == 0 && lane == 0) __hip_atomic_store(p.rerun_seen, ln, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     // what does not depend on the channel, once per workgroup: sine table, decimator taps (lane-distributed), Hilbert taps
     if (NCO == 1u || NCO == 4u)
         for (int i = lane; i < 513; i += kWave) tab[i] = p.sintab[i];
@@ -580,7 +581,16 @@ static hipError_t launch_one(const RxParams &p, const FusedArgs &fa_in, const vo
     }
     // (rerun pass of SELENITE_ARITH_AUTO: which channels are flagged is only known on the device -- a resident-sized grid strides
     // over the dense list of them)
-    static const uint32_t rerun_grid = [] { const char *e = std::getenv("SELENITE_RX_RERUN_GRID"); return e && std::atoi(e) > 0 ? (uint32_t)std::atoi(e) : 2048u; }();
+    // 2048 workgroups when the last call's list was short (the empty pass of a clean workload costs ~3 us; 16 384 would cost 8), 16 384
+    // when it held more than an eighth of the channels: more workgroups than the device keeps resident let the dispatcher even the load
+    // out -- 3-6 % on a call that recomputes 80 % of the channels (profiles/r4/rerun_grid_sweep.txt).  The count is the one the LAST
+    // rerun pass wrote into a page-locked host word, read here without synchronising: a hint, never a result.
+    static const uint32_t rerun_grid_env = [] { const char *e = std::getenv("SELENITE_RX_RERUN_GRID"); return e && std::atoi(e) > 0 ? (uint32_t)std::atoi(e) : 0u; }();
+    uint32_t rerun_grid = rerun_grid_env;
+    if (!rerun_grid) {
+        const uint32_t seen = p.rerun_seen ? __atomic_load_n(p.rerun_seen, __ATOMIC_RELAXED) : 0u;
+        rerun_grid = seen > p.channels / 8u ? 16384u : 2048u;
+    }
     const uint32_t grid = p.chan_flags ? (p.channels < rerun_grid ? p.channels : rerun_grid) : p.channels;
     hipLaunchKernelGGL(k, dim3(grid), dim3(64), lds, st, p, fa, static_cast<const TIn *>(src),
                        static_cast<TOut *>(dst));
