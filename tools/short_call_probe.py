@@ -7,7 +7,7 @@ sys.path.insert(0, os.environ.get("PROBE_PKG") or os.path.join(ROOT, "selenite-l
 import selenite_rx as sr
 from selenite_rx import chain as ch
 C_ = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
-for bs, block in ((96, 96), (256, 256), (512, 256), (1024, 256)):
+for bs, block in ((96, 96), (256, 256), (512, 256), (1024, 256), (2048, 256), (4096, 256)):
     for an, arith in (("auto", sr.ARITH_AUTO), ("cmsis", sr.ARITH_CMSIS), ("split16", sr.ARITH_SPLIT16)):
         rx = sr.Rx(ch.ChainSpec(C_, block, 4, 256, 63, 0, sr.MODE_USB, arith, nco=True, nco_step_all=0x01000000).config())
         d_in, d_out = sr.DeviceBuffer(C_ * bs * 8), sr.DeviceBuffer(C_ * (bs // 4) * 4)
