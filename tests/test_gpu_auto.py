@@ -755,3 +755,46 @@ def test_any_even_decimator_length_runs_on_the_matrix_kernel(nd, M, nh, q15):
     st = g.guard_stats()
     assert st["handover_blocks"] == 0 and st["rerun_channel_calls"] > 0
     g.close()
+
+
+_GRID_SCRIPT = r"""
+import hashlib, os, sys
+import numpy as np
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[2])
+import rxcommon as rc
+import selenite_rx as sr
+nch = 6144
+steps = np.where(np.arange(nch) % 4 == 0, 0x01000000, 0x40000000).astype(np.uint32)      # three channels in four out of band: guarded
+g = sr.Rx(rc.ChainSpec(nch, 256, 4, 256, 63, 0, rc.MODE_USB, rc.ARITH_AUTO, nco=True, nco_steps=steps).config())
+h = hashlib.sha256()
+for k in range(4):
+    y = g.process(rc.synth_iq(0, nch, 2048 * k, 2048))
+    h.update(np.ascontiguousarray(y).tobytes())
+st = g.state()
+for key in ("dec_state", "fir_state", "nco_phase", "agc_gain"):
+    h.update(np.ascontiguousarray(st[key]).tobytes())
+h.update(np.ascontiguousarray(g.auto_words()).tobytes())
+print(h.hexdigest(), g.guard_stats()["rerun_channel_calls"])
+"""
+
+
+def test_the_size_of_the_rerun_grid_never_changes_a_result():
+    """The rerun pass of SELENITE_ARITH_AUTO strides a dense list whose ORDER varies from run to run (one atomic per 1024 channels) with
+    a grid the host sizes from the last call's list length (2048 or 16 384 workgroups; SELENITE_RX_RERUN_GRID pins it).  Every channel is
+    computed on its own, so audio, state and channel words must be the same bits for any grid -- here 64, 2048, 16 384 workgroups and the
+    adaptive default (which switches after the first call: three channels in four are guarded), each in a process of its own."""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    pkg = os.path.join(os.path.dirname(here), "selenite-lite_amd")
+    outs = []
+    for grid in ("64", "2048", "16384", None):
+        env = dict(os.environ)
+        env.pop("SELENITE_RX_RERUN_GRID", None)
+        if grid:
+            env["SELENITE_RX_RERUN_GRID"] = grid
+        r = subprocess.run([sys.executable, "-c", _GRID_SCRIPT, here, pkg], capture_output=True, text=True, timeout=300, env=env)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(r.stdout.split())
+    assert int(outs[0][1]) >= 3 * 4608                                 # the guarded channels were recomputed (held from the second call on)
+    assert all(o == outs[0] for o in outs), outs
