@@ -282,6 +282,7 @@ __global__ __launch_bounds__(64, 2) void k_ssb_fused(RxParams p, FusedArgs fa, c
     uint32_t li = blockIdx.x;
     const uint32_t ln = p.chan_flags ? *p.chan_count : 0u;
     if (p.chan_flags && p.rerun_seen && blockIdx.x == 0 && lane == 0) __hip_atomic_store(p.rerun_seen, ln, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (p.chan_flags && li >= ln) return;                // rerun pass: nothing on the list for this workgroup (every workgroup, in the steady state of a clean workload)
     // what does not depend on the channel, once per workgroup: sine table, decimator taps (lane-distributed), Hilbert taps
     if (NCO == 1u || NCO == 4u)
         for (int i = lane; i < 513; i += kWave) tab[i] = p.sintab[i];

@@ -198,7 +198,7 @@ __global__ __launch_bounds__(64) void k_front_generic(RxParams p, const TIn *__r
 // accumulator from 0, taps ascending, product rounded, then sum rounded -- from the exact mixed samples k_ssb_split16 left behind:
 // T = (one unused slot) ++ hist_ext[0 .. L - 1) (positions [E - H - L + 1, E - H)) ++ decimator state ([E - H, E)), H = nd - 1, L = ext_len = M * HH4.  History entry r
 // (r = nh - 2 the newest) is the decimator output whose newest sample sits at E - M (nh - 1 - r): T[t0 .. t0 + nd), t0 = L - M (nh - 1 - r).
-// One wavefront per flagged channel, the flag array walked in 16-channel windows (which channels, and how many, only the
+// One wavefront per flagged channel, the flag array walked 64 channels per workgroup and trip (which channels, and how many, only the
 // device knows); rare by construction (a channel whose level crosses the guard ratio downwards at a call boundary).
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void k_hist_exact(RxParams p, uint32_t all, uint32_t repair)     // all: every channel with that provenance (a call that runs the exact kernel on all channels), not only the flagged ones
@@ -207,7 +207,6 @@ __global__ __launch_bounds__(64) void k_hist_exact(RxParams p, uint32_t all, uin
     const int lane = threadIdx.x;
     const uint32_t nd = p.nd, M = p.decim, HH = p.nh - 1u, L = p.ext_len, H = nd - 1u;
     float *TI = lds, *TQ = lds + (L + H);
-    const uint32_t nwin = (p.channels + 15u) / 16u;
     if (blockIdx.x == 0 && lane == 0 && p.chan_count_next) *p.chan_count_next = 0u;      // the counter the NEXT call's launch counts in
     if (p.chan_list) {
         // round 4: the channels to recompute as a dense list for the rerun pass.  A workgroup takes 1024 channels at a time: 16 words
@@ -240,12 +239,14 @@ __global__ __launch_bounds__(64) void k_hist_exact(RxParams p, uint32_t all, uin
         }
     }
     if (!repair) return;
-    for (uint32_t win = blockIdx.x; win < nwin; win += gridDim.x) {
-        const uint32_t ci = 16u * win + (uint32_t)(lane & 15);
-        const uint32_t f = (lane < 16 && ci < p.channels) ? p.chan_flags[ci] : 0u;
+    // (64 channels per workgroup and trip: one wave load of words -- 65 536 channels on 1024 workgroups are ONE memory round trip; the
+    // 16-channel windows of round 3 were four dependent ones, 2-3 us of a launch that runs in front of every rerun pass)
+    for (uint32_t base = 64u * blockIdx.x; base < p.channels; base += 64u * gridDim.x) {
+        const uint32_t ci = base + (uint32_t)lane;
+        const uint32_t f = ci < p.channels ? p.chan_flags[ci] : 0u;
         uint64_t todo = __builtin_amdgcn_ballot_w64(((f & kFlagRerun) != 0u || all != 0u) && ((f >> kProvShift) & kProvMask) == kProvSplitExt);
         while (todo != 0) {                                           // wave-uniform
-            const uint32_t c = 16u * win + (uint32_t)__builtin_ctzll(todo);
+            const uint32_t c = base + (uint32_t)__builtin_ctzll(todo);
             todo &= todo - 1;
             const uint32_t word = p.chan_flags[c], buf = (word >> kExtBufShift) & 1u;
             // (the row starts one sample late -- rx_split16_kernels.h: T[0] meets no tap; its last entry repeats the state's first one)
@@ -624,7 +625,7 @@ hipError_t launch_hist_exact(const RxParams &p, bool all, hipStream_t st)
     static const bool off = std::getenv("SELENITE_RX_NO_HIST_EXACT") != nullptr;      // diagnostic: what the rerun does without it
     const bool repair = p.hist_ext && p.nd >= 2 && p.nh >= 2 && !off;
     if (!repair && !p.chan_list) return hipSuccess;
-    const uint32_t nwin = (p.channels + 15u) / 16u;
+    const uint32_t nwin = (p.channels + 63u) / 64u;
     const size_t lds = repair ? 2 * (size_t)(p.ext_len + p.nd - 1u) * sizeof(float) : 0;
     hipLaunchKernelGGL(k_hist_exact, dim3(nwin < 1024u ? nwin : 1024u), dim3(64), lds, st, p, all ? 1u : 0u, repair ? 1u : 0u);
     return hipGetLastError();
