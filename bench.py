@@ -250,6 +250,7 @@ def main():
     if world > 1 or os.environ.get("SELENITE_BENCH_FORCE_DIST") == "1":      # (the env var lets a 1-GPU box exercise this path)
         env.local_rank = local_rank
         env.init_process_group(args.dist_backend)
+        local_rank = env.local_rank                  # (wrapped when the launcher gave this rank fewer visible devices than LOCAL_RANK + 1)
         comm = env.comm_count()
     elif args.global_gain:
         import torch

@@ -174,6 +174,12 @@ class RankEnv:
         import torch.distributed as dist
         self.torch, self.dist, self.backend = torch, dist, backend
         if use_gpu:
+            # a launcher that hands every rank ONE visible device (HIP_VISIBLE_DEVICES per rank) leaves LOCAL_RANK pointing past the
+            # devices this process sees: take the device the rank was given.  (Counting devices does not initialise the GPU.)  Ranks that
+            # really share a device are refused later, by PCI bus id (bench.py: check_ranks).
+            n = torch.cuda.device_count()
+            if n > 0 and self.local_rank >= n:
+                self.local_rank %= n
             torch.cuda.set_device(self.local_rank)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
