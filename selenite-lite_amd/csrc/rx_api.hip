@@ -716,7 +716,7 @@ static int run_chain(selenite_rx_instance *S, const void *src, bool src_q15, voi
     const uint32_t nout = block_size / g.decim;
     const bool global = g.agc_enable && g.agc_global;
     if (phase == kAll && !global && !S->force_generic && S->plan.kind != 0 && fused_tail_split(S->plan, g, block_size)) {
-        const uint32_t na = g.block / g.decim, unit = 256u / na * na * g.decim, bs1 = block_size / unit * unit;
+        const uint32_t unit = split16_pass_out(g.block, g.decim) * g.decim, bs1 = block_size / unit * unit;
         {
             int rc = run_part(S, src, src_q15, dst, dst_q15, bs1, kAll, nullptr, block_size, nout);
             if (rc) return rc;

@@ -367,6 +367,7 @@ int split16_template_nd(int nd, int m, int nh)
 {
     int best = -1;
     if (nd < 2 || (nd & 1)) return -1;
+    if (m == 8) m = 4;                                    // decimation by 8 runs on the by-4 Toeplitz product, every second output kept (FusedArgs::dec2)
 #define X(ND_, M_, NH_) if (m == M_ && nh == NH_ && ND_ >= nd && (best < 0 || ND_ < best)) best = ND_;
     SRX_SPLIT16_SHAPES(X)
 #undef X
@@ -444,7 +445,8 @@ static hipError_t build_tables(const selenite_rx_config &g, FusedPlan &plan, boo
         }
         if (NH > 0) {                                                 // the split-precision decimator's operand, for ITS shape
             const int nds = split16_template_nd(ndr, M, NH);
-#define X(ND_, M_, NH_) if (nds == ND_ && M == M_ && NH == NH_) return build_split16_table<ND_, M_, NH_>(g, plan);
+            constexpr int MT = M == 8 ? 4 : M;                        // (by 8: the by-4 product's table)
+#define X(ND_, M_, NH_) if (nds == ND_ && MT == M_ && NH == NH_) return build_split16_table<ND_, M_, NH_>(g, plan);
             SRX_SPLIT16_SHAPES(X)
 #undef X
         }
@@ -550,16 +552,25 @@ static hipError_t launch_shape(const RxParams &p, const FusedArgs &fa, const Fus
     const uint32_t kHS = nds > 0 ? (uint32_t)(((((nds - 1 + M - 1) / M) + 3) & ~3) * M) : 0u;      // GeoS::HS: decimator history in the image
     // k_ssb_split16 also takes passes of fewer than 256 outputs when they are whole 16-output tiles (240 for the firmware's
     // 96-frame blocks by 4, 192 for its 96-sample audio blocks): its run-time DSP-block flavour advances by pass_out * M samples
-    const uint32_t tq = fa.pass_out * M;
+    // (decimation by 8, round 4 late: the by-4 kernel with every second output kept -- passes of at most 128 outputs = 1024 inputs)
+    FusedArgs fa16 = fa;
+    if constexpr (M == 8) {
+        fa16.pass_out = split16_pass_out(p.block, p.decim);
+        // (which half: the tile's output j ends at input sample 4 j of the pass in this kernel's bookkeeping, a by-8 output n at 8 n -- the
+        // even ones; SELENITE_RX_DEC2_PARITY=2 selects the odd ones: a diagnostic that shows the tests notice)
+        static const uint32_t par = [] { const char *e = std::getenv("SELENITE_RX_DEC2_PARITY"); return e ? (uint32_t)std::atoi(e) : 1u; }();
+        fa16.dec2 = par;
+    }
+    const uint32_t tq = fa16.pass_out * M;
     // (a last pass shorter than the decimator history: only as a call of its own -- fused_tail_split cuts it off)
-    const bool split_ok = split16_pass_ok(fa.pass_out) && (p.block_size % tq == 0 || p.block_size % tq >= kHS || p.block_size < tq);
+    const bool split_ok = split16_pass_ok(fa16.pass_out) && (p.block_size % tq == 0 || p.block_size % tq >= kHS || p.block_size < tq);
     // SELENITE_ARITH_AUTO (round 4: "handover_blocks == 0 by construction"): the matrix kernel only takes calls long enough to leave the
     // mixed samples in front of the decimator state behind (hist_ext: nd - 1 + M HH4 - 1 samples) -- every state it leaves can then be
     // repaired by k_hist_exact.  Shorter calls (the firmware's literal one-slot callback, a tail cut off by fused_tail_split) run on the
     // bit-exact kernel, from a history repaired first (below): they are state-traffic bound either way.  With the repair switched
     // off (a diagnostic: selenite_rx_set_handover_repair) nothing is kept and such calls stay on the matrix kernel, counted.
     const bool auto_ok = !auto_ || p.hist_ext == nullptr || p.block_size + 1u >= (uint32_t)(ND > 0 ? p.nd - 1 : 0) + p.ext_len;
-    if constexpr (ND > 0 && (M == 4 || M == 2) && NH > 0) {
+    if constexpr (ND > 0 && (M == 4 || M == 2 || M == 8) && NH > 0) {
         if (split && plan.d_btab16 && split_ok && auto_ok) {
             if (auto_ && fa.am == 1u && p.rerun_flag) {
                 // AM neither reads nor moves the Hilbert-pair history while the decimator state moves on: the samples kept in front of
@@ -569,7 +580,7 @@ static hipError_t launch_shape(const RxParams &p, const FusedArgs &fa, const Fus
                 p3.chan_list = nullptr; p3.chan_count_next = nullptr;
                 if (hipError_t e = launch_hist_exact(p3, true, st); e != hipSuccess) return e;
             }
-            hipError_t e = launch_ssb_split16(nds, M, NH, p, fa, src, src_q15, dst, st);     // rx_split16.hip
+            hipError_t e = launch_ssb_split16(nds, M == 8 ? 4 : M, NH, p, fa16, src, src_q15, dst, st);     // rx_split16.hip
             if (e == hipSuccess && auto_ && p.rerun_flag) e = rerun();
             return e;
         }
@@ -693,7 +704,7 @@ hipError_t plan_fused(const selenite_rx_config &g, bool delay_is_impulse, int de
     (void)name;
     if (plan.use_mfma && g.arith != SELENITE_ARITH_CMSIS) plan.name_buf = "k_ssb_mfma" + shape;     // split16 without a matrix kernel of its own runs as fma
     if (g.arith == SELENITE_ARITH_AUTO) plan.name_buf = "k_ssb_fused" + shape;                      // without a matrix kernel of its own: bit-exact
-    const bool split_pass = g.nd_taps ? split16_pass_ok(256u / na * na) : true;      // (k_hilb_split16 takes any pass of whole 4-sample lanes)
+    const bool split_pass = g.nd_taps ? split16_pass_ok(split16_pass_out(g.block, g.decim)) : true;      // (k_hilb_split16 takes any pass of whole 4-sample lanes; by 8: passes of at most 128 outputs)
     if (256 % na != 0) plan.name_buf = "k_ssb_fused" + shape;                                        // DSP blocks that do not divide a pass: variable-length passes
     if (split_pass && plan.d_btab16 && (g.arith == SELENITE_ARITH_SPLIT16 || g.arith == SELENITE_ARITH_AUTO)) {
         const char *tail = g.arith == SELENITE_ARITH_AUTO ? "+exact rerun of guarded channels" : "";
@@ -733,7 +744,7 @@ bool fused_tail_split(const FusedPlan &plan, const selenite_rx_config &g, uint32
     // SELENITE_ARITH_AUTO: the bit-exact arithmetic, from a history k_hist_exact repairs first -- launch_shape's auto_ok, the tail
     // being too short to leave the mixed samples behind) -- true when the call should be cut that way.
     if (!(g.arith == SELENITE_ARITH_SPLIT16 || g.arith == SELENITE_ARITH_AUTO) || !plan.d_btab16 || !g.nd_taps) return false;
-    const uint32_t na = g.block / g.decim, pq = 256u / na * na, unit = pq * g.decim;
+    const uint32_t pq = split16_pass_out(g.block, g.decim), unit = pq * g.decim;
     if (!split16_pass_ok(pq) || block_size % unit == 0 || block_size < unit) return false;
     const int nds = split16_template_nd((int)g.nd_taps, (int)g.decim, (int)g.nh_taps);
     if (nds < 0) return false;
@@ -754,6 +765,7 @@ hipError_t launch_fused(const FusedPlan &plan, const RxParams &p, int arith, con
     fa.btab16 = plan.d_btab16;
     fa.split_post = plan.split_post;
     fa.split_sc = plan.split_sc;
+    fa.dec2 = 0u;                                         // (launch_shape sets it for decimation by 8 on the by-4 matrix kernel)
     {
         const char *e = std::getenv("SELENITE_RX_GRP_SHIFT");
         fa.grp_shift = e ? (uint32_t)std::atoi(e) : 2u;

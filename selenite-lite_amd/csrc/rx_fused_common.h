@@ -53,6 +53,9 @@ struct FusedArgs {
     const void *btab16;     // k_ssb_split16: Toeplitz operand, f16 hi/lo fragments
     float split_post;       // k_hilb_split16: exact power-of-two rescale of the MFMA result
     int split_sc;           // k_ssb_split16: the taps were scaled by 2^split_sc before their f16 hi/lo split
+    uint32_t dec2;          // k_ssb_split16 (run-time-geometry instantiations): decimation by 2 M on the by-M Toeplitz product -- a pass is
+                            // pass_out * 2 M input samples and only every second output of the tile is an output of the chain (1: the even ones,
+                            // 2: the odd ones); 0: the plain by-M kernel
     unsigned long long *dbg; // diagnostics (SELENITE_RX_DEBUG_TIMING): s_memtime stamps of workgroup 0, else NULL
 };
 

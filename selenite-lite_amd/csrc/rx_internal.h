@@ -152,6 +152,13 @@ hipError_t plan_fused(const selenite_rx_config &cfg, bool delay_is_impulse, int 
 void free_fused(FusedPlan &plan);
 // passes k_ssb_split16 runs: 256 audio samples, or fewer when the DSP block does not divide 256 -- whole 16-output tiles
 inline bool split16_pass_ok(uint32_t pass_out) { return pass_out != 0 && pass_out <= 256u && pass_out % 16u == 0; }
+// audio samples a full pass of k_ssb_split16 produces: the largest whole number of DSP blocks in its tile -- 256 outputs, or 128 when the
+// chain decimates by 8 (the by-4 product with every second output kept: FusedArgs::dec2)
+inline uint32_t split16_pass_out(uint32_t block, uint32_t decim)
+{
+    const uint32_t na = decim ? block / decim : 0u;
+    return na ? (decim == 8u ? 128u : 256u) / na * na : 0u;
+}
 bool fused_tail_split(const FusedPlan &plan, const selenite_rx_config &cfg, uint32_t block_size);
 hipError_t launch_fused(const FusedPlan &plan, const RxParams &p, int arith, const void *src,
                         bool src_q15, void *dst, bool dst_q15, int delay_index, hipStream_t st);

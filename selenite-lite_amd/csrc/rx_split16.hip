@@ -38,6 +38,7 @@ bool ssb_split16_has_shape(int nd, int m, int nh)
 
 bool ssb_split16_periodic_lo(int nd, int m, int nh)
 {
+    if (m == 8) m = 4;                                    // (decimation by 8 runs the by-4 kernel: FusedArgs::dec2)
 #define X(ND_, M_, NH_) if (nd == ND_ && m == M_ && nh == NH_) return Geo<ND_, M_, NH_>::T % 256 == 0;
     SRX_SPLIT16_SHAPES(X)
 #undef X

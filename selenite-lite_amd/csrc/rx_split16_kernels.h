@@ -275,7 +275,15 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
     // a full pass produces pq audio samples: 256, or (GROUP == 0 launches only) the largest whole number of DSP blocks in 256 when the
     // block does not divide it -- 240 for the firmware's 96-frame blocks by 4 (dsp_if.h:69-73).  Such passes run the "partial" code
     // path every time: the tile is computed in full, 16 of its outputs are dropped, the histories advance by pq * M samples.
-    const uint32_t pq = GROUP == 0 ? fa.pass_out : (uint32_t)G::P, tq = pq * M;
+    // DECIMATION BY 2 M (round 4, late: by 8 on the by-4 kernel).  A by-8 Toeplitz band is nd + 15 x 8 wide -- twelve k-steps, 96 VGPRs of
+    // fragments -- and a 256-output pass would be 2048 inputs, sixteen loads in flight: neither fits this one-wave pipeline.  But the
+    // by-8 outputs are every second by-4 output: the SAME 1024-input tile, images, fragments and k-steps as the by-4 kernel, with half of
+    // the tile's 256 results dropped where the accumulators are written to LDS (`dwrite`) -- the matrix work per INPUT sample is that of
+    // the by-4 chain, the demodulator's halves.  Everything behind the decimator runs on pass_out <= 128 outputs per pass through the
+    // run-time geometry (GROUP == 0) that the 240- / 192-output passes already use.  fa.dec2: 0 off, 1 / 2 the even / odd outputs.
+    const uint32_t dec2 = GROUP == 0 ? fa.dec2 : 0u;                // wave-uniform; a compile-time 0 in the 16- / 32- / 64-lane instantiations
+    const uint32_t MO = dec2 ? 2u * (uint32_t)M : (uint32_t)M;      // input samples per audio sample
+    const uint32_t pq = GROUP == 0 ? fa.pass_out : (uint32_t)G::P, tq = pq * MO;
     const uint32_t npass = (p.nout + pq - 1) / pq;
     const uint32_t tail_out = p.nout - (npass - 1) * pq;         // audio samples of the last pass: pq when the call is whole passes
     auto cur_out = [&](uint32_t pass) { return pass + 1 == npass ? tail_out : pq; };
@@ -520,7 +528,7 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
     auto mix = [&](uint32_t pass, auto partial_c) {
         constexpr bool PARTIAL = decltype(partial_c)::value;     // the call's last pass, with fewer than T input samples
         const uint32_t n0 = pass * tq;
-        const uint32_t cur_in = cur_out(pass) * M;                    // input samples of this pass that belong to it
+        const uint32_t cur_in = cur_out(pass) * MO;                   // input samples of this pass that belong to it
         const uint32_t ph_lane = ph0 + 2u * lane * step;
         v2f m[2 * NLD];
 #pragma unroll
@@ -709,6 +717,17 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
         asm volatile("" :: "v"(accI), "v"(accQ), "s"(ex)); (void)o0;
         return;
 #endif
+        if (dec2) {                                                   // wave-uniform: tile output 64 (l >> 4) + 16 r + (l & 15) is chain output (that - parity) / 2
+            const int oh = G::HH4 + 32 * (lane >> 4) + ((lane & 15) >> 1);
+            if ((uint32_t)(lane & 1) + 1u == dec2) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    dI[oh + 8 * r] = __builtin_ldexpf(accI[r], ex);
+                    dQ[oh + 8 * r] = __builtin_ldexpf(accQ[r], ex);
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
 #if SRX_ACC4
@@ -814,7 +833,7 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
     bool nonfinite = false;                                           // any audio sample of this workgroup NaN / Inf (x * 0 is NaN iff x is)
     auto store_audio = [&](uint32_t q, const float (&au)[4]) {
         const float z = __builtin_fmaf(au[3], 0.0f, __builtin_fmaf(au[2], 0.0f, __builtin_fmaf(au[1], 0.0f, au[0] * 0.0f)));
-        nonfinite = nonfinite || (z != z);
+        nonfinite = nonfinite || ((z != z) && (GROUP != 0 || (uint32_t)lane < pq / 4u));      // (lanes past a short pass hold no output of the chain)
 #ifdef SRX_X_NOSTORE
         asm volatile("" :: "v"(au[0]), "v"(au[1]), "v"(au[2]), "v"(au[3]));
 #else
@@ -1578,6 +1597,7 @@ template <int NCO, int ND, int M, int NH, typename TIn, typename TOut>
 static hipError_t launch_io(const RxParams &p, const FusedArgs &fa, const void *src, void *dst, hipStream_t st)
 {
     if (fa.am) return launch_k<NCO, ND, M, NH, TIn, TOut, 1, 0>(p, fa, src, dst, st);
+    if (fa.dec2) return launch_k<NCO, ND, M, NH, TIn, TOut, 0, 0>(p, fa, src, dst, st);     // by 2 M on the by-M product: run-time geometry only
     if constexpr (NCO != 0 && M == 2) {
         if (fa.group == 32) return launch_k<NCO, ND, M, NH, TIn, TOut, 0, 32>(p, fa, src, dst, st);      // DSP block 256 inputs / 2
     } else if constexpr (NCO != 0) {

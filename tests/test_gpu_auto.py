@@ -562,12 +562,61 @@ def test_auto_partial_passes_global_gain_and_shapes_without_a_matrix_kernel():
         d, m = per_block(g.process(iq), yo, 64)
         assert (d <= 1e-5 * m).all(), call
     g.close()
-    # (c) decimation by 8: no split-precision kernel -- AUTO is the bit-exact kernel there
-    g = sr.Rx(spec_of((256, 8, 63), nch, ARITH_AUTO, **dict(nco=True, nco_steps=steps)).config())
-    o = CpuChain(spec_of((256, 8, 63), nch, ARITH_CMSIS, **dict(nco=True, nco_steps=steps)), "orc")
-    assert g.kernel_name() == "k_ssb_fused<256,8,63>"
+    # (c) a shape without a split-precision kernel (decimation by 8 in front of a 127-tap pair: no type-III instantiation, the dense
+    #     flavour of the fused kernel) -- AUTO is the bit-exact kernel there
+    g = sr.Rx(spec_of((256, 8, 127), nch, ARITH_AUTO, **dict(nco=True, nco_steps=steps)).config())
+    o = CpuChain(spec_of((256, 8, 127), nch, ARITH_CMSIS, **dict(nco=True, nco_steps=steps)), "orc")
+    assert g.kernel_name() == "k_ssb_fused<256,8,127> (dense FIR pair)"
     iq = synth_iq(0, nch, 0, 4096)
     assert bits_equal(g.process(iq), o.process(iq))
+    g.close()
+
+
+@pytest.mark.parametrize("nd,nh,block", [(256, 63, 256), (128, 63, 512), (64, 63, 256), (200, 63, 1024), (256, 63, 128)])
+@pytest.mark.parametrize("arith", [ARITH_SPLIT16, ARITH_AUTO])
+@pytest.mark.parametrize("q15", [False, True])
+@pytest.mark.parametrize("nco", ["shared", "grid", "per_channel"])
+def test_decimation_by_8_on_the_matrix_kernel(nd, nh, block, arith, q15, nco):
+    """Round 4: arm_fir_decimate_f32 by 8 (arm_fir_decimate_f32.c:129-508) on k_ssb_split16 -- the by-4 Toeplitz
+    product with every second output of the tile kept (FusedArgs::dec2), passes of 128 outputs through the run-time geometry.
+    Calls of whole passes, a partial last pass, a short call in between; AUTO on the plain bar d <= 1e-5 max|ref| per DSP block, raw
+    SPLIT16 with the input-referred term for guarded blocks; decimator state and NCO phase bit-exact after every call; in AUTO the
+    sideband flip at a call boundary (the handover repair with its 8 x HH4 samples per channel) leaves the recomputed channels exact."""
+    import selenite_rx as sr
+    nch = 48
+    rng = np.random.default_rng(nd + block)
+    if nco == "shared":
+        kw = dict(nco=True, nco_step_all=0x01000000)
+    elif nco == "grid":
+        kw = dict(nco=True, nco_steps=(rng.integers(0, 3, nch).astype(np.uint32) << 24))
+    else:
+        kw = dict(nco=True, nco_steps=(0x01000000 + rng.integers(-40000, 40000, nch)).astype(np.uint32))
+    g = sr.Rx(rc.ChainSpec(nch, block, 8, nd, nh, 0, rc.MODE_USB, arith, **kw).config())
+    o = CpuChain(rc.ChainSpec(nch, block, 8, nd, nh, 0, rc.MODE_USB, ARITH_CMSIS, **kw), "orc")
+    assert g.kernel_name().startswith("k_ssb_split16<%d,8,%d>" % (nd, nh)), g.kernel_name()
+    na, pos = block // 8, 0
+    for call, bs in enumerate((4096, 2048 + 1024, block, 8192, 1024 + block)):
+        if call == 3 and not q15 and arith == ARITH_AUTO:
+            assert g.set_mode(rc.MODE_LSB) == 0 and o.set_mode(rc.MODE_LSB) == 0      # the tone is in the upper sideband: LSB cancels it
+        iq = synth_iq(0, nch, pos, bs)
+        pos += bs
+        if q15:
+            iq16 = np.clip(np.round(iq * 20000.0), -32768, 32767).astype(np.int16)
+            yg, yo = g.process_q15(iq16).astype(np.float64), o.process_q15(iq16).astype(np.float64)
+            assert np.abs(yg - yo).max() <= 1.0, (call, np.abs(yg - yo).max())
+        else:
+            yg, yo = g.process(iq), o.process(iq)
+            d, m = per_block(yg, yo, na)
+            if arith == ARITH_AUTO:
+                assert (d <= 1e-5 * m).all(), (call, (d / np.maximum(m, 1e-30)).max())
+            else:
+                lvl = np.abs(iq).max()
+                assert (d <= 1e-5 * m + 1e-6 * lvl).all(), (call, (d / np.maximum(m, 1e-30)).max())
+        sg, so = g.state(), o.state()
+        for key in ("dec_state", "nco_phase"):
+            assert (sg[key].view(np.uint32) == so[key].view(np.uint32)).all(), (call, key)
+    if arith == ARITH_AUTO:
+        assert g.guard_stats()["handover_blocks"] == 0
     g.close()
 
 

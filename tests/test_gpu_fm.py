@@ -62,7 +62,7 @@ def test_fm_on_the_fused_kernel(shape, arith, nco):
           "per_channel": dict(nco=True, nco_steps=steps), "off": dict()}[nco]
     ref = {ARITH_SPLIT16: ARITH_FMA, ARITH_AUTO: ARITH_CMSIS}.get(arith, arith)
     mk = lambda a: rc.ChainSpec(nch, 256, M, nd, nh, 0, rc.MODE_FM, a, agc=True, **kw)
-    matrix = arith == ARITH_AUTO and nd and M in (2, 4)                # AUTO on a shape with k_ssb_split16
+    matrix = arith == ARITH_AUTO and nd and M in (2, 4, 8)              # AUTO on a shape with k_ssb_split16
     name = run(mk(arith), mk(ref), [256, 1024, 768, 256, 4352], bar=matrix)
     mfma = ref == ARITH_FMA and nd and M == 4                          # whole-pass calls of the fma arithmetic by 4: f32 matrix cores
     assert name.startswith(("k_ssb_split16<%d,%d,%d>" if matrix else "k_ssb_mfma<%d,%d,%d>" if mfma else "k_ssb_fused<%d,%d,%d>") % shape)

@@ -53,7 +53,7 @@ def one_case(rng, idx):
     g = sr.Rx(spec_g.config())
     tol_mode = arith in (rc.ARITH_SPLIT16, rc.ARITH_AUTO) and "split16" in g.kernel_name()
     auto = arith == rc.ARITH_AUTO
-    has_split = (nd == 0 and (nd, M, nh) in SPLIT_SHAPES) or (nd >= 2 and M in (2, 4) and not odd_nd)
+    has_split = (nd == 0 and (nd, M, nh) in SPLIT_SHAPES) or (nd >= 2 and M in (2, 4) and not odd_nd) or (nd >= 2 and M == 8 and nh == 63 and not odd_nd)      # (by 8: the by-4 matrix kernel, every second output)
     assert ("split16" in g.kernel_name()) == (arith in (rc.ARITH_SPLIT16, rc.ARITH_AUTO) and has_split), (g.kernel_name(), nd, M, nh)
     # AUTO without a matrix kernel of its own is the bit-exact kernel; raw split16 without one runs as fma
     ref_arith = ARITH_CMSIS if (tol_mode or auto) else (ARITH_FMA if arith == rc.ARITH_SPLIT16 else arith)

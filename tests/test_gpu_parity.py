@@ -864,13 +864,13 @@ def test_periodic_shared_lo_in_registers_equals_the_table_path_bit_for_bit(q15):
 def test_other_decimation_ratios_and_a_64_tap_decimator_run_the_fused_kernels(nd, M, nh, arith, q15):
     """arm_fir_decimate_f32 with M = 2 and M = 8 (and a 64-tap decimator by 4) on the fused kernels: bit-exact in
     the CMSIS and fma modes.  split16: decimation by 2 has its own k_ssb_split16 instantiations and a 64-tap decimator runs on the
-    128-tap one (tolerance against CMSIS, mixed samples bit-exact); by 8 there is no matrix kernel: it runs as fma (header contract),
-    bit-exact against the fma oracle.  DSP blocks of 256 inputs = 128 / 32 / 64 audio samples: AGC groups of 32 / 8 / 16 lanes.
+    128-tap one (tolerance against CMSIS, mixed samples bit-exact); by 8 (round 4, late) runs the by-4 matrix kernel with every second
+    output of the tile kept.  DSP blocks of 256 inputs = 128 / 32 / 64 audio samples: AGC groups of 32 / 8 / 16 lanes.
     Whole-pass calls and a call with a ragged tail."""
     nch = 37
     kw = dict(nco=True, nco_step_all=0x01234567, agc=True)
     g = gpu_rx(rc.ChainSpec(nch, 256, M, nd, nh, 0, rc.MODE_USB, arith, **kw))
-    split = arith == rc.ARITH_SPLIT16 and M in (2, 4)    # by 2 and by 4: k_ssb_split16 (round 4: the 64-tap decimator on the 128-tap kernel, taps zero-padded in front)
+    split = arith == rc.ARITH_SPLIT16 and M in (2, 4, 8)    # k_ssb_split16 (round 4: the 64-tap decimator on the 128-tap kernel, taps zero-padded in front; by 8: the by-4 product, every second output kept)
     ref_arith = ARITH_CMSIS if split else (ARITH_FMA if arith == rc.ARITH_SPLIT16 else arith)
     o = CpuChain(rc.ChainSpec(nch, 256, M, nd, nh, 0, rc.MODE_USB, ref_arith, **kw), "orc")
     want = "k_ssb_split16" if split else ("k_ssb_mfma" if (arith != ARITH_CMSIS and M == 4) else "k_ssb_fused")
