@@ -73,7 +73,7 @@ extern "C" {
                                     NCO, biquad recurrence and AGC keep the reference rounding.  Bit-exact
                                     vs the oracle's fmaf restatement, <=1e-5 relative vs CMSIS */
 #define SELENITE_ARITH_SPLIT16 2 /* the many-tap FIR of the shape as a split-precision matrix product on the 16-bit
-                                    matrix cores (decimator of the /4 shapes; Hilbert FIR of the no-decimator
+                                    matrix cores (decimator of the /2, /4 and /8 shapes; Hilbert FIR of the no-decimator
                                     shapes; TX interpolator): samples and taps are split into f16 hi + lo
                                     parts, the three significant products (hi*hi, hi*lo, lo*hi) are
                                     accumulated in f32 by MFMA, with a block exponent taken from the data of
@@ -97,7 +97,8 @@ extern "C" {
                                     (selenite_rx_set_handover_repair); a recomputed channel stays with the bit-exact
                                     kernel until its level is back (selenite_rx_set_guard_ratio).  Split-precision
                                     kernels exist for every decimator of 2 .. 256 taps (even count) by 2 or by 4 in
-                                    front of a 31- / 63- / 127-tap type-III pair, and for those pairs alone;
+                                    front of a 31- / 63- / 127-tap type-III pair, by 8 in front of a 63-tap one (the
+                                    by-4 product with every second output kept), and for those pairs alone;
                                     other configurations run as SELENITE_ARITH_CMSIS. */
 
 typedef struct selenite_rx_config {
