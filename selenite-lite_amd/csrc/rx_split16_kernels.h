@@ -862,7 +862,7 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
         float au[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
         lds_order();
         STAMP(0);
-        if (cur_out(0) != G::P) mix(0, std::true_type{});
+        if (cur_out(0) * MO != (uint32_t)G::T) mix(0, std::true_type{});       // (a pass that does not fill the tile's inputs: a call's tail, 240- / 192-output passes)
         else mix(0, std::false_type{});
         STAMP(0);
         prefetch(1);
@@ -879,7 +879,7 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
         STAMP(0);
         for (uint32_t pass = 1; pass < npass; ++pass) {
             STAMP(1);                                                 // wait for the prefetched pass
-            if (cur_out(pass) != G::P) mix(pass, std::true_type{});
+            if (cur_out(pass) * MO != (uint32_t)G::T) mix(pass, std::true_type{});
             else mix(pass, std::false_type{});
             STAMP(0);
             store_audio(pass - 2, au);                                // pass 1: offset -1 pass = out of range, dropped
