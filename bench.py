@@ -37,7 +37,8 @@ TRAFFIC_JSON = next((p for p in (os.path.join(ROOT, "profiles", r, "traffic.json
                     os.path.join(ROOT, "profiles", "r3", "traffic.json"))
 
 WORKLOAD_TEXT = {"cfg3": "NCO + 256-tap arm_fir_decimate/4 + 63-tap Hilbert SSB (USB) + AGC",
-                 "cfg2": "127-tap Hilbert SSB (USB) + AGC, DSP block 192 (48 000 samples = 250 blocks)",
+                 "cfg2": "127-tap Hilbert SSB (USB) + AGC, DSP block 128 (48 000 samples = 375 blocks)",
+                 "cfg2_192": "127-tap Hilbert SSB (USB) + AGC, DSP block 192 (48 000 samples = 250 blocks)",
                  "cfg4": "CW: NCO + 4-stage DF1 biquad @500 Hz + AGC",
                  "cfg5": "127-tap Hilbert SSB (USB) + AGC, cfg5 weak-scaling shape"}
 

@@ -588,7 +588,7 @@ static hipError_t launch_shape(const RxParams &p, const FusedArgs &fa, const Fus
     if constexpr (ND == 0 && M == 1 && NH > 0) {
         // k_hilb_split16: whole passes of the largest whole number of DSP blocks in 256 (256 itself, or e.g. 192: BASELINE cfg2's
         // literal 48 000 samples are 250 blocks of 192); whole 4-sample lanes per block
-        const bool hilb_ok = fa.pass_out != 0 && p.nout % fa.pass_out == 0;
+        const bool hilb_ok = fa.pass_out != 0;                        // (any call length: the last pass may be partial, round 4 late)
         if (split && plan.d_btab16 && hilb_ok) {
             hipError_t e = launch_hilb_split16(NH, p, fa, src, src_q15, dst, st);            // rx_split16.hip
             if (e == hipSuccess && auto_ && p.rerun_flag) e = rerun();

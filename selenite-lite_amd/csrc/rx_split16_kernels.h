@@ -1339,8 +1339,12 @@ __global__ __launch_bounds__(64, 2) void k_hilb_split16(RxParams p, FusedArgs fa
     // it -- 192 for DSP blocks of 192 frames, BASELINE cfg2's literal 48 000 samples = 250 of them.  The 256-sample
     // tile is always mixed and multiplied in full (input beyond the call reads as zeros); with pq < 256 its last outputs belong to
     // the next pass and are dropped by the store's lane mask, and the histories take the samples in front of pq.
+    // (round 4, late) the LAST pass of a call may be shorter (a call is a whole number of DSP blocks, not of passes -- cfg2's 48 000
+    // samples in DSP blocks of 128 are 187 passes of 256 and one of 128): its missing input reads as zeros and its surplus audio is
+    // dropped by the buffer range checks, the AGC walks the blocks that exist, the state is taken behind the last sample that exists.
     const uint32_t pq = fa.pass_out;
-    const uint32_t npass = p.nout / pq;
+    const uint32_t npass = (p.nout + pq - 1u) / pq;
+    const uint32_t tail_out = p.nout - (npass - 1u) * pq;
     const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(src + (size_t)c * p.in_stride * 2, p.block_size * (R::kBytes / 2));
     const __amdgpu_buffer_rsrc_t rs_out = make_rsrc(dst + (size_t)c * p.out_stride, p.nout * (W::kBytes / 4));
     const __amdgpu_buffer_rsrc_t rs_lo = make_rsrc(p.lo, NCO == 2 ? p.block_size * 8u : 0u);
@@ -1399,7 +1403,6 @@ __global__ __launch_bounds__(64, 2) void k_hilb_split16(RxParams p, FusedArgs fa
         gd.first = 0ull;
         for (int l = 0; l < 64; l += group) gd.first |= 1ull << l;
     }
-    const int nvb = (int)(pq / (4u * (uint32_t)group));
     const uint32_t ph0 = NCO ? p.phase[c] : 0u, step = NCO ? p.step[c] : 0u;
     float gain = p.gain[c];
     const int mcol = lane & 15, rg = lane >> 4;
@@ -1407,8 +1410,11 @@ __global__ __launch_bounds__(64, 2) void k_hilb_split16(RxParams p, FusedArgs fa
     bool nonfinite = false;                                           // any audio sample NaN / Inf (x * 0 is NaN iff x is)
     lds_order();
 
-    for (uint32_t pass = 0; pass < npass; ++pass) {
+    // (the pass as a function of its length: the loop over the whole passes calls it with pq -- the code of round 3, instruction for
+    // instruction --, the partial last pass is a second copy of it with its own length)
+    auto one_pass = [&](uint32_t pass, uint32_t cur) {               // cur: audio samples of this pass (whole DSP blocks)
         const uint32_t n0 = pass * pq;
+        const int nvb = (int)(cur / (4u * (uint32_t)group));
         // ---- 1. NCO mix; both rails f32 into LDS; Q rail split into the f16 images at the block scale ----
         v2f ma[2], mb[2];
 #pragma unroll
@@ -1503,10 +1509,10 @@ __global__ __launch_bounds__(64, 2) void k_hilb_split16(RxParams p, FusedArgs fa
         W::store(rs_out, (uint32_t)lane < pq / 4u ? lane * W::kBytes : 0x40000000, (int)(pass * pq) * (W::kBytes / 4), au);
         // ---- 6. history: last NH-1 samples of both f32 rails and of both images to the front ----
         if constexpr (AM == 0) {
-            const float2 ti = *reinterpret_cast<const float2 *>(dI + pq + hv);
-            const float2 tq = *reinterpret_cast<const float2 *>(dQ + pq + hv);
-            const uint32_t th = *reinterpret_cast<const uint32_t *>(Xh + GH::phys((int)pq + hv));
-            const uint32_t tl = *reinterpret_cast<const uint32_t *>(Xl + GH::phys((int)pq + hv));
+            const float2 ti = *reinterpret_cast<const float2 *>(dI + cur + hv);
+            const float2 tq = *reinterpret_cast<const float2 *>(dQ + cur + hv);
+            const uint32_t th = *reinterpret_cast<const uint32_t *>(Xh + GH::phys((int)cur + hv));
+            const uint32_t tl = *reinterpret_cast<const uint32_t *>(Xl + GH::phys((int)cur + hv));
             lds_order();
             *reinterpret_cast<float2 *>(dI + hv) = ti;
             *reinterpret_cast<float2 *>(dQ + hv) = tq;
@@ -1514,7 +1520,10 @@ __global__ __launch_bounds__(64, 2) void k_hilb_split16(RxParams p, FusedArgs fa
             *reinterpret_cast<uint32_t *>(Xl + GH::phys(hv)) = tl;
         }
         lds_order();
-    }
+    };
+    const uint32_t nfull = tail_out == pq ? npass : npass - 1u;
+    for (uint32_t pass = 0; pass < nfull; ++pass) one_pass(pass, pq);
+    if (nfull != npass) one_pass(nfull, tail_out);
     // ---- parity guard: count (per-channel words: no atomics); SELENITE_ARITH_AUTO: a guarded channel keeps its pre-call state
     // and raises its rerun flag (the flag of every channel is rewritten every call) ----
     {

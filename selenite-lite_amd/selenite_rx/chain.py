@@ -126,6 +126,8 @@ def baseline_spec(name, channels, arith=ARITH_CMSIS, **kw):
         return ChainSpec(channels, 256, 1, 0, 127, 0, MODE_USB, arith, **kw)
     if name == "cfg2_48k":   # the same chain with DSP blocks of 192 frames: BASELINE cfg2's literal 48 000 samples per second are 250 of them
         return ChainSpec(channels, 192, 1, 0, 127, 0, MODE_USB, arith, **kw)
+    if name == "cfg2_48k128":   # ... and with DSP blocks of 128 frames (375 of them): passes of 256 outputs = two blocks, the last pass of a call one block
+        return ChainSpec(channels, 128, 1, 0, 127, 0, MODE_USB, arith, **kw)
     if name == "cfg3":   # NCO + 256-tap /4 + 63-tap SSB + AGC  (the headline config)
         return ChainSpec(channels, 256, 4, 256, 63, 0, MODE_USB, arith, nco=True,
                          nco_step_all=0x01000000, **kw)
@@ -138,7 +140,8 @@ def baseline_spec(name, channels, arith=ARITH_CMSIS, **kw):
 # bench.py workloads: name -> (BASELINE configuration, channels per GPU, complex samples per channel and call)
 WORKLOADS = {
     "cfg3": ("cfg3", 65536, 4096),     # headline: NCO + 256-tap /4 + 63-tap SSB + AGC
-    "cfg2": ("cfg2_48k", 4096, 48000),  # BASELINE cfg2 literally: 4096 channels x 48 kS/s (one second per call), DSP block 192 = 250 blocks
+    "cfg2": ("cfg2_48k128", 4096, 48000),  # BASELINE cfg2 literally: 4096 channels x 48 kS/s (one second per call), DSP block 128 = 375 blocks (187 passes of 256 outputs + one of 128)
+    "cfg2_192": ("cfg2_48k", 4096, 48000),  # the same second in DSP blocks of 192 frames (250 blocks, passes of 192 outputs: three quarters of every tile)
     "cfg4": ("cfg4", 65536, 4096),
     "cfg5": ("cfg2", 131072, 1024),    # weak-scaling shape of BASELINE cfg5 (cfg2 chain)
 }

@@ -26,6 +26,7 @@ FULL = {
     "cfg3": ("cfg3", 65536, 4096),
     "cfg4": ("cfg4", 65536, 4096),
     "cfg2": ("cfg2_48k", 4096, 48000),      # BASELINE cfg2 literally: 48 kS/s per call = 250 DSP blocks of 192 frames
+    "cfg2_128": ("cfg2_48k128", 4096, 48000),   # ... = 375 DSP blocks of 128 frames: whole 256-output passes and a partial last one (what bench.py --workload cfg2 runs)
     "cfg2_256": ("cfg2", 4096, 48000 - 48000 % 256),
     "cfg5": ("cfg2", 131072, 1024),
 }
@@ -70,6 +71,7 @@ class FullRun:
     ("cfg3", ARITH_CMSIS), ("cfg3", ARITH_FMA), ("cfg3", rc.ARITH_SPLIT16), ("cfg3", rc.ARITH_AUTO),
     ("cfg4", ARITH_CMSIS), ("cfg4", ARITH_FMA),
     ("cfg2", ARITH_CMSIS), ("cfg2", ARITH_FMA), ("cfg2", rc.ARITH_SPLIT16), ("cfg2", rc.ARITH_AUTO), ("cfg2_256", rc.ARITH_AUTO),
+    ("cfg2_128", ARITH_CMSIS), ("cfg2_128", rc.ARITH_SPLIT16), ("cfg2_128", rc.ARITH_AUTO),
     ("cfg5", ARITH_CMSIS), ("cfg5", rc.ARITH_SPLIT16), ("cfg5", rc.ARITH_AUTO),
 ])
 def test_full_size_sampled_channels_match_oracle(name, arith):

@@ -188,7 +188,7 @@ def test_cw_kernel_for_other_dsp_blocks(stages, block, q15):
 def test_the_hilbert_matrix_kernel_with_passes_of_fewer_than_256_outputs(nh, block, arith, nco):
     """k_hilb_split16 (no decimator) with DSP blocks that do not divide the 256-sample tile: passes of the largest whole number of
     blocks in it (192 for blocks of 192 frames -- BASELINE cfg2's literal 48 000 samples are 250 of them --, 192 = two blocks of 96,
-    160, 256 = two of 128); calls of whole passes stay on the matrix kernel, anything else runs bit-exactly on k_ssb_fused in AUTO.
+    160, 256 = two of 128); the last pass of a call may be shorter (round 4, late: calls of one block, of passes + one block).
     Raw split16: input-referred bar; AUTO: plain bar.  The FIR pair's state (the mixed samples) bit-exact after every call."""
     import selenite_rx as sr
     nch, na = 27, block
