@@ -195,10 +195,16 @@ __device__ __forceinline__ void agc_pass(const AgcParams &ap, uint32_t agc_on, i
 //   The pass loop body is branch-free apart from the (rare) history re-split: no exec-masked copy
 //   loops, no conditional prefetch (buffer range check instead), state written after the loop.
 // ------------------------------------------------------------------------------------------
-template <int NCO, int ND, int M, int NH, typename TIn, typename TOut, int AM, int GROUP, int ENV = 0>
+template <int NCO, int ND, int M, int NH, typename TIn, typename TOut, int AM, int GROUP, int FLAVOUR = 0>
 __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa, const TIn *__restrict__ src,
                                                        TOut *__restrict__ dst)
 {
+    // FLAVOUR: 0 the plain kernel; 1 (GROUP == 16) phase 1 of the global-gain call, which also leaves the block maxima behind; 2 (GROUP == 0)
+    // decimation by 2 M on the by-M product (FusedArgs::dec2) -- instantiations of their own: compiled into the plain run-time-geometry
+    // kernel, the by-8 bookkeeping cost the firmware's one-slot calls 13 % (a kernel already short of scalar registers)
+    constexpr int ENV = FLAVOUR == 1 ? 1 : 0;
+    constexpr bool DEC2 = FLAVOUR == 2;
+    static_assert(!DEC2 || GROUP == 0, "decimation by 2 M: run-time geometry only");
     using G = Geo<ND, M, NH>;
     using GS = GeoS<NCO, ND, M, NH>;
     using R = BRaw<TIn>;
@@ -281,7 +287,7 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
     // the tile's 256 results dropped where the accumulators are written to LDS (`dwrite`) -- the matrix work per INPUT sample is that of
     // the by-4 chain, the demodulator's halves.  Everything behind the decimator runs on pass_out <= 128 outputs per pass through the
     // run-time geometry (GROUP == 0) that the 240- / 192-output passes already use.  fa.dec2: 0 off, 1 / 2 the even / odd outputs.
-    const uint32_t dec2 = GROUP == 0 ? fa.dec2 : 0u;                // wave-uniform; a compile-time 0 in the 16- / 32- / 64-lane instantiations
+    const uint32_t dec2 = DEC2 ? fa.dec2 : 0u;                      // wave-uniform; a compile-time 0 in every other instantiation
     const uint32_t MO = dec2 ? 2u * (uint32_t)M : (uint32_t)M;      // input samples per audio sample
     const uint32_t pq = GROUP == 0 ? fa.pass_out : (uint32_t)G::P, tq = pq * MO;
     const uint32_t npass = (p.nout + pq - 1) / pq;
@@ -833,7 +839,7 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
     bool nonfinite = false;                                           // any audio sample of this workgroup NaN / Inf (x * 0 is NaN iff x is)
     auto store_audio = [&](uint32_t q, const float (&au)[4]) {
         const float z = __builtin_fmaf(au[3], 0.0f, __builtin_fmaf(au[2], 0.0f, __builtin_fmaf(au[1], 0.0f, au[0] * 0.0f)));
-        nonfinite = nonfinite || ((z != z) && (GROUP != 0 || (uint32_t)lane < pq / 4u));      // (lanes past a short pass hold no output of the chain)
+        nonfinite = nonfinite || ((z != z) && (!DEC2 || (uint32_t)lane < pq / 4u));            // (by 2 M: the lanes past the pass hold no output of the chain)
 #ifdef SRX_X_NOSTORE
         asm volatile("" :: "v"(au[0]), "v"(au[1]), "v"(au[2]), "v"(au[3]));
 #else
@@ -862,7 +868,7 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
         float au[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
         lds_order();
         STAMP(0);
-        if (cur_out(0) * MO != (uint32_t)G::T) mix(0, std::true_type{});       // (a pass that does not fill the tile's inputs: a call's tail, 240- / 192-output passes)
+        if (DEC2 ? cur_out(0) * MO != (uint32_t)G::T : cur_out(0) != G::P) mix(0, std::true_type{});       // (a pass that does not fill the tile's inputs: a call's tail, 240- / 192-output passes)
         else mix(0, std::false_type{});
         STAMP(0);
         prefetch(1);
@@ -879,7 +885,7 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
         STAMP(0);
         for (uint32_t pass = 1; pass < npass; ++pass) {
             STAMP(1);                                                 // wait for the prefetched pass
-            if (cur_out(pass) * MO != (uint32_t)G::T) mix(pass, std::true_type{});
+            if (DEC2 ? cur_out(pass) * MO != (uint32_t)G::T : cur_out(pass) != G::P) mix(pass, std::true_type{});
             else mix(pass, std::false_type{});
             STAMP(0);
             store_audio(pass - 2, au);                                // pass 1: offset -1 pass = out of range, dropped
@@ -1556,7 +1562,7 @@ __global__ __launch_bounds__(64, 2) void k_hilb_split16(RxParams p, FusedArgs fa
 // ------------------------------------------------------------------------------------------
 // host side: dispatch over the instantiated shapes
 // ------------------------------------------------------------------------------------------
-template <int NCO, int ND, int M, int NH, typename TIn, typename TOut, int AM, int GROUP>
+template <int NCO, int ND, int M, int NH, typename TIn, typename TOut, int AM, int GROUP, int FLAVOUR = 0>
 static hipError_t launch_k(const RxParams &p, const FusedArgs &fa, const void *src, void *dst, hipStream_t st)
 {
     using GS = GeoS<NCO, ND, M, NH>;
@@ -1579,7 +1585,7 @@ static hipError_t launch_k(const RxParams &p, const FusedArgs &fa, const void *s
     if (resident == 0) {
         int per_cu = 0, dev = 0;
         hipDeviceProp_t prop;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_ssb_split16<NCO, ND, M, NH, TIn, TOut, AM, GROUP>, 64, lds) != hipSuccess ||
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_ssb_split16<NCO, ND, M, NH, TIn, TOut, AM, GROUP, FLAVOUR>, 64, lds) != hipSuccess ||
             hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess || per_cu <= 0)
             resident = -1;
         else
@@ -1595,7 +1601,7 @@ static hipError_t launch_k(const RxParams &p, const FusedArgs &fa, const void *s
         }
     }
     if (p.env_part) return hipErrorNotSupported;  // the host side asks for the maxima only from launches that provide them
-    hipLaunchKernelGGL((k_ssb_split16<NCO, ND, M, NH, TIn, TOut, AM, GROUP>), dim3(grid), dim3(64), lds, st, p, fa,
+    hipLaunchKernelGGL((k_ssb_split16<NCO, ND, M, NH, TIn, TOut, AM, GROUP, FLAVOUR>), dim3(grid), dim3(64), lds, st, p, fa,
                        static_cast<const TIn *>(src), static_cast<TOut *>(dst));
     return hipGetLastError();
 }
@@ -1605,8 +1611,14 @@ static hipError_t launch_k(const RxParams &p, const FusedArgs &fa, const void *s
 template <int NCO, int ND, int M, int NH, typename TIn, typename TOut>
 static hipError_t launch_io(const RxParams &p, const FusedArgs &fa, const void *src, void *dst, hipStream_t st)
 {
-    if (fa.am) return launch_k<NCO, ND, M, NH, TIn, TOut, 1, 0>(p, fa, src, dst, st);
-    if (fa.dec2) return launch_k<NCO, ND, M, NH, TIn, TOut, 0, 0>(p, fa, src, dst, st);     // by 2 M on the by-M product: run-time geometry only
+    if constexpr (M == 4) {
+        if (fa.am && fa.dec2) return launch_k<NCO, ND, M, NH, TIn, TOut, 1, 0, 2>(p, fa, src, dst, st);
+    }
+    if (fa.am && !fa.dec2) return launch_k<NCO, ND, M, NH, TIn, TOut, 1, 0>(p, fa, src, dst, st);
+    if constexpr (M == 4) {
+        if (fa.dec2) return launch_k<NCO, ND, M, NH, TIn, TOut, 0, 0, 2>(p, fa, src, dst, st);     // by 2 M on the by-M product: run-time geometry, its own instantiation
+    }
+    if (fa.dec2) return hipErrorNotSupported;
     if constexpr (NCO != 0 && M == 2) {
         if (fa.group == 32) return launch_k<NCO, ND, M, NH, TIn, TOut, 0, 32>(p, fa, src, dst, st);      // DSP block 256 inputs / 2
     } else if constexpr (NCO != 0) {

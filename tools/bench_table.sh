@@ -25,6 +25,7 @@ run --arith cmsis
 run --workload cfg2
 run --workload cfg2 --arith split16
 run --workload cfg2 --io q15
+run --workload cfg2_192
 run --workload cfg5
 run --workload cfg5 --arith split16
 run --workload cfg4

@@ -16,6 +16,7 @@ bash tools/profile_run.sh cfg3_fma --arith fma > /dev/null 2>&1
 bash tools/profile_run.sh cfg3_cmsis --arith cmsis > /dev/null 2>&1
 bash tools/profile_run.sh cfg4 --workload cfg4 --arith cmsis > /dev/null 2>&1
 bash tools/profile_run.sh cfg2_auto --workload cfg2 > /dev/null 2>&1
+bash tools/profile_run.sh cfg2_192_auto --workload cfg2_192 > /dev/null 2>&1
 bash tools/profile_run.sh cfg5_auto --workload cfg5 > /dev/null 2>&1
 bash tools/pmc_sq2.sh cfg3_auto > gpurun_out/sq2_cfg3_auto.txt 2>&1
 bash tools/pmc_sq2.sh cfg3_cmsis --arith cmsis > gpurun_out/sq2_cfg3_cmsis.txt 2>&1
