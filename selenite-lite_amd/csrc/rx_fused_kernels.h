@@ -49,6 +49,62 @@ __device__ __forceinline__ void decim_quad(const float *S, int lane, const float
     }
 }
 
+// The same FIR for a SHORT pass (round 4: calls of up to 64 audio samples -- the firmware's one- and two-slot callbacks, the 256-sample
+// call: most of what SELENITE_ARITH_AUTO sends here because it is too short for the matrix kernel): output j = lane, ONE output
+// per lane instead of four adjacent ones, so that every lane works on an output that exists -- a quarter of the tile's multiply-adds.  Per accumulator the same visit order (q ascending, p ascending), the same products: the same bits.  Element j + q of
+// phase p sits at elem(j + q) = 12 ((j + q) >> 2) + 2 ((j + q) & 3); with q = 4 a + b that is a per-lane base for each b plus the
+// compile-time offset 12 a: four address registers, immediate offsets, one ds_read_b64 per tap.  The 4 M reads of step a + 1 are issued
+// before step a's products are formed (left to the compiler, every read was followed by its own s_waitcnt: 257 LDS round trips per
+// pass, as long as the four-output form).
+// The same FIR for a SHORT pass (round 4: calls of up to 64 audio samples -- the firmware's one- and two-slot callbacks, the 256-sample
+// call: most of what SELENITE_ARITH_AUTO sends to this kernel because it is too short for the matrix kernel): output j = lane (+ 64 k),
+// ONE output per lane instead of four adjacent ones, so that every lane works on an output that exists -- a quarter of the tile's
+// multiply-adds.  Per accumulator the same visit order (q ascending, p ascending), the same products: the same bits.  Element j + q of
+// phase p sits at elem(j + q) = 12 ((j + q) >> 2) + 2 ((j + q) & 3); with q = 4 a + b that is a per-lane base for each b plus the
+// compile-time offset 12 (a + 16 k): four address registers, immediate offsets, one ds_read_b64 per tap.  The 4 M reads of step a + 1
+// are issued before step a's products are formed -- left to the compiler every read was followed by its own s_waitcnt, 257 LDS round
+// trips per pass: as long as the four-output form.  (Only K = 1 is used: a second round for outputs 64 .. 127 -- a second copy of the
+// walk, a loop around it, or K = 2 -- and even this function returning its sum by value cost the kernel 1.6 KB of scratch.)
+template <int ARITH, int ND, int M, int NH, int K>
+__device__ __forceinline__ void decim_spread(const float *S, int lane, const float (&creg)[Geo<ND, M, NH>::NCR], v2f (&acc)[K])
+{
+    using G = Geo<ND, M, NH>;
+    const float *bs[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) bs[b] = S + G::elem(lane + b);
+    // software pipeline over a: the 4 M K reads of step a + 1 are in flight while step a's products are formed
+    v2f w[2][4][M][K];
+    auto load = [&](int a, int slot) {
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int p = 0; p < M; ++p)
+#pragma unroll
+                for (int k = 0; k < K; ++k)
+                    w[slot][b][p][k] = *reinterpret_cast<const v2f *>(bs[b] + 12 * (a + 16 * k) + p * G::PSF);
+    };
+    load(0, 0);
+#pragma unroll
+    for (int a = 0; a <= G::HQ4 / 4; ++a) {
+        if (a < G::HQ4 / 4) load(a + 1, (a + 1) & 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int q = 4 * a + b;
+            if (q > G::HQ4) continue;
+#pragma unroll
+            for (int p = 0; p < M; ++p) {
+                const int kk = q * M + p;
+                if ((q == G::HQ4 && p > 0) || kk < G::F) continue;
+                const float c = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(creg[kk >> 6]), kk & 63));
+#pragma unroll
+                for (int k = 0; k < K; ++k) acc[k] = mac2<ARITH>(acc[k], w[a & 1][b][p][k], c);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 // Steps 3-5 of a pass, shared by the VALU and the MFMA kernels: Hilbert FIR on Q (structural zeros
 // skipped) and unit-impulse delay on I from the decimated rails in LDS, sideband combine, AGC per
 // DSP block (group lanes), one 4-sample store per lane.
@@ -460,10 +516,21 @@ __global__ __launch_bounds__(64, 2) void k_ssb_fused(RxParams p, FusedArgs fa, c
         }
         // ---- 2. arm_fir_decimate_f32 on both rails, 4 adjacent outputs per lane ----
         if constexpr (ND > 0) {
-            v2f acc[4] = { { 0.0f, 0.0f }, { 0.0f, 0.0f }, { 0.0f, 0.0f }, { 0.0f, 0.0f } };
-            decim_quad<ARITH, ND, M, NH>(S, lane, creg, acc);
-            *reinterpret_cast<float4 *>(dI + G::HH4 + 4 * lane) = make_float4(acc[0].x, acc[1].x, acc[2].x, acc[3].x);
-            *reinterpret_cast<float4 *>(dQ + G::HH4 + 4 * lane) = make_float4(acc[0].y, acc[1].y, acc[2].y, acc[3].y);
+            if (ARITH == 0 && M == 4 && DENSE == 0 && cur <= 64u) {     // wave-uniform: a short pass -- only the outputs that exist (decim_spread; the bit-exact /4 kernels: what AUTO's short calls run on)
+                v2f a1[1] = { { 0.0f, 0.0f } };
+                decim_spread<ARITH, ND, M, NH, 1>(S, lane, creg, a1);
+                dI[G::HH4 + lane] = a1[0].x; dQ[G::HH4 + lane] = a1[0].y;
+                if (lane >= 16) {                                     // the rest of the tile: not computed, never stored, in no DSP block the AGC looks at -- but read by the demodulator: zeros
+                    const float4 z4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                    *reinterpret_cast<float4 *>(dI + G::HH4 + 4 * lane) = z4;
+                    *reinterpret_cast<float4 *>(dQ + G::HH4 + 4 * lane) = z4;
+                }
+            } else {
+                v2f acc[4] = { { 0.0f, 0.0f }, { 0.0f, 0.0f }, { 0.0f, 0.0f }, { 0.0f, 0.0f } };
+                decim_quad<ARITH, ND, M, NH>(S, lane, creg, acc);
+                *reinterpret_cast<float4 *>(dI + G::HH4 + 4 * lane) = make_float4(acc[0].x, acc[1].x, acc[2].x, acc[3].x);
+                *reinterpret_cast<float4 *>(dQ + G::HH4 + 4 * lane) = make_float4(acc[0].y, acc[1].y, acc[2].y, acc[3].y);
+            }
             wave_lds_sync();
         }
         // ---- 3-5. Hilbert pair + sideband, AGC, store ----
