@@ -131,6 +131,9 @@ def baseline_spec(name, channels, arith=ARITH_CMSIS, **kw):
     if name == "cfg3":   # NCO + 256-tap /4 + 63-tap SSB + AGC  (the headline config)
         return ChainSpec(channels, 256, 4, 256, 63, 0, MODE_USB, arith, nco=True,
                          nco_step_all=0x01000000, **kw)
+    if name == "cfg3_by8":   # the cfg3 chain decimating by 8 (k_ssb_split16 on the by-4 product, every second output kept)
+        return ChainSpec(channels, 256, 8, 256, 63, 0, MODE_USB, arith, nco=True,
+                         nco_step_all=0x01000000, **kw)
     if name == "cfg4":   # CW narrow: NCO (BFO) + 4-stage biquad @500 Hz + AGC
         return ChainSpec(channels, 256, 1, 0, 0, 4, MODE_CW, arith, nco=True,
                          nco_step_all=0x00800000, **kw)

@@ -29,6 +29,7 @@ FULL = {
     "cfg2_128": ("cfg2_48k128", 4096, 48000),   # ... = 375 DSP blocks of 128 frames: whole 256-output passes and a partial last one (what bench.py --workload cfg2 runs)
     "cfg2_256": ("cfg2", 4096, 48000 - 48000 % 256),
     "cfg5": ("cfg2", 131072, 1024),
+    "cfg3_by8": ("cfg3_by8", 65536, 4096),      # decimation by 8 on the matrix kernel (round 4, late), at the bench's channel count
 }
 
 
@@ -72,6 +73,7 @@ class FullRun:
     ("cfg4", ARITH_CMSIS), ("cfg4", ARITH_FMA),
     ("cfg2", ARITH_CMSIS), ("cfg2", ARITH_FMA), ("cfg2", rc.ARITH_SPLIT16), ("cfg2", rc.ARITH_AUTO), ("cfg2_256", rc.ARITH_AUTO),
     ("cfg2_128", ARITH_CMSIS), ("cfg2_128", rc.ARITH_SPLIT16), ("cfg2_128", rc.ARITH_AUTO),
+    ("cfg3_by8", ARITH_CMSIS), ("cfg3_by8", rc.ARITH_SPLIT16), ("cfg3_by8", rc.ARITH_AUTO),
     ("cfg5", ARITH_CMSIS), ("cfg5", rc.ARITH_SPLIT16), ("cfg5", rc.ARITH_AUTO),
 ])
 def test_full_size_sampled_channels_match_oracle(name, arith):
