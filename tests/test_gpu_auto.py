@@ -847,3 +847,41 @@ def test_the_size_of_the_rerun_grid_never_changes_a_result():
         outs.append(r.stdout.split())
     assert int(outs[0][1]) >= 3 * 4608                                 # the guarded channels were recomputed (held from the second call on)
     assert all(o == outs[0] for o in outs), outs
+
+
+@pytest.mark.parametrize("mode", [rc.MODE_AM, rc.MODE_FM, rc.MODE_LSB, rc.MODE_DIG])
+def test_decimation_by_8_in_the_other_modes(mode):
+    """AM (arm_cmplx_mag_f32), FM (the discriminator on min|z|-guarded blocks), LSB / DIG by 8 on the matrix kernel in SELENITE_ARITH_AUTO:
+    the plain bar on every DSP block, nothing left to the handover counter."""
+    import selenite_rx as sr
+    nch = 40
+    kw = dict(nco=True, nco_step_all=0x01000000)
+    g = sr.Rx(rc.ChainSpec(nch, 256, 8, 256, 63, 0, mode, ARITH_AUTO, **kw).config())
+    o = CpuChain(rc.ChainSpec(nch, 256, 8, 256, 63, 0, mode, ARITH_CMSIS, **kw), "orc")
+    assert g.kernel_name().startswith("k_ssb_split16<256,8,63>"), g.kernel_name()
+    for call in range(3):
+        iq = synth_iq(0, nch, 4096 * call, 4096)
+        d, m = per_block(g.process(iq), o.process(iq), 32)
+        assert (d <= 1e-5 * m).all(), (call, (d / np.maximum(m, 1e-30)).max())
+    assert g.guard_stats()["handover_blocks"] == 0
+    g.close()
+
+
+@pytest.mark.parametrize("block", [128, 256, 512, 2048])
+@pytest.mark.parametrize("arith", [ARITH_AUTO, ARITH_SPLIT16])
+def test_decimation_by_8_with_a_global_gain(block, arith):
+    """agc_global by 8: the fused kernel runs with its own AGC off, the envelope is folded over channels, the gain pass applies it.  DSP blocks
+    of 2048 frames are 256 audio samples -- more than a 128-output pass holds: that geometry stays on the vector kernels (bit-exact in AUTO)."""
+    import selenite_rx as sr
+    nch = 40
+    kw = dict(nco=True, nco_step_all=0x01000000, agc_global=True)
+    g = sr.Rx(rc.ChainSpec(nch, block, 8, 256, 63, 0, rc.MODE_USB, arith, **kw).config())
+    o = CpuChain(rc.ChainSpec(nch, block, 8, 256, 63, 0, rc.MODE_USB, ARITH_CMSIS, **kw), "orc")
+    assert ("split16" in g.kernel_name()) == (block <= 1024), g.kernel_name()
+    for call in range(3):
+        iq = synth_iq(0, nch, 4096 * call, 4096)
+        yo, _ = o.process_env(iq)
+        d, m = per_block(g.process(iq), yo, block // 8)
+        bar = 1e-5 * m if arith == ARITH_AUTO else 1e-5 * m + 1e-6 * np.abs(iq).max()
+        assert (d <= bar).all(), (call, (d / np.maximum(m, 1e-30)).max())
+    g.close()
