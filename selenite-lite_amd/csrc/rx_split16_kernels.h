@@ -150,7 +150,13 @@ __device__ __forceinline__ void agc_pass(const AgcParams &ap, uint32_t agc_on, i
         g = agc_step(ap, g, agc_desired(ap, m));
         mine = g;
     } else {
-        if ((group & (group - 1)) == 0) {
+        if (group == 8) {
+            // eight lanes per DSP block (decimation by 8 of 256-frame blocks, round 4): two quad permutes and a half-row mirror on the
+            // DPP path instead of three LDS round trips (ds_bpermute)
+            m = fmaxf(m, __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(m), 0xB1, 0xf, 0xf, false)));    // quad_perm [1,0,3,2]
+            m = fmaxf(m, __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(m), 0x4E, 0xf, 0xf, false)));    // quad_perm [2,3,0,1]
+            m = fmaxf(m, __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(m), 0x141, 0xf, 0xf, false)));   // row_half_mirror
+        } else if ((group & (group - 1)) == 0) {
 #pragma unroll
             for (int off = 1; off < 64; off <<= 1)
                 if (off < group) m = fmaxf(m, __shfl_xor(m, off, 64));
