@@ -215,3 +215,38 @@ def test_every_channel_of_the_bench_workload_split16_within_the_north_star_toler
     assert np.array_equal(sg["nco_phase"], so["nco_phase"])
     assert rel_err(sg["fir_state"], so["fir_state"]) <= TOL
     assert np.allclose(sg["agc_gain"], so["agc_gain"], rtol=1e-5, atol=0)
+
+
+@pytest.mark.parametrize("name,nch,bs,arith,q15", [
+    ("cfg3", 16384, 4096, rc.ARITH_AUTO, False), ("cfg3", 16384, 4096, rc.ARITH_SPLIT16, True), ("cfg3", 16384, 1024 + 256, ARITH_CMSIS, False),
+    ("cfg3_by8", 16384, 4096, rc.ARITH_AUTO, False), ("cfg3_by8", 16384, 4096 + 256, rc.ARITH_SPLIT16, True),
+    ("cfg2_48k128", 4096, 48000, rc.ARITH_AUTO, True), ("cfg2_48k", 4096, 48000, rc.ARITH_SPLIT16, False), ("cfg2", 8192, 4096, rc.ARITH_AUTO, False),
+    ("cfg3", 16384, 96 * 4, rc.ARITH_AUTO, False),
+])
+def test_replicated_channels_give_replicated_audio(name, nch, bs, arith, q15):
+    """Every group of 64 channels gets the same input: a kernel that computes every channel on its own must give every group the same
+    bits -- audio and state --, whatever workgroup, compute unit or residency slot a channel lands on.  (How a first version of the partial
+    last pass of k_hilb_split16 showed: denormal audio on channels >= 768 of a 4096-channel launch, fine at 64 channels; the sampled-channel
+    tests above caught it too, this one looks at every channel.)"""
+    import selenite_rx as sr
+    spec = baseline_spec(name, nch, arith)
+    if name == "cfg3" and bs == 96 * 4:
+        spec = rc.ChainSpec(nch, 96, 4, 256, 63, 0, rc.MODE_USB, arith, nco=True, nco_step_all=0x01000000)      # the firmware's slot geometry: short calls on the bit-exact kernel
+    g = sr.Rx(spec.config())
+    for k in range(3):
+        iq = np.concatenate([synth_iq(c, 1, k * bs, bs) for c in range(64)], axis=0)
+        if q15:
+            full = np.tile(np.clip(np.round(iq * 20000.0), -32768, 32767).astype(np.int16), (nch // 64, 1, 1))
+            y = g.process_q15(full)
+        else:
+            y = g.process(np.tile(iq, (nch // 64, 1, 1)))
+        rep = y.reshape(nch // 64, 64, -1)
+        same = (rep.view(np.uint16 if q15 else np.uint32) == rep[0].view(np.uint16 if q15 else np.uint32)).all(axis=(1, 2))
+        assert same.all(), (k, np.flatnonzero(~same)[:8])
+    st = g.state()
+    for key in ("dec_state", "fir_state", "agc_gain", "nco_phase"):
+        a = st[key]
+        if a.size:
+            r = np.ascontiguousarray(a).reshape(nch // 64, -1).view(np.uint32)
+            assert (r == r[0]).all(), key
+    g.close()
