@@ -221,7 +221,8 @@ def test_every_channel_of_the_bench_workload_split16_within_the_north_star_toler
     ("cfg3", 16384, 4096, rc.ARITH_AUTO, False), ("cfg3", 16384, 4096, rc.ARITH_SPLIT16, True), ("cfg3", 16384, 1024 + 256, ARITH_CMSIS, False),
     ("cfg3_by8", 16384, 4096, rc.ARITH_AUTO, False), ("cfg3_by8", 16384, 4096 + 256, rc.ARITH_SPLIT16, True),
     ("cfg2_48k128", 4096, 48000, rc.ARITH_AUTO, True), ("cfg2_48k", 4096, 48000, rc.ARITH_SPLIT16, False), ("cfg2", 8192, 4096, rc.ARITH_AUTO, False),
-    ("cfg3", 16384, 96 * 4, rc.ARITH_AUTO, False),
+    ("cfg3", 16384, 96 * 4, rc.ARITH_AUTO, False), ("cfg4", 16384, 4096, ARITH_CMSIS, False), ("cfg4", 16384, 2048, ARITH_CMSIS, True),
+    ("cfg3", 16384, 4096, ARITH_FMA, False),
 ])
 def test_replicated_channels_give_replicated_audio(name, nch, bs, arith, q15):
     """Every group of 64 channels gets the same input: a kernel that computes every channel on its own must give every group the same
@@ -244,7 +245,7 @@ def test_replicated_channels_give_replicated_audio(name, nch, bs, arith, q15):
         same = (rep.view(np.uint16 if q15 else np.uint32) == rep[0].view(np.uint16 if q15 else np.uint32)).all(axis=(1, 2))
         assert same.all(), (k, np.flatnonzero(~same)[:8])
     st = g.state()
-    for key in ("dec_state", "fir_state", "agc_gain", "nco_phase"):
+    for key in ("dec_state", "fir_state", "biq_state", "agc_gain", "nco_phase"):
         a = st[key]
         if a.size:
             r = np.ascontiguousarray(a).reshape(nch // 64, -1).view(np.uint32)
