@@ -153,6 +153,117 @@ def parity_check(name, workloads, arith, q15, nch=64, calls=2):
             "rerun_channel_calls": st["rerun_channel_calls"]}
 
 
+def side_workload(name, q15, arith, spinup_ms, iters=100, rank=0, parity=True, channels_override=0):
+    """One of the other single-GPU BASELINE configurations on its own resident synthetic batch (the `workloads` block of the default line):
+    own instance, own buffers, own clock spin-up, `iters` launches with a HIP event between launches -> MEDIAN per-launch duration
+    (SURVEY.md 8d); roofline.frac = SURVEY 8d algorithmic bytes / that / 8 TB/s; `traffic` from the committed PMC passes of the same shape;
+    parity.worst_rel on a 64-channel sample against the compiled reference.  Buffers are freed before the next workload."""
+    import numpy as np
+    import selenite_rx as sr
+    from selenite_rx import chain as ch
+    cfg_name, channels, bs = ch.WORKLOADS[name]
+    channels = channels_override or channels               # (--channels: a scaled run scales these too; `traffic` is then None)
+    spec = ch.baseline_spec(cfg_name, channels, arith)
+    rx = sr.Rx(spec.config())
+    nout = bs // spec.decim
+    d_in = sr.DeviceBuffer(channels * bs * 8)
+    d_out = sr.DeviceBuffer(channels * nout * 4)
+    rx.synth_device(d_in.ptr, rank * channels, channels, 0, bs, ch.SEED)
+    rx.sync()
+    note = None
+    if q15:
+        # int16 slots: the synthetic signal through the reference's float->q15 rule (arm_float_to_q15.c:117), converted on the host for the first
+        # `rep` channels and repeated (the conversion of 2 GB through numpy would cost the default run seconds; the kernels' time does not
+        # depend on which channel's samples a channel carries)
+        rep = min(channels, 8192)
+        f = np.empty((rep, bs, 2), np.float32)
+        sr.lib().selenite_rx_memcpy_d2h(f.ctypes.data, d_in.ptr, f.nbytes)
+        q = np.clip(np.trunc(f * np.float32(32768.0)), -32768, 32767).astype(np.int16)
+        d_in.free()
+        d_in = sr.DeviceBuffer(channels * bs * 4)
+        for c0 in range(0, channels, rep):
+            n = min(rep, channels - c0)
+            sr.lib().selenite_rx_memcpy_h2d(d_in.ptr + c0 * bs * 4, q.ctypes.data, n * bs * 4)
+        note = "int16 input: the first %d channels' signal, repeated" % rep if rep < channels else None
+    run = (lambda: rx.process_q15_device(d_in.ptr, d_out.ptr, bs)) if q15 else (lambda: rx.process_device(d_in.ptr, d_out.ptr, bs))
+    t = time.perf_counter()
+    while (time.perf_counter() - t) * 1e3 < spinup_ms:
+        for _ in range(16):
+            run()
+        rx.sync()
+    rx.guard_clear()
+    ms = np.sort(rx.time_process_each(d_in.ptr, d_out.ptr, bs, iters, q15))
+    rx.check()
+    guard = rx.guard_stats()
+    med = float(ms[len(ms) // 2])
+    alg_bytes, rd_bytes = rx.algorithmic_bytes(bs)
+    if q15:
+        alg_bytes -= channels * (4 * bs + 2 * nout)
+        rd_bytes -= channels * 4 * bs
+    kernel, nco = rx.kernel_name(), rx.nco_path()
+    rx.close(); d_in.free(); d_out.free()
+    wl = dict(ch.WORKLOADS, **{k + "_q15": v for k, v in ch.WORKLOADS.items()})
+    traffic = pmc_traffic(name + ("_q15" if q15 else ""), {sr.ARITH_AUTO: "auto", sr.ARITH_CMSIS: "cmsis", sr.ARITH_FMA: "fma", sr.ARITH_SPLIT16: "split16"}[arith],
+                          kernel, channels, bs, wl)
+    out = {"workload": "%s%s: %d channels x %d complex samples/call, %s" % (name, " (int16 slots)" if q15 else "", channels, bs, WORKLOAD_TEXT[name]),
+           "io": "q15" if q15 else "f32", "kernel": kernel, "nco": nco,
+           "value": round(channels * bs / (med * 1e-3) / 1e6, 2), "unit": "Msamples/s",
+           "ms_per_step": round(med, 4), "ms_min": round(float(ms[0]), 4), "ms_p90": round(float(ms[int(0.9 * len(ms))]), 4), "launches": int(iters),
+           "guard_blocks": guard["blocks"],
+           "roofline": {"bound": "hbm", "achieved": round(alg_bytes / (med * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(alg_bytes / (med * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                        "read_frac": round(rd_bytes / (med * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                        "algorithmic_bytes_per_launch": alg_bytes, "traffic": traffic,
+                        "traffic_source": None if traffic is None else os.path.relpath(TRAFFIC_JSON, ROOT) + " (committed rocprofv3 --pmc passes of this kernel and shape)"}}
+    if note:
+        out["note"] = note
+    if name == "cfg5":
+        out["mall_note"] = ("per-channel state of this shape: %.0f MB read + as much written per call -- inside the 256 MiB Infinity Cache, whose hits the "
+                            "memory-side counters count (MI355X_MICROARCH.md): part of the algorithmic bytes of this figure is served on-die"
+                            % (channels * 2 * (spec.nh_taps - 1) * 4 / 1e6))
+    if parity:
+        pc = parity_check(name, ch.WORKLOADS, arith, q15)
+        out["parity"] = {k: pc[k] for k in ("worst_rel", "worst_lsb", "bar", "blocks", "channels", "calls", "against", "guard_blocks")}
+    return out
+
+
+def cfg5_scaling_leg(env, rank, world, arith, steps, warmup, spinup_ms):
+    """N > 1: the shape BASELINE.json's weak-scaling config names -- 131 072 channels per GPU of the cfg2 chain, 1024 samples per call -- timed on
+    every rank the way the headline is (barrier + synchronize on both sides, MAX over ranks), beside the default cfg3 leg of the same line."""
+    import selenite_rx as sr
+    from selenite_rx import chain as ch
+    cfg_name, channels, bs = ch.WORKLOADS["cfg5"]
+    spec = ch.baseline_spec(cfg_name, channels, arith)
+    rx = sr.Rx(spec.config())
+    d_in = sr.DeviceBuffer(channels * bs * 8)
+    d_out = sr.DeviceBuffer(channels * (bs // spec.decim) * 4)
+    rx.synth_device(d_in.ptr, rank * channels, channels, 0, bs, ch.SEED)
+    rx.sync()
+    t = time.perf_counter()
+    while (time.perf_counter() - t) * 1e3 < spinup_ms:
+        for _ in range(16):
+            rx.process_device(d_in.ptr, d_out.ptr, bs)
+        rx.sync()
+    for _ in range(warmup):
+        rx.process_device(d_in.ptr, d_out.ptr, bs)
+    rx.sync(); env.barrier()
+    t0 = time.perf_counter()
+    rx.time_process(d_in.ptr, d_out.ptr, bs, steps)
+    rx.sync(); env.barrier()
+    t1 = time.perf_counter()
+    rx.check()
+    elapsed = env.max_over_ranks(t1 - t0)
+    alg_bytes, _ = rx.algorithmic_bytes(bs)
+    kernel = rx.kernel_name()
+    rx.close(); d_in.free(); d_out.free()
+    ms = elapsed * 1e3 / steps
+    return {"workload": "cfg5: %d channels/GPU x %d complex samples/call, %s" % (channels, bs, WORKLOAD_TEXT["cfg5"]), "kernel": kernel,
+            "value": round(float(world) * channels * bs * steps / elapsed / 1e6, 2), "unit": "Msamples/s", "n_gpus": world, "scaling": "weak",
+            "steps": steps, "ms_per_step": round(ms, 4), "per_gpu_msamples_s": round(channels * bs * steps / elapsed / 1e6, 2),
+            "roofline_frac_per_gpu": round(alg_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "note": "whole-job aggregate over all ranks, max-over-ranks wall clock; no data-path collective"}
+
+
 def dist_block(env, devices, collectives_per_step, per_rank_ms, comm_count=None):
     """What lets the driver verify the ranks of an N > 1 line: backend, world, the communicator's size as the backend counted it
     (one all-reduce of ones before anything is timed), one device per rank, collectives per step."""
@@ -227,6 +338,9 @@ def main():
     ap.add_argument("--io", default="f32", choices=["f32", "q15"],
                     help="f32: the canonical float I/Q in / float audio out signature (headline); q15: the firmware's "
                          "int16 slot format either side (dsp_if.c:286-289, arm_q15_to_float / arm_float_to_q15 fused in)")
+    ap.add_argument("--auto-launches", type=int, default=1, choices=[1, 3],
+                    help="--arith auto: 1 (the library's default) = the matrix kernel recomputes a channel it guarded itself where it can (the "
+                         "no-decimator shapes: one launch per call), 3 = always k_hist_exact + the rerun pass behind it (selenite_rx_set_auto_launches; same bits)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--main-only", action="store_true", help="profiling runs: skip the cpu_baseline and other-mode legs")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"])
@@ -293,6 +407,8 @@ def main():
 
     spec = ch.baseline_spec(cfg_name, channels, arith, agc_global=args.global_gain)
     rx = make_rx(arith, args.nco, agc_global=args.global_gain)
+    if args.auto_launches != 1:
+        rx.set_auto_launches(args.auto_launches)
     nout = bs // spec.decim
 
     d_in = sr.DeviceBuffer(channels * bs * 8)
@@ -388,6 +504,10 @@ def main():
             spin(lambda: rx.time_streaming_roof(d_in.ptr, d_out.ptr, bs, 8, q15), rx.sync, args.spinup_ms / 3.0)
             roof_ms = np.sort(rx.time_streaming_roof(d_in.ptr, d_out.ptr, bs, 200, q15))
     env.barrier()
+    cfg5_line = None
+    if world > 1 and args.workload == "cfg3" and not args.global_gain and not q15 and not args.channels and not args.block_size:
+        env.stage("cfg5 weak-scaling leg")
+        cfg5_line = cfg5_scaling_leg(env, rank, world, arith, args.steps, args.warmup, args.spinup_ms / 3.0)
 
     if rank == 0:
         ms_per_step = elapsed * 1e3 / args.steps
@@ -477,6 +597,8 @@ def main():
                         "the no-arithmetic streaming kernel of the same run sets what that figure can be at most for this traffic shape"}
         if world > 1 or env.dist is not None:
             out["dist"] = dist_block(env, devices, 1 if args.global_gain else 0, per_rank_ms, comm)
+        if cfg5_line is not None:
+            out["cfg5_weak_scaling"] = cfg5_line
         if world == 1 and not args.global_gain and not args.main_only:
             # the same workload in the other arithmetic contracts and with the general NCO flavours, outside the timed
             # region; every leg: own spin-up, >= 100 launches, median of per-launch HIP-event durations
@@ -529,6 +651,17 @@ def main():
                     out["auto_stopband_cost"] = dict(r, roofline_frac=frac(r), rerun_fraction=round(g1["rerun_channel_calls"] / channels, 4),
                                                      note="SELENITE_ARITH_AUTO with per-channel steps anywhere on the fs/256 grid (--nco per_channel_grid_wide): the guarded fraction of the channels "
                                                           "is recomputed by the bit-exact kernel every call")
+        if world == 1 and not args.global_gain and not args.main_only and args.workload == "cfg3" and not q15 and not args.block_size and args.arith == "auto" and args.nco == "default":
+            # the other single-GPU BASELINE configurations, in the same driver-run line: the headline's buffers are released first
+            d_in.free(); d_out.free()
+            wls = {}
+            for nm, wq in (("cfg2", False), ("cfg4", False), ("cfg5", False), ("cfg3", True)):
+                wls[nm + ("_q15" if wq else "")] = side_workload(nm, wq, arith, args.spinup_ms / 3.0, parity=not args.no_cpu_baseline, channels_override=args.channels)
+            wls["note"] = ("every entry: its own instance and resident synthetic batch, own spin-up, median of 100 per-launch HIP-event durations; cfg2 = BASELINE's 4096 channels x "
+                           "48 000 samples (one second per call); cfg4 = the CW chain (bit-exact in every arithmetic mode); cfg5 = the per-GPU shard of the weak-scaling "
+                           "config (131 072 channels x 1024); cfg3_q15 = the headline with int16 slots in and out")
+            out["workloads"] = wls
+            d_in = sr.DeviceBuffer(8); d_out = sr.DeviceBuffer(8)      # (freed below)
         if world == 1 and not args.no_cpu_baseline and not args.main_only:
             out["cpu_baseline"] = cpu_baseline(args.workload, ch.WORKLOADS)
             if not args.global_gain:

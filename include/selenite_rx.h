@@ -262,6 +262,14 @@ int selenite_rx_auto_words(selenite_rx_instance *S, uint32_t *per_channel);
  * stayed on the matrix kernel carry the error of a guarded block of raw SELENITE_ARITH_SPLIT16 (up to ~1e-3 of a block maximum that
  * is the residue of a sideband cancellation) and are COUNTED: */
 int selenite_rx_set_handover_repair(selenite_rx_instance *S, int on);
+/* SELENITE_ARITH_AUTO, where the recomputation runs.  launches = 1 (default): on the no-decimator shapes (k_hilb_split16: one channel per
+ * workgroup) the workgroup that guarded a channel recomputes it itself, with the body of the bit-exact kernel -- one launch per call.
+ * launches = 3: always in two launches behind the matrix kernel (a dense list of the channels; what the decimating shapes do anyway).
+ * The RESULT does not depend on the choice: which arithmetic serves a channel is decided by the channel's word alone; both forms run
+ * the same code on it and give the same bits (tests/test_gpu_auto_forms.py). */
+int selenite_rx_set_auto_launches(selenite_rx_instance *S, int launches);
+/* Diagnostic: the form the last SELENITE_ARITH_AUTO call on a matrix kernel took, 1 or 3 (0: none yet). */
+int selenite_rx_auto_launches_last(const selenite_rx_instance *S);
 int selenite_rx_guard_handover(selenite_rx_instance *S, uint64_t *handover_blocks);
 int selenite_rx_guard_clear(selenite_rx_instance *S);
 

@@ -444,6 +444,18 @@ extern "C" int selenite_rx_guard_clear(selenite_rx_instance *S)
     return SELENITE_RX_SUCCESS;
 }
 
+extern "C" int selenite_rx_set_auto_launches(selenite_rx_instance *S, int launches)
+{
+    if (!S || !(launches == 1 || launches == 3)) return SELENITE_RX_ARGUMENT_ERROR;
+    S->auto_launches = launches;
+    return SELENITE_RX_SUCCESS;
+}
+
+extern "C" int selenite_rx_auto_launches_last(const selenite_rx_instance *S)
+{
+    return S ? (int)S->auto_form_last : 0;
+}
+
 extern "C" int selenite_rx_set_handover_repair(selenite_rx_instance *S, int on)
 {
     if (!S) return SELENITE_RX_ARGUMENT_ERROR;
@@ -651,6 +663,8 @@ static int run_part(selenite_rx_instance *S, const void *src, bool src_q15, void
             pf.chan_count = S->d_rerun_list;              // the two counters; launch_shape picks by *rerun_par_host where it launches the prepare kernel
             pf.rerun_par_host = &S->rerun_par;
             pf.rerun_seen = S->h_rerun_seen;
+            pf.auto_inline = S->auto_launches == 1 ? 1u : 0u;
+            pf.form_host = &S->auto_form_last;
         }
         void *fdst = dst;
         bool fq15 = dst_q15;

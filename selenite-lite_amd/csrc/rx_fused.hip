@@ -284,14 +284,7 @@ __global__ __launch_bounds__(64 * kMfmaWaves, 2) void k_ssb_mfma(RxParams p, Fus
     stage(0);
     // half-steps: group 0 runs M(k) at h = 2k and V(k) at h = 2k+1; group 1 one half-step later
     const uint32_t nhalf = 2 * npass + 1;
-    // diagnostics: stamp slot s of half-step h for wave w at dbg[w*128 + h*8 + s] (workgroup 0 only)
-    uint32_t hcur = 0;
-    auto stamp = [&](int slot) {
-        if (fa.dbg && blockIdx.x == 0 && lane == 0) fa.dbg[wave * 128 + hcur * 8 + slot] = __builtin_amdgcn_s_memtime();
-    };
     for (uint32_t h = 0; h < nhalf; ++h) {
-        hcur = h;
-        stamp(0);
         if (h >= (uint32_t)grp) {
             const uint32_t hh = h - grp, k = hh >> 1;
             if (k < npass) {
@@ -299,12 +292,10 @@ __global__ __launch_bounds__(64 * kMfmaWaves, 2) void k_ssb_mfma(RxParams p, Fus
                     mfma_phase();
                 } else {
                     finish(k);
-                    stamp(3);
                     if (k + 1 < npass) stage(k + 1);
                 }
             }
         }
-        stamp(7);
         __builtin_amdgcn_s_barrier();                                 // timing alignment only: no shared data
     }
 
@@ -558,7 +549,12 @@ static hipError_t launch_shape(const RxParams &p, const FusedArgs &fa, const Fus
         fa16.pass_out = split16_pass_out(p.block, p.decim);
         // (which half: the tile's output j ends at input sample 4 j of the pass in this kernel's bookkeeping, a by-8 output n at 8 n -- the
         // even ones; SELENITE_RX_DEC2_PARITY=2 selects the odd ones: a diagnostic that shows the tests notice)
-        static const uint32_t par = [] { const char *e = std::getenv("SELENITE_RX_DEC2_PARITY"); return e ? (uint32_t)std::atoi(e) : 1u; }();
+        // (only the value 2 is taken, and said so on stderr: anything else keeps the chain's outputs)
+        static const uint32_t par = [] {
+            const char *e = std::getenv("SELENITE_RX_DEC2_PARITY");
+            if (e && e[0] == '2' && e[1] == 0) { fprintf(stderr, "selenite_rx: SELENITE_RX_DEC2_PARITY=2 -- decimation by 8 keeps the ODD by-4 outputs (diagnostic, wrong audio)\n"); return 2u; }
+            return 1u;
+        }();
         fa16.dec2 = par;
     }
     const uint32_t tq = fa16.pass_out * M;
@@ -580,6 +576,7 @@ static hipError_t launch_shape(const RxParams &p, const FusedArgs &fa, const Fus
                 p3.chan_list = nullptr; p3.chan_count_next = nullptr;
                 if (hipError_t e = launch_hist_exact(p3, true, st); e != hipSuccess) return e;
             }
+            if (auto_ && p.rerun_flag && p.form_host) *p.form_host = 3u;
             hipError_t e = launch_ssb_split16(nds, M == 8 ? 4 : M, NH, p, fa16, src, src_q15, dst, st);     // rx_split16.hip
             if (e == hipSuccess && auto_ && p.rerun_flag) e = rerun();
             return e;
@@ -590,8 +587,12 @@ static hipError_t launch_shape(const RxParams &p, const FusedArgs &fa, const Fus
         // literal 48 000 samples are 250 blocks of 192); whole 4-sample lanes per block
         const bool hilb_ok = fa.pass_out != 0;                        // (any call length: the last pass may be partial, round 4 late)
         if (split && plan.d_btab16 && hilb_ok) {
-            hipError_t e = launch_hilb_split16(NH, p, fa, src, src_q15, dst, st);            // rx_split16.hip
-            if (e == hipSuccess && auto_ && p.rerun_flag) e = rerun();
+            FusedArgs fah = fa;
+            const bool inl = auto_ && p.rerun_flag && p.auto_inline && !fa.am;     // (every SSB instantiation of k_hilb_split16 carries the exact body)
+            fah.inl = inl ? 1u : 0u;
+            if (auto_ && p.rerun_flag && p.form_host) *p.form_host = inl ? 1u : 3u;
+            hipError_t e = launch_hilb_split16(NH, p, fah, src, src_q15, dst, st);           // rx_split16.hip
+            if (e == hipSuccess && auto_ && p.rerun_flag && !inl) e = rerun();
             return e;
         }
     }
@@ -765,32 +766,11 @@ hipError_t launch_fused(const FusedPlan &plan, const RxParams &p, int arith, con
     fa.btab16 = plan.d_btab16;
     fa.split_post = plan.split_post;
     fa.split_sc = plan.split_sc;
+    fa.inl = 0u;                                          // (launch_shape: SELENITE_ARITH_AUTO in one launch)
     fa.dec2 = 0u;                                         // (launch_shape sets it for decimation by 8 on the by-4 matrix kernel)
     {
         const char *e = std::getenv("SELENITE_RX_GRP_SHIFT");
         fa.grp_shift = e ? (uint32_t)std::atoi(e) : 2u;
-        fa.dbg = nullptr;
-        static unsigned long long *dbg_buf = nullptr;
-        static int dbg_calls = 0;
-        if (const char *dn = std::getenv("SELENITE_RX_DEBUG_TIMING")) {   // s_memtime stamps of a diagnostics build
-            constexpr int NB = 64, NS = 64;
-            if (!dbg_buf) { (void)hipMalloc((void **)&dbg_buf, NB * NS * 8); }
-            fa.dbg = dbg_buf;
-            const int at = std::atoi(dn) > 0 ? std::atoi(dn) : 8;
-            if (dbg_calls == at) {                                    // dump the stamps of call #at (cleared before it)
-                (void)hipDeviceSynchronize();
-                static unsigned long long h[NB * NS];
-                (void)hipMemcpy(h, dbg_buf, sizeof h, hipMemcpyDeviceToHost);
-                for (int b = 0; b < NB; ++b) {
-                    if (!h[b * NS]) continue;
-                    fprintf(stderr, "stamp wg %d:", b * 1024 + 511);
-                    for (int i = 1; i < NS && h[b * NS + i]; ++i) fprintf(stderr, " %llu", h[b * NS + i] - h[b * NS + i - 1]);
-                    fprintf(stderr, "\n");
-                }
-            }
-            if (dbg_calls == at - 1) { (void)hipDeviceSynchronize(); (void)hipMemset(dbg_buf, 0, NB * NS * 8); }
-            ++dbg_calls;
-        }
     }
     if (plan.dense) {
         // the FIR pair with arbitrary taps: k_ssb_fused's DENSE flavour, bit-exact (CMSIS; AUTO runs as CMSIS) or fma (FMA; SPLIT16 runs as fma)

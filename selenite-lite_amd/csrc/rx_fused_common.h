@@ -53,10 +53,11 @@ struct FusedArgs {
     const void *btab16;     // k_ssb_split16: Toeplitz operand, f16 hi/lo fragments
     float split_post;       // k_hilb_split16: exact power-of-two rescale of the MFMA result
     int split_sc;           // k_ssb_split16: the taps were scaled by 2^split_sc before their f16 hi/lo split
+    uint32_t inl;           // k_ssb_split16 / k_hilb_split16, SELENITE_ARITH_AUTO: 1 = the workgroup recomputes its flagged and held channels itself, behind
+                            // its last channel (one launch per call); 0 = it only raises their flags (k_hist_exact and the rerun pass follow)
     uint32_t dec2;          // k_ssb_split16 (run-time-geometry instantiations): decimation by 2 M on the by-M Toeplitz product -- a pass is
                             // pass_out * 2 M input samples and only every second output of the tile is an output of the chain (1: the even ones,
                             // 2: the odd ones); 0: the plain by-M kernel
-    unsigned long long *dbg; // diagnostics (SELENITE_RX_DEBUG_TIMING): s_memtime stamps of workgroup 0, else NULL
 };
 
 // Workgroups of these kernels are ONE wavefront: LDS instructions of a wave execute in issue order,
@@ -172,14 +173,10 @@ __device__ __forceinline__ void cmul_pk2(v2f A, v2f B, v2f LA, v2f LB, v2f &ra, 
         : "v"(A), "v"(B), "v"(LA), "v"(LB));
 }
 
-#ifndef SRX_IN_AUX
-#define SRX_IN_AUX 2             // cache policy of the streamed input loads (2 = nt)
-#endif
-#ifndef SRX_OUT_AUX
-#define SRX_OUT_AUX 2            // cache policy of the audio stores: 2 = nt.  Written once, never read by the chain: streaming them past the caches
+constexpr int SRX_IN_AUX = 2;    // cache policy of the streamed input loads (2 = nt)
+constexpr int SRX_OUT_AUX = 2;   // cache policy of the audio stores: 2 = nt.  Written once, never read by the chain: streaming them past the caches
                                  // leaves the 256 MB Infinity Cache to the per-channel state, which IS read back by the next call (measured: -1.6 % time;
                                  // the same policy on the state loads / stores costs +1.6 %: profiles/r3/README.md)
-#endif
 typedef unsigned int u4v __attribute__((ext_vector_type(4)));
 typedef unsigned int u2v __attribute__((ext_vector_type(2)));
 
@@ -309,9 +306,7 @@ __device__ __forceinline__ void hilbert_quad(const float *dq, int lane, const fl
 }
 
 
-#ifndef SRX_IMG_ALIGN
-#define SRX_IMG_ALIGN 128      // halfs
-#endif
+constexpr int SRX_IMG_ALIGN = 128;     // halfs
 // ---- SELENITE_ARITH_SPLIT16 geometry (rx_split16.hip; the host-side table builder in rx_fused.hip
 // needs KS and the fragment order) ----
 template <int NCO, int ND, int M, int NH>

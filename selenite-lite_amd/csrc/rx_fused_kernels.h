@@ -4,6 +4,7 @@
 // ~1000 instantiations compile in parallel (the single unit took 6 minutes).
 #pragma once
 #include "rx_fused_common.h"
+#include "rx_hist_exact.h"
 
 #include <cmath>
 #include <cstdio>
@@ -300,9 +301,12 @@ __device__ __forceinline__ void demod_agc_store(const RxParams &p, const FusedAr
 // NCO flavour (fa.nco: 0 off, 1 per-channel per sample, 2 shared table, 4 per-channel periodic) and demodulator (fa.am) are RUN-TIME
 // switches, wave-uniform, outside the hot loops (round 4): one kernel per arithmetic, shape and slot format -- the sixteen
 // instantiations per shape this replaced were most of a 35 MB library and of its four-minute build.
-template <int ARITH, int ND, int M, int NH, typename TIn, typename TOut, int DENSE = 0>
-__global__ __launch_bounds__(64, 2) void k_ssb_fused(RxParams p, FusedArgs fa, const TIn *__restrict__ src,
-                                                     TOut *__restrict__ dst)
+// The kernel body is a function of its own: k_ssb_fused runs it over the channels of its grid (or, as the rerun pass, over the dense list);
+// the matrix kernels of rx_split16_kernels.h call it for ONE channel they recompute themselves (INL: channel inl.c, whose word -- as the
+// rerun pass would find it -- is inl.word; p.chan_flags is set, the list and its counters are not looked at).
+struct FusedInl { uint32_t c, word; };
+template <int ARITH, int ND, int M, int NH, typename TIn, typename TOut, int DENSE, bool INL>
+__device__ __forceinline__ void ssb_fused_body(RxParams p, FusedArgs fa, const TIn *__restrict__ src, TOut *__restrict__ dst, FusedInl inl)
 {
     using G = Geo<ND, M, NH>;
     const uint32_t NCO = fa.nco;                         // wave-uniform
@@ -335,9 +339,9 @@ __global__ __launch_bounds__(64, 2) void k_ssb_fused(RxParams p, FusedArgs fa, c
     // rerun bit the split16 kernel of the same call raised for the channels under the parity guard and the exact kernel keeps up for
     // the channels it holds), entries blockIdx.x, blockIdx.x + gridDim.x, ... of the dense list k_hist_exact made of them: which
     // channels, and how many, is only known on the device; every workgroup gets an even share.
-    uint32_t li = blockIdx.x;
-    const uint32_t ln = p.chan_flags ? *p.chan_count : 0u;
-    if (p.chan_flags && p.rerun_seen && blockIdx.x == 0 && lane == 0) __hip_atomic_store(p.rerun_seen, ln, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    uint32_t li = INL ? 0u : blockIdx.x;
+    const uint32_t ln = INL ? 1u : (p.chan_flags ? *p.chan_count : 0u);
+    if (!INL && p.chan_flags && p.rerun_seen && blockIdx.x == 0 && lane == 0) __hip_atomic_store(p.rerun_seen, ln, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     if (p.chan_flags && li >= ln) return;                // rerun pass: nothing on the list for this workgroup (every workgroup, in the steady state of a clean workload)
     // what does not depend on the channel, once per workgroup: sine table, decimator taps (lane-distributed), Hilbert taps
     if (NCO == 1u || NCO == 4u)
@@ -349,7 +353,7 @@ __global__ __launch_bounds__(64, 2) void k_ssb_fused(RxParams p, FusedArgs fa, c
     }
     float hreg[(NH + 63) / 64 ? (NH + 63) / 64 : 1];
 #pragma unroll
-    for (int v = 0; v < (NH + 63) / 64; ++v) hreg[v] = (64 * v + lane < NH) ? p.hilb_c[64 * v + lane] : 0.0f;
+    for (int v = 0; v < (NH + 63) / 64; ++v) hreg[v] = (DENSE == 0 && 64 * v + lane < NH) ? p.hilb_c[64 * v + lane] : 0.0f;     // (DENSE: p.hilb_c holds p.nh <= NH taps and is read from LDS)
     if constexpr (DENSE != 0) {                          // the FIR pair's tap tables (both rails) behind the kernel's own LDS image
         float *pt = lds + G::total;
         for (int i = lane; i < 2 * DenseTab<NH>::LEN; i += kWave) pt[i] = fa.ptab[i];
@@ -358,8 +362,8 @@ __global__ __launch_bounds__(64, 2) void k_ssb_fused(RxParams p, FusedArgs fa, c
     auto in_rsrc = [&](uint32_t ch, bool valid) { return make_rsrc(src + (size_t)ch * p.in_stride * 2, valid ? p.block_size * (R::kBytes / 2) : 0u); };
     // the first pass of a channel is in flight before the channel starts: loaded here for the first one, under the last pass of the
     // channel before it for the others (rerun pass: the list says which channel comes next)
-    uint32_t c_cur = blockIdx.x;
-    if (p.chan_flags) c_cur = li < ln ? p.chan_list[li] : 0u;
+    uint32_t c_cur = INL ? inl.c : blockIdx.x;
+    if (!INL && p.chan_flags) c_cur = li < ln ? p.chan_list[li] : 0u;
     typename R::type raw[NLD];
     {
         const __amdgpu_buffer_rsrc_t rs0 = in_rsrc(c_cur, !p.chan_flags || li < ln);
@@ -372,7 +376,7 @@ __global__ __launch_bounds__(64, 2) void k_ssb_fused(RxParams p, FusedArgs fa, c
     bool has_nxt = false;
     if (p.chan_flags) {
         if (li >= ln) break;
-        li += gridDim.x;
+        li += INL ? 1u : gridDim.x;
         has_nxt = li < ln;
         c_nxt = has_nxt ? p.chan_list[li] : 0u;
     }
@@ -382,7 +386,7 @@ __global__ __launch_bounds__(64, 2) void k_ssb_fused(RxParams p, FusedArgs fa, c
     // rerun pass of SELENITE_ARITH_AUTO: the parity guard is evaluated here too (GuardEx); a channel that came in HELD (not raised by
     // the matrix kernel of this call, which skipped it) gets its guard counters from this kernel
     const bool rerun_pass = p.chan_flags != nullptr;                 // wave-uniform
-    const uint32_t word_in = rerun_pass ? p.chan_flags[c] : 0u;
+    const uint32_t word_in = INL ? inl.word : (rerun_pass ? p.chan_flags[c] : 0u);
     const bool held_in = (word_in & kFlagHold) != 0u;
     GuardEx gx{ 0.0f, 0.0f, 0u, 0u };
     float hmax = 0.0f;                                               // largest |component| of the FIR history the channel came in with
@@ -629,6 +633,13 @@ __global__ __launch_bounds__(64, 2) void k_ssb_fused(RxParams p, FusedArgs fa, c
     wave_lds_sync();                                     // the state reads above before the next channel's prologue fills
   }
     if (nonfinite) p.flags[kFlagNanInf] = 1u;            // ARM_MATH_NANINF, read by selenite_rx_sync
+}
+
+template <int ARITH, int ND, int M, int NH, typename TIn, typename TOut, int DENSE = 0>
+__global__ __launch_bounds__(64, 2) void k_ssb_fused(RxParams p, FusedArgs fa, const TIn *__restrict__ src,
+                                                     TOut *__restrict__ dst)
+{
+    ssb_fused_body<ARITH, ND, M, NH, TIn, TOut, DENSE, false>(p, fa, src, dst, FusedInl{ 0u, 0u });
 }
 
 

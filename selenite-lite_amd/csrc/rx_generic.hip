@@ -11,6 +11,7 @@
 //   k_agc_generic     one wavefront per channel; arm_abs+arm_max by shuffle reduction, gain law,
 //                     arm_scale, optional arm_float_to_q15 on the store
 #include "rx_internal.h"
+#include "rx_hist_exact.h"
 
 #include <type_traits>
 
@@ -205,8 +206,6 @@ __global__ __launch_bounds__(64) void k_hist_exact(RxParams p, uint32_t all, uin
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x;
-    const uint32_t nd = p.nd, M = p.decim, HH = p.nh - 1u, L = p.ext_len, H = nd - 1u;
-    float *TI = lds, *TQ = lds + (L + H);
     if (blockIdx.x == 0 && lane == 0 && p.chan_count_next) *p.chan_count_next = 0u;      // the counter the NEXT call's launch counts in
     if (p.chan_list) {
         // round 4: the channels to recompute as a dense list for the rerun pass.  A workgroup takes 1024 channels at a time: 16 words
@@ -248,46 +247,8 @@ __global__ __launch_bounds__(64) void k_hist_exact(RxParams p, uint32_t all, uin
         while (todo != 0) {                                           // wave-uniform
             const uint32_t c = base + (uint32_t)__builtin_ctzll(todo);
             todo &= todo - 1;
-            const uint32_t word = p.chan_flags[c], buf = (word >> kExtBufShift) & 1u;
-            // (the row starts one sample late -- rx_split16_kernels.h: T[0] meets no tap; its last entry repeats the state's first one)
-            const float2 *ext = p.hist_ext + (size_t)buf * p.ext_buf_stride + (size_t)c * L;
-            if (word & kExtQ15) {
-                // an int16-slot call left its RAW samples: arm_q15_to_float and the NCO mix again, sample by sample, with the arithmetic
-                // of the chain (same phases: T[i] sits H + L - i samples in front of the channel's current phase)
-                const short2 *raw = reinterpret_cast<const short2 *>(ext);
-                const uint32_t ph_e = p.nco ? p.phase[c] : 0u, step = p.nco ? p.step[c] : 0u;
-                for (uint32_t i = lane; i < L; i += kWave) {
-                    float2 v = make_float2(0.0f, 0.0f);
-                    if (i) {
-                        const short2 q = raw[i - 1];
-                        v = make_float2(q15_to_float(q.x), q15_to_float(q.y));
-                        if (p.nco) v = cmul<0>(v, nco_lo<0>(p.sintab, ph_e - (H + L - i) * step));
-                    }
-                    TI[i] = v.x; TQ[i] = v.y;
-                }
-            } else {
-                for (uint32_t i = lane; i < L; i += kWave) {
-                    const float2 v = i ? ext[i - 1] : make_float2(0.0f, 0.0f);
-                    TI[i] = v.x; TQ[i] = v.y;
-                }
-            }
-            for (uint32_t i = lane; i < H; i += kWave) {
-                TI[L + i] = p.dec_state[((size_t)c * 2 + 0) * H + i];
-                TQ[L + i] = p.dec_state[((size_t)c * 2 + 1) * H + i];
-            }
-            __syncthreads();
-            for (uint32_t r = lane; r < HH; r += kWave) {
-                const uint32_t t0 = L - M * (HH - r);
-                float ai = 0.0f, aq = 0.0f;
-                for (uint32_t k = 0; k < nd; ++k) {
-                    const float ck = p.dec_c[k];
-                    const float pi_ = TI[t0 + k] * ck, pq_ = TQ[t0 + k] * ck;
-                    ai = ai + pi_;
-                    aq = aq + pq_;
-                }
-                p.fir_state[((size_t)c * 2 + 0) * HH + r] = ai;
-                p.fir_state[((size_t)c * 2 + 1) * HH + r] = aq;
-            }
+            const uint32_t word = p.chan_flags[c];
+            hist_exact_channel(p, c, word, lds, lane);
             // the channel's Hilbert-pair history is exact now: say so (what follows may be a kernel that hands the provenance on as it
             // finds it -- AM, which neither reads nor writes that history; everything else rewrites the word anyway)
             if (lane == 0) p.chan_flags[c] = word & ~(kProvMask << kProvShift);

@@ -84,6 +84,9 @@ struct RxParams {
     uint32_t *rerun_par_host;    // HOST word (the instance's): which of the two counters the next prepare kernel counts in -- read and
                                  // flipped where that kernel is launched (rx_fused.hip: launch_shape), so a call that never launches it
                                  // (a short call on the bit-exact kernel) leaves the pair in step
+    uint32_t auto_inline;        // SELENITE_ARITH_AUTO: 1 = ONE launch where the matrix kernel can recompute the channel it flagged itself (k_hilb_split16:
+                                 // FusedArgs::inl); 0 = always k_hist_exact + the rerun pass behind it.  The bits of the result do not depend on it.
+    uint32_t *form_host;         // HOST word (the instance's): the form the last SELENITE_ARITH_AUTO launch took, 1 or 3 (launch_shape writes it; a diagnostic)
     uint32_t *rerun_seen;        // page-locked HOST word the device can write (the instance's): how many channels the rerun pass of the
                                  // last call found on its list -- written by that pass, read by the host WITHOUT synchronising when it sizes
                                  // the next rerun pass (a stale value only picks the other grid: results do not depend on it)
@@ -209,6 +212,8 @@ struct selenite_rx_instance {
     uint32_t *d_rerun_list = nullptr;  // [channels + 2] dense list of the channels to recompute, behind its two alternating counters (RxParams::chan_list)
     uint32_t rerun_par = 0;            // which counter the next call counts in
     uint32_t *h_rerun_seen = nullptr;  // page-locked, device-writable: entries of the last rerun pass's list (RxParams::rerun_seen)
+    int auto_launches = 1;             // selenite_rx_set_auto_launches: 1 = one launch where the matrix kernel recomputes a channel itself, 3 = never
+    uint32_t auto_form_last = 0;       // 1 / 3: the form of the last SELENITE_ARITH_AUTO launch on a matrix kernel (selenite_rx_auto_launches_last)
     float2 *d_hist_ext = nullptr;      // [2][channels][ext_len] SELENITE_ARITH_AUTO with k_ssb_split16: RxParams::hist_ext
     uint32_t ext_len = 0;
     bool handover_repair = true;       // selenite_rx_set_handover_repair

@@ -68,7 +68,7 @@ template <int NH, typename TIn, typename TOut>
 static hipError_t launch_hilb16(const RxParams &p, const FusedArgs &fa, const void *src, void *dst, hipStream_t st)
 {
     using GH = GeoH<NH>;
-    constexpr size_t lds = (size_t)GH::total * sizeof(float);
+    constexpr size_t lds = (size_t)(Geo<0, 1, NH>::total > GH::total ? Geo<0, 1, NH>::total : GH::total) * sizeof(float);     // (+ the bit-exact kernel's image: FusedArgs::inl)
     static_assert(lds <= 48 * 1024, "k_hilb_split16 LDS image");
     auto k = fa.am ? (p.nco == 2 ? k_hilb_split16<2, NH, TIn, TOut, 1>
                                  : (p.nco == 1 ? k_hilb_split16<1, NH, TIn, TOut, 1> : k_hilb_split16<0, NH, TIn, TOut, 1>))

@@ -1,59 +1,25 @@
 // rx_split16_kernels.h -- the SELENITE_ARITH_SPLIT16 kernels (k_ssb_split16, k_hilb_split16) and their launchers, shared by
 // rx_split16.hip (f32 slots, the no-decimator kernels, dispatch) and rx_split16_q15.hip (int16 slots).
 #pragma once
-#include "rx_fused_common.h"
+#include "rx_fused_kernels.h"
 
 #include <cstdlib>
 #include <type_traits>
 
 #pragma clang fp contract(off)
 
-// tuning knobs of k_ssb_split16 (tools/build_variants.sh builds A/B libraries from them)
-#ifndef SRX_SPLIT16_VPM
-#define SRX_SPLIT16_VPM 0        // vector instructions scheduled under each MFMA of the matrix stage (0: compiler's choice; 3 measured 2 % slower)
-#endif
-#ifndef SRX_MIXSPLIT
-#define SRX_MIXSPLIT 0           // f16 hi/lo split by v_fma_mixlo/hi_f16 (1; 8 instead of 12 instructions per sample pair, measured 1 % slower) or convert / subtract / convert (0)
-#endif
-#ifndef SRX_ACC4
-#define SRX_ACC4 0               // separate accumulators for the big and the small terms (1) or one per rail (0)
-#endif
-#ifndef SRX_IN_AUX
-#define SRX_IN_AUX 2             // cache policy of the streamed input loads (2 = nt)
-#endif
-#ifndef SRX_LO_AUX
-#define SRX_LO_AUX 0             // cache policy of the shared-LO loads
-#endif
-#ifndef SRX_SPLIT16_W2
-#define SRX_SPLIT16_W2 0         // 1: also build k_ssb_split16w2 (two waves per channel); measured equal to the one-wave kernel -- both sit at the package power cap
-#endif
-#ifndef SRX_HS_SGPR
-#define SRX_HS_SGPR 0            // Hilbert taps resident in SGPRs (1; 32 fewer v_readlane per pass, 29 SGPR spills, measured 5 % slower) or v_readlane per use (0)
-#endif
-
 namespace srx {
 
 // streaming state of a channel: written by one call and read back by the next -- 0.17 GB for 65 536 channels, which the 256 MB
-// Infinity Cache can hold between calls if nothing streams through it: plain (cacheable) accesses; the non-temporal variant
-// (A/B knob SRX_STATE_NT=1) measured 1.6 % slower
-#ifndef SRX_STATE_NT
-#define SRX_STATE_NT 0
-#endif
+// Infinity Cache can hold between calls if nothing streams through it: plain (cacheable) accesses (non-temporal ones measured
+// 1.6 % slower: they defeat exactly that residency)
 __device__ __forceinline__ float st_ld(const float *p)
 {
-#if SRX_STATE_NT
-    return __builtin_nontemporal_load(p);
-#else
     return *p;
-#endif
 }
 __device__ __forceinline__ void st_st(float *p, float v)
 {
-#if SRX_STATE_NT
-    __builtin_nontemporal_store(v, p);
-#else
     *p = v;
-#endif
 }
 
 // sticky per-channel counters do not wrap (advisor, round 3: a uint32 of guarded blocks wraps after days at firmware slot rates)
@@ -79,9 +45,6 @@ __device__ __forceinline__ void lds_order()
 // gd.hist / gd.nh (k_ssb_split16, SELENITE_ARITH_AUTO): the guarded blocks among the first ones of a call, those that still see the
 // Hilbert-pair history the previous call left -- a history of split16 precision when that call kept the channel on the matrix
 // kernel: the "handover" blocks of DESIGN.md section 3, which the exact rerun cannot make exact; they are counted on their own.
-#ifndef SRX_EXT_AUX
-#define SRX_EXT_AUX SRX_OUT_AUX
-#endif
 struct GuardPass {
     float thr;
     uint64_t first;
@@ -104,11 +67,7 @@ __device__ __forceinline__ void agc_pass(const AgcParams &ap, uint32_t agc_on, i
     auto guard = [&](float env) {                    // env: the block envelope, in (at least) the first lane of every block
         const int lanes = nvb * (GROUP ? GROUP : group);
         const uint64_t exist = lanes >= 64 ? ~0ull : ((1ull << lanes) - 1ull);
-#ifdef SRX_X_GUARD1      // timing experiment: the round-3 guard (one threshold)
-        const uint64_t hit = __builtin_amdgcn_ballot_w64(env < gd.thr) & gd.first & exist;
-#else
         const uint64_t hit = (__builtin_amdgcn_ballot_w64(env < gd.thr) | (__builtin_amdgcn_ballot_w64(env < gd.thr_h) & gd.hm)) & gd.first & exist;
-#endif
         gd.n += (uint32_t)__builtin_popcountll(hit);
         gd.nh += (uint32_t)__builtin_popcountll(hit & gd.hist);
     };
@@ -258,19 +217,6 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
     // (the first channel of the sequence is blockIdx.x unless the exact kernel holds it: its first pass is prefetched at once, as in round 3,
     // and prefetched again for the right channel in that rare case -- waiting for the words first cost 1 % of the headline)
     uint32_t c = blockIdx.x, c_nx = 0u;
-#ifdef SRX_STAMP       // diagnostics build (make STAMP=1): s_memtime stamps of one wave in 1024 (tools/stamp_split16.py)
-    unsigned long long *stamp_p = (fa.dbg && (c & 1023u) == 511u) ? fa.dbg + (c >> 10) * 64 : nullptr;
-    int stamp_i = 0;
-#define STAMP(drain)                                                                   \
-    do {                                                                               \
-        if (drain) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    \
-        if (stamp_p && stamp_i < 64) stamp_p[stamp_i] = __builtin_amdgcn_s_memtime();  \
-        ++stamp_i;                                                                     \
-    } while (0)
-#else
-#define STAMP(drain) do { } while (0)
-#endif
-    STAMP(0);
     float *tab = lds + GS::oTab;
     _Float16 *X = reinterpret_cast<_Float16 *>(lds + GS::oX);     // [rail][hi/lo][IMG]
     v2f *Hf = reinterpret_cast<v2f *>(lds + GS::oHf);             // f32 (I, Q) history, HS samples
@@ -319,7 +265,7 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
     constexpr int LOD = 3;
     u4v lo4[LOD];
     auto lo_load = [&](int slot, int i, int sl) {
-        lo4[slot] = __builtin_amdgcn_raw_buffer_load_b128(rs_lo, lane * 16 + i * 1024, sl, SRX_LO_AUX);
+        lo4[slot] = __builtin_amdgcn_raw_buffer_load_b128(rs_lo, lane * 16 + i * 1024, sl, 0);
     };
     auto lo_base = [&](uint32_t pass) { return pass < npass ? (int)(pass * tq) * 8 : 0; };   // pass == npass: the next channel's pass 0
     // periodic shared LO (NCO == 3: the table repeats every 256 samples and a pass is a whole number of periods): load
@@ -336,18 +282,11 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
         const int so = pass < npass ? (int)pass * kInPass : 0;
         const __amdgpu_buffer_rsrc_t rs = pass < npass ? rs_in : rs_in_next;
 #pragma unroll
-#ifdef SRX_X_NOINPUT
-        for (int i = 0; i < NLD; ++i) { raw[i] = typename R::type{}; asm volatile("" : "+v"(raw[i])); }
-        (void)rs; (void)so;
-#else
         for (int i = 0; i < NLD; ++i) raw[i] = R::load(rs, lane * R::kBytes + i * 64 * R::kBytes, so);      // (BRaw: aux = SRX_IN_AUX)
-#endif
-#ifndef SRX_X_NOLO
         if constexpr (NCO == 2) {
 #pragma unroll
             for (int i = 0; i < LOD; ++i) lo_load(i, i, lo_base(pass));
         }
-#endif
     };
     prefetch(0);
     // Toeplitz B fragments (8 halfs per lane): [kk][hi/lo]
@@ -366,9 +305,6 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
 #pragma unroll
     for (int v = 0; v < (NH + 63) / 64; ++v) hreg[v] = (64 * v + lane < NH) ? p.hilb_c[64 * v + lane] : 0.0f;
     ch_take(w_first, mine_first);
-#ifdef SRX_X_STRIDE      // timing experiment: the round-3 channel sequence (no hold bits)
-    c_nx = blockIdx.x + gridDim.x;
-#else
     {
         const uint32_t c_real = ch_next();
         if (c_real >= p.channels) return;                         // (every channel of this workgroup is held)
@@ -381,17 +317,9 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
         }
         c_nx = ch_next();
     }
-#endif
     rs_in_next = in_rsrc(c_nx);
 
-#if SRX_HS_SGPR
-    float hs[NH];
-#pragma unroll
-    for (int k = 0; k < NH; ++k) hs[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(hreg[k >> 6]), k & 63));
-    auto htap = [&](int k) { return hs[k]; };
-#else
     auto htap = [&](int k) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(hreg[k >> 6]), k & 63)); };
-#endif
     if constexpr (NCO == 1 || NCO == 4)
         for (int i = lane; i < 513; i += kWave) tab[i] = p.sintab[i];
 
@@ -509,18 +437,6 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
     // (4 of them packed) for scale, convert, convert back, subtract, convert.
     auto put_iq = [&](int f, v2f a, v2f b, float pre) {
         uint32_t hI, hQ, lI, lQ;
-#if SRX_MIXSPLIT
-        asm("v_fma_mixlo_f16 %0, %2, %6, 0\n\t"
-            "v_fma_mixlo_f16 %1, %3, %6, 0\n\t"
-            "v_fma_mixhi_f16 %0, %4, %6, 0\n\t"
-            "v_fma_mixhi_f16 %1, %5, %6, 0"
-            : "=&v"(hI), "=&v"(hQ) : "v"(a.x), "v"(a.y), "v"(b.x), "v"(b.y), "s"(pre));
-        asm("v_fma_mixlo_f16 %0, %2, %6, -%7 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n\t"
-            "v_fma_mixlo_f16 %1, %3, %6, -%8 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n\t"
-            "v_fma_mixhi_f16 %0, %4, %6, -%7 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
-            "v_fma_mixhi_f16 %1, %5, %6, -%8 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
-            : "=&v"(lI), "=&v"(lQ) : "v"(a.x), "v"(a.y), "v"(b.x), "v"(b.y), "s"(pre), "v"(hI), "v"(hQ));
-#else
         const v2f pre2 = { pre, pre };
         const v2f sa = a * pre2, sb = b * pre2;
         const h2 hhI = __builtin_convertvector(v2f{ sa.x, sb.x }, h2), hhQ = __builtin_convertvector(v2f{ sa.y, sb.y }, h2);
@@ -528,7 +444,6 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
         const h2 llI = __builtin_convertvector(v2f{ ra.x, rb.x }, h2), llQ = __builtin_convertvector(v2f{ ra.y, rb.y }, h2);
         hI = __builtin_bit_cast(uint32_t, hhI); hQ = __builtin_bit_cast(uint32_t, hhQ);
         lI = __builtin_bit_cast(uint32_t, llI); lQ = __builtin_bit_cast(uint32_t, llQ);
-#endif
         const int ph = GS::phys(f);
         *reinterpret_cast<uint32_t *>(X + 0 * GS::IMG + ph) = hI;
         *reinterpret_cast<uint32_t *>(X + 1 * GS::IMG + ph) = lI;
@@ -547,9 +462,6 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
         for (int i = 0; i < NLD; ++i) {
             v2f a, b;
             R::unpack(raw[i], a, b);
-#ifdef SRX_X_NOLO
-            if constexpr (NCO == 2) { m[2 * i] = a; m[2 * i + 1] = b; } else
-#else
             if constexpr (NCO == 2) {
                 const u4v l = lo4[i % LOD];
                 cmul_pk2(a, b, v2f{ __uint_as_float(l.x), __uint_as_float(l.y) }, v2f{ __uint_as_float(l.z), __uint_as_float(l.w) },
@@ -560,7 +472,6 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
                 cmul_pk2(a, b, v2f{ __uint_as_float(l.x), __uint_as_float(l.y) }, v2f{ __uint_as_float(l.z), __uint_as_float(l.w) },
                          m[2 * i], m[2 * i + 1]);
             } else
-#endif
             if constexpr (NCO == 1) {
                 // phase of sample n0 + 128 i + 2 lane: a per-channel lane term plus a wave-uniform term
                 const uint32_t pe = ph_lane + (n0 + 128u * i) * step;
@@ -581,10 +492,10 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
                 asm volatile("" : "+s"(e0));
                 if (e0 + 128 > 0 && e0 < (int)p.ext_len) {        // wave-uniform: this load meets the window (pairs outside it: out of range, dropped)
                     if constexpr (sizeof(TIn) == 2) {                 // int16 slots: the raw samples as they came (half the bytes; the NCO phase of every one is known)
-                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2v, raw[i]), rs_ext, (e0 + 2 * lane) * 4, 0, SRX_EXT_AUX);
+                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2v, raw[i]), rs_ext, (e0 + 2 * lane) * 4, 0, SRX_OUT_AUX);
                     } else {
                         const u4v pr = { __float_as_uint(m[2 * i].x), __float_as_uint(m[2 * i].y), __float_as_uint(m[2 * i + 1].x), __float_as_uint(m[2 * i + 1].y) };
-                        __builtin_amdgcn_raw_buffer_store_b128(pr, rs_ext, (e0 + 2 * lane) * 8, 0, SRX_EXT_AUX);      // (non-temporal: read back only by a rerun)
+                        __builtin_amdgcn_raw_buffer_store_b128(pr, rs_ext, (e0 + 2 * lane) * 8, 0, SRX_OUT_AUX);      // (non-temporal: read back only by a rerun)
                     }
                 }
             }
@@ -640,11 +551,7 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
             const int n = 128 * i + 2 * lane;
-#ifdef SRX_X_NOSPLIT
-            asm volatile("" :: "v"(m[2 * i]), "v"(m[2 * i + 1]));
-#else
             put_iq(GS::HS + n, m[2 * i], m[2 * i + 1], pre);
-#endif
             if constexpr (PARTIAL) {                                  // the history is the last HS samples that exist
                 const int hidx = n - ((int)cur_in - GS::HS);
                 if (hidx >= 0 && hidx < GS::HS)
@@ -660,15 +567,8 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
     // rounded at the accumulator's ulp as they arrive (~20 extra roundings of 2^-24 relative, against a 1e-5 bar)
     // and the sum never has to be formed on the vector ALU
     v4f accI, accQ;
-#if SRX_ACC4
-    v4f smlI, smlQ;
-#endif
-    constexpr int VPM = SRX_SPLIT16_VPM;                              // vector instructions issued under each MFMA (0: scheduler's choice)
-    auto mfma_phase = [&](auto &&side, int PIN) {
+    auto mfma_phase = [&](auto &&side) {
         accI = accQ = v4f{ 0.0f, 0.0f, 0.0f, 0.0f };
-#if SRX_ACC4
-        smlI = smlQ = accI;
-#endif
         const _Float16 *xIh = X + 0 * GS::IMG + abase, *xIl = X + 1 * GS::IMG + abase;
         const _Float16 *xQh = X + 2 * GS::IMG + abase, *xQl = X + 3 * GS::IMG + abase;
         auto offA = [](int kk) { return GS::phys(32 * kk); };                // fragments never straddle a row (GeoS)
@@ -677,58 +577,25 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
 #pragma unroll
         for (int kk = 0; kk < GS::KS; ++kk) {
             h8 nIh = aIh, nIl = aIl, nQh = aQh, nQl = aQl;
-#ifdef SRX_X_NOAREAD
-            if (false) {
-#else
             if (kk + 1 < GS::KS) {
-#endif
                 const int off = offA(kk + 1);
                 nIh = *reinterpret_cast<const h8 *>(xIh + off); nIl = *reinterpret_cast<const h8 *>(xIl + off);
                 nQh = *reinterpret_cast<const h8 *>(xQh + off); nQl = *reinterpret_cast<const h8 *>(xQl + off);
             }
-#ifdef SRX_X_NOMFMA
-            asm volatile("" :: "v"(aIh), "v"(aIl), "v"(aQh), "v"(aQl));
-#elif SRX_ACC4
-            accI = __builtin_amdgcn_mfma_f32_16x16x32_f16(aIh, Bh[kk], accI, 0, 0, 0);
-            accQ = __builtin_amdgcn_mfma_f32_16x16x32_f16(aQh, Bh[kk], accQ, 0, 0, 0);
-            smlI = __builtin_amdgcn_mfma_f32_16x16x32_f16(aIh, Bl[kk], smlI, 0, 0, 0);
-            smlQ = __builtin_amdgcn_mfma_f32_16x16x32_f16(aQh, Bl[kk], smlQ, 0, 0, 0);
-            smlI = __builtin_amdgcn_mfma_f32_16x16x32_f16(aIl, Bh[kk], smlI, 0, 0, 0);
-            smlQ = __builtin_amdgcn_mfma_f32_16x16x32_f16(aQl, Bh[kk], smlQ, 0, 0, 0);
-#else
             accI = __builtin_amdgcn_mfma_f32_16x16x32_f16(aIh, Bl[kk], accI, 0, 0, 0);     // small terms first
             accQ = __builtin_amdgcn_mfma_f32_16x16x32_f16(aQh, Bl[kk], accQ, 0, 0, 0);
             accI = __builtin_amdgcn_mfma_f32_16x16x32_f16(aIl, Bh[kk], accI, 0, 0, 0);
             accQ = __builtin_amdgcn_mfma_f32_16x16x32_f16(aQl, Bh[kk], accQ, 0, 0, 0);
             accI = __builtin_amdgcn_mfma_f32_16x16x32_f16(aIh, Bh[kk], accI, 0, 0, 0);
             accQ = __builtin_amdgcn_mfma_f32_16x16x32_f16(aQh, Bh[kk], accQ, 0, 0, 0);
-#endif
             aIh = nIh; aIl = nIl; aQh = nQh; aQl = nQl;
             side(kk);                                                 // vector work that runs under this k-step's MFMAs
-            if constexpr (VPM > 0) {
-                // issue pattern of the k-step: the A fragments of the next k-step (and two LDS reads of whatever
-                // else the block holds: the demodulator of the previous pass), then every MFMA followed by VPM
-                // vector instructions of the demodulator -- a 16x16x32 MFMA occupies the matrix pipe for 16
-                // cycles, the wave's issue port for 4
-                if (kk + 1 < GS::KS) __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
-                else __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-#pragma unroll
-                for (int j = 0; j < 6; ++j) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);
-                }
-                if (kk < PIN) __builtin_amdgcn_sched_barrier(0);      // the k-steps that carry Hilbert pieces do not mix
-            }
         }
     };
     // decimated rails of the pass into D behind the Hilbert history (exact power-of-two rescale)
     auto dwrite = [&]() {
         const int o0 = G::HH4 + 64 * (lane >> 4) + (lane & 15);
         const int ex = -(s_cur + fa.split_sc);
-#ifdef SRX_X_NODWRITE
-        asm volatile("" :: "v"(accI), "v"(accQ), "s"(ex)); (void)o0;
-        return;
-#endif
         if (dec2) {                                                   // wave-uniform: tile output 64 (l >> 4) + 16 r + (l & 15) is chain output (that - parity) / 2
             const int oh = G::HH4 + 32 * (lane >> 4) + ((lane & 15) >> 1);
             if ((uint32_t)(lane & 1) + 1u == dec2) {
@@ -742,13 +609,8 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-#if SRX_ACC4
-            dI[o0 + 16 * r] = __builtin_ldexpf(accI[r] + smlI[r], ex);
-            dQ[o0 + 16 * r] = __builtin_ldexpf(accQ[r] + smlQ[r], ex);
-#else
             dI[o0 + 16 * r] = __builtin_ldexpf(accI[r], ex);
             dQ[o0 + 16 * r] = __builtin_ldexpf(accQ[r], ex);
-#endif
         }
     };
     // history of the four images: last HS samples of the pass back to the front, 16 bytes per move
@@ -760,17 +622,10 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
         return img * GS::IMG + GS::RSTR * (rem / CPR) + 8 * (rem % CPR);
     };
     auto cb_read = [&](u4v (&cb)[NCB]) {
-#ifdef SRX_X_NOCB
-        for (int k = 0; k < NCB; ++k) cb[k] = u4v{ 0u, 0u, 0u, 0u };
-        return;
-#endif
 #pragma unroll
         for (int k = 0; k < NCB; ++k) cb[k] = *reinterpret_cast<const u4v *>(X + cb_addr(k) + GS::RSTR * (int)(tq / GS::RL));      // (whole rows: the host sends pq * M % RL == 0 only)
     };
     auto cb_write = [&](const u4v (&cb)[NCB]) {
-#ifdef SRX_X_NOCB
-        return;
-#endif
 #pragma unroll
         for (int k = 0; k < NCB; ++k) *reinterpret_cast<u4v *>(X + cb_addr(k)) = cb[k];
     };
@@ -809,31 +664,21 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
                     au[0] = cmag<0>(vi.x, vq.x); au[1] = cmag<0>(vi.y, vq.y);
                     au[2] = cmag<0>(vi.z, vq.z); au[3] = cmag<0>(vi.w, vq.w);
                 }
-#ifndef SRX_X_NOAGC
                 agc_pass<GROUP>(p.agcp, p.agc, lane, group, au, gain, nvb, gd);
-#endif
             }
         } else {
             if (kk == 0) q2[0] = q2[1] = q2[2] = q2[3] = 0.0f;
 #pragma unroll
             for (int j = 0; j < TPK; ++j)
-#ifndef SRX_X_NOHILB
                 if (kk * TPK + j < NTS) hilbert_tstep<1, ND, M, NH>(kk * TPK + j, dQ, lane, htap, q2);
-#endif
             if (kk == (NTS + TPK - 1) / TPK - 1 || (kk == GS::KS - 1 && (NTS + TPK - 1) / TPK > GS::KS)) {
                 const float *di = dI + G::FH + fa.delay_idx + 4 * lane;   // unit-impulse delay FIR
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-#ifdef SRX_X_NODI
-                    const float i2 = q2[(r + 1) & 3] + 0.0f; (void)di;
-#else
                     const float i2 = di[r] + 0.0f;                    // 0.0f + 1.0f*x of the dense loop
-#endif
                     au[r] = fa.upper ? (i2 - q2[r]) : (i2 + q2[r]);   // arm_sub_f32 / arm_add_f32
                 }
-#ifndef SRX_X_NOAGC
                 agc_pass<GROUP>(p.agcp, p.agc, lane, group, au, gain, nvb, gd);
-#endif
             }
         }
     };
@@ -846,13 +691,9 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
     auto store_audio = [&](uint32_t q, const float (&au)[4]) {
         const float z = __builtin_fmaf(au[3], 0.0f, __builtin_fmaf(au[2], 0.0f, __builtin_fmaf(au[1], 0.0f, au[0] * 0.0f)));
         nonfinite = nonfinite || ((z != z) && (!DEC2 || (uint32_t)lane < pq / 4u));            // (by 2 M: the lanes past the pass hold no output of the chain)
-#ifdef SRX_X_NOSTORE
-        asm volatile("" :: "v"(au[0]), "v"(au[1]), "v"(au[2]), "v"(au[3]));
-#else
         // (pq < 256: the last lanes hold outputs of the NEXT pass's region, computed from its first samples -- not stored)
         const int vo = (GROUP != 0 || (uint32_t)lane < pq / 4u) ? lane * W::kBytes : 0x40000000;
         W::store(rs_out, vo, (int)(q * pq) * (W::kBytes / 4), au, ENV != 0);      // (ENV: phase 1 of the global-gain call -- the gain pass reads this audio back: default policy, known at compile time)
-#endif
         if constexpr (GROUP == 16 && ENV != 0) {
             {
                 const float m = row16_fmax(fmaxf(fmaxf(fabsf(au[0]), fabsf(au[1])), fmaxf(fabsf(au[2]), fabsf(au[3]))));
@@ -873,27 +714,22 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
         install_state();
         float au[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
         lds_order();
-        STAMP(0);
         if (DEC2 ? cur_out(0) * MO != (uint32_t)G::T : cur_out(0) != G::P) mix(0, std::true_type{});       // (a pass that does not fill the tile's inputs: a call's tail, 240- / 192-output passes)
         else mix(0, std::false_type{});
-        STAMP(0);
         prefetch(1);
         lds_order();
         {
             u4v cb[NCB];
-            mfma_phase([](int) {}, 0);
+            mfma_phase([](int) {});
             cb_read(cb);
             lds_order();
             cb_write(cb);
             dwrite();
         }
         lds_order();
-        STAMP(0);
         for (uint32_t pass = 1; pass < npass; ++pass) {
-            STAMP(1);                                                 // wait for the prefetched pass
             if (DEC2 ? cur_out(pass) * MO != (uint32_t)G::T : cur_out(pass) != G::P) mix(pass, std::true_type{});
             else mix(pass, std::false_type{});
-            STAMP(0);
             store_audio(pass - 2, au);                                // pass 1: offset -1 pass = out of range, dropped
             prefetch(pass + 1);
             lds_order();
@@ -903,14 +739,13 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
             gd.thr = thr_prev; gd.thr_h = fmaxf(thr_prev, thr_pp);    // the demodulator below belongs to the pass before
             gd.hist = pass == 1 ? hist_mask : 0ull;
             const int nvb_full = GROUP == 0 ? (int)(pq / (4u * (uint32_t)group)) : 64;
-            mfma_phase([&](int kk) { demod_piece(kk, au, nvb_full); }, (NTS + TPK - 1) / TPK - 1);   // matrix pipe over the vector work of the pass before
+            mfma_phase([&](int kk) { demod_piece(kk, au, nvb_full); });   // matrix pipe over the vector work of the pass before
             cb_read(cb);
             lds_order();
             cb_write(cb);
             if (keeps) *reinterpret_cast<v4f *>(D + dt_off) = dt;
             dwrite();
             lds_order();
-            STAMP(0);
         }
         store_audio(npass - 2, au);
         load_state(c_nx);                                             // the next channel's state, under this channel's last demodulator pass
@@ -918,7 +753,6 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
         gd.hist = npass == 1 ? hist_mask : 0ull;
         demod(au, (int)(tail_out / (4u * (uint32_t)group)));          // DSP blocks of the last pass that exist
         store_audio(npass - 1, au);
-        STAMP(0);
 
         // ---- parity guard: count (per-channel words: no atomics); SELENITE_ARITH_AUTO: a guarded channel keeps its pre-call
         // state and raises its rerun flag (the flag of every channel is rewritten every call) ----
@@ -965,11 +799,7 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
         }
         c = c_nx;
         if (c >= p.channels) break;
-#ifdef SRX_X_STRIDE
-        c_nx = c + gridDim.x;
-#else
         c_nx = ch_next();
-#endif
         lds_order();                                                  // the state reads above before the next channel's installs
         rs_in = rs_in_next;
         rs_in_next = in_rsrc(c_nx);
@@ -977,345 +807,6 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
         if constexpr (ENV != 0) rs_env = env_rsrc(c);
     }
     if (nonfinite) p.flags[0] = 1u;                                   // ARM_MATH_NANINF, read by selenite_rx_sync
-    STAMP(1);
-#undef STAMP
-}
-
-// ------------------------------------------------------------------------------------------
-// k_ssb_split16w2 -- the same chain with TWO wavefronts per channel (128-thread workgroups).
-//
-// Counters of the one-wave kernel (profiles/r2): every unit under 55 % busy, the waves 34 % of their time in
-// s_waitcnt and 29 % stalled at issue -- two long dependent chains per SIMD cannot cover each other, and
-// 80 VGPRs of Toeplitz fragments pin the kernel at two waves per SIMD.  Here the matrix stage is split in K
-// between the two waves of a channel (half the fragments each, partial sums meet in LDS) and the vector work is
-// split by role: the FRONT wave streams the input (prefetch, NCO mix, block exponent, f16 split into the LDS
-// images), the BACK wave turns the decimated rails into audio (combine, Hilbert pair, AGC, store).  Two
-// s_barrier per pass; while the front wave mixes pass p+1 the back wave demodulates pass p.  Under 168 VGPRs:
-// three waves per SIMD, six channels in flight per CU, each with half the serial work per wave.
-// The block exponent of a pass comes from a BOUND on the mixed samples, |x * LO| <= 2 max(|I|, |Q|), taken on
-// the raw samples, so the complex multiplies do not wait for the wave reduction; the history part uses the
-// exact maximum of the mixed samples (what a call's prologue can recompute from the state: partition-invariant).
-// ------------------------------------------------------------------------------------------
-template <int NCO, int ND, int M, int NH, typename TIn, typename TOut, int AM, int GROUP>
-__global__ __launch_bounds__(128, 3) void k_ssb_split16w2(RxParams p, FusedArgs fa, const TIn *__restrict__ src,
-                                                          TOut *__restrict__ dst)
-{
-    using G = Geo<ND, M, NH>;
-    using GS = GeoS<NCO, ND, M, NH>;
-    using R = BRaw<TIn>;
-    using W = BOut<TOut>;
-    static_assert(ND > 0 && M == 4 && NH > 0 && G::T % 64 == 0 && GS::HS % 128 == 0 && GS::KS % 2 == 0, "split16 decimator: /4 + Hilbert");
-    constexpr int KH = GS::KS / 2;                                  // k-steps per wave
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t c = blockIdx.x;
-    float *tab = lds + GS::oTab;
-    _Float16 *X = reinterpret_cast<_Float16 *>(lds + GS::oX);     // [rail][hi/lo][IMG]
-    v2f *Hf = reinterpret_cast<v2f *>(lds + GS::oHf);             // f32 (I, Q) history, HS samples
-    float *D = lds + GS::oD;
-    float *dI = D, *dQ = D + G::DLEN;
-    float *P = lds + GS::total;                                   // front wave's partial sums [rail][lane][4]
-    int *SX = reinterpret_cast<int *>(P + 512);                   // block exponent of pass p at SX[p & 1]
-    constexpr int NLD = G::T / 128, NTL = GS::HS / 128;
-    const uint32_t npass = p.nout / G::P;
-    const int abase = 80 * (lane & 15) + 8 * (lane >> 4);         // A-fragment lane base (halfs)
-
-    // workgroup barrier that leaves the prefetch loads in flight: LDS traffic only is drained
-    auto wg_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
-
-    // this wave's half of the Toeplitz B fragments
-    h8 Bh[KH], Bl[KH];
-    {
-        const h8 *bt = static_cast<const h8 *>(fa.btab16) + (size_t)wave * KH * 2 * 64;
-#pragma unroll
-        for (int kk = 0; kk < KH; ++kk) {
-            Bh[kk] = bt[(2 * kk + 0) * 64 + lane];
-            Bl[kk] = bt[(2 * kk + 1) * 64 + lane];
-        }
-    }
-    v4f accI, accQ;
-    auto mfma_half = [&](auto k0c) {                              // k-steps [K0, K0 + KH)
-        constexpr int K0 = decltype(k0c)::value;
-        accI = accQ = v4f{ 0.0f, 0.0f, 0.0f, 0.0f };
-        const _Float16 *xIh = X + 0 * GS::IMG + abase, *xIl = X + 1 * GS::IMG + abase;
-        const _Float16 *xQh = X + 2 * GS::IMG + abase, *xQl = X + 3 * GS::IMG + abase;
-        auto offA = [](int kk) { return 80 * (kk >> 1) + 32 * (kk & 1); };
-        h8 aIh = *reinterpret_cast<const h8 *>(xIh + offA(K0)), aIl = *reinterpret_cast<const h8 *>(xIl + offA(K0));
-        h8 aQh = *reinterpret_cast<const h8 *>(xQh + offA(K0)), aQl = *reinterpret_cast<const h8 *>(xQl + offA(K0));
-#pragma unroll
-        for (int j = 0; j < KH; ++j) {
-            h8 nIh = aIh, nIl = aIl, nQh = aQh, nQl = aQl;
-#ifdef SRX_X_NOAREAD
-            if (false) {
-#else
-            if (j + 1 < KH) {
-#endif
-                const int off = offA(K0 + j + 1);
-                nIh = *reinterpret_cast<const h8 *>(xIh + off); nIl = *reinterpret_cast<const h8 *>(xIl + off);
-                nQh = *reinterpret_cast<const h8 *>(xQh + off); nQl = *reinterpret_cast<const h8 *>(xQl + off);
-            }
-#ifdef SRX_X_NOMFMA
-            asm volatile("" :: "v"(aIh), "v"(aIl), "v"(aQh), "v"(aQl));
-#else
-            accI = __builtin_amdgcn_mfma_f32_16x16x32_f16(aIh, Bl[j], accI, 0, 0, 0);      // small terms first
-            accQ = __builtin_amdgcn_mfma_f32_16x16x32_f16(aQh, Bl[j], accQ, 0, 0, 0);
-            accI = __builtin_amdgcn_mfma_f32_16x16x32_f16(aIl, Bh[j], accI, 0, 0, 0);
-            accQ = __builtin_amdgcn_mfma_f32_16x16x32_f16(aQl, Bh[j], accQ, 0, 0, 0);
-            accI = __builtin_amdgcn_mfma_f32_16x16x32_f16(aIh, Bh[j], accI, 0, 0, 0);
-            accQ = __builtin_amdgcn_mfma_f32_16x16x32_f16(aQh, Bh[j], accQ, 0, 0, 0);
-#endif
-#ifndef SRX_X_NOAREAD
-            aIh = nIh; aIl = nIl; aQh = nQh; aQl = nQl;
-#endif
-        }
-    };
-
-    if (wave == 0) {
-        // =============================== FRONT wave: input side ===============================
-        const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(src + (size_t)c * p.in_stride * 2, p.block_size * (R::kBytes / 2));
-        const __amdgpu_buffer_rsrc_t rs_lo = make_rsrc(p.lo, NCO == 2 ? p.block_size * 8u : 0u);
-        constexpr int kInPass = G::T * (R::kBytes / 2);
-        const int in_end = (int)(p.block_size * (R::kBytes / 2));
-        typename R::type raw[NLD];
-        constexpr int LOD = 3;
-        u4v lo4[LOD];
-        auto lo_load = [&](int slot, int i, int sl) { lo4[slot] = __builtin_amdgcn_raw_buffer_load_b128(rs_lo, lane * 16 + i * 1024, sl, 0); };
-        auto lo_base = [&](uint32_t pass) { return pass < npass ? (int)pass * G::T * 8 : (int)p.block_size * 8; };
-        auto prefetch = [&](uint32_t pass) {
-            const int so = pass < npass ? (int)pass * kInPass : in_end;
-#pragma unroll
-            for (int i = 0; i < NLD; ++i) raw[i] = R::load(rs_in, lane * R::kBytes + i * 64 * R::kBytes, so);
-#ifndef SRX_X_NOLO
-            if constexpr (NCO == 2) {
-#pragma unroll
-                for (int i = 0; i < LOD; ++i) lo_load(i, i, lo_base(pass));
-            }
-#endif
-        };
-        prefetch(0);
-        if constexpr (NCO == 1)
-            for (int i = lane; i < 513; i += kWave) tab[i] = p.sintab[i];
-        uint32_t e_hist;
-        {   // CMSIS pState of the decimator -> f32 history; flat sample f is state sample f - F (older slots: zero)
-            constexpr int NHI = GS::HS / kWave;
-            const float *stI = p.dec_state + (size_t)c * 2 * (ND - 1), *stQ = stI + (ND - 1);
-            v2f hv[NHI];
-#pragma unroll
-            for (int j = 0; j < NHI; ++j) {
-                const int s = j * kWave + lane - G::F, sc = s < 0 ? 0 : s;
-                const float xi = stI[sc], xq = stQ[sc];
-                hv[j] = s < 0 ? v2f{ 0.0f, 0.0f } : v2f{ xi, xq };
-            }
-            float mh = 0.0f;
-#pragma unroll
-            for (int j = 0; j < NHI; ++j) {
-                Hf[j * kWave + lane] = hv[j];
-                mh = amax2(hv[j], mh);
-            }
-            e_hist = wave_umax_bits(mh) >> 23;
-        }
-        const uint32_t ph0 = NCO ? p.phase[c] : 0u;
-        const uint32_t step = NCO ? p.step[c] : 0u;
-        int s_cur = 0x7fff;
-        auto put_iq = [&](int f, v2f a, v2f b, float pre) {
-            const v2f pre2 = { pre, pre };
-            const v2f sa = a * pre2, sb = b * pre2;
-            const h2 hhI = __builtin_convertvector(v2f{ sa.x, sb.x }, h2), hhQ = __builtin_convertvector(v2f{ sa.y, sb.y }, h2);
-            const v2f ra = sa - v2f{ (float)hhI.x, (float)hhQ.x }, rb = sb - v2f{ (float)hhI.y, (float)hhQ.y };
-            const h2 llI = __builtin_convertvector(v2f{ ra.x, rb.x }, h2), llQ = __builtin_convertvector(v2f{ ra.y, rb.y }, h2);
-            const int ph = GS::phys(f);
-            *reinterpret_cast<h2 *>(X + 0 * GS::IMG + ph) = hhI;
-            *reinterpret_cast<h2 *>(X + 1 * GS::IMG + ph) = llI;
-            *reinterpret_cast<h2 *>(X + 2 * GS::IMG + ph) = hhQ;
-            *reinterpret_cast<h2 *>(X + 3 * GS::IMG + ph) = llQ;
-        };
-        auto mix = [&](uint32_t pass) {
-            const uint32_t n0 = pass * G::T;
-            // bound on the mixed samples from the raw ones: the complex multiplies below do not wait for it
-            float mr = 0.0f;
-#pragma unroll
-            for (int i = 0; i < NLD; ++i) {
-                v2f a, b;
-                R::unpack(raw[i], a, b);
-                mr = amax2(a, mr);
-                mr = amax2(b, mr);
-            }
-            const uint32_t e_raw = (wave_umax_bits(mr) >> 23) + (NCO != 0 ? 1u : 0u);
-            const uint32_t e_need = max(e_raw, e_hist);
-            int s_new = 141 - (int)e_need;
-            s_new = s_new > 127 ? 127 : (s_new < -126 ? -126 : s_new);
-            if (s_new != s_cur) {                                     // wave-uniform; always in the first pass
-                const float pre = __uint_as_float((uint32_t)(s_new + 127) << 23);
-#pragma unroll
-                for (int j = 0; j < GS::HS / 128; ++j) {
-                    const int f = 2 * (j * kWave + lane);
-                    const float4 hq = lds_ld4f(reinterpret_cast<const float *>(Hf + f));
-                    put_iq(f, v2f{ hq.x, hq.y }, v2f{ hq.z, hq.w }, pre);
-                }
-                s_cur = s_new;
-            }
-            if (lane == 0) SX[pass & 1] = s_cur;
-            lds_order();                                              // history reads above, history writes below
-            const float pre = __uint_as_float((uint32_t)(s_cur + 127) << 23);
-            float mt = 0.0f;
-#pragma unroll
-            for (int i = 0; i < NLD; ++i) {
-                v2f a, b, ma, mb;
-                R::unpack(raw[i], a, b);
-#ifdef SRX_X_NOLO
-                if constexpr (NCO == 2) { ma = a; mb = b; } else if
-#else
-                if constexpr (NCO == 2) {
-                    const u4v l = lo4[i % LOD];
-                    cmul_pk2(a, b, v2f{ __uint_as_float(l.x), __uint_as_float(l.y) }, v2f{ __uint_as_float(l.z), __uint_as_float(l.w) }, ma, mb);
-                    if (i + LOD < NLD) lo_load(i % LOD, i + LOD, lo_base(pass));
-                } else if
-#endif
-                constexpr (NCO == 1) {
-                    const uint32_t pe = ph0 + 2u * lane * step + (n0 + 128u * i) * step;
-                    v2f la, lb;
-                    nco_lo_pair(tab, pe, pe + step, la, lb);
-                    cmul_pk2(a, b, la, lb, ma, mb);
-                } else {
-                    ma = a; mb = b;
-                }
-                const int n = 128 * i + 2 * lane;
-#ifdef SRX_X_NOSPLIT
-                asm volatile("" :: "v"(ma), "v"(mb));
-#else
-                put_iq(GS::HS + n, ma, mb, pre);
-#endif
-                if (i >= NLD - NTL) {                                 // the next pass's history: exact f32 copy and exact maximum
-                    *reinterpret_cast<float4 *>(Hf + (n - (G::T - GS::HS))) = make_float4(ma.x, ma.y, mb.x, mb.y);
-                    mt = amax2(ma, mt);
-                    mt = amax2(mb, mt);
-                }
-            }
-            e_hist = wave_umax_bits(mt) >> 23;
-        };
-        constexpr int NCB = 4 * (GS::HS / 64) * 8 / kWave;
-        auto cb_addr = [&](int k) {
-            const int i = k * kWave + lane, img = i / (8 * (GS::HS / 64)), rem = i % (8 * (GS::HS / 64));
-            return img * GS::IMG + 80 * (rem >> 3) + 8 * (rem & 7);
-        };
-
-        lds_order();
-        mix(0);
-        prefetch(1);
-        wg_barrier();                                                 // X: images of pass 0 complete
-        for (uint32_t pass = 0; pass < npass; ++pass) {
-            mfma_half(std::integral_constant<int, 0>{});
-            u4v cb[NCB];
-#pragma unroll
-            for (int k = 0; k < NCB; ++k) cb[k] = *reinterpret_cast<const u4v *>(X + cb_addr(k) + 80 * (G::T / 64));
-            *reinterpret_cast<v4f *>(P + 4 * lane) = accI;
-            *reinterpret_cast<v4f *>(P + 256 + 4 * lane) = accQ;
-            wg_barrier();                                             // Y: partial sums out, every A read of the pass issued
-#pragma unroll
-            for (int k = 0; k < NCB; ++k) *reinterpret_cast<u4v *>(X + cb_addr(k)) = cb[k];
-            lds_order();
-            if (pass + 1 < npass) {
-                mix(pass + 1);
-                prefetch(pass + 2);
-            }
-            wg_barrier();                                             // X: images of the next pass complete
-        }
-        // ---- epilogue: decimator state back to HBM (exact f32) ----
-        {
-            float *stI = p.dec_state + (size_t)c * 2 * (ND - 1), *stQ = stI + (ND - 1);
-#pragma unroll
-            for (int j = 0; j < GS::HS / kWave; ++j) {
-                const int s = j * kWave + lane - G::F;
-                const v2f h = Hf[j * kWave + lane];
-                if (s >= 0) { stI[s] = h.x; stQ[s] = h.y; }
-            }
-        }
-        if (lane == 0) {
-            if constexpr (NCO != 0) p.phase[c] = ph0 + p.block_size * step;
-        }
-    } else {
-        // =============================== BACK wave: audio side ===============================
-        const __amdgpu_buffer_rsrc_t rs_out = make_rsrc(dst + (size_t)c * p.out_stride, p.nout * (W::kBytes / 4));
-        float hreg[(NH + 63) / 64];
-#pragma unroll
-        for (int v = 0; v < (NH + 63) / 64; ++v) hreg[v] = (64 * v + lane < NH) ? p.hilb_c[64 * v + lane] : 0.0f;
-        {
-            constexpr int NFI = 2 * G::HH4 / kWave;
-            static_assert((2 * G::HH4) % kWave == 0, "prologue fills are whole wave loads");
-            const float *stF = p.fir_state + (size_t)c * 2 * G::HH;
-            float fv[NFI];
-#pragma unroll
-            for (int j = 0; j < NFI; ++j) {
-                const int i = j * kWave + lane;
-                const int rail = i / G::HH4, sidx = i % G::HH4 - G::FH;
-                const float x = stF[rail * G::HH + (sidx < 0 ? 0 : sidx)];
-                fv[j] = sidx < 0 ? 0.0f : x;
-            }
-#pragma unroll
-            for (int j = 0; j < NFI; ++j) {
-                const int i = j * kWave + lane;
-                D[(i / G::HH4) * G::DLEN + i % G::HH4] = fv[j];
-            }
-        }
-        float gain = p.gain[c];
-        const int group = (int)fa.group;
-        constexpr int NDV = 2 * (G::HH4 / 4);
-        static_assert(NDV == 16 || NDV == 32 || NDV == 64, "Hilbert history move is one float4 per lane (lanes beyond NDV repeat the first ones)");
-        const int dt_off = ((lane % NDV) / (G::HH4 / 4)) * G::DLEN + 4 * (lane % (G::HH4 / 4));
-        auto htap = [&](int k) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(hreg[k >> 6]), k & 63)); };
-
-        wg_barrier();                                                 // X
-        for (uint32_t pass = 0; pass < npass; ++pass) {
-            mfma_half(std::integral_constant<int, KH>{});
-            wg_barrier();                                             // Y
-            // combine the two K halves, exact power-of-two rescale, decimated rails into D behind the Hilbert history
-            {
-                const v4f pI = *reinterpret_cast<const v4f *>(P + 4 * lane), pQ = *reinterpret_cast<const v4f *>(P + 256 + 4 * lane);
-                const int ex = -(SX[pass & 1] + fa.split_sc);
-                const int o0 = G::HH4 + 64 * (lane >> 4) + (lane & 15);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    dI[o0 + 16 * r] = __builtin_ldexpf(accI[r] + pI[r], ex);
-                    dQ[o0 + 16 * r] = __builtin_ldexpf(accQ[r] + pQ[r], ex);
-                }
-            }
-            lds_order();
-            float au[4];
-            if constexpr (AM != 0) {
-                const float4 vi = lds_ld4f(dI + G::HH4 + 4 * lane);
-                const float4 vq = lds_ld4f(dQ + G::HH4 + 4 * lane);
-                au[0] = cmag<0>(vi.x, vq.x); au[1] = cmag<0>(vi.y, vq.y);
-                au[2] = cmag<0>(vi.z, vq.z); au[3] = cmag<0>(vi.w, vq.w);
-            } else {
-                float q2[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
-#ifndef SRX_X_NOHILB
-#pragma unroll
-                for (int t = 0; t < HilbertSteps<ND, M, NH>::N; ++t) hilbert_tstep<1, ND, M, NH>(t, dQ, lane, htap, q2);
-#endif
-                const float *di = dI + G::FH + fa.delay_idx + 4 * lane;   // unit-impulse delay FIR
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float i2 = di[r] + 0.0f;
-                    au[r] = fa.upper ? (i2 - q2[r]) : (i2 + q2[r]);
-                }
-                const v4f dt = *reinterpret_cast<const v4f *>(D + dt_off + G::P);   // Hilbert-pair history for the next pass
-                lds_order();
-                *reinterpret_cast<v4f *>(D + dt_off) = dt;
-            }
-            GuardPass gdw{ 0.0f, 0ull, 0u };                           // (experimental kernel: no parity guard)
-            agc_pass<GROUP>(p.agcp, p.agc, lane, group, au, gain, 64, gdw);
-            W::store(rs_out, lane * W::kBytes, (int)pass * (G::P * (W::kBytes / 4)), au);
-            wg_barrier();                                             // X
-        }
-        if constexpr (AM == 0) {                                      // AM never ran the Hilbert pair: its state stays
-            for (int i = lane; i < 2 * G::HH4; i += kWave) {
-                const int rail = i / G::HH4, mi = i % G::HH4, s = mi - G::FH;
-                if (s >= 0) p.fir_state[((size_t)c * 2 + rail) * G::HH + s] = D[rail * G::DLEN + mi];
-            }
-        }
-        if (lane == 0 && p.agc) p.gain[c] = gain;
-    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1342,8 +833,27 @@ __global__ __launch_bounds__(64, 2) void k_hilb_split16(RxParams p, FusedArgs fa
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x;
     const uint32_t c = blockIdx.x;
+    // SELENITE_ARITH_AUTO in ONE launch (round 5; FusedArgs::inl).  Until round 4 a call was three launches: this kernel (which raises the rerun
+    // bit of a channel it guards and leaves its state alone), k_hist_exact (the dense list of those channels) and the rerun pass of the
+    // bit-exact kernel -- the last two empty in the steady state of a clean workload and still 4 us per call (1 % of a cfg5-sized call,
+    // profiles/r5/ab_forms_hilb.txt).  One channel per workgroup: the workgroup that guarded the channel recomputes it ITSELF, with the body
+    // of the bit-exact kernel (ssb_fused_body as the rerun pass: same guard evaluation, same hysteresis, same words), behind the matrix pass
+    // (a channel it has just flagged) or instead of it (a channel the exact arithmetic holds) -- word_t != 0.  Which arithmetic serves a
+    // channel is decided by its word alone, so both forms give the same bits; the load stays even by construction (the grid IS the channels).
+    // (The persistent k_ssb_split16 keeps the three launches: its workgroups share channels statically, a dense list evens the recomputation
+    // out -- and the bit-exact body inlined behind its pass pipeline took the registers the pipeline has to spare: 12 bytes of scratch or
+    // four more v_readlane per pass, +0.6 % on the raw kernel for 0.2 % off the AUTO call, profiles/r5/ab_forms.txt.)
+    constexpr bool INLT = AM == 0;
+    uint32_t word_t = 0u;
+    do {                                                              // (the matrix pass: left by `break`)
     // SELENITE_ARITH_AUTO, hysteresis (round 4): a channel the exact kernel holds is its alone -- the rerun pass of this call serves it
-    if (p.rerun_flag != nullptr && (p.rerun_flag[c] & kFlagHold) != 0u) return;
+    if (p.rerun_flag != nullptr) {
+        const uint32_t w0 = p.rerun_flag[c];
+        if ((w0 & kFlagHold) != 0u) {                                 // wave-uniform
+            if (INLT && fa.inl != 0u) word_t = w0;
+            break;
+        }
+    }
     float *tab = lds + GH::oTab;
     _Float16 *Xh = reinterpret_cast<_Float16 *>(lds + GH::oX), *Xl = Xh + GH::IMG;
     float *dI = lds + GH::oDI, *dQ = lds + GH::oDQ, *O = lds + GH::oO;      // f32 rails [HH history | 256 new]
@@ -1546,7 +1056,8 @@ __global__ __launch_bounds__(64, 2) void k_hilb_split16(RxParams p, FusedArgs fa
         }
         if (keep_state) {
             if (nonfinite) p.flags[0] = 1u;
-            return;
+            if (INLT && fa.inl != 0u) word_t = kFlagRerun;            // (the word just written)
+            break;
         }
     }
     // ---- epilogue: arm_fir_f32 pState tails (the last NH-1 samples of each rail), exact f32 ----
@@ -1563,6 +1074,19 @@ __global__ __launch_bounds__(64, 2) void k_hilb_split16(RxParams p, FusedArgs fa
         if constexpr (NCO != 0) p.phase[c] = ph0 + p.block_size * step;
         if (p.agc) p.gain[c] = gain;
     }
+    } while (0);
+    if constexpr (INLT) {
+        if (word_t != 0u) {                                           // wave-uniform
+            RxParams p2 = p;                                          // the rerun pass's view (rx_fused.hip: launch_shape, rerun())
+            p2.chan_flags = p.rerun_flag;
+            p2.rerun_flag = nullptr;
+            p2.chan_list = nullptr; p2.chan_count = nullptr; p2.chan_count_next = nullptr; p2.rerun_seen = nullptr;
+            FusedArgs fa2 = fa;
+            fa2.nco = p.nco == 2 ? 2u : (p.nco == 1 ? ((p.lo_period == 256 && fa.pass_out == 256) ? 4u : 1u) : 0u);      // (launch_one)
+            __syncthreads();
+            ssb_fused_body<0, 0, 1, NH, TIn, TOut, 0, true>(p2, fa2, src, dst, FusedInl{ c, word_t });
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1574,17 +1098,7 @@ static hipError_t launch_k(const RxParams &p, const FusedArgs &fa, const void *s
     using GS = GeoS<NCO, ND, M, NH>;
     constexpr size_t lds = (size_t)GS::total * sizeof(float);
     static_assert(lds <= 48 * 1024, "k_ssb_split16 LDS image");
-#if SRX_SPLIT16_W2
-    if constexpr (GS::KS % 2 == 0 && NCO != 3 && M == 4) {
-        static const bool one_wave = std::getenv("SELENITE_RX_SPLIT16_W1") != nullptr;      // A/B: the one-wave kernel
-        if (!one_wave && p.nout % 256 == 0) {
-            constexpr size_t lds2 = lds + (512 + 4) * sizeof(float);                         // + partial sums + exponents
-            hipLaunchKernelGGL((k_ssb_split16w2<NCO, ND, M, NH, TIn, TOut, AM, GROUP>), dim3(p.channels), dim3(128), lds2, st, p, fa,
-                               static_cast<const TIn *>(src), static_cast<TOut *>(dst));
-            return hipGetLastError();
-        }
-    }
-#endif
+    if (fa.inl) return hipErrorNotSupported;                      // (the one-launch form of SELENITE_ARITH_AUTO: k_hilb_split16 only)
     // persistent grid: as many single-wave workgroups as the device keeps resident, each running channels
     // b, b + grid, b + 2 grid, ...  (SELENITE_RX_SPLIT16_GRID=0: one workgroup per channel, the round-1 launch shape)
     static int resident = 0;

@@ -63,7 +63,7 @@ ABI_SYMBOLS = [
     "selenite_rx_global_process_f32_device",
     "selenite_rx_host_alloc", "selenite_rx_host_free", "selenite_rx_host_register", "selenite_rx_host_unregister",
     "selenite_rx_time_process_each_device", "selenite_rx_time_streaming_roof_device", "selenite_rx_device_pci_bus_id",
-    "selenite_rx_set_guard_ratio", "selenite_rx_guard_stats", "selenite_rx_guard_channels", "selenite_rx_auto_words", "selenite_rx_guard_handover", "selenite_rx_set_handover_repair", "selenite_rx_guard_clear",
+    "selenite_rx_set_guard_ratio", "selenite_rx_guard_stats", "selenite_rx_guard_channels", "selenite_rx_auto_words", "selenite_rx_guard_handover", "selenite_rx_set_handover_repair", "selenite_rx_set_auto_launches", "selenite_rx_auto_launches_last", "selenite_rx_guard_clear",
 ]
 
 class TxConfig(C.Structure):
@@ -172,6 +172,8 @@ def lib():
         L.selenite_rx_guard_clear.argtypes = [vp]
         L.selenite_rx_guard_handover.argtypes = [vp, u64p]
         L.selenite_rx_set_handover_repair.argtypes = [vp, C.c_int]
+        L.selenite_rx_set_auto_launches.argtypes = [vp, C.c_int]
+        L.selenite_rx_auto_launches_last.argtypes = [vp]
         L.selenite_rx_design_lowpass.argtypes = [f32p, C.c_uint32, C.c_double]
         L.selenite_rx_design_hilbert.argtypes = [f32p, f32p, C.c_uint32]
         L.selenite_rx_design_bandpass.argtypes = [f32p, C.c_uint32, C.c_double, C.c_double]
@@ -380,6 +382,15 @@ class Rx:
 
     def set_handover_repair(self, on):
         return self.L.selenite_rx_set_handover_repair(self.h, int(bool(on)))
+
+    def set_auto_launches(self, launches):
+        """SELENITE_ARITH_AUTO: 1 (default) = the matrix kernel recomputes a channel it guarded itself where it can (k_hilb_split16: one launch
+        per call), 3 = always k_hist_exact and the rerun pass behind it.  Same bits either way."""
+        return self.L.selenite_rx_set_auto_launches(self.h, int(launches))
+
+    def auto_launches_last(self):
+        """1 / 3: the form the last SELENITE_ARITH_AUTO call on a matrix kernel took (0: none yet)."""
+        return int(self.L.selenite_rx_auto_launches_last(self.h))
 
     def guard_channels(self):
         out = np.zeros(self.cfg.channels, np.uint32)

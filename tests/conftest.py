@@ -26,3 +26,19 @@ def ref():
     if not rxcommon.ref_available():
         pytest.skip("oracle/_ref/libcmsis_ref.so not built (needs /root/reference; build container only)")
     return rxcommon.ref_lib()
+
+
+@pytest.fixture(params=[1, 3], ids=["one-launch", "three-launch"])
+def auto_form(request, monkeypatch):
+    """SELENITE_ARITH_AUTO in both of its forms (selenite_rx_set_auto_launches): every Rx the test opens is pinned to the one-launch form
+    (the matrix kernel recomputes its guarded channels itself, where it can) or to the three-launch form (k_hist_exact + the rerun pass).
+    Modules opt in with `pytestmark = pytest.mark.usefixtures("auto_form")`."""
+    import selenite_rx as sr
+    init = sr.Rx.__init__
+
+    def patched(self, *a, **k):
+        init(self, *a, **k)
+        self.set_auto_launches(request.param)
+
+    monkeypatch.setattr(sr.Rx, "__init__", patched)
+    return request.param

@@ -14,7 +14,7 @@ import pytest
 import rxcommon as rc
 from rxcommon import ARITH_AUTO, ARITH_CMSIS, ARITH_SPLIT16, CpuChain, bits_equal, synth_iq
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("auto_form")]      # every test in both forms of SELENITE_ARITH_AUTO (conftest.py)
 
 
 def per_block(yg, yo, na):

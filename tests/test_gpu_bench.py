@@ -62,6 +62,26 @@ def test_bench_json_contract_default_shape():
     assert 0 < d["auto_stopband_cost"]["rerun_fraction"] <= 1 and d["auto_stopband_cost"]["value"] > 0
     assert d["fma_roof"]["flops_per_sample"] == 293.5                  # shared LO: 6 NCO flops per sample, not 20
     assert d["value"] > 0 and d["ms_per_step"] > 0
+    # round 5: every other single-GPU BASELINE configuration in the same line -- median of >= 100 launches, roofline from
+    # the SURVEY 8d bytes, parity on a 64-channel sample against the compiled reference
+    w = d["workloads"]
+    per_ch = {"cfg2": 8 * 48000 + 4 * 48000 + 2 * 4 * 2 * 126 + 8, "cfg4": 8 * 4096 + 4 * 4096 + 2 * (16 * 4) + 2 * 8,
+              "cfg5": 8 * 1024 + 4 * 1024 + 2 * 4 * 2 * 126 + 8, "cfg3_q15": 41952 - 4 * 4096 - 2 * 1024}
+    for n in ("cfg2", "cfg4", "cfg5", "cfg3_q15"):
+        e = w[n]
+        assert e["launches"] >= 100 and e["ms_min"] <= e["ms_per_step"] <= e["ms_p90"] and e["value"] > 0, n
+        r2 = e["roofline"]
+        assert r2["bound"] == "hbm" and 0 < r2["frac"] < 1 and abs(r2["frac"] - r2["achieved"] / 8000.0) < 1e-3, n
+        assert r2["algorithmic_bytes_per_launch"] == 1024 * per_ch[n], (n, r2["algorithmic_bytes_per_launch"] / 1024)
+        p2 = e["parity"]
+        assert p2["channels"] == 64 and p2["blocks"] > 0 and p2["against"] in ("reference", "port"), n
+        if n == "cfg3_q15":
+            assert p2["worst_lsb"] <= 1
+        else:
+            assert p2["worst_rel"] <= 1e-5, (n, p2)
+    assert w["cfg4"]["kernel"] == "k_cw_fused<4,256>" and w["cfg4"]["parity"]["worst_rel"] == 0.0      # bit-exact in every arithmetic mode
+    assert w["cfg2"]["kernel"].startswith("k_hilb_split16<127>") and w["cfg5"]["kernel"].startswith("k_hilb_split16<127>")
+    assert "mall_note" in w["cfg5"] and w["cfg3_q15"]["io"] == "q15"
 
 
 def test_bench_q15_slots_cw_shape_and_global_gain():

@@ -12,7 +12,7 @@ import pytest
 import rxcommon as rc
 from rxcommon import ARITH_CMSIS, ARITH_FMA, CpuChain, bits_equal, synth_iq
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("auto_form")]      # every test in both forms of SELENITE_ARITH_AUTO (conftest.py)
 SHAPES = [(256, 4, 63), (128, 4, 63), (256, 4, 127), (128, 4, 127), (256, 4, 31), (0, 1, 63), (0, 1, 127), (0, 1, 31),
           (256, 2, 63), (128, 2, 63), (256, 8, 63), (64, 4, 63), (128, 8, 63), (64, 2, 63), (64, 8, 63),
           (128, 4, 31), (256, 2, 127), (128, 2, 127), (256, 2, 31), (128, 2, 31)]
