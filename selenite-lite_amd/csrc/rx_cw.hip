@@ -12,17 +12,22 @@
 // output sequence, left-to-right sums, feedback added, no fusion (both arithmetic modes -- the
 // recurrence keeps the reference rounding).
 //
-// Per DSP block (BLK samples) and workgroup (one wavefront, 16 channels):
-//   1. coalesced dwordx4 loads (2 complex samples per lane), NCO mix real part, into ONE LDS tile
-//      x[16][BLK+4] (f32).  Shared LO: all 8 loads of a chunk use the same LO float4.
-//   2. BLK+NS-1 systolic steps (NS-1 masked fill + NS-1 masked drain steps so a block's envelope is complete
-//      before it is scaled); the last stage writes y[n] over x[n] in place (x[n] was consumed NS-1 steps ago)
-//      and tracks max|y|.
-//   3. AGC gain law per channel; the tile goes out as 16 rows of 1 KiB: ds_read_b128, scale by the
-//      channel's gain (v_readlane), one global dwordx4 store per lane per row.
+// Per DSP block (BLK samples) and workgroup (one wavefront, 16 channels with 4 stages):
+//   1. buffer loads (2 complex samples per lane, 1 KB of one channel per instruction with 4 stages), NCO mix real part -- into
+//      REGISTERS first, then into ONE LDS tile x[16][BLK+4] (f32).  Shared LO: all loads of a chunk use the same LO float4.
+//   2. BLK+NS-1 systolic steps (NS-1 masked fill + NS-1 masked drain steps so a block's envelope is complete before it is scaled), 9 vector
+//      instructions each; the last stage writes y[n] over x[n] in place (x[n] was consumed NS-1 steps ago) and tracks max|y|.
+//   3. AGC gain law per channel; the tile goes out as 16 rows of 1 KiB: ds_read_b128, scale by the channel's gain (v_readlane), one
+//      non-temporal buffer store per lane per row.
 // State (4 floats per channel-stage) is one coalesced dwordx4 load/store per lane per call.
+// Round 5 (profiles/r5/README.md): the audio stores of a block are a 16 KB burst, and a wait for loaded data is a wait for every vector-memory
+// operation in flight (loads and stores complete out of order with respect to each other: s_waitcnt vmcnt(0)) -- the first chunk of a
+// block is therefore taken out of its load registers BEFORE the burst of the block in front of it goes out (-6.5 %); the step's delay
+// lines became (x1, y1) / (x2, y2) register pairs that swap names (52 -> 39 vector instructions per four steps: -12 % with int16 slots,
+// nothing with f32 slots, which are bound by the memory system at 5.0 TB/s of a 2 : 1 read / write mix).
 #include "rx_internal.h"
 #include <cstdlib>
+#include <type_traits>
 
 #pragma clang fp contract(off)
 
@@ -35,6 +40,10 @@ __device__ __forceinline__ void cw_lds_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+typedef float cw_v2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u4v_cw __attribute__((ext_vector_type(4)));
+typedef unsigned int u2v_cw __attribute__((ext_vector_type(2)));
+
 __device__ __forceinline__ float dpp_row_shr1(float v)
 {
     // lane l receives lane l-1 (within its row of 16); lanes 0,16,32,48 read 0 (bound_ctrl: they are stage 0
@@ -42,19 +51,26 @@ __device__ __forceinline__ float dpp_row_shr1(float v)
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x111, 0xf, 0xf, true));
 }
 
+// two complex samples per lane and load, through a buffer descriptor over the workgroup's channels: the lane's part of the address is
+// one 32-bit offset for the whole call (no 64-bit address arithmetic per load), and lanes past the last channel read zeros
 template <typename T> struct CwRaw;
 template <> struct CwRaw<float> {
-    typedef float4 type;
-    static __device__ __forceinline__ type load(const float *src, size_t cplx) { return *reinterpret_cast<const float4 *>(src + 2 * cplx); }
-    static __device__ __forceinline__ void unpack(const type &r, float2 &a, float2 &b) { a = make_float2(r.x, r.y); b = make_float2(r.z, r.w); }
+    typedef u4v_cw type;
+    static constexpr int kBytes = 16;
+    static __device__ __forceinline__ type load(__amdgpu_buffer_rsrc_t r, int voff, int soff) { return __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 2); }      // nt: streamed once
+    static __device__ __forceinline__ void unpack(const type &r, cw_v2 &a, cw_v2 &b)
+    {
+        a = cw_v2{ __uint_as_float(r.x), __uint_as_float(r.y) }; b = cw_v2{ __uint_as_float(r.z), __uint_as_float(r.w) };
+    }
 };
 template <> struct CwRaw<int16_t> {
-    typedef short4 type;
-    static __device__ __forceinline__ type load(const int16_t *src, size_t cplx) { return *reinterpret_cast<const short4 *>(src + 2 * cplx); }
-    static __device__ __forceinline__ void unpack(const type &r, float2 &a, float2 &b)
+    typedef u2v_cw type;
+    static constexpr int kBytes = 8;
+    static __device__ __forceinline__ type load(__amdgpu_buffer_rsrc_t r, int voff, int soff) { return __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 2); }
+    static __device__ __forceinline__ void unpack(const type &r, cw_v2 &a, cw_v2 &b)
     {
-        a = make_float2(q15_to_float(r.x), q15_to_float(r.y));
-        b = make_float2(q15_to_float(r.z), q15_to_float(r.w));
+        a = cw_v2{ q15_to_float((int16_t)(r.x & 0xffffu)), q15_to_float((int16_t)(r.x >> 16)) };
+        b = cw_v2{ q15_to_float((int16_t)(r.y & 0xffffu)), q15_to_float((int16_t)(r.y >> 16)) };
     }
 };
 
@@ -63,29 +79,35 @@ template <> struct CwRaw<int16_t> {
 // dwordx4 loads of two complex samples per lane and chunk), D = NS - 1 fill / drain steps per DSP block.  Stage NS-1
 // emits y[k - D] at step k; trips are four steps, so an aligned float4 of outputs is NCAR values carried from the
 // trip before plus the first 4 - NCAR of this one (NCAR = 4 - D mod 4), PRO = D / 4 + 1 trips behind the input.
-template <int NS>
+template <int NS, int NL = 8>
 struct CwGeo {
     static_assert(NS == 2 || NS == 4 || NS == 8, "systolic CW kernel: 2, 4 or 8 biquad stages");
     static constexpr int CH = 64 / NS;
-    static constexpr int CS = 1024 / CH;
+    static constexpr int CS = NL * 128 / CH;        // samples per input chunk: NL wave loads of two complex samples per lane
     static constexpr int LPC = CS / 2;              // lanes per channel row of a load
     static constexpr int CPL = 64 / LPC;            // channels per load
     static constexpr int D = NS - 1;
     static constexpr int R = D % 4;                 // outputs of a trip that complete the pending group
     static constexpr int NCAR = 4 - R;
     static constexpr int PRO = D / 4 + 1;
+    static_assert(LPC <= 64 && 64 % LPC == 0, "a load covers whole channel rows");
 };
+// loads per chunk:
+// 16 where the DSP block is whole chunks of that size and a chunk row still fits a wave load (2 / 4 stages): 1 KB of ONE channel per load
+// instruction with 4 stages, half as many chunk prologues; else 8
+template <int NS, int BLK> struct CwLoads { static constexpr int NL = (NS <= 4 && BLK % (2048 / (64 / NS)) == 0) ? 16 : 8; };      // (16 -- 1 KB of one channel per load, half as many chunk prologues -- measured 1.5 % slower: profiles/r5/README.md)
 
 template <int NS, int NCO, int BLK, typename TIn, typename TOut>
 __global__ __launch_bounds__(64) void k_cw_fused(RxParams p, const TIn *__restrict__ src, TOut *__restrict__ dst)
 {
-    using CG = CwGeo<NS>;
+    constexpr int NL = CwLoads<NS, BLK>::NL;
+    using CG = CwGeo<NS, NL>;
     constexpr int CH = CG::CH, CS = CG::CS, D = CG::D, R = CG::R, NCAR = CG::NCAR, PRO = CG::PRO;
     constexpr int RS = BLK + 4;                         // tile row stride (floats); rows stay 16 B aligned
     constexpr int NCHUNK = BLK / CS;                    // input chunks of CS samples x CH channels
     constexpr int TPC = CS / 4;                         // trips per chunk
     static_assert(BLK % CS == 0 && PRO <= TPC && 4 * PRO <= BLK, "block holds whole chunks; prologue inside the first chunk");
-    __shared__ __attribute__((aligned(16))) float tile[CH * RS + 4 * 64];
+    __shared__ __attribute__((aligned(16))) float tile[CH * RS];
     __shared__ float tab[NCO == 1 ? 516 : 4];
     const int lane = threadIdx.x;
     const int s = lane & (NS - 1), ch = lane / NS;
@@ -100,108 +122,125 @@ __global__ __launch_bounds__(64) void k_cw_fused(RxParams p, const TIn *__restri
     // per-lane stage constants and state
     const float b0 = p.biq_c[5 * s], b1 = p.biq_c[5 * s + 1], b2 = p.biq_c[5 * s + 2];
     const float a1 = p.biq_c[5 * s + 3], a2 = p.biq_c[5 * s + 4];
-    float4 st = *reinterpret_cast<const float4 *>(p.biq_state + ((size_t)c * NS + s) * 4);
-    float x1 = st.x, x2 = st.y, y1 = st.z, y2 = st.w;
+    const float4 st = *reinterpret_cast<const float4 *>(p.biq_state + ((size_t)c * NS + s) * 4);      // { x1, x2, y1, y2 } (arm_biquad_cascade_df1_f32.c:73-82)
     float gain = p.agc ? p.gain[c] : 1.0f;
     bool nonfinite = false;                                           // any audio sample of this wavefront NaN / Inf
     // load-phase geometry: load j of a chunk covers channel CPL*j + lane/LPC, samples 2*(lane%LPC), +1
     const int lch = lane / CG::LPC, lsm = 2 * (lane % CG::LPC);
     const uint32_t ph_own = NCO ? p.phase[c] : 0u, st_own = NCO ? p.step[c] : 0u;
-    // last-stage lanes write y[4i..4i+3] at tile[ch][4i]; other lanes write a private dummy float4
-    float *wbase = (s == NS - 1) ? (tile + ch * RS) : (tile + CH * RS + 4 * lane);
-    const int wstride = (s == NS - 1) ? 1 : 0;
+    // last-stage lanes write y[4i..4i+3] over x[4i..4i+3] of their channel's row (the other lanes are masked out: four dwords from wherever
+    // the step left them -- a 16-byte store would want them copied into one aligned register quad first, and vector instructions are what
+    // this kernel is short of)
+    const bool last = s == NS - 1;
+    float *wrow = tile + ch * RS;
     const float *rbase = tile + ch * RS;
 
     typedef typename CwRaw<TIn>::type raw_t;
-    raw_t raw[8];
-    float4 lo4 = make_float4(1.0f, 0.0f, 1.0f, 0.0f);
+    // input prefetch: one chunk ahead (NL wave loads in flight while the chunk before them is worked through: ~2.4 us of systolic steps at
+    // NL = 16.  Two chunks of 8 loads ahead, in alternating register slots, measured the same: profiles/r5/README.md)
+    raw_t raw[NL];
+    u4v_cw lo4 = { 0u, 0u, 0u, 0u };
+    // the workgroup's CH channels (fewer in the last workgroup: the range ends with the array), 32-bit offsets inside them
+    constexpr int EB = CwRaw<TIn>::kBytes / 2;                        // bytes per complex sample
+    const uint32_t chs = min((uint32_t)CH, p.channels - c0);
+    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<TIn *>(src) + (size_t)c0 * p.in_stride * 2, 0,
+                                                                           (int)(((chs - 1) * p.in_stride + p.block_size) * EB), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_lo = __builtin_amdgcn_make_buffer_rsrc(const_cast<float2 *>(p.lo), 0, NCO == 2 ? (int)(p.block_size * 8u) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(dst + (size_t)c0 * p.out_stride, 0,
+                                                                            (int)(((chs - 1) * p.out_stride + p.block_size) * (uint32_t)sizeof(TOut)), 0x00020000);
+    const int voff_in = (int)((lch * p.in_stride + lsm) * EB);        // this lane's part of every load address
+    const int joff_in = (int)(CG::CPL * p.in_stride * EB);            // ... load j of a chunk adds j of these (wave-uniform)
     auto issue_loads = [&](uint32_t n_first) {          // chunk of CS samples x CH channels starting at n_first
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
-            raw[j] = CwRaw<TIn>::load(src, (size_t)min(c0 + CG::CPL * j + lch, p.channels - 1) * p.in_stride + n_first + lsm);
-        if constexpr (NCO == 2) lo4 = *reinterpret_cast<const float4 *>(p.lo + n_first + lsm);
+        for (int j = 0; j < NL; ++j) raw[j] = CwRaw<TIn>::load(rs_in, voff_in, (int)(n_first * EB) + j * joff_in);
+        if constexpr (NCO == 2) lo4 = __builtin_amdgcn_raw_buffer_load_b128(rs_lo, lsm * 8, (int)(n_first * 8u), 0);
     };
-    auto mix_write = [&](uint32_t n_first, int q) {      // NCO mix (real part) of the loaded chunk into the tile
+    float *mrow = tile + lch * RS + lsm;                 // this lane's slot of load 0 in chunk 0
+    // The chunk's samples are mixed into REGISTERS (mix_regs: this is where the wave waits for its loads) and written to the tile later
+    // (tile_write).  In between sits, at a block boundary, the audio store burst of the block before: loads and stores complete out of
+    // order with respect to each other on this target, so a wait for loaded data is a wait for every vector-memory operation in flight
+    // (s_waitcnt vmcnt(0)) -- behind the burst that was a wait for 16 KB of write acknowledgements per block.
+    float xm[NL][2];
+    auto mix_regs = [&](uint32_t n_first) {             // NCO mix (real part) of the loaded chunk
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            float2 a, b;
+        for (int j = 0; j < NL; ++j) {
+            cw_v2 a, b;
             CwRaw<TIn>::unpack(raw[j], a, b);
             float xa, xb;
             if constexpr (NCO == 0) {
                 xa = a.x; xb = b.x;
             } else {
-                float2 la, lb;
+                cw_v2 la, lb;
                 if constexpr (NCO == 2) {
-                    la = make_float2(lo4.x, lo4.y); lb = make_float2(lo4.z, lo4.w);
+                    la = cw_v2{ __uint_as_float(lo4.x), __uint_as_float(lo4.y) }; lb = cw_v2{ __uint_as_float(lo4.z), __uint_as_float(lo4.w) };
                 } else {
                     const uint32_t cj = min(c0 + CG::CPL * j + lch, p.channels - 1);
                     const uint32_t phj = p.phase[cj], stj = p.step[cj];
                     lo_v2f va, vb;                                    // arm_sin/cos_f32 restated for the vector ALU: same bits (rx_device.h)
                     const uint32_t pe = phj + (n_first + lsm) * stj;
                     nco_lo_pair(tab, pe, pe + stj, va, vb);
-                    la = make_float2(va.x, va.y); lb = make_float2(vb.x, vb.y);
+                    la = cw_v2{ va.x, va.y }; lb = cw_v2{ vb.x, vb.y };
                 }
-                xa = cmul<0>(a, la).x;                        // arm_cmplx_mult_cmplx_f32 real part: ac - bd
-                xb = cmul<0>(b, lb).x;
+                // arm_cmplx_mult_cmplx_f32 real part, a c - b d: both products of a sample in one packed multiply, rounded, then the difference
+                // (the differences through asm: left to itself the vectorizer gathers them into one packed subtract behind four register copies)
+                const cw_v2 ta = a * la, tb = b * lb;
+                asm("v_sub_f32 %0, %1, %2" : "=v"(xa) : "v"(ta.x), "v"(ta.y));
+                asm("v_sub_f32 %0, %1, %2" : "=v"(xb) : "v"(tb.x), "v"(tb.y));
             }
-            *reinterpret_cast<float2 *>(tile + (CG::CPL * j + lch) * RS + CS * q + lsm) = make_float2(xa, xb);
+            xm[j][0] = xa; xm[j][1] = xb;
         }
     };
-    // one DF1 step of this lane's stage; xs = stage-0 input of the step
-    auto step = [&](float xs) -> float {
-        const float prev = dpp_row_shr1(y1);
+    auto tile_write = [&](int q) {
+#pragma unroll
+        for (int j = 0; j < NL; ++j) *reinterpret_cast<float2 *>(mrow + CG::CPL * j * RS + CS * q) = make_float2(xm[j][0], xm[j][1]);
+    };
+    // One DF1 step of this lane's stage; xs = stage-0 input of the step.  The delay lines live in TWO register pairs, A = (x1, y1) and
+    // B = (x2, y2): the four products of a step are two packed multiplies, A * (b1, a1) and B * (b2, a2), and the shift of both delay
+    // lines is a change of NAMES -- B's registers are dead once its products are formed, so the step writes the new (x1, y1) = (xin, y)
+    // into them and the next step calls the pairs the other way round.  No register copy, no operand swizzle: 9 vector instructions per
+    // step (DPP move, select, 1 + 2 multiplies, 4 adds).  Same products, same left-to-right sum as the reference
+    // (arm_biquad_cascade_df1_f32.c:220: b0 x + b1 x1 + b2 x2 + a1 y1 + a2 y2).
+    typedef float cw_v2f __attribute__((ext_vector_type(2)));
+    const cw_v2f c1 = { b1, a1 }, c2 = { b2, a2 };
+    cw_v2f PA = { st.x, st.z }, PB = { st.y, st.w };                  // (x1, y1), (x2, y2)
+    auto step = [&](float xs, cw_v2f &A, cw_v2f &B) -> float {        // on return B holds the new (x1, y1), A the new (x2, y2)
+        const float prev = dpp_row_shr1(A.y);
         const float xin = (s == 0) ? xs : prev;
-        const float p0 = b0 * xin, p1 = b1 * x1, p2 = b2 * x2, p3 = a1 * y1, p4 = a2 * y2;
-        float y = p0 + p1;
-        y = y + p2;
-        y = y + p3;
-        y = y + p4;
-        x2 = x1; x1 = xin; y2 = y1; y1 = y;
+        const cw_v2f t1 = A * c1, t2 = B * c2;
+        const float p0 = b0 * xin;
+        float y = p0 + t1.x;
+        y = y + t2.x;
+        y = y + t1.y;
+        y = y + t2.y;
+        B = cw_v2f{ xin, y };
         return y;
     };
-    // four steps of the steady state.  Each delay line is ONE register pair whose halves swap roles every step: on
-    // an even step (x1, x2) = (lo, hi) and the new input overwrites hi (x2 is dead by then), on an odd step
-    // (x1, x2) = (hi, lo) and the packed multiply reads its first operand's halves swapped (op_sel).  So the packed
-    // products (b1 x1, b2 x2) and (a1 y1, a2 y2) never need a register copy: 9 vector instructions per step (DPP
-    // move, select, 1 + 2 multiplies, 4 adds).  Same products, same left-to-right sum as step().
-    typedef float cw_v2f __attribute__((ext_vector_type(2)));
-    const cw_v2f b12 = { b1, b2 }, a12 = { a1, a2 };
+    // four steps of the steady state: an even number, so PA is (x1, y1) again behind them
     auto trip4 = [&](const float4 &xq, float (&o)[4]) {
-        cw_v2f X = { x1, x2 }, Y = { y1, y2 };
-        const float xs[4] = { xq.x, xq.y, xq.z, xq.w };
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float prev = dpp_row_shr1((j & 1) ? Y.y : Y.x);
-            const float xin = (s == 0) ? xs[j] : prev;
-            cw_v2f px, py;
-            if (j & 1) {
-                asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[0,1]" : "=v"(px) : "v"(X), "v"(b12));
-                asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[0,1]" : "=v"(py) : "v"(Y), "v"(a12));
-            } else {
-                px = X * b12;
-                py = Y * a12;
-            }
-            const float p0 = b0 * xin;
-            float y = p0 + px.x;
-            y = y + px.y;
-            y = y + py.x;
-            y = y + py.y;
-            if (j & 1) { X.x = xin; Y.x = y; } else { X.y = xin; Y.y = y; }
-            o[j] = y;
-        }
-        x1 = X.x; x2 = X.y; y1 = Y.x; y2 = Y.y;
+        o[0] = step(xq.x, PA, PB);
+        o[1] = step(xq.y, PB, PA);
+        o[2] = step(xq.z, PA, PB);
+        o[3] = step(xq.w, PB, PA);
     };
-    // the same with the state update suppressed where stage s has no sample at step k (fill / drain)
+    // one step with the state update suppressed where stage s has no sample at step k (fill / drain); PA stays (x1, y1)
     auto step_masked = [&](float xs, int k) -> float {
-        const float ox1 = x1, ox2 = x2, oy1 = y1, oy2 = y2;
-        const float y = step(xs);
+        const cw_v2f oa = PA, ob = PB;
+        const float y = step(xs, PA, PB);                             // PB = new (x1, y1), PA = old (x1, y1) = new (x2, y2)
         const bool valid = (k - s >= 0) && (k - s < BLK);
-        x1 = valid ? x1 : ox1; x2 = valid ? x2 : ox2; y1 = valid ? y1 : oy1; y2 = valid ? y2 : oy2;
+        const cw_v2f n1 = PB;
+        PA.x = valid ? n1.x : oa.x; PA.y = valid ? n1.y : oa.y;
+        PB.x = valid ? oa.x : ob.x; PB.y = valid ? oa.y : ob.y;
         return y;
     };
 
     const uint32_t nblk = p.block_size / BLK;
+    auto mix_and_prefetch = [&](uint32_t n_first) {     // the loaded chunk (at n_first) out of its registers, the chunk behind it requested
+        mix_regs(n_first);
+        const uint32_t nxt = n_first + CS;                 // (may be in the next block)
+        if (nxt < p.block_size) issue_loads(nxt);
+    };
     issue_loads(0);
+    mix_and_prefetch(0);
     cw_lds_sync();
     for (uint32_t blk = 0; blk < nblk; ++blk) {
         const uint32_t n0 = blk * BLK;
@@ -209,14 +248,11 @@ __global__ __launch_bounds__(64) void k_cw_fused(RxParams p, const TIn *__restri
         float car[NCAR];                                              // outputs waiting for the rest of their float4
 #pragma unroll
         for (int v = 0; v < NCAR; ++v) car[v] = 0.0f;
-#pragma unroll 1
-        for (int q = 0; q < NCHUNK; ++q) {
-            // ---- 1. this chunk's input into the tile; next chunk's HBM loads in flight meanwhile ----
-            mix_write(n0 + CS * q, q);
-            {
-                const uint32_t nxt = n0 + CS * (q + 1);               // next chunk (may be the next block's first)
-                if (nxt < p.block_size) issue_loads(nxt);
-            }
+        auto chunk = [&](int q) {
+            // ---- 1. this chunk's input into the tile; the HBM loads of the chunk that takes its register slot next go out meanwhile
+            // (the first chunk of a block was mixed in front of the store burst of the block before it: below) ----
+            if (q != 0) mix_and_prefetch(n0 + CS * q);
+            tile_write(q);
             cw_lds_sync();
             // ---- 2. TPC trips of 4 systolic steps; stage-0 input is one aligned float4 per trip ----
             int i = TPC * q;
@@ -238,24 +274,39 @@ __global__ __launch_bounds__(64) void k_cw_fused(RxParams p, const TIn *__restri
                 }
                 i = PRO;
             }
-#pragma unroll 1
-            for (; i < TPC * q + TPC; ++i) {
-                // prefetch the next trip's input (stays inside this chunk; harmless re-read at the end)
-                const int inext = (i + 1 < TPC * q + TPC) ? i + 1 : i;
-                const float4 xn = lds_ld4f(rbase + 4 * inext);
+            // one trip: four steps, the aligned group y[4(i-PRO) .. +3] -- NCAR outputs carried from the trip before, then the first R of
+            // this one -- into the tile (last-stage lanes; four dword stores from the registers the steps left them in)
+            auto do_trip = [&](int it, const float4 &xin4) {
                 float o[4];
-                trip4(xq, o);
-                // the aligned group y[4(i-PRO) .. +3]: NCAR carried outputs, then the first R of this trip
+                trip4(xin4, o);
                 float gq[4];
 #pragma unroll
                 for (int v = 0; v < 4; ++v) gq[v] = v < NCAR ? car[v] : o[v - NCAR];
-                *reinterpret_cast<float4 *>(wbase + 4 * (i - PRO) * wstride) = make_float4(gq[0], gq[1], gq[2], gq[3]);
+                if (last) {
+                    // (volatile, in the LDS address space: four ds_write_b32 -- merged into one 16-byte store they cost three register copies)
+                    typedef __attribute__((address_space(3))) float lds_f32;
+                    volatile lds_f32 *w = (volatile lds_f32 *)(wrow + 4 * (it - PRO));
+                    w[0] = gq[0]; w[1] = gq[1]; w[2] = gq[2]; w[3] = gq[3];
+                }
                 m = fmaxf(fmaxf(m, fabsf(o[0])), fmaxf(fabsf(o[1]), fmaxf(fabsf(o[2]), fabsf(o[3]))));
 #pragma unroll
                 for (int v = 0; v < NCAR; ++v) car[v] = o[R + v];
-                xq = xn;
+            };
+            // two trips per round: the input of trip i + 1 is read while trip i runs, that of trip i + 2 -- straight into the registers
+            // trip i has just emptied -- while trip i + 1 runs (the read behind a chunk's last trip lands in the next chunk's columns or
+            // in the row's slack: never used)
+            const int iend = TPC * q + TPC;
+#pragma unroll 1
+            for (; i + 1 < iend; i += 2) {
+                const float4 xb = lds_ld4f(rbase + 4 * (i + 1));
+                do_trip(i, xq);
+                xq = lds_ld4f(rbase + 4 * (i + 2));
+                do_trip(i + 1, xb);
             }
-        }
+            if (i < iend) do_trip(i, xq);                             // (the first chunk of a block: an odd number of trips behind the prologue)
+        };
+#pragma unroll 1
+        for (int q = 0; q < NCHUNK; ++q) chunk(q);
         // ---- drain: stages 1..NS-1 finish samples BLK-D .. BLK-1 ----
         {
             float seq[4 * PRO];
@@ -268,36 +319,39 @@ __global__ __launch_bounds__(64) void k_cw_fused(RxParams p, const TIn *__restri
             }
 #pragma unroll
             for (int tpro = 0; tpro < PRO; ++tpro)
-                *reinterpret_cast<float4 *>(wbase + (BLK - 4 * PRO + 4 * tpro) * wstride) =
-                    make_float4(seq[4 * tpro], seq[4 * tpro + 1], seq[4 * tpro + 2], seq[4 * tpro + 3]);
+                if (last)
+                    *reinterpret_cast<float4 *>(wrow + BLK - 4 * PRO + 4 * tpro) =
+                        make_float4(seq[4 * tpro], seq[4 * tpro + 1], seq[4 * tpro + 2], seq[4 * tpro + 3]);
         }
         cw_lds_sync();
         // ---- 3. AGC gain law (last-stage lanes hold max|y| of their channel) and scaled store ----
         if (p.agc) gain = agc_update<0>(p.agcp, gain, m);
+        if (blk + 1 < nblk) mix_and_prefetch(n0 + BLK);
 #pragma unroll 4
         for (int r = 0; r < CH; ++r) {
-            const float g = __shfl(gain, NS * r + NS - 1, 64);
+            const float g = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(gain), NS * r + NS - 1));     // (r is wave-uniform: a scalar lane select)
 #pragma unroll
             for (int h = 0; h < (BLK / 4 + 63) / 64; ++h) {
                 const int t = 4 * (lane + 64 * h);
-                if (t < BLK && c0 + r < p.channels) {
-                    float4 v = lds_ld4f(tile + r * RS + t);
-                    v.x = v.x * g; v.y = v.y * g; v.z = v.z * g; v.w = v.w * g;
-                    {   // ARM_MATH_NANINF (arm_math.h:405): x * 0 is NaN iff x is not finite
-                        const float z = __builtin_fmaf(v.w, 0.0f, __builtin_fmaf(v.z, 0.0f, __builtin_fmaf(v.y, 0.0f, v.x * 0.0f)));
-                        nonfinite = nonfinite || (z != z);
-                    }
-                    const size_t o = (size_t)(c0 + r) * p.out_stride + n0 + t;
-                    // (non-temporal: written once, never read by the chain)
-                    if constexpr (sizeof(TOut) == 4) {
-                        v4f *at = reinterpret_cast<v4f *>(reinterpret_cast<float *>(dst) + o);
-                        if (p.out_cached) *at = v4f{ v.x, v.y, v.z, v.w };       // global gain, phase 1: the gain pass reads it back
-                        else __builtin_nontemporal_store(v4f{ v.x, v.y, v.z, v.w }, at);
-                    } else {
-                        typedef short s4v __attribute__((ext_vector_type(4)));
-                        __builtin_nontemporal_store(s4v{ float_to_q15(v.x), float_to_q15(v.y), float_to_q15(v.z), float_to_q15(v.w) },
-                                                    reinterpret_cast<s4v *>(reinterpret_cast<int16_t *>(dst) + o));
-                    }
+                float4 v = lds_ld4f(tile + r * RS + (t < BLK ? t : 0));
+                v.x = v.x * g; v.y = v.y * g; v.z = v.z * g; v.w = v.w * g;
+                {   // ARM_MATH_NANINF (arm_math.h:405): x * 0 is NaN iff x is not finite
+                    const float z = __builtin_fmaf(v.w, 0.0f, __builtin_fmaf(v.z, 0.0f, __builtin_fmaf(v.y, 0.0f, v.x * 0.0f)));
+                    nonfinite = nonfinite || (t < BLK && (uint32_t)r < chs && z != z);
+                }
+                // buffer stores: rows past the workgroup's last channel and lanes past the block fall outside the descriptor's range and are dropped.
+                // Non-temporal (written once, never read by the chain) unless a gain pass reads the audio back -- two instructions that differ in
+                // their cache-policy immediate (as `if (cached) *p = v; else __builtin_nontemporal_store(v, p)` the two stores were merged into ONE
+                // plain store: the audio of every CW call went through the caches)
+                const int voff = t < BLK ? t * (int)sizeof(TOut) : 0x40000000;
+                const int soff = (int)((r * p.out_stride + n0) * (uint32_t)sizeof(TOut));
+                if constexpr (sizeof(TOut) == 4) {
+                    const u4v_cw u = { __float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w) };
+                    if (p.out_cached) __builtin_amdgcn_raw_buffer_store_b128(u, rs_out, voff, soff, 0);       // global gain, phase 1: the gain pass reads it back
+                    else __builtin_amdgcn_raw_buffer_store_b128(u, rs_out, voff, soff, 2);
+                } else {
+                    const uint32_t qa = (uint16_t)float_to_q15(v.x), qb = (uint16_t)float_to_q15(v.y), qc = (uint16_t)float_to_q15(v.z), qd = (uint16_t)float_to_q15(v.w);
+                    __builtin_amdgcn_raw_buffer_store_b64(u2v_cw{ qa | (qb << 16), qc | (qd << 16) }, rs_out, voff, soff, 2);
                 }
             }
         }
@@ -305,7 +359,7 @@ __global__ __launch_bounds__(64) void k_cw_fused(RxParams p, const TIn *__restri
     }
     if (nonfinite) p.flags[kFlagNanInf] = 1u;                         // read by selenite_rx_sync / the host-pointer calls
     if (!live) return;
-    *reinterpret_cast<float4 *>(p.biq_state + ((size_t)c * NS + s) * 4) = make_float4(x1, x2, y1, y2);
+    *reinterpret_cast<float4 *>(p.biq_state + ((size_t)c * NS + s) * 4) = make_float4(PA.x, PB.x, PA.y, PB.y);
     if (s == NS - 1) {
         if (p.agc) p.gain[c] = gain;
         if constexpr (NCO != 0) p.phase[c] = ph_own + p.block_size * st_own;
@@ -325,8 +379,9 @@ static bool cw_block_ok(uint32_t ns, uint32_t blk)
 
 bool cw_fused_ok(const selenite_rx_config &g, uint32_t block_size)
 {
+    // (block_size: the kernel addresses its workgroup's channels -- up to 32 rows of the input -- with 32-bit byte offsets)
     return mode_is_cw(g.mode) && g.nd_taps == 0 && g.decim == 1 && g.nh_taps == 0 && cw_block_ok(g.n_biquad, g.block) &&
-           block_size % g.block == 0;
+           block_size % g.block == 0 && block_size <= (1u << 22);
 }
 
 template <int NS, int NCO, typename TIn, typename TOut>
@@ -366,6 +421,7 @@ static hipError_t cw_launch_ns(const RxParams &p, const void *src, bool q15, voi
 hipError_t launch_cw_fused(const RxParams &p, const void *src, bool src_q15, void *dst, bool dst_q15, hipStream_t st)
 {
     if (src_q15 != dst_q15) return hipErrorNotSupported;
+    if ((uint64_t)p.in_stride * 32u * 8u >= (1ull << 31) || (uint64_t)p.out_stride * 32u * 4u >= (1ull << 31)) return hipErrorNotSupported;      // 32-bit offsets inside a workgroup's channels (cw_fused_ok)
     if (p.nbiq == 2) return cw_launch_ns<2>(p, src, src_q15, dst, st);
     if (p.nbiq == 4) return cw_launch_ns<4>(p, src, src_q15, dst, st);
     if (p.nbiq == 8) return cw_launch_ns<8>(p, src, src_q15, dst, st);

@@ -288,8 +288,12 @@ __device__ __forceinline__ void demod_agc_store(const RxParams &p, const FusedAr
         // (non-temporal: the audio is written once and never read by the chain -- the caches are left to the streaming state)
         if constexpr (sizeof(TOut) == 4) {
             v4f *at = reinterpret_cast<v4f *>(reinterpret_cast<float *>(dst) + o);
-            if (p.out_cached) *at = v4f{ au[0], au[1], au[2], au[3] };          // global gain, phase 1: the gain pass reads it back
-            else __builtin_nontemporal_store(v4f{ au[0], au[1], au[2], au[3] }, at);
+            // (the non-temporal store as the instruction itself: __builtin_nontemporal_store of a 16-byte vector came out as a plain
+            // global_store_dwordx4 -- and merged with the cached store of the other branch -- so the f32 audio of every launch of this kernel
+            // went through the caches until round 5)
+            const v4f av = { au[0], au[1], au[2], au[3] };
+            if (p.out_cached) *at = av;                                       // global gain, phase 1: the gain pass reads it back
+            else asm volatile("global_store_dwordx4 %0, %1, off nt" :: "v"(at), "v"(av) : "memory");
         } else {
             typedef short s4v __attribute__((ext_vector_type(4)));
             __builtin_nontemporal_store(s4v{ float_to_q15(au[0]), float_to_q15(au[1]), float_to_q15(au[2]), float_to_q15(au[3]) },
