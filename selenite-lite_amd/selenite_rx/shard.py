@@ -71,10 +71,20 @@ def launch_ranks(nproc, script, argv, env=None, timeout=None):
     port = str(free_port())
     stage_dir = tempfile.mkdtemp(prefix="selenite_ranks_")
     procs = []
+
+    def die_with_parent():
+        # a rank outlives its launcher only if the launcher is killed outright (SIGKILL skips every handler below): ask the kernel to
+        # kill the rank then.  Runs in the child between fork and exec -- the rank has not touched the GPU yet.
+        try:
+            import ctypes
+            ctypes.CDLL("libc.so.6", use_errno=True).prctl(1, signal.SIGKILL, 0, 0, 0)      # PR_SET_PDEATHSIG
+        except Exception:
+            pass
+
     for r in range(nproc):
         e = dict(base, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(nproc), LOCAL_WORLD_SIZE=str(nproc),
                  MASTER_ADDR="127.0.0.1", MASTER_PORT=port, SELENITE_RANK_STAGE_DIR=stage_dir)
-        procs.append(subprocess.Popen([sys.executable, script] + list(argv), env=e, start_new_session=True))
+        procs.append(subprocess.Popen([sys.executable, script] + list(argv), env=e, start_new_session=True, preexec_fn=die_with_parent))
 
     def stage(r):
         try:
@@ -95,6 +105,19 @@ def launch_ranks(nproc, script, argv, env=None, timeout=None):
             except subprocess.TimeoutExpired:
                 pass
 
+    # the ranks sit in sessions of their own, outside this process's group: a SIGTERM / SIGHUP / SIGINT aimed at the launcher (a driver's
+    # timeout, a killpg of its group) must take them along -- raise SystemExit so that the `finally` below runs (torch.distributed.run,
+    # which this replaces, forwards the signal to its children)
+    def on_signal(signum, frame):
+        raise SystemExit(128 + signum)
+
+    previous = {}
+    if threading.current_thread() is threading.main_thread():
+        for sg in (signal.SIGTERM, signal.SIGHUP, signal.SIGINT):
+            try:
+                previous[sg] = signal.signal(sg, on_signal)
+            except (OSError, ValueError):
+                pass
     t0, rc = time.monotonic(), 0
     try:
         while True:
@@ -117,6 +140,11 @@ def launch_ranks(nproc, script, argv, env=None, timeout=None):
             time.sleep(0.05)
     finally:
         kill_all()
+        for sg, h in previous.items():
+            try:
+                signal.signal(sg, h)
+            except (OSError, ValueError):
+                pass
         for r in range(nproc):
             try:
                 os.unlink(_stage_file(stage_dir, r))
@@ -143,6 +171,7 @@ class RankEnv:
         self.backend = None
         self._stage_dir = environ.get("SELENITE_RANK_STAGE_DIR")
         self._stage = "started"
+        self._stage_t = time.monotonic()
         self._done = threading.Event()
         self.stage("started")
         # a rank of an N > 1 job never waits for ever (a peer that died before the rendezvous, a hung RCCL bootstrap): past the limit it
@@ -154,6 +183,7 @@ class RankEnv:
     def stage(self, name):
         """Where this rank is (launch_ranks and the watchdog name it when the rank is stuck)."""
         self._stage = name
+        self._stage_t = time.monotonic()                     # (the watchdog measures from here: progress re-arms it)
         if self._stage_dir:
             try:
                 with open(_stage_file(self._stage_dir, self.rank), "w") as f:
@@ -162,10 +192,17 @@ class RankEnv:
                 pass
 
     def _watchdog(self, limit):
-        if not self._done.wait(limit):
-            sys.stderr.write("RankEnv: rank %d of %d still at '%s' after %.0f s -- giving up (exit 3)\n" % (self.rank, self.world, self._stage, limit))
-            sys.stderr.flush()
-            os._exit(3)
+        # a HANG detector, not a cap on the job: the rank leaves only when its CURRENT stage has lasted `limit` seconds (a healthy long job
+        # moves from stage to stage; the total-run cap is launch_ranks' timeout)
+        while True:
+            idle = time.monotonic() - self._stage_t
+            if self._done.wait(max(0.05, min(limit - idle, 5.0))):
+                return
+            idle = time.monotonic() - self._stage_t
+            if idle >= limit:
+                sys.stderr.write("RankEnv: rank %d of %d still at '%s' after %.0f s -- giving up (exit 3)\n" % (self.rank, self.world, self._stage, idle))
+                sys.stderr.flush()
+                os._exit(3)
 
     def init_process_group(self, backend, use_gpu=True):
         """torch FIRST: its bundled libamdhip64 (same soname) then serves libselenite_rx.so too, so the process

@@ -92,3 +92,44 @@ def test_the_c_host_of_the_rccl_path_has_a_watchdog():
     out = subprocess.run([exe], capture_output=True, text=True, timeout=60,
                          env=dict(os.environ, GLOBAL_GAIN_SELFTEST_HANG="1", GLOBAL_GAIN_TIMEOUT_S="2"))
     assert out.returncode == 3 and "still at 'hung on purpose (selftest)' after 2 s" in out.stderr
+
+
+def test_a_sigterm_to_the_launcher_takes_the_ranks_along():
+    """Advisor, round 4: the ranks sit in sessions of their own, so a SIGTERM aimed at the launcher (a driver's timeout) used to leave them
+    behind until their own watchdog fired.  Rank 1 hangs on purpose; the launcher gets SIGTERM; within seconds no rank is left."""
+    import signal
+    import time
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env.update(SELENITE_SELFTEST_HANG_RANK="1", SELENITE_LAUNCH_TIMEOUT_S="120", SELENITE_SELFTEST_TAG="sigterm-%d" % os.getpid())
+    p = subprocess.Popen([sys.executable, BENCH, "--gpus", "2", "--dist-backend", "gloo", "--selftest-launch"], env=env,
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+
+    def ranks():            # the children of the launcher: processes whose environment carries this test's tag and a RANK
+        found = []
+        for pid in os.listdir("/proc"):
+            if not pid.isdigit() or int(pid) == p.pid:
+                continue
+            try:
+                e = open("/proc/%s/environ" % pid, "rb").read()
+            except OSError:
+                continue
+            if env["SELENITE_SELFTEST_TAG"].encode() in e and b"\0RANK=" in b"\0" + e:
+                found.append(int(pid))
+        return found
+
+    t0 = time.monotonic()
+    while len(ranks()) < 2 and time.monotonic() - t0 < 60:
+        time.sleep(0.2)
+    assert len(ranks()) == 2, "the ranks never started"
+    time.sleep(1.0)
+    p.send_signal(signal.SIGTERM)
+    try:
+        p.wait(timeout=30)
+    except subprocess.TimeoutExpired:
+        p.kill()
+        raise AssertionError("the launcher ignored SIGTERM")
+    assert p.returncode == 128 + signal.SIGTERM, p.returncode
+    t1 = time.monotonic()
+    while ranks() and time.monotonic() - t1 < 15:
+        time.sleep(0.2)
+    assert ranks() == [], "ranks left behind: %s" % ranks()

@@ -1,7 +1,7 @@
 #!/bin/bash
 # tools/ab_bench.sh <outdir> [bench args] -- bench.py --main-only once per library in selenite-lite_amd/variants/
 # (plus the product library), same box, same run; prints one line per variant.
-R=${GRAFT_REPO_ROOT:-$(pwd)}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$R/gpurun_out/$1; shift
 mkdir -p $O
 for rep in 1 2; do

@@ -1,7 +1,7 @@
 #!/bin/bash
 # tools/bench_table.sh <outfile> -- bench.py --main-only for every workload / option of interest on ONE box:
 # "<args> | Msamples/s  ms per launch  roofline.frac  kernel  [nco path]"
-R=${GRAFT_REPO_ROOT:-$(pwd)}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$1
 : > $OUT
 run() {

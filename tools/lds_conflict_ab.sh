@@ -2,7 +2,7 @@
 # tools/lds_conflict_ab.sh <outdir> [bench args] -- LDS counters (one --pmc pass, counters only) of the bench kernel for the
 # product library and every A/B library in selenite-lite_amd/variants/: which access of k_ssb_split16 owns the bank conflicts.
 set -u
-R=${GRAFT_REPO_ROOT:-$(pwd)}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$R/gpurun_out/$1; shift
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp

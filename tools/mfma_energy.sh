@@ -1,6 +1,6 @@
 #!/bin/bash
 # tools/mfma_energy.sh -- tools/mfma_energy for each variant with rocm-smi sampled beside it
-R=${GRAFT_REPO_ROOT:-$(pwd)}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 for v in 0 1 2 3; do
   $R/tools/mfma_energy $v > /tmp/me_$v.txt &
   P=$!

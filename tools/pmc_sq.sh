@@ -2,7 +2,7 @@
 # tools/pmc_sq.sh <tag> [bench args] -- SQ counter passes (counters only, no trace domains)
 set -u
 TAG=$1; shift
-R=${GRAFT_REPO_ROOT:-$(pwd)}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out/sq_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp

@@ -5,7 +5,7 @@
 # arithmetic modes, the NCO flavours and the other BASELINE shapes (cfg2 at its literal 48 000 samples); SQ counters of the headline
 # kernel, of the bit-exact kernel and of k_cw_fused.
 set -u
-cd $GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; cd "$R"
 bash tools/profile_run.sh cfg3_auto > /dev/null 2>&1
 bash tools/profile_run.sh cfg3_q15_auto --io q15 > /dev/null 2>&1
 bash tools/profile_run.sh cfg3_auto_stopband --nco per_channel_grid_wide > /dev/null 2>&1
