@@ -33,7 +33,7 @@ sys.path.insert(0, os.path.join(ROOT, "selenite-lite_amd"))
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 F32_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: f32 vector (= f32 MFMA) peak
-TRAFFIC_JSON = next((p for p in (os.path.join(ROOT, "profiles", r, "traffic.json") for r in ("r4", "r3", "r2")) if os.path.exists(p)),
+TRAFFIC_JSON = next((p for p in (os.path.join(ROOT, "profiles", r, "traffic.json") for r in ("r5", "r4", "r3", "r2")) if os.path.exists(p)),
                     os.path.join(ROOT, "profiles", "r3", "traffic.json"))
 
 WORKLOAD_TEXT = {"cfg3": "NCO + 256-tap arm_fir_decimate/4 + 63-tap Hilbert SSB (USB) + AGC",

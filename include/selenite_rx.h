@@ -57,13 +57,12 @@ extern "C" {
 #define SELENITE_MODE_CW  0x02
 #define SELENITE_MODE_CWR 0x03
 #define SELENITE_MODE_AM  0x04
-#define SELENITE_MODE_FM  0x08   /* round 3.  Build-defined (the reference has no FM demodulator, CMSIS-DSP 1.5.3 no arctangent):
+#define SELENITE_MODE_FM  0x08   /* Build-defined (the reference has no FM demodulator, CMSIS-DSP 1.5.3 no arctangent):
                                   * audio[n] = angle(z[n] * conj(z[n-1])) / pi on the decimated I/Q -- arm_cmplx_conj_f32,
                                   * arm_cmplx_mult_cmplx_f32, a stated arctangent, arm_scale_f32.  The
                                   * sample in front of a block comes from the delay lines of the FIR pair, which this mode keeps
-                                  * running without evaluating the taps: needs nh_taps >= 2 (ARGUMENT_ERROR otherwise).  Exact /
-                                  * fma kernels (SPLIT16 runs as FMA); round 4: AUTO runs the split-precision decimator guarded on
-                                  * min|z| x max|audio| (the discriminator's error is |dz| / (pi |z|)) with the bit-exact rerun. */
+                                  * running without evaluating the taps: needs nh_taps >= 2 (ARGUMENT_ERROR otherwise).
+                                  * SELENITE_ARITH_SPLIT16 runs FM as _FMA; _AUTO guards it on min|z| x max|audio|. */
 #define SELENITE_MODE_DIG 0x0A   /* = USB */
 #define SELENITE_MODE_PKT 0x0C   /* = LSB */
 
@@ -72,34 +71,31 @@ extern "C" {
 #define SELENITE_ARITH_FMA   1   /* same operation order, the multiply-add of the FIR tap loops fused (fmaf);
                                     NCO, biquad recurrence and AGC keep the reference rounding.  Bit-exact
                                     vs the oracle's fmaf restatement, <=1e-5 relative vs CMSIS */
-#define SELENITE_ARITH_SPLIT16 2 /* the many-tap FIR of the shape as a split-precision matrix product on the 16-bit
-                                    matrix cores (decimator of the /2, /4 and /8 shapes; Hilbert FIR of the no-decimator
-                                    shapes; TX interpolator): samples and taps are split into f16 hi + lo
-                                    parts, the three significant products (hi*hi, hi*lo, lo*hi) are
-                                    accumulated in f32 by MFMA, with a block exponent taken from the data of
-                                    every pass (any amplitude a float can hold).  NOT bit-exact against any CPU
-                                    order; <=1e-5 relative vs CMSIS per DSP block wherever the audio is within
-                                    ~12 dB of the input level (measured <2e-6 on the BASELINE signals) and as
-                                    close to exact arithmetic as the CMSIS f32 chain itself (~1e-7 of the input
-                                    level); on channels with an EMPTY pass band the small block maximum makes
-                                    the figure against CMSIS up to 2.7e-5.  Everything
-                                    else, and every configuration without such a kernel, runs as
-                                    SELENITE_ARITH_FMA.  Streaming filter state stays exact f32.  Every DSP block
-                                    that falls outside the guaranteed zone is COUNTED (selenite_rx_guard_stats). */
-#define SELENITE_ARITH_AUTO 3    /* SELENITE_ARITH_SPLIT16 with the conditional zone closed: a channel with a guarded DSP
-                                    block in a call (max |audio| more than 12 dB under the largest sample its matrix
-                                    product saw -- selenite_rx_set_guard_ratio) is recomputed for that call, from its
-                                    pre-call streaming state, by the bit-exact SELENITE_ARITH_CMSIS kernel, on the device,
-                                    inside the same process call.  <=1e-5 relative vs CMSIS per DSP block on EVERY
-                                    block: unguarded blocks by the split product's accuracy (~1e-6 of the input level,
-                                    so <=1e-5 of a block maximum within 12 dB of it), guarded channels with 0 ULP.
-                                    Round 4: on every block of every call, whatever the call lengths and mode switches
-                                    (selenite_rx_set_handover_repair); a recomputed channel stays with the bit-exact
-                                    kernel until its level is back (selenite_rx_set_guard_ratio).  Split-precision
-                                    kernels exist for every decimator of 2 .. 256 taps (even count) by 2 or by 4 in
-                                    front of a 31- / 63- / 127-tap type-III pair, by 8 in front of a 63-tap one (the
-                                    by-4 product with every second output kept), and for those pairs alone;
-                                    other configurations run as SELENITE_ARITH_CMSIS. */
+#define SELENITE_ARITH_SPLIT16 2 /* the many-tap FIR of the shape as a split-precision matrix product on the 16-bit matrix
+                                    cores (decimator of the /2, /4 and /8 shapes; Hilbert FIR of the no-decimator shapes; TX
+                                    interpolator): samples and taps split into f16 hi + lo parts, the three significant
+                                    products (hi*hi, hi*lo, lo*hi) accumulated in f32 by MFMA, with a block exponent taken
+                                    from the data of every pass (any amplitude a float can hold).  NOT bit-exact against any
+                                    CPU order.  Guarantee: per DSP block max|out - ref| <= 1e-5 max|ref| against the CMSIS
+                                    chain wherever the block's audio is within 12 dB of the largest sample its matrix product
+                                    saw; every DSP block outside that zone is COUNTED (selenite_rx_guard_stats), and there the
+                                    figure is the split product's error against the INPUT level (~1e-6 of it).  Everything
+                                    else in the chain, and every configuration without such a kernel, runs as _FMA.
+                                    Streaming filter state stays exact f32. */
+#define SELENITE_ARITH_AUTO 3    /* _SPLIT16 with the conditional zone closed -- the default of the benchmarks.  A channel with
+                                    a guarded DSP block in a call (selenite_rx_set_guard_ratio) is recomputed for that call,
+                                    from its pre-call streaming state, by the bit-exact _CMSIS kernel, on the device, inside
+                                    the same process call.  Guarantee: per DSP block max|out - ref| <= 1e-5 max|ref| against
+                                    the CMSIS chain on EVERY block of every call, for any input, call length and mode switch
+                                    (unguarded blocks by the split product's accuracy, recomputed channels with 0 ULP;
+                                    selenite_rx_set_handover_repair keeps the recomputation exact across call boundaries).
+                                    int16 slots: the bar holds for the float audio in front of arm_float_to_q15; the int16
+                                    words are within 1 LSB + 1e-5 x (block maximum of that float audio) x 32768 of the
+                                    reference's (a float inside the bar can still flip the truncation; only _CMSIS / _FMA
+                                    are bit-exact there).
+                                    Split-precision kernels exist for every decimator of 2 .. 256 taps (even count) by 2 or
+                                    by 4 in front of a 31- / 63- / 127-tap type-III pair, by 8 in front of a 63-tap one, and
+                                    for those pairs alone; other configurations run as _CMSIS. */
 
 typedef struct selenite_rx_config {
     uint32_t struct_size;     /* = sizeof(selenite_rx_config) */
@@ -219,17 +215,15 @@ int selenite_rx_global_process_f32_device(selenite_rx_instance *S, const float *
 
 /* ---- parity guard of the split-precision arithmetic (SELENITE_ARITH_SPLIT16 / _AUTO) -------------------------- */
 
-/* A DSP block is GUARDED when max |audio| of the block (before the AGC) is below `ratio` x the largest |component| of the
- * mixed samples its pass of the matrix product held (new samples and FIR history) -- for the blocks that still read Hilbert-pair
- * history the pass before computed (the first nh_taps - 1 audio samples of a pass) also of that pass, and at a call's start of the
- * level the call before left (round 4): there the 1e-5-of-the-block-maximum figure against CMSIS is not guaranteed for the split
- * product.  FM (SELENITE_ARITH_AUTO on the decimating shapes, round 4): guarded when min|z| x max|audio| is
- * below `ratio` x that maximum (the discriminator's error is |dz| / (pi |z|)).  Default ratio 0.25 (-12 dB);
- * 0 disables the guard, +inf guards every block with non-zero input (SELENITE_ARITH_AUTO then recomputes every channel
- * bit-exactly: a test hook).  Takes effect with the next process call.
- * SELENITE_ARITH_AUTO recomputes a channel that owns a guarded block with the bit-exact kernel, inside the same call, and then
- * HOLDS it there (round 4): the matrix kernel skips the channel in the following calls -- a channel whose pass band is empty call
- * after call costs the bit-exact kernel's time, not both kernels' -- until two calls in a row show no block under 1.25 x ratio. */
+/* A DSP block is GUARDED when max |audio| of the block (before the AGC) is below `ratio` x the largest |component| of the mixed
+ * samples whose split-precision error can reach it: those its pass of the matrix product held (new samples and FIR history); for
+ * the blocks that still read FIR-pair history of the pass before (the first nh_taps - 1 audio samples of a pass) also that pass's;
+ * at a call's start also the level the call before left.  FM: guarded when min|z| x max|audio| is below `ratio` x that maximum (the
+ * discriminator's error is |dz| / (pi |z|)).  Default ratio 0.25 (-12 dB); 0 disables the guard, +inf guards every block with
+ * non-zero input (SELENITE_ARITH_AUTO then recomputes every channel bit-exactly: a test hook).  Takes effect with the next call.
+ * SELENITE_ARITH_AUTO recomputes a channel that owns a guarded block with the bit-exact kernel, inside the same call, and then HOLDS
+ * it there: the matrix kernel skips the channel in the following calls (a channel whose pass band is empty call after call costs
+ * the bit-exact kernel's time, not both kernels') until two calls in a row show no block under 1.25 x ratio. */
 int selenite_rx_set_guard_ratio(selenite_rx_instance *S, float ratio);
 /* Counters since init / the last selenite_rx_guard_clear (any pointer may be NULL); drains the instance's stream:
  *   guard_blocks         DSP blocks guarded
@@ -244,23 +238,19 @@ int selenite_rx_guard_channels(selenite_rx_instance *S, uint32_t *per_channel);
  * call before left the streaming state as -- 0 exact, 1 matrix kernel with the samples for the repair, 2 without; bit 5: the channel is
  * HELD by the bit-exact kernel, bit 6: its last call there was clean; bits 8-31: level of the last pass).  Zeros in the other modes. */
 int selenite_rx_auto_words(selenite_rx_instance *S, uint32_t *per_channel);
-/* SELENITE_ARITH_AUTO across calls ("across a call boundary").  A channel the previous call left on the
- * matrix kernel carries a Hilbert-pair history (the last nh_taps - 1 decimated samples) of split16 precision; if THIS call has to be
- * recomputed for it, its first blocks -- those inside the reach of that history -- would start from it.  Handover repair (default on):
- * k_ssb_split16 also leaves the exact mixed samples in front of the decimator state behind (decim * (nh_taps - 1) samples per channel
- * and call, rounded up to whole quads of audio samples: 2 KB for the cfg3 chain; two buffers -- 4 KB of device memory per channel,
- * 0.27 GB at 65 536 channels, allocated by the first call that needs them and released when the repair is switched off), and the
- * rerun recomputes the Hilbert-pair history from them in exact arithmetic first: the recomputed call is CMSIS bit for bit from its
- * first sample (apart from the gain the previous call's AGC left: ~1e-6 relative).  Cost: those bytes (2.4 % of the headline at 4096
- * samples per call, half that at 8192).
- * Round 4: with the repair ON there is no exception left.  A call too short to hold those samples (under nd_taps + decim *
- * (nh_taps - 1) per channel: the firmware's literal one-slot callback) runs on the bit-exact kernel in AUTO, the history is repaired
- * in front of an AM call (which neither reads nor moves it) and in front of the CW / generic kernels, so no block ever starts from
- * a history of split16 precision: selenite_rx_guard_handover stays 0 by construction and every DSP block of every call holds
- * max|out - ref| <= 1e-5 max|ref|.
+/* SELENITE_ARITH_AUTO across calls.  A channel the previous call left on the matrix kernel carries a FIR-pair history (the last
+ * nh_taps - 1 decimated samples) of split16 precision; if THIS call has to be recomputed for it, its first blocks would start from
+ * that history.  Handover repair (default ON): the matrix kernel also leaves the exact mixed samples in front of the decimator state
+ * behind (decim * (nh_taps - 1) samples per channel and call, rounded up to whole quads of audio samples: 2 KB for the cfg3 chain;
+ * two buffers -- 4 KB of device memory per channel, allocated by the first call that needs them and released when the repair is
+ * switched off), and the recomputation derives the FIR-pair history from them in exact arithmetic first: a recomputed call is CMSIS
+ * bit for bit from its first sample (apart from the gain the previous call's AGC left: ~1e-6 relative).  A call too short to hold
+ * those samples (under nd_taps + decim * (nh_taps - 1) per channel: the firmware's literal one-slot callback) runs on the bit-exact
+ * kernel in _AUTO, and the history is repaired in front of an AM call and in front of the CW / generic kernels -- so with the repair
+ * ON no block ever starts from a history of split16 precision: selenite_rx_guard_handover stays 0 and the _AUTO guarantee is
+ * unconditional.  Cost: those bytes (2 % of the headline at 4096 samples per call).
  * OFF (a diagnostic: what the repair is worth): nothing is kept; guarded blocks inside the reach of the history behind a call that
- * stayed on the matrix kernel carry the error of a guarded block of raw SELENITE_ARITH_SPLIT16 (up to ~1e-3 of a block maximum that
- * is the residue of a sideband cancellation) and are COUNTED: */
+ * stayed on the matrix kernel carry the error of a guarded block of raw _SPLIT16 and are COUNTED (selenite_rx_guard_handover): */
 int selenite_rx_set_handover_repair(selenite_rx_instance *S, int on);
 /* SELENITE_ARITH_AUTO, where the recomputation runs.  launches = 1 (default): on the no-decimator shapes (k_hilb_split16: one channel per
  * workgroup) the workgroup that guarded a channel recomputes it itself, with the body of the bit-exact kernel -- one launch per call.

@@ -3,7 +3,7 @@
 # trace domains).  SELENITE_RX_LIB selects an A/B library.  Prints per-wave and per-CU figures.
 set -u
 TAG=$1; shift
-R=${GRAFT_REPO_ROOT:-$(pwd)}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out/sq2_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp

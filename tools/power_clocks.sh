@@ -2,7 +2,7 @@
 # tools/power_clocks.sh <outfile> <label> -- [bench args]: sample rocm-smi (package power, sclk) while bench.py runs a long
 # timed region; prints the median of the samples taken while the kernel was running.
 OUT=$1; LABEL=$2; shift 2; [ "$1" == "--" ] && shift
-R=${GRAFT_REPO_ROOT:-$(pwd)}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 python3 $R/bench.py --main-only --steps 12000 "$@" > /tmp/pc_bench.json 2>/tmp/pc_bench.err &
 BP=$!
 sleep 3.5

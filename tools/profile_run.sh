@@ -6,7 +6,7 @@
 # Results land in gpurun_out/prof_<tag>/ ; summaries worth keeping are copied to profiles/ by hand.
 set -u
 TAG=$1; shift
-R=${GRAFT_REPO_ROOT:-$(pwd)}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
