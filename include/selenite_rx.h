@@ -124,6 +124,10 @@ typedef struct selenite_rx_config {
     float agc_gain_max;
     float agc_env_floor;      /* envelope is clamped from below to this before target/env */
     float agc_gain_init;      /* gain before the first block */
+    uint32_t q15_rounding;    /* int16 output (arm_float_to_q15): 0 = truncate -- the reference's code as the firmware builds it
+                                 (ARM_MATH_ROUNDING undefined, arm_float_to_q15.c:117) --, 1 = the ARM_MATH_ROUNDING variant
+                                 (arm_float_to_q15.c:90-101: +-0.5 in float before the truncation).  The field sits where the struct had
+                                 tail padding: zero the struct before filling it in (memset / = {0}); any other value is an ARGUMENT_ERROR. */
 } selenite_rx_config;
 
 /* Host-side view of the per-channel streaming state (what CMSIS keeps in pState).

@@ -18,6 +18,9 @@
 #include <stdlib.h>
 #include <string.h>
 
+/* SupportFunctions/arm_float_to_q15.c compiled a second time with -DARM_MATH_ROUNDING under this name (oracle/Makefile) */
+void arm_float_to_q15_rounding(float32_t *pSrc, q15_t *pDst, uint32_t blockSize);
+
 #define REF_NCO_K 0x1.921fb6p-22f      /* 2*pi / 2^24 in f32 (same constant as the oracle) */
 
 typedef struct ref_rx {
@@ -248,7 +251,8 @@ void ref_rx_process_q15(ref_rx *S, const int16_t *iq, int16_t *audio, uint32_t b
     float *fi = (float *)malloc(nin * sizeof(float)), *fo = (float *)malloc(nout * sizeof(float));
     arm_q15_to_float((q15_t *)iq, fi, (uint32_t)nin);
     ref_rx_process_f32(S, fi, fo, block_size);
-    arm_float_to_q15(fo, audio, (uint32_t)nout);
+    if (g->q15_rounding) arm_float_to_q15_rounding(fo, audio, (uint32_t)nout);   /* the same source file built with -DARM_MATH_ROUNDING (Makefile) */
+    else arm_float_to_q15(fo, audio, (uint32_t)nout);
     free(fi); free(fo);
 }
 

@@ -263,10 +263,11 @@ void orc_q15_to_float(const int16_t *src, float *dst, uint32_t n)
 }
 /* SupportFunctions/arm_float_to_q15.c:64-122, ARM_MATH_ROUNDING undefined (firmware build,
  * .cproject:44): (q15_t)__SSAT((q31_t)(x * 32768.0f), 16): truncate toward zero, saturate */
-void orc_float_to_q15(const float *src, int16_t *dst, uint32_t n)
+static void float_to_q15(const float *src, int16_t *dst, uint32_t n, int rounding)
 {
     for (uint32_t i = 0; i < n; ++i) {
         float v = src[i] * 32768.0f;
+        if (rounding) v += v > 0.0f ? 0.5f : -0.5f;     /* arm_float_to_q15.c:90-101 (#ifdef ARM_MATH_ROUNDING) */
         int32_t q;
         if (v != v) q = 0;                              /* NaN: UB in C; the firmware's VCVT.S32.F32 (and v_cvt_i32_f32) give 0 */
         else if (v >= 2147483648.0f) q = INT32_MAX;     /* out of int32 range is UB in C too: the FPU saturates */
@@ -277,6 +278,9 @@ void orc_float_to_q15(const float *src, int16_t *dst, uint32_t n)
         dst[i] = (int16_t)q;
     }
 }
+void orc_float_to_q15(const float *src, int16_t *dst, uint32_t n) { float_to_q15(src, dst, n, 0); }
+/* the same function built with ARM_MATH_ROUNDING (selenite_rx_config::q15_rounding = 1): +-0.5 in float before the truncation */
+void orc_float_to_q15_rounding(const float *src, int16_t *dst, uint32_t n) { float_to_q15(src, dst, n, 1); }
 
 /* AGC gain law -- build-defined (DESIGN.md "AGC"): per DSP block,
  *   e = max(env, floor); d = clamp(target / e, gmin, gmax);
@@ -566,7 +570,7 @@ void orc_rx_process_q15(orc_rx *S, const int16_t *iq, int16_t *audio, uint32_t b
     float *fi = (float *)malloc(nin * sizeof(float)), *fo = (float *)malloc(nout * sizeof(float));
     orc_q15_to_float(iq, fi, (uint32_t)nin);
     orc_rx_process_f32(S, fi, fo, block_size, nthreads);
-    orc_float_to_q15(fo, audio, (uint32_t)nout);
+    float_to_q15(fo, audio, (uint32_t)nout, g->q15_rounding != 0);
     free(fi); free(fo);
 }
 

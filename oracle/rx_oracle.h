@@ -49,6 +49,7 @@ void  orc_max_f32(const float *src, uint32_t n, float *result, uint32_t *index);
 void  orc_scale_f32(const float *src, float scale, float *dst, uint32_t n);
 void  orc_q15_to_float(const int16_t *src, float *dst, uint32_t n);
 void  orc_float_to_q15(const float *src, int16_t *dst, uint32_t n);
+void  orc_float_to_q15_rounding(const float *src, int16_t *dst, uint32_t n);   /* the ARM_MATH_ROUNDING build of the same function */
 
 /* AGC gain law (build-defined): returns the new gain */
 float orc_agc_update(const selenite_rx_config *cfg, float gain, float env, int arith);

@@ -183,6 +183,8 @@ extern "C" int selenite_rx_init(selenite_rx_instance **out, const selenite_rx_co
     *out = nullptr;
     if (!cfg || cfg->struct_size != sizeof(selenite_rx_config))
         return fail(nullptr, SELENITE_RX_ARGUMENT_ERROR, "selenite_rx_init: bad config / struct_size");
+    if (cfg->q15_rounding > 1u)
+        return fail(nullptr, SELENITE_RX_ARGUMENT_ERROR, "selenite_rx_init: q15_rounding is 0 or 1 (zero the struct before filling it in)");
     if (cfg->channels == 0 || cfg->block == 0 || cfg->decim == 0)
         return fail(nullptr, SELENITE_RX_ARGUMENT_ERROR, "selenite_rx_init: channels, block, decim must be non-zero");
     if (!mode_valid(cfg->mode, cfg->nh_taps))
@@ -514,7 +516,7 @@ static RxParams make_params(selenite_rx_instance *S, uint32_t block_size)
     const selenite_rx_config &g = S->cfg;
     RxParams p{};
     p.channels = g.channels; p.block = g.block; p.decim = g.decim;
-    p.nd = g.nd_taps; p.nh = g.nh_taps; p.nbiq = g.n_biquad; p.mode = g.mode;
+    p.nd = g.nd_taps; p.nh = g.nh_taps; p.nbiq = g.n_biquad; p.mode = g.mode; p.q15_round = g.q15_rounding ? 1u : 0u;
     p.nco = g.nco_enable ? 1 : 0; p.agc = g.agc_enable ? 1 : 0;
     p.block_size = block_size; p.nout = block_size / g.decim;
     p.in_stride = p.block_size; p.out_stride = p.nout;

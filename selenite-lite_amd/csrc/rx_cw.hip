@@ -95,7 +95,7 @@ struct CwGeo {
 // loads per chunk:
 // 16 where the DSP block is whole chunks of that size and a chunk row still fits a wave load (2 / 4 stages): 1 KB of ONE channel per load
 // instruction with 4 stages, half as many chunk prologues; else 8
-template <int NS, int BLK> struct CwLoads { static constexpr int NL = (NS <= 4 && BLK % (2048 / (64 / NS)) == 0) ? 16 : 8; };      // (16 -- 1 KB of one channel per load, half as many chunk prologues -- measured 1.5 % slower: profiles/r5/README.md)
+template <int NS, int BLK> struct CwLoads { static constexpr int NL = (NS <= 4 && BLK % (2048 / (64 / NS)) == 0) ? 16 : 8; };
 
 template <int NS, int NCO, int BLK, typename TIn, typename TOut>
 __global__ __launch_bounds__(64) void k_cw_fused(RxParams p, const TIn *__restrict__ src, TOut *__restrict__ dst)
@@ -350,8 +350,9 @@ __global__ __launch_bounds__(64) void k_cw_fused(RxParams p, const TIn *__restri
                     if (p.out_cached) __builtin_amdgcn_raw_buffer_store_b128(u, rs_out, voff, soff, 0);       // global gain, phase 1: the gain pass reads it back
                     else __builtin_amdgcn_raw_buffer_store_b128(u, rs_out, voff, soff, 2);
                 } else {
-                    const uint32_t qa = (uint16_t)float_to_q15(v.x), qb = (uint16_t)float_to_q15(v.y), qc = (uint16_t)float_to_q15(v.z), qd = (uint16_t)float_to_q15(v.w);
-                    __builtin_amdgcn_raw_buffer_store_b64(u2v_cw{ qa | (qb << 16), qc | (qd << 16) }, rs_out, voff, soff, 2);
+                    uint32_t w0, w1;
+                    float4_to_q15(v.x, v.y, v.z, v.w, p.q15_round, w0, w1);
+                    __builtin_amdgcn_raw_buffer_store_b64(u2v_cw{ w0, w1 }, rs_out, voff, soff, 2);
                 }
             }
         }

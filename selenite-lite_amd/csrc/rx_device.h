@@ -226,15 +226,33 @@ __device__ __forceinline__ float agc_step(const AgcParams &p, float gain, float 
     return gain + q;
 }
 
-// SupportFunctions/arm_q15_to_float.c:87 and arm_float_to_q15.c:117 (ARM_MATH_ROUNDING off)
+// SupportFunctions/arm_q15_to_float.c:87 and arm_float_to_q15.c:117 (ARM_MATH_ROUNDING off: what the firmware builds) / :90-101 (`round`:
+// the ARM_MATH_ROUNDING variant -- in = in * 32768; in += in > 0 ? 0.5 : -0.5; truncate, saturate -- selenite_rx_config::q15_rounding)
 __device__ __forceinline__ float q15_to_float(int16_t v) { return (float)v / 32768.0f; }
-__device__ __forceinline__ int16_t float_to_q15(float f)
+__device__ __forceinline__ int16_t float_to_q15(float f, uint32_t round = 0u)
 {
     float v = f * 32768.0f;
+    if (round) v = v + (v > 0.0f ? 0.5f : -0.5f);
     int q = (int)v;                      // v_cvt_i32_f32: truncates, saturates at int32 range
     q = q > 32767 ? 32767 : q;
     q = q < -32768 ? -32768 : q;
     return (int16_t)q;
+}
+
+// Four audio samples as two dwords of int16, the form the fused kernels store: the same conversion (v_cvt_i32_f32 truncates and saturates at the
+// int32 range, v_cvt_pk_i16_i32 saturates to 16 bit and packs).  The ARM_MATH_ROUNDING build is a wave-uniform BRANCH the compiler cannot turn
+// into selects (the empty volatile asm cannot be speculated): the truncating build, which is the firmware's, pays one scalar test per store.
+typedef short q15x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void float4_to_q15(float a, float b, float c, float d, uint32_t round, uint32_t &w0, uint32_t &w1)
+{
+    a *= 32768.0f; b *= 32768.0f; c *= 32768.0f; d *= 32768.0f;
+    if (round) {
+        a = a + (a > 0.0f ? 0.5f : -0.5f); b = b + (b > 0.0f ? 0.5f : -0.5f);
+        c = c + (c > 0.0f ? 0.5f : -0.5f); d = d + (d > 0.0f ? 0.5f : -0.5f);
+        asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+    }
+    w0 = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pk_i16((int)a, (int)b));
+    w1 = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pk_i16((int)c, (int)d));
 }
 
 // max over the 64 lanes of a wavefront (exact: max is associative/commutative for non-NaN)
@@ -278,6 +296,17 @@ __device__ __forceinline__ uint32_t wave_umax_bits(float nonneg)
     return max(max(a, b), max(c, d));
 }
 
+// the same maximum with the cross-row step on the DPP path too (row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3: lane 63 holds
+// the maximum of the wave): 6 v_max_u32_dpp + 1 v_readlane instead of 4 + 4 v_readlane + the moves back into vector registers -- for the
+// kernels that are bound by their vector-instruction count (k_hilb_split16)
+__device__ __forceinline__ uint32_t wave_umax_bits_dpp(float nonneg)
+{
+    uint32_t v = row16_umax(__float_as_uint(nonneg));
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false));
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false));
+    return __builtin_amdgcn_readlane(v, 63);
+}
+
 // sample loaders: f32 slot or q15 slot (int16 interleaved I/Q, dsp_if.c:286-289)
 __device__ __forceinline__ float2 load_iq(const float *p, size_t i)
 {
@@ -288,7 +317,7 @@ __device__ __forceinline__ float2 load_iq(const int16_t *p, size_t i)
     short2 v = reinterpret_cast<const short2 *>(p)[i];
     return make_float2(q15_to_float(v.x), q15_to_float(v.y));
 }
-__device__ __forceinline__ void store_audio(float *p, size_t i, float v) { p[i] = v; }
-__device__ __forceinline__ void store_audio(int16_t *p, size_t i, float v) { p[i] = float_to_q15(v); }
+__device__ __forceinline__ void store_audio(float *p, size_t i, float v, uint32_t = 0u) { p[i] = v; }
+__device__ __forceinline__ void store_audio(int16_t *p, size_t i, float v, uint32_t round = 0u) { p[i] = float_to_q15(v, round); }
 
 }  // namespace srx

@@ -295,9 +295,10 @@ __device__ __forceinline__ void demod_agc_store(const RxParams &p, const FusedAr
             if (p.out_cached) *at = av;                                       // global gain, phase 1: the gain pass reads it back
             else asm volatile("global_store_dwordx4 %0, %1, off nt" :: "v"(at), "v"(av) : "memory");
         } else {
-            typedef short s4v __attribute__((ext_vector_type(4)));
-            __builtin_nontemporal_store(s4v{ float_to_q15(au[0]), float_to_q15(au[1]), float_to_q15(au[2]), float_to_q15(au[3]) },
-                                        reinterpret_cast<s4v *>(reinterpret_cast<int16_t *>(dst) + o));
+            typedef uint32_t w2v __attribute__((ext_vector_type(2)));
+            uint32_t w0, w1;
+            float4_to_q15(au[0], au[1], au[2], au[3], p.q15_round, w0, w1);
+            __builtin_nontemporal_store(w2v{ w0, w1 }, reinterpret_cast<w2v *>(reinterpret_cast<int16_t *>(dst) + o));
         }
     }
 }

@@ -288,9 +288,9 @@ __global__ __launch_bounds__(64) void k_agc_generic(RxParams p, const float *aud
             for (uint32_t i = lane; i < na; i += kWave) m = fmaxf(m, fabsf(audio[base + i]));
             const float env = wave_max(m);                 // arm_abs_f32 + arm_max_f32
             g = agc_update<ARITH>(p.agcp, g, env);
-            for (uint32_t i = lane; i < na; i += kWave) store_audio(dst, base + i, audio[base + i] * g);
+            for (uint32_t i = lane; i < na; i += kWave) store_audio(dst, base + i, audio[base + i] * g, p.q15_round);
         } else {
-            for (uint32_t i = lane; i < na; i += kWave) store_audio(dst, base + i, audio[base + i]);
+            for (uint32_t i = lane; i < na; i += kWave) store_audio(dst, base + i, audio[base + i], p.q15_round);
         }
     }
     if (p.agc && lane == 0) p.gain[c] = g;
@@ -427,10 +427,9 @@ __global__ __launch_bounds__(64) void k_agc_apply_global(RxParams p, const float
             if constexpr (sizeof(TOut) == 4) {
                 *reinterpret_cast<float4 *>(reinterpret_cast<float *>(dst) + at) = r;
             } else {
-                short4 s4;
-                s4.x = float_to_q15(r.x); s4.y = float_to_q15(r.y);
-                s4.z = float_to_q15(r.z); s4.w = float_to_q15(r.w);
-                *reinterpret_cast<short4 *>(reinterpret_cast<int16_t *>(dst) + at) = s4;
+                uint2 w;
+                float4_to_q15(r.x, r.y, r.z, r.w, p.q15_round, w.x, w.y);
+                *reinterpret_cast<uint2 *>(reinterpret_cast<int16_t *>(dst) + at) = w;
             }
         };
         if (gm.L <= kWave) {
@@ -466,7 +465,7 @@ __global__ __launch_bounds__(64) void k_agc_apply_global(RxParams p, const float
     for (uint32_t b = 0; b < nblk; ++b) {
         const size_t base = (size_t)c * p.out_stride + (size_t)b * na;
         g = agc_update<ARITH>(p.agcp, g, env[b]);
-        for (uint32_t i = lane; i < na; i += kWave) store_audio(dst, base + i, audio[base + i] * g);
+        for (uint32_t i = lane; i < na; i += kWave) store_audio(dst, base + i, audio[base + i] * g, p.q15_round);
     }
     if (lane == 0) p.gain[c] = g;
 }

@@ -27,6 +27,7 @@ struct RxParams {
     uint32_t in_stride;    // complex samples between consecutive channels in the source buffer (>= block_size)
     uint32_t out_stride;   // audio samples between consecutive channels in the destination buffer (>= nout)
     uint32_t pass_out;     // generic front kernel: decimated outputs per pass
+    uint32_t q15_round;    // int16 output: 1 = the ARM_MATH_ROUNDING variant of arm_float_to_q15 (arm_float_to_q15.c:90-101), 0 = truncation (the firmware's build)
     uint32_t out_cached;   // 1: the audio this launch writes is read back by a later kernel of the same call (global gain, phase 1):
                            // default store policy; 0: written once -- non-temporal stores
     const float *dec_c, *hilb_c, *delay_c, *biq_c, *sintab;

@@ -104,7 +104,7 @@ __device__ __forceinline__ void agc_pass(const AgcParams &ap, uint32_t agc_on, i
             mine = (b == myblk) ? g : mine;
         }
     } else if constexpr (GROUP == 64) {
-        m = __uint_as_float(wave_umax_bits(m));
+        m = __uint_as_float(wave_umax_bits_dpp(m));
         guard(m);
         g = agc_step(ap, g, agc_desired(ap, m));
         mine = g;
@@ -693,7 +693,7 @@ __global__ __launch_bounds__(64, 2) void k_ssb_split16(RxParams p, FusedArgs fa,
         nonfinite = nonfinite || ((z != z) && (!DEC2 || (uint32_t)lane < pq / 4u));            // (by 2 M: the lanes past the pass hold no output of the chain)
         // (pq < 256: the last lanes hold outputs of the NEXT pass's region, computed from its first samples -- not stored)
         const int vo = (GROUP != 0 || (uint32_t)lane < pq / 4u) ? lane * W::kBytes : 0x40000000;
-        W::store(rs_out, vo, (int)(q * pq) * (W::kBytes / 4), au, ENV != 0);      // (ENV: phase 1 of the global-gain call -- the gain pass reads this audio back: default policy, known at compile time)
+        W::store(rs_out, vo, (int)(q * pq) * (W::kBytes / 4), au, ENV != 0, p.q15_round);      // (ENV: phase 1 of the global-gain call -- the gain pass reads this audio back: default policy, known at compile time)
         if constexpr (GROUP == 16 && ENV != 0) {
             {
                 const float m = row16_fmax(fmaxf(fmaxf(fabsf(au[0]), fabsf(au[1])), fmaxf(fabsf(au[2]), fabsf(au[3]))));
@@ -917,7 +917,7 @@ __global__ __launch_bounds__(64, 2) void k_hilb_split16(RxParams p, FusedArgs fa
         const float i0 = stI[hv], i1 = stI[hv + 1], q0 = stQ[hv], q1 = stQ[hv + 1];
         *reinterpret_cast<float2 *>(dI + hv) = make_float2(i0, i1);
         *reinterpret_cast<float2 *>(dQ + hv) = make_float2(q0, q1);
-        b_hist = wave_umax_bits(fmaxf(fabsf(q0), fabsf(q1)));
+        b_hist = wave_umax_bits_dpp(fmaxf(fabsf(q0), fabsf(q1)));
     }
     GuardPass gd{ 0.0f, 1ull, 0u };                                   // parity guard: one DSP block per pass ...
     const int group = (int)fa.group;
@@ -974,8 +974,8 @@ __global__ __launch_bounds__(64, 2) void k_hilb_split16(RxParams p, FusedArgs fa
                 mq = fmaxf(mq, m2);
                 mt = fmaxf(mt, (n >= (int)pq - GH::HH || pq != 256u) ? m2 : 0.0f);   // HH is even: a pair is inside or outside as a whole (pq < 256: the whole tile, a safe bound)
             }
-            const uint32_t b_tail = wave_umax_bits(mt);
-            const uint32_t b_need = max(max(wave_umax_bits(mq), b_tail), b_hist);      // the largest |Q| the matrix product sees
+            const uint32_t b_tail = wave_umax_bits_dpp(mt);
+            const uint32_t b_need = max(max(wave_umax_bits_dpp(mq), b_tail), b_hist);  // the largest |Q| the matrix product sees
             const uint32_t e_need = b_need >> 23;
             gd.thr = __uint_as_float(b_need) * p.guard_ratio;
             int s_new = 141 - (int)e_need;
@@ -997,10 +997,13 @@ __global__ __launch_bounds__(64, 2) void k_hilb_split16(RxParams p, FusedArgs fa
             lds_order();
             // ---- 2. Hilbert FIR of the Q rail: 3 f16 MFMAs per k-step (small terms first, one accumulator) ----
             v4f acc = { 0.0f, 0.0f, 0.0f, 0.0f };
+            float i2[4];                                                  // the delayed I rail of this lane's four outputs, read while the matrix pipe works
+#pragma unroll                                                            // (behind the product each read would wait for the O[] store in front of it)
+            for (int r = 0; r < 4; ++r) i2[r] = dI[64 * rg + 16 * r + mcol + fa.delay_idx] + 0.0f;
 #pragma unroll
             for (int kk = 0; kk < GH::KS; ++kk) {
                 const int u = 16 * mcol + 8 * rg + 32 * kk;                // A[i = l&15][k = 32kk + 8(l>>4) ..+7] = st[16 i + k]
-                const int ph = u + 8 * (u >> 7);
+                const int ph = GH::phys(u);
                 const h8 ah = *reinterpret_cast<const h8 *>(Xh + ph), al = *reinterpret_cast<const h8 *>(Xl + ph);
                 acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, Bl[kk], acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, Bh[kk], acc, 0, 0, 0);
@@ -1008,12 +1011,19 @@ __global__ __launch_bounds__(64, 2) void k_hilb_split16(RxParams p, FusedArgs fa
             }
             // ---- 3. delay on I, sideband combine; transpose through LDS ----
             const int ex = -(s_cur + fa.split_sc);
+            float q2[4];                                                  // -+ the Hilbert rail: the sign rides on v_ldexp_f32's input modifier, the sideband is a
+            if (fa.upper) {                                               // wave-uniform BRANCH (the empty asm cannot be speculated): four selects less per pass
+#pragma unroll
+                for (int r = 0; r < 4; ++r) q2[r] = __builtin_ldexpf(-acc[r], ex);
+                asm volatile("" : "+v"(q2[0]), "+v"(q2[1]), "+v"(q2[2]), "+v"(q2[3]));
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) q2[r] = __builtin_ldexpf(acc[r], ex);
+            }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int n = 64 * rg + 16 * r + mcol;                     // D[row 4 rg + r][col mcol]
-                const float q2 = __builtin_ldexpf(acc[r], ex);
-                const float i2 = dI[n + fa.delay_idx] + 0.0f;
-                O[n] = fa.upper ? (i2 - q2) : (i2 + q2);
+                O[n] = i2[r] + q2[r];                                      // (i2 - q == i2 + (-q) bit for bit)
             }
             lds_order();
         }
@@ -1023,12 +1033,13 @@ __global__ __launch_bounds__(64, 2) void k_hilb_split16(RxParams p, FusedArgs fa
             au[0] = o4.x; au[1] = o4.y; au[2] = o4.z; au[3] = o4.w;
         }
         if (pq == 256u && group == 64) agc_pass<64>(p.agcp, p.agc, lane, 64, au, gain, 1, gd);   // (AM: exact arithmetic, thr stays 0: never guarded)
+        else if (pq == 256u && group == 32) agc_pass<32>(p.agcp, p.agc, lane, 32, au, gain, nvb, gd);   // DSP blocks of 128 frames (cfg2 literally): DPP, no LDS round trips
         else agc_pass<0>(p.agcp, p.agc, lane, group, au, gain, nvb, gd);
         {
             const float z = __builtin_fmaf(au[3], 0.0f, __builtin_fmaf(au[2], 0.0f, __builtin_fmaf(au[1], 0.0f, au[0] * 0.0f)));
             nonfinite = nonfinite || (z != z);
         }
-        W::store(rs_out, (uint32_t)lane < pq / 4u ? lane * W::kBytes : 0x40000000, (int)(pass * pq) * (W::kBytes / 4), au);
+        W::store(rs_out, (uint32_t)lane < pq / 4u ? lane * W::kBytes : 0x40000000, (int)(pass * pq) * (W::kBytes / 4), au, false, p.q15_round);
         // ---- 6. history: last NH-1 samples of both f32 rails and of both images to the front ----
         if constexpr (AM == 0) {
             const float2 ti = *reinterpret_cast<const float2 *>(dI + cur + hv);

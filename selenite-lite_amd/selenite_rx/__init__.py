@@ -38,6 +38,7 @@ class Config(C.Structure):
         ("agc_target", C.c_float), ("agc_attack", C.c_float), ("agc_decay", C.c_float),
         ("agc_gain_min", C.c_float), ("agc_gain_max", C.c_float), ("agc_env_floor", C.c_float),
         ("agc_gain_init", C.c_float),
+        ("q15_rounding", C.c_uint32),
     ]
 
 

@@ -68,13 +68,14 @@ class ChainSpec:
     def __init__(self, channels, block, decim=1, nd_taps=0, nh_taps=0, n_biquad=0, mode=MODE_USB,
                  arith=ARITH_CMSIS, nco=False, nco_step_all=0, nco_steps=None, agc=True,
                  agc_global=False, dec_cutoff=None, bp_f0=500.0 / 48000.0, bp_q=4.0,
-                 agc_params=None):
+                 agc_params=None, q15_rounding=False):
         self.channels, self.block, self.decim = channels, block, decim
         self.nd_taps, self.nh_taps, self.n_biquad = nd_taps, nh_taps, n_biquad
         self.mode, self.arith = mode, arith
         self.nco, self.nco_step_all = nco, nco_step_all
         self.nco_steps = None if nco_steps is None else np.ascontiguousarray(nco_steps, dtype=np.uint32)
         self.agc, self.agc_global = agc, agc_global
+        self.q15_rounding = bool(q15_rounding)   # int16 output: the ARM_MATH_ROUNDING variant of arm_float_to_q15
         if dec_cutoff is None:
             dec_cutoff = 0.4 / decim
         self.dec = design_lowpass(nd_taps, dec_cutoff) if nd_taps else None
@@ -100,6 +101,7 @@ class ChainSpec:
         g.agc_target, g.agc_attack, g.agc_decay = p["target"], p["attack"], p["decay"]
         g.agc_gain_min, g.agc_gain_max = p["gain_min"], p["gain_max"]
         g.agc_env_floor, g.agc_gain_init = p["env_floor"], p["gain_init"]
+        g.q15_rounding = int(self.q15_rounding)
         g._keepalive = self          # the struct only holds raw pointers into this spec's arrays
         return g
 

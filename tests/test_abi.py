@@ -83,8 +83,9 @@ def test_ring_refuses_to_run_without_a_gpu():
 
 
 def test_config_struct_layout_matches_header():
-    # C layout of selenite_rx_config on LP64: 8 u32, 4 u8, u32, 5 pointers, 7 floats (+4 tail pad)
+    # C layout of selenite_rx_config on LP64: 8 u32, 4 u8, u32, 5 pointers, 7 floats, u32 (q15_rounding, where the tail padding was)
     assert C.sizeof(sr.Config) == 8 * 4 + 4 + 4 + 5 * 8 + 7 * 4 + 4
+    assert sr.Config.q15_rounding.offset == 108
     assert sr.Config.dec_coeffs.offset == 40 and sr.Config.agc_target.offset == 80
     assert C.sizeof(sr.StateView) == 40
 
@@ -107,6 +108,7 @@ def init_rc(spec, mutate=None):
 def test_init_argument_validation_precedes_device_use():
     ok = rc.baseline_spec("cfg3", 2)
     assert init_rc(ok, lambda g: setattr(g, "struct_size", 12)) == rc.ARGUMENT_ERROR
+    assert init_rc(ok, lambda g: setattr(g, "q15_rounding", 2)) == rc.ARGUMENT_ERROR     # sits in former tail padding: garbage there must not switch the rounding silently
     assert init_rc(ok, lambda g: setattr(g, "channels", 0)) == rc.ARGUMENT_ERROR
     assert init_rc(ok, lambda g: (setattr(g, "mode", rc.MODE_FM), setattr(g, "nh_taps", 0))) == rc.ARGUMENT_ERROR   # FM needs the FIR pair's delay lines
     assert init_rc(ok, lambda g: setattr(g, "mode", 0x05)) == rc.ARGUMENT_ERROR          # not a value of the firmware's Mode enum (rxtx_if.h:33-43)
