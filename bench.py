@@ -201,6 +201,11 @@ def side_workload(name, q15, arith, spinup_ms, iters=100, rank=0, parity=True, c
         alg_bytes -= channels * (4 * bs + 2 * nout)
         rd_bytes -= channels * 4 * bs
     kernel, nco = rx.kernel_name(), rx.nco_path()
+    # the same traffic with no arithmetic, right behind the timed launches (same clocks, same memory temperature): what this box can do for
+    # this shape at this moment -- the memory-bound shapes move with it from box to box and with what ran before them (d_out is overwritten)
+    rx.time_streaming_roof(d_in.ptr, d_out.ptr, bs, 16, q15)
+    roof = float(np.median(rx.time_streaming_roof(d_in.ptr, d_out.ptr, bs, 60, q15)))
+    rx.sync()
     rx.close(); d_in.free(); d_out.free()
     wl = dict(ch.WORKLOADS, **{k + "_q15": v for k, v in ch.WORKLOADS.items()})
     traffic = pmc_traffic(name + ("_q15" if q15 else ""), {sr.ARITH_AUTO: "auto", sr.ARITH_CMSIS: "cmsis", sr.ARITH_FMA: "fma", sr.ARITH_SPLIT16: "split16"}[arith],
@@ -214,7 +219,8 @@ def side_workload(name, q15, arith, spinup_ms, iters=100, rank=0, parity=True, c
                         "frac": round(alg_bytes / (med * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                         "read_frac": round(rd_bytes / (med * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                         "algorithmic_bytes_per_launch": alg_bytes, "traffic": traffic,
-                        "traffic_source": None if traffic is None else os.path.relpath(TRAFFIC_JSON, ROOT) + " (committed rocprofv3 --pmc passes of this kernel and shape)"}}
+                        "traffic_source": None if traffic is None else os.path.relpath(TRAFFIC_JSON, ROOT) + " (committed rocprofv3 --pmc passes of this kernel and shape)",
+                        "streaming_roof_ms": round(roof, 4), "frac_of_streaming_roof": round(roof / med, 4)}}
     if note:
         out["note"] = note
     if name == "cfg5":

@@ -284,8 +284,9 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 constexpr int kZS = 64;                                            // image slots in front of the new samples
 constexpr int kKS = 3;                                             // k-steps of 32 (K = 80 <= 96)
 constexpr int kZN = 240 + 32 * kKS;                                // highest image index read + 1
-__host__ __device__ constexpr int zphys(int u) { return u + 8 * (u >> 7); }      // 16 B pad per 128 samples
-constexpr int kZIMG = ((kZN + 8 * (kZN >> 7) + 8) + 7) & ~7;       // halfs per image
+__host__ __device__ constexpr int zphys(int u) { return u; }        // linear: the A-fragment ds_read_b128 (16-byte slot 2 (l&15) + (l>>4) + 4 kk of lane l) is conflict free
+                                                                    // under the instruction's real lane groups (GeoH::phys, rx_fused_common.h); the pad per 128 samples of rounds 3-4 made it 2-way
+constexpr int kZIMG = (kZN + 8 + 7) & ~7;                          // halfs per image
 constexpr int oZ16 = oHQ + kHLen, oZF = oZ16 + 2 * kZIMG;          // 4 images of kZIMG halfs = 2 kZIMG floats
 constexpr int kTotal16 = oZF + 2 * kPass;                          // + the pass's interpolator input in f32, both rails
 
@@ -467,7 +468,7 @@ __global__ __launch_bounds__(64, 2) void k_tx_split16(TxParams p, uint32_t delay
 #pragma unroll
         for (int kk = 0; kk < kKS; ++kk) {
             const int u = 16 * mcol + 8 * rg + 32 * kk;
-            const int pz = u + 8 * (u >> 7);
+            const int pz = zphys(u);
             const h8 xIh = *reinterpret_cast<const h8 *>(ZI + 0 * kZIMG + pz), xIl = *reinterpret_cast<const h8 *>(ZI + 1 * kZIMG + pz);
             const h8 xQh = *reinterpret_cast<const h8 *>(ZI + 2 * kZIMG + pz), xQl = *reinterpret_cast<const h8 *>(ZI + 3 * kZIMG + pz);
 #pragma unroll

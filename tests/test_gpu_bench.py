@@ -73,6 +73,9 @@ def test_bench_json_contract_default_shape():
         r2 = e["roofline"]
         assert r2["bound"] == "hbm" and 0 < r2["frac"] < 1 and abs(r2["frac"] - r2["achieved"] / 8000.0) < 1e-3, n
         assert r2["algorithmic_bytes_per_launch"] == 1024 * per_ch[n], (n, r2["algorithmic_bytes_per_launch"] / 1024)
+        # the same bytes with no arithmetic, timed right behind the launches (the memory-bound shapes move with the box and with what ran before)
+        assert 0 < r2["streaming_roof_ms"] and abs(r2["frac_of_streaming_roof"] - r2["streaming_roof_ms"] / e["ms_per_step"]) < 5e-3, n
+        assert r2["frac_of_streaming_roof"] < 1.1, (n, r2)
         p2 = e["parity"]
         assert p2["channels"] == 64 and p2["blocks"] > 0 and p2["against"] in ("reference", "port"), n
         if n == "cfg3_q15":
