@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""tools/placement_probe2.py <pattern> -- cfg2 timed on buffers allocated in different ways (one process per pattern):
+"""tools/placement_probe2.py <pattern> [workload] -- cfg2 (or another bench workload) timed on buffers allocated in different ways (one process per pattern):
 A separate hipMalloc of input and output (what bench.py does); B a 3 GB allocation first; C one allocation holding both; D output first;
 E as A after allocating and freeing 6 GB; F input and output each inside its own larger (4 GB) allocation"""
 import os
@@ -12,9 +12,11 @@ import selenite_rx as sr  # noqa: E402
 from selenite_rx import chain as ch  # noqa: E402
 
 pat = sys.argv[1]
-name, channels, bs = ch.WORKLOADS["cfg2"]
-rx = sr.Rx(ch.baseline_spec(name, channels, sr.ARITH_AUTO).config())
-nin, nout = channels * bs * 8, channels * bs * 4
+wl = sys.argv[2] if len(sys.argv) > 2 else "cfg2"
+name, channels, bs = ch.WORKLOADS[wl]
+spec = ch.baseline_spec(name, channels, sr.ARITH_AUTO)
+nin, nout = channels * bs * 8, channels * (bs // spec.decim) * 4
+rx = sr.Rx(spec.config())
 keep = []
 if pat == "B":
     keep.append(sr.DeviceBuffer(3 << 30))
@@ -40,4 +42,4 @@ for _ in range(300):
 rx.sync()
 ms = np.sort(rx.time_process_each(d_in, d_out, bs, 100, False))
 roof = np.sort(rx.time_streaming_roof(d_in, d_out, bs, 60, False))
-print("%s  in %#x out %#x  kernel %.4f ms  copy %.4f ms" % (pat, d_in, d_out, ms[50], roof[30]), flush=True)
+print("%s %s  in %#x out %#x  kernel %.4f ms  copy %.4f ms" % (pat, wl, d_in, d_out, ms[50], roof[30]), flush=True)
