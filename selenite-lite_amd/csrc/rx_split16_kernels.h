@@ -60,9 +60,12 @@ struct GuardPass {
 };
 template <int GROUP>
 __device__ __forceinline__ void agc_pass(const AgcParams &ap, uint32_t agc_on, int lane, int group, float (&au)[4], float &gain,
-                                         int nvb, GuardPass &gd)   // nvb: DSP blocks of the pass that exist (a call's last pass may be partial)
+                                         int nvb, GuardPass &gd,   // nvb: DSP blocks of the pass that exist (a call's last pass may be partial)
+                                         float m_lane = -1.0f)     // >= 0: max |.| of FOUR samples of this lane's 16-lane row of the pass, taken by the caller (GROUP 16 / 32 / 64)
 {
-    float m = fmaxf(fmaxf(fabsf(au[0]), fabsf(au[1])), fmaxf(fabsf(au[2]), fabsf(au[3])));
+    // (k_hilb_split16 takes the maxima in the matrix layout, where lane l holds samples 64 (l>>4) + 16 r + (l&15): the same 16-lane rows as the
+    // store layout's 4 l + r, so every row / half-wave / wave maximum is the same number -- and the gain law no longer waits for the LDS transpose)
+    float m = m_lane >= 0.0f ? m_lane : fmaxf(fmaxf(fabsf(au[0]), fabsf(au[1])), fmaxf(fabsf(au[2]), fabsf(au[3])));
     float g = gain, mine = gain;
     auto guard = [&](float env) {                    // env: the block envelope, in (at least) the first lane of every block
         const int lanes = nvb * (GROUP ? GROUP : group);
@@ -957,7 +960,7 @@ __global__ __launch_bounds__(64, 2) void k_hilb_split16(RxParams p, FusedArgs fa
             }
         }
         prefetch(pass + 1);
-        float au[4];
+        float au[4], m_pre = -1.0f;                                   // m_pre: this lane's max |audio| in the matrix layout (the SSB modes)
         if constexpr (AM != 0) {
 #pragma unroll
             for (int i = 0; i < 2; ++i)
@@ -1011,6 +1014,7 @@ __global__ __launch_bounds__(64, 2) void k_hilb_split16(RxParams p, FusedArgs fa
             }
             // ---- 3. delay on I, sideband combine; transpose through LDS ----
             const int ex = -(s_cur + fa.split_sc);
+            float m_mx = 0.0f;
             float q2[4];                                                  // -+ the Hilbert rail: the sign rides on v_ldexp_f32's input modifier, the sideband is a
             if (fa.upper) {                                               // wave-uniform BRANCH (the empty asm cannot be speculated): four selects less per pass
 #pragma unroll
@@ -1023,8 +1027,11 @@ __global__ __launch_bounds__(64, 2) void k_hilb_split16(RxParams p, FusedArgs fa
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int n = 64 * rg + 16 * r + mcol;                     // D[row 4 rg + r][col mcol]
-                O[n] = i2[r] + q2[r];                                      // (i2 - q == i2 + (-q) bit for bit)
+                const float o = i2[r] + q2[r];                             // (i2 - q == i2 + (-q) bit for bit)
+                O[n] = o;
+                m_mx = fmaxf(m_mx, fabsf(o));
             }
+            m_pre = m_mx;
             lds_order();
         }
         // ---- 4.-5. AGC on the DSP block (= the pass), coalesced store ----
@@ -1032,8 +1039,8 @@ __global__ __launch_bounds__(64, 2) void k_hilb_split16(RxParams p, FusedArgs fa
             const float4 o4 = lds_ld4f(O + 4 * lane);
             au[0] = o4.x; au[1] = o4.y; au[2] = o4.z; au[3] = o4.w;
         }
-        if (pq == 256u && group == 64) agc_pass<64>(p.agcp, p.agc, lane, 64, au, gain, 1, gd);   // (AM: exact arithmetic, thr stays 0: never guarded)
-        else if (pq == 256u && group == 32) agc_pass<32>(p.agcp, p.agc, lane, 32, au, gain, nvb, gd);   // DSP blocks of 128 frames (cfg2 literally): DPP, no LDS round trips
+        if (pq == 256u && group == 64) agc_pass<64>(p.agcp, p.agc, lane, 64, au, gain, 1, gd, m_pre);   // (AM: exact arithmetic, thr stays 0: never guarded)
+        else if (pq == 256u && group == 32) agc_pass<32>(p.agcp, p.agc, lane, 32, au, gain, nvb, gd, m_pre);   // DSP blocks of 128 frames (cfg2 literally): DPP, no LDS round trips
         else agc_pass<0>(p.agcp, p.agc, lane, group, au, gain, nvb, gd);
         {
             const float z = __builtin_fmaf(au[3], 0.0f, __builtin_fmaf(au[2], 0.0f, __builtin_fmaf(au[1], 0.0f, au[0] * 0.0f)));
