@@ -112,7 +112,21 @@ __device__ __forceinline__ void agc_pass(const AgcParams &ap, uint32_t agc_on, i
         g = agc_step(ap, g, agc_desired(ap, m));
         mine = g;
     } else {
-        if (group == 8) {
+        if ((group & 15) == 0) {
+            // whole 16-lane rows per DSP block (blocks of 64 / 128 / 192 / 256 audio samples at run time: BASELINE cfg2 in DSP blocks of 192 frames is
+            // one block of three rows per pass): row maxima by DPP, the rows of a block joined on the scalar unit (|.| >= 0: the bit patterns
+            // order like the values) -- instead of up to six LDS round trips (ds_bpermute) of the general scan below
+            m = row16_fmax(m);
+            const uint32_t r0 = __builtin_amdgcn_readlane(__float_as_uint(m), 0), r1 = __builtin_amdgcn_readlane(__float_as_uint(m), 16);
+            const uint32_t r2 = __builtin_amdgcn_readlane(__float_as_uint(m), 32), r3 = __builtin_amdgcn_readlane(__float_as_uint(m), 48);
+            const int rows = group >> 4;                     // rows per block; row i belongs to block i / rows (a last, partial block is never looked at)
+            uint32_t e0 = r0, e1 = r1, e2 = r2, e3 = r3;
+            if (rows == 2) { e0 = e1 = max(r0, r1); e2 = e3 = max(r2, r3); }
+            else if (rows == 3) { e0 = e1 = e2 = max(max(r0, r1), r2); }
+            else if (rows >= 4) { e0 = e1 = e2 = e3 = max(max(r0, r1), max(r2, r3)); }
+            const int row = lane >> 4;
+            m = __uint_as_float(row == 0 ? e0 : (row == 1 ? e1 : (row == 2 ? e2 : e3)));
+        } else if (group == 8) {
             // eight lanes per DSP block (decimation by 8 of 256-frame blocks, round 4): two quad permutes and a half-row mirror on the
             // DPP path instead of three LDS round trips (ds_bpermute)
             m = fmaxf(m, __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(m), 0xB1, 0xf, 0xf, false)));    // quad_perm [1,0,3,2]
