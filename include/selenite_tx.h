@@ -55,6 +55,8 @@ typedef struct {
     const float *delay_coeffs;    /* [nh_taps] */
     const uint32_t *nco_step;     /* [channels] or NULL */
     float alc_target, alc_attack, alc_decay, alc_gain_min, alc_gain_max, alc_env_floor, alc_gain_init;
+    uint32_t q15_rounding;     /* int16 I/Q output (arm_float_to_q15): 0 = truncate (the firmware's build, arm_float_to_q15.c:117), 1 = the ARM_MATH_ROUNDING
+                                  build (arm_float_to_q15.c:90-101).  Sits where the struct had tail padding: zero the struct first; other values: ARGUMENT_ERROR */
 } selenite_tx_config;
 
 typedef struct {

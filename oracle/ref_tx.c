@@ -13,6 +13,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+void arm_float_to_q15_rounding(float32_t *pSrc, q15_t *pDst, uint32_t blockSize);   /* arm_float_to_q15.c built with -DARM_MATH_ROUNDING under this name (oracle/Makefile) */
+
 #define REF_NCO_K 0x1.921fb6p-22f
 
 typedef struct ref_tx {
@@ -154,7 +156,8 @@ void ref_tx_process_q15(ref_tx *S, const int16_t *audio, int16_t *iq, uint32_t b
     float *fi = (float *)malloc(ni * sizeof(float)), *fo = (float *)malloc(no * sizeof(float));
     arm_q15_to_float((q15_t *)audio, fi, (uint32_t)ni);
     ref_tx_process_f32(S, fi, fo, block_size);
-    arm_float_to_q15(fo, (q15_t *)iq, (uint32_t)no);
+    if (S->cfg.q15_rounding) arm_float_to_q15_rounding(fo, (q15_t *)iq, (uint32_t)no);   /* SupportFunctions/arm_float_to_q15.c built with -DARM_MATH_ROUNDING (oracle/Makefile) */
+    else arm_float_to_q15(fo, (q15_t *)iq, (uint32_t)no);
     free(fi); free(fo);
 }
 

@@ -71,7 +71,7 @@ static float *dupf(const float *p, size_t n)
 int orc_tx_create(orc_tx **out, const selenite_tx_config *g)
 {
     *out = NULL;
-    if (!g || g->struct_size != sizeof(*g) || !g->channels || !g->block || !g->interp || !mode_ok(g->mode) || g->arith > 2)
+    if (!g || g->struct_size != sizeof(*g) || g->q15_rounding > 1u || !g->channels || !g->block || !g->interp || !mode_ok(g->mode) || g->arith > 2)
         return SELENITE_RX_ARGUMENT_ERROR;
     if ((g->interp > 1) != (g->ni_taps > 0)) return SELENITE_RX_ARGUMENT_ERROR;
     if (g->ni_taps && !g->interp_coeffs) return SELENITE_RX_ARGUMENT_ERROR;
@@ -199,7 +199,8 @@ void orc_tx_process_q15(orc_tx *S, const int16_t *audio, int16_t *iq, uint32_t b
     float *fi = malloc(ni * sizeof(float)), *fo = malloc(no * sizeof(float));
     orc_q15_to_float(audio, fi, (uint32_t)ni);
     orc_tx_process_f32(S, fi, fo, block_size);
-    orc_float_to_q15(fo, iq, (uint32_t)no);
+    if (S->cfg.q15_rounding) orc_float_to_q15_rounding(fo, iq, (uint32_t)no);    /* the ARM_MATH_ROUNDING build of the same function (rx_oracle.c) */
+    else orc_float_to_q15(fo, iq, (uint32_t)no);
     free(fi); free(fo);
 }
 

@@ -44,15 +44,15 @@ using namespace srx;
 
 __device__ __forceinline__ float load_audio(const float *p, size_t i) { return p[i]; }
 __device__ __forceinline__ float load_audio(const int16_t *p, size_t i) { return q15_to_float(p[i]); }
-__device__ __forceinline__ void store_iq(float *p, size_t i, float re, float im)
+__device__ __forceinline__ void store_iq(float *p, size_t i, float re, float im, uint32_t = 0u)
 {
     reinterpret_cast<float2 *>(p)[i] = make_float2(re, im);
 }
-__device__ __forceinline__ void store_iq(int16_t *p, size_t i, float re, float im)
+__device__ __forceinline__ void store_iq(int16_t *p, size_t i, float re, float im, uint32_t round = 0u)
 {
     short2 v;
-    v.x = float_to_q15(re);
-    v.y = float_to_q15(im);
+    v.x = float_to_q15(re, round);
+    v.y = float_to_q15(im, round);
     reinterpret_cast<short2 *>(p)[i] = v;
 }
 
@@ -184,7 +184,7 @@ __global__ __launch_bounds__(64) void k_tx_generic(TxParams p, const TIn *__rest
                 const float2 r = cmul<0>(make_float2(u.x, u.y), make_float2(lc, ls));
                 re = r.x; im = r.y;
             }
-            store_iq(dst, ob + o, re, im);
+            store_iq(dst, ob + o, re, im, p.q15_round);
         }
         __syncthreads();
         if (p.ni) {
@@ -236,7 +236,7 @@ TxParams make_params(const selenite_tx_instance *S, uint32_t block_size)
     TxParams p{};
     p.channels = g.channels; p.block = g.block; p.L = g.interp; p.ni = g.ni_taps;
     p.P = g.ni_taps ? g.ni_taps / g.interp : 1; p.nh = g.nh_taps; p.mode = g.mode;
-    p.nco = g.nco_enable ? 1 : 0; p.alc = g.alc_enable ? 1 : 0; p.block_size = block_size;
+    p.nco = g.nco_enable ? 1 : 0; p.alc = g.alc_enable ? 1 : 0; p.block_size = block_size; p.q15_round = g.q15_rounding ? 1u : 0u;
     p.ic = S->d_ic; p.hc = S->d_hc; p.dc = S->d_dc; p.sintab = S->d_sintab;
     p.step = S->d_step; p.phase = S->d_phase;
     p.fir_state = S->d_fir_state; p.int_state = S->d_int_state; p.gain = S->d_gain;
@@ -367,7 +367,7 @@ extern "C" int selenite_tx_init(selenite_tx_instance **out, const selenite_tx_co
 {
     if (!out) return SELENITE_RX_ARGUMENT_ERROR;
     *out = nullptr;
-    if (!g || g->struct_size != sizeof(*g) || !g->channels || !g->block || !g->interp || !tx_mode_ok(g->mode) ||
+    if (!g || g->struct_size != sizeof(*g) || g->q15_rounding > 1u || !g->channels || !g->block || !g->interp || !tx_mode_ok(g->mode) ||
         g->arith > SELENITE_ARITH_SPLIT16)
         return SELENITE_RX_ARGUMENT_ERROR;
     if ((g->interp > 1) != (g->ni_taps > 0)) return SELENITE_RX_ARGUMENT_ERROR;

@@ -60,7 +60,7 @@ template <> struct AudioIO<float> {
         return make_float4(v.x, v.y, v.z, v.w);
     }
     static __device__ __forceinline__ void unpack(const raw &r, float (&a)[4]) { a[0] = r.x; a[1] = r.y; a[2] = r.z; a[3] = r.w; }
-    static __device__ __forceinline__ void store4(float *p, size_t cplx, const v2f (&o)[4])
+    static __device__ __forceinline__ void store4(float *p, size_t cplx, const v2f (&o)[4], uint32_t = 0u)
     {
         tx_v4f *d = reinterpret_cast<tx_v4f *>(p + 2 * cplx);                    // non-temporal: written once, never read back
         __builtin_nontemporal_store(tx_v4f{ o[0].x, o[0].y, o[1].x, o[1].y }, d);
@@ -74,12 +74,12 @@ template <> struct AudioIO<int16_t> {
     {
         a[0] = q15_to_float(r.x); a[1] = q15_to_float(r.y); a[2] = q15_to_float(r.z); a[3] = q15_to_float(r.w);
     }
-    static __device__ __forceinline__ void store4(int16_t *p, size_t cplx, const v2f (&o)[4])
+    static __device__ __forceinline__ void store4(int16_t *p, size_t cplx, const v2f (&o)[4], uint32_t round = 0u)
     {
-        short4 a, b;
-        a.x = float_to_q15(o[0].x); a.y = float_to_q15(o[0].y); a.z = float_to_q15(o[1].x); a.w = float_to_q15(o[1].y);
-        b.x = float_to_q15(o[2].x); b.y = float_to_q15(o[2].y); b.z = float_to_q15(o[3].x); b.w = float_to_q15(o[3].y);
-        short4 *d = reinterpret_cast<short4 *>(p + 2 * cplx);
+        uint2 a, b;
+        float4_to_q15(o[0].x, o[0].y, o[1].x, o[1].y, round, a.x, a.y);
+        float4_to_q15(o[2].x, o[2].y, o[3].x, o[3].y, round, b.x, b.y);
+        uint2 *d = reinterpret_cast<uint2 *>(p + 2 * cplx);
         d[0] = a; d[1] = b;
     }
 };
@@ -237,7 +237,7 @@ __global__ __launch_bounds__(64, 2) void k_tx_fused(TxParams p, uint32_t delay_i
 #pragma unroll
                 for (int ph = 0; ph < kL; ++ph) out[ph] = acc[s][ph];
             }
-            OO::store4(dst, out_base + (size_t)pass * kPass * kL + o, out);
+            OO::store4(dst, out_base + (size_t)pass * kPass * kL + o, out, p.q15_round);
         }
         wave_lds_sync();
         {   // interpolator history: last 64 pairs to the front
@@ -517,9 +517,9 @@ __global__ __launch_bounds__(64, 2) void k_tx_split16(TxParams p, uint32_t delay
                 if constexpr (sizeof(TOut) == 4) {
                     __builtin_nontemporal_store(v4f{ y0.x, y0.y, y1.x, y1.y }, reinterpret_cast<v4f *>(reinterpret_cast<float *>(dst) + 2 * at));   // written once, never read back
                 } else {
-                    short4 q;
-                    q.x = float_to_q15(y0.x); q.y = float_to_q15(y0.y); q.z = float_to_q15(y1.x); q.w = float_to_q15(y1.y);
-                    *reinterpret_cast<short4 *>(reinterpret_cast<int16_t *>(dst) + 2 * at) = q;
+                    uint2 q;
+                    float4_to_q15(y0.x, y0.y, y1.x, y1.y, p.q15_round, q.x, q.y);
+                    *reinterpret_cast<uint2 *>(reinterpret_cast<int16_t *>(dst) + 2 * at) = q;
                 }
             }
         }

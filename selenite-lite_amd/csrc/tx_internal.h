@@ -11,6 +11,7 @@ namespace srx {
 
 struct TxParams {
     uint32_t channels, block, L, ni, P, nh, mode, nco, alc, block_size;
+    uint32_t q15_round;    // int16 output: 1 = the ARM_MATH_ROUNDING build of arm_float_to_q15 (selenite_tx_config::q15_rounding)
     uint32_t lo_period;    // shared LO: 256 when it repeats every 256 output samples (NCO step a multiple of 2^24), else 0
     const float *ic, *hc, *dc, *sintab;
     const uint32_t *step;

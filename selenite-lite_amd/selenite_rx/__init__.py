@@ -78,6 +78,7 @@ class TxConfig(C.Structure):
         ("alc_target", C.c_float), ("alc_attack", C.c_float), ("alc_decay", C.c_float),
         ("alc_gain_min", C.c_float), ("alc_gain_max", C.c_float), ("alc_env_floor", C.c_float),
         ("alc_gain_init", C.c_float),
+        ("q15_rounding", C.c_uint32),
     ]
 
 

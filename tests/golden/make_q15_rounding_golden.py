@@ -36,6 +36,21 @@ def case_spec(arg, channels, rounding=True, **kw):
     return rc.ChainSpec(channels, q15_rounding=rounding, **dict(arg, **kw))
 
 
+# TX chain (int16 audio in, int16 I/Q out): name -> (TxSpec kwargs, channels, audio samples per call, calls)
+TX_CASES = {
+    "tx_usb": (dict(), 2, 256, 2),                                                    # the fused shape: L = 4, 256-tap interpolator, 63-tap Hilbert, ALC block 64
+    "tx_lsb_small": (dict(block=32, interp=2, ni_taps=16, nh_taps=15, mode=rc.MODE_LSB, nco_step_all=0x01234567), 3, 96, 2),   # the generic kernels
+}
+
+
+def tx_spec(arg, channels, rounding=True, **kw):
+    return rc.TxSpec(channels, q15_rounding=rounding, **dict(arg, **kw))
+
+
+def tx_input(channels, call, bs):
+    return np.clip(np.trunc(rc.synth_audio(0, channels, call * bs, bs) * 32768.0), -32768, 32767).astype(np.int16)
+
+
 def case_input(channels, call, bs):
     iq = rc.synth_iq(0, channels, call * bs, bs)
     return np.clip(np.trunc(iq * 32768.0), -32768, 32767).astype(np.int16)
@@ -64,6 +79,10 @@ def main():
         assert ch.ok(), name
         out["chain_" + name] = np.stack([ch.process_q15(case_input(channels, call, bs)) for call in range(ncalls)])
         ch.close()
+    for name, (arg, channels, bs, ncalls) in TX_CASES.items():
+        ch = rc.TxCpuChain(tx_spec(arg, channels), "ref")
+        assert ch.ok(), name
+        out["chain_" + name] = np.stack([ch.process_q15(tx_input(channels, call, bs)) for call in range(ncalls)])
     np.savez_compressed(os.path.join(HERE, "q15_rounding.npz"), **out)
     print("written", os.path.join(HERE, "q15_rounding.npz"))
 

@@ -371,8 +371,9 @@ class TxSpec:
     """Python-side description of one TX instance; keeps the numpy arrays alive for ctypes."""
 
     def __init__(self, channels, block=64, interp=4, ni_taps=256, nh_taps=63, mode=MODE_USB, arith=ARITH_CMSIS,
-                 nco=True, nco_step_all=0x01000000, nco_steps=None, alc=True, interp_cutoff=None, alc_params=None):
+                 nco=True, nco_step_all=0x01000000, nco_steps=None, alc=True, interp_cutoff=None, alc_params=None, q15_rounding=False):
         self.channels, self.block, self.interp = channels, block, interp
+        self.q15_rounding = bool(q15_rounding)       # int16 I/Q output: the ARM_MATH_ROUNDING build of arm_float_to_q15
         self.ni_taps, self.nh_taps, self.mode, self.arith = ni_taps, nh_taps, mode, arith
         self.nco, self.nco_step_all, self.alc = nco, nco_step_all, alc
         self.nco_steps = None if nco_steps is None else np.ascontiguousarray(nco_steps, dtype=np.uint32)
@@ -398,6 +399,7 @@ class TxSpec:
         g.alc_target, g.alc_attack, g.alc_decay = p["target"], p["attack"], p["decay"]
         g.alc_gain_min, g.alc_gain_max = p["gain_min"], p["gain_max"]
         g.alc_env_floor, g.alc_gain_init = p["env_floor"], p["gain_init"]
+        g.q15_rounding = int(self.q15_rounding)
         g._keepalive = self
         return g
 

@@ -50,7 +50,7 @@ def test_tx_header_symbols_are_exported_and_bound_and_struct_layout():
     assert sorted(sr.TX_ABI_SYMBOLS) == names
     # C layout on LP64: 6 u32, 4 u8, u32, 4 pointers, 7 floats (+4 tail pad)
     assert C.sizeof(sr.TxConfig) == 6 * 4 + 4 + 4 + 4 * 8 + 7 * 4 + 4
-    assert sr.TxConfig.interp_coeffs.offset == 32 and sr.TxConfig.alc_target.offset == 64
+    assert sr.TxConfig.interp_coeffs.offset == 32 and sr.TxConfig.alc_target.offset == 64 and sr.TxConfig.q15_rounding.offset == 92
     assert C.sizeof(sr.TxStateView) == 32
 
 

@@ -84,3 +84,36 @@ def test_f32_slots_do_not_care():
     spec_r, spec_t = rc.baseline_spec("cfg3", 5, q15_rounding=True), rc.baseline_spec("cfg3", 5)
     iq = rc.synth_iq(0, 5, 0, 2048)
     assert rc.bits_equal(gpu_rx(spec_r).process(iq), gpu_rx(spec_t).process(iq))
+
+
+@pytest.mark.parametrize("name", ["tx_usb", "tx_lsb_small"])
+@pytest.mark.parametrize("arith", [rc.ARITH_CMSIS, rc.ARITH_FMA, rc.ARITH_SPLIT16])
+def test_tx_fixture(name, arith):
+    """selenite_tx_config::q15_rounding on the TX kernels (k_tx_fused / k_tx_split16 / the generic ones): CMSIS arithmetic gives the fixture's words,
+    the other arithmetics move the float I/Q by rounding errors -- at most one LSB"""
+    import selenite_rx as sr
+    m = _gen()
+    arg, channels, bs, ncalls = m.TX_CASES[name]
+    gold = np.load(os.path.join(G, "q15_rounding.npz"))["chain_" + name]
+    tx = sr.Tx(m.tx_spec(arg, channels, arith=arith).config())
+    tr = sr.Tx(m.tx_spec(arg, channels, rounding=False, arith=arith).config())
+    moved = 0
+    for call in range(ncalls):
+        a = m.tx_input(channels, call, bs)
+        y = tx.process_q15(a)
+        if arith == rc.ARITH_CMSIS:
+            assert np.array_equal(y, gold[call]), (name, call, tx.kernel_name())
+        else:
+            assert np.abs(y.astype(np.int32) - gold[call]).max() <= 1, (name, call, tx.kernel_name())
+        moved += np.count_nonzero(y != tr.process_q15(a))
+    assert moved > y.size // 4
+
+
+def test_tx_init_refuses_other_values():
+    import ctypes as C
+    import selenite_rx as sr
+    g = _gen().tx_spec({}, 2).config()
+    g.q15_rounding = 7
+    h = C.c_void_p()
+    sr.lib().selenite_tx_init.argtypes = [C.POINTER(C.c_void_p), C.POINTER(sr.TxConfig)]
+    assert sr.lib().selenite_tx_init(C.byref(h), C.byref(g)) == rc.ARGUMENT_ERROR

@@ -82,3 +82,28 @@ def test_oracle_against_the_rounding_build_of_the_reference():
         q = _gen().case_input(3, call, 640)
         assert np.array_equal(o.process_q15(q), r.process_q15(q))
     o.close(); r.close()
+
+
+@pytest.mark.parametrize("name", ["tx_usb", "tx_lsb_small"])
+def test_tx_chain_vectors(gold, name):
+    """selenite_tx_config::q15_rounding: the TX oracle against what the reference's arm_float_to_q15 built with ARM_MATH_ROUNDING left behind the
+    real-CMSIS TX composition (oracle/ref_tx.c)"""
+    m = _gen()
+    arg, channels, bs, ncalls = m.TX_CASES[name]
+    o = rc.TxCpuChain(m.tx_spec(arg, channels), "orc")
+    t = rc.TxCpuChain(m.tx_spec(arg, channels, rounding=False), "orc")
+    assert o.ok() and t.ok()
+    differs = 0
+    for call in range(ncalls):
+        a = m.tx_input(channels, call, bs)
+        y = o.process_q15(a)
+        assert np.array_equal(y, gold["chain_" + name][call]), (name, call)
+        differs += np.count_nonzero(y != t.process_q15(a))
+    assert differs > 0
+    bad = m.tx_spec(arg, channels)
+    bad_cfg = bad.config()
+    bad_cfg.q15_rounding = 2                                  # sits in former tail padding: garbage there is refused, not taken for a mode
+    h = C.c_void_p()
+    L = rc.oracle_lib()
+    L.orc_tx_create.argtypes = [C.POINTER(C.c_void_p), C.POINTER(rc.TxConfig)]
+    assert L.orc_tx_create(C.byref(h), C.byref(bad_cfg)) != 0
