@@ -660,7 +660,7 @@ def main():
         if world == 1 and not args.global_gain and not args.main_only and args.workload == "cfg3" and not q15 and not args.block_size and args.arith == "auto" and args.nco == "default":
             # the other single-GPU BASELINE configurations, in the same driver-run line.  The headline's batch STAYS resident (2.7 GB
             # of 288): where hipMalloc puts a workload's buffers decides which of two modes the memory system runs cfg2 in -- kernel and plain copy
-            # alike, profiles/r5/placement_probe.txt -- and behind a resident allocation it has been the faster one every time; each entry carries the
+            # alike, profiles/r5/placement_probe.txt -- and behind a resident allocation it has been the faster one on two boxes of three (6 of 6 runs; the third: 0 of 2); each entry carries the
             # copy's time (streaming_roof_ms) so that the kernel's share of the figure can be told from the placement's
             wls = {}
             for nm, wq in (("cfg2", False), ("cfg4", False), ("cfg5", False), ("cfg3", True)):
