@@ -136,10 +136,17 @@ __global__ __launch_bounds__(64) void k_cw_fused(RxParams p, const TIn *__restri
     const float *rbase = tile + ch * RS;
 
     typedef typename CwRaw<TIn>::type raw_t;
-    // input prefetch: one chunk ahead (NL wave loads in flight while the chunk before them is worked through: ~2.4 us of systolic steps at
-    // NL = 16.  Two chunks of 8 loads ahead, in alternating register slots, measured the same: profiles/r5/README.md)
-    raw_t raw[NL];
-    u4v_cw lo4 = { 0u, 0u, 0u, 0u };
+    // input prefetch: TWO chunks ahead where a DSP block is an even number of chunks (chunk q of every block lives in register slot q & 1:
+    // 2 x NL wave loads in flight), else one.  The systolic steps of a chunk are ~1500 dependent vector instructions, about as long as the
+    // loaded memory system takes to deliver a burst (profiles/r6/cfg4_pattern_roof.txt: a no-arithmetic kernel with this fetch pattern and
+    // that many instructions between its bursts runs 9 % faster with two bursts in flight than with one; the pattern itself -- sixteen
+    // 1 KB pieces 32 KB apart -- costs nothing against 4 KB runs).  (Round 5's "two chunks of 8 loads ahead" kept the same 16 KB in flight.)
+    // (per-channel arm_sin/cos with f32 slots: its registers do not leave room for a second slot at two waves per SIMD)
+    constexpr int DEPTH = (NCHUNK % 2 == 0 && !(NCO == 1 && sizeof(TIn) == 4)) ? 2 : 1;
+    raw_t raw[DEPTH][NL];
+    u4v_cw lo4[DEPTH];
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) lo4[d] = u4v_cw{ 0u, 0u, 0u, 0u };
     // the workgroup's CH channels (fewer in the last workgroup: the range ends with the array), 32-bit offsets inside them
     constexpr int EB = CwRaw<TIn>::kBytes / 2;                        // bytes per complex sample
     const uint32_t chs = min((uint32_t)CH, p.channels - c0);
@@ -150,10 +157,11 @@ __global__ __launch_bounds__(64) void k_cw_fused(RxParams p, const TIn *__restri
                                                                             (int)(((chs - 1) * p.out_stride + p.block_size) * (uint32_t)sizeof(TOut)), 0x00020000);
     const int voff_in = (int)((lch * p.in_stride + lsm) * EB);        // this lane's part of every load address
     const int joff_in = (int)(CG::CPL * p.in_stride * EB);            // ... load j of a chunk adds j of these (wave-uniform)
-    auto issue_loads = [&](uint32_t n_first) {          // chunk of CS samples x CH channels starting at n_first
+    auto issue_loads = [&](auto slot, uint32_t n_first) {          // chunk of CS samples x CH channels starting at n_first, into register slot `slot`
+        constexpr int SL = decltype(slot)::value;
 #pragma unroll
-        for (int j = 0; j < NL; ++j) raw[j] = CwRaw<TIn>::load(rs_in, voff_in, (int)(n_first * EB) + j * joff_in);
-        if constexpr (NCO == 2) lo4 = __builtin_amdgcn_raw_buffer_load_b128(rs_lo, lsm * 8, (int)(n_first * 8u), 0);
+        for (int j = 0; j < NL; ++j) raw[SL][j] = CwRaw<TIn>::load(rs_in, voff_in, (int)(n_first * EB) + j * joff_in);
+        if constexpr (NCO == 2) lo4[SL] = __builtin_amdgcn_raw_buffer_load_b128(rs_lo, lsm * 8, (int)(n_first * 8u), 0);
     };
     float *mrow = tile + lch * RS + lsm;                 // this lane's slot of load 0 in chunk 0
     // The chunk's samples are mixed into REGISTERS (mix_regs: this is where the wave waits for its loads) and written to the tile later
@@ -161,18 +169,22 @@ __global__ __launch_bounds__(64) void k_cw_fused(RxParams p, const TIn *__restri
     // order with respect to each other on this target, so a wait for loaded data is a wait for every vector-memory operation in flight
     // (s_waitcnt vmcnt(0)) -- behind the burst that was a wait for 16 KB of write acknowledgements per block.
     float xm[NL][2];
-    auto mix_regs = [&](uint32_t n_first) {             // NCO mix (real part) of the loaded chunk
+    auto mix_regs = [&](auto slot, uint32_t n_first) {  // NCO mix (real part) of the chunk loaded into `slot`
+        constexpr int SL = decltype(slot)::value;
 #pragma unroll
         for (int j = 0; j < NL; ++j) {
             cw_v2 a, b;
-            CwRaw<TIn>::unpack(raw[j], a, b);
+            CwRaw<TIn>::unpack(raw[SL][j], a, b);
             float xa, xb;
             if constexpr (NCO == 0) {
-                xa = a.x; xb = b.x;
+                // (a move, so that the load registers are free for the next request: left as an alias the loads of the slot's next chunk
+                // get registers of their own -- three chunks of them)
+                asm("v_mov_b32 %0, %1" : "=v"(xa) : "v"(a.x));
+                asm("v_mov_b32 %0, %1" : "=v"(xb) : "v"(b.x));
             } else {
                 cw_v2 la, lb;
                 if constexpr (NCO == 2) {
-                    la = cw_v2{ __uint_as_float(lo4.x), __uint_as_float(lo4.y) }; lb = cw_v2{ __uint_as_float(lo4.z), __uint_as_float(lo4.w) };
+                    la = cw_v2{ __uint_as_float(lo4[SL].x), __uint_as_float(lo4[SL].y) }; lb = cw_v2{ __uint_as_float(lo4[SL].z), __uint_as_float(lo4[SL].w) };
                 } else {
                     const uint32_t cj = min(c0 + CG::CPL * j + lch, p.channels - 1);
                     const uint32_t phj = p.phase[cj], stj = p.step[cj];
@@ -234,13 +246,16 @@ __global__ __launch_bounds__(64) void k_cw_fused(RxParams p, const TIn *__restri
     };
 
     const uint32_t nblk = p.block_size / BLK;
-    auto mix_and_prefetch = [&](uint32_t n_first) {     // the loaded chunk (at n_first) out of its registers, the chunk behind it requested
-        mix_regs(n_first);
-        const uint32_t nxt = n_first + CS;                 // (may be in the next block)
-        if (nxt < p.block_size) issue_loads(nxt);
+    typedef std::integral_constant<int, 0> slot0_t;
+    typedef std::integral_constant<int, DEPTH - 1> slot1_t;
+    auto mix_and_prefetch = [&](auto slot, uint32_t n_first) {     // the loaded chunk (at n_first) out of its registers, the chunk DEPTH behind it requested into them
+        mix_regs(slot, n_first);
+        const uint32_t nxt = n_first + DEPTH * CS;         // (may be in the next block)
+        if (nxt < p.block_size) issue_loads(slot, nxt);
     };
-    issue_loads(0);
-    mix_and_prefetch(0);
+    issue_loads(slot0_t{}, 0);
+    if constexpr (DEPTH == 2) issue_loads(slot1_t{}, CS);   // (a call is whole DSP blocks: at least two chunks)
+    mix_and_prefetch(slot0_t{}, 0);
     cw_lds_sync();
     for (uint32_t blk = 0; blk < nblk; ++blk) {
         const uint32_t n0 = blk * BLK;
@@ -248,10 +263,10 @@ __global__ __launch_bounds__(64) void k_cw_fused(RxParams p, const TIn *__restri
         float car[NCAR];                                              // outputs waiting for the rest of their float4
 #pragma unroll
         for (int v = 0; v < NCAR; ++v) car[v] = 0.0f;
-        auto chunk = [&](int q) {
+        auto chunk = [&](int q, auto slot) {
             // ---- 1. this chunk's input into the tile; the HBM loads of the chunk that takes its register slot next go out meanwhile
             // (the first chunk of a block was mixed in front of the store burst of the block before it: below) ----
-            if (q != 0) mix_and_prefetch(n0 + CS * q);
+            if (q != 0) mix_and_prefetch(slot, n0 + CS * q);
             tile_write(q);
             cw_lds_sync();
             // ---- 2. TPC trips of 4 systolic steps; stage-0 input is one aligned float4 per trip ----
@@ -305,8 +320,13 @@ __global__ __launch_bounds__(64) void k_cw_fused(RxParams p, const TIn *__restri
             }
             if (i < iend) do_trip(i, xq);                             // (the first chunk of a block: an odd number of trips behind the prologue)
         };
+        if constexpr (DEPTH == 2) {
 #pragma unroll 1
-        for (int q = 0; q < NCHUNK; ++q) chunk(q);
+            for (int q = 0; q < NCHUNK; q += 2) { chunk(q, slot0_t{}); chunk(q + 1, slot1_t{}); }
+        } else {
+#pragma unroll 1
+            for (int q = 0; q < NCHUNK; ++q) chunk(q, slot0_t{});
+        }
         // ---- drain: stages 1..NS-1 finish samples BLK-D .. BLK-1 ----
         {
             float seq[4 * PRO];
@@ -326,7 +346,7 @@ __global__ __launch_bounds__(64) void k_cw_fused(RxParams p, const TIn *__restri
         cw_lds_sync();
         // ---- 3. AGC gain law (last-stage lanes hold max|y| of their channel) and scaled store ----
         if (p.agc) gain = agc_update<0>(p.agcp, gain, m);
-        if (blk + 1 < nblk) mix_and_prefetch(n0 + BLK);
+        if (blk + 1 < nblk) mix_and_prefetch(slot0_t{}, n0 + BLK);   // (chunk 0 of every block: slot 0)
 #pragma unroll 4
         for (int r = 0; r < CH; ++r) {
             const float g = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(gain), NS * r + NS - 1));     // (r is wave-uniform: a scalar lane select)
