@@ -4,10 +4,12 @@
 // The DF1 recurrence (arm_biquad_cascade_df1_f32.c:220) has no time parallelism without changing
 // the rounding, so parallelism is channels x stages.  A wavefront is a SYSTOLIC array:
 //
-//      lane = NS*channel + stage       (NS = 2, 4 or 8 stages: 32, 16 or 8 channels per wavefront)
+//      lane = 16*row + CPR*stage + channel-in-row      (NS = 2, 4 or 8 stages; CPR = 16 / NS channels per 16-lane DPP row:
+//                                                       32, 16 or 8 channels per wavefront, stage-major inside a row)
 //
 // at step k stage s works on sample k-s; a stage's output reaches the next stage's lane with one
-// DPP row_shr:1 (lanes of a channel are adjacent and never straddle a 16-lane row: NS divides 16).  Value for
+// DPP row_shr:CPR.  Stage-major rows put the stage-0 lanes of a row into whole DPP banks (2 and 4 stages), so the
+// choice "stage 0 takes the input sample, the others their neighbour's output" is the bank mask of that one DPP move.  Value for
 // value this is the reference's stage-outer loop: each stage consumes exactly the previous stage's
 // output sequence, left-to-right sums, feedback added, no fusion (both arithmetic modes -- the
 // recurrence keeps the reference rounding).
@@ -41,14 +43,37 @@ __device__ __forceinline__ void cw_lds_sync()
 }
 
 typedef float cw_v2 __attribute__((ext_vector_type(2)));
+
+// four consecutive stage-0 inputs of a channel row, as FOUR dword reads (volatile: not merged into one 16-byte read): each lands in a
+// register of its own, and the step's DPP move turns it in place into the x half of an (x, y) delay-line pair -- out of an aligned quad
+// it had to be copied there, one vector move per step
+struct cw_x4 { float x, y, z, w; };
+__device__ __forceinline__ cw_x4 cw_ld4(const float *p)
+{
+    typedef __attribute__((address_space(3))) float lds_f32;
+    const volatile lds_f32 *q = (const volatile lds_f32 *)p;
+    cw_x4 r;
+    r.x = q[0]; r.y = q[1]; r.z = q[2]; r.w = q[3];
+    return r;
+}
 typedef unsigned int u4v_cw __attribute__((ext_vector_type(4)));
 typedef unsigned int u2v_cw __attribute__((ext_vector_type(2)));
 
-__device__ __forceinline__ float dpp_row_shr1(float v)
+// the input of a lane's stage at one step: the sample `xs` in the stage-0 lanes, elsewhere the output `y` of the lane CPR below (the
+// stage before it, same channel) -- lanes of a row are stage-major, so the stage-0 lanes are banks 0 .. CPR/4-1 of the row
+template <int NS>
+__device__ __forceinline__ float cw_stage_input(float xs, float y, bool first)
 {
-    // lane l receives lane l-1 (within its row of 16); lanes 0,16,32,48 read 0 (bound_ctrl: they are stage 0
-    // lanes and never use the shifted value) -- no `old` operand, so no register copy in front of the DPP move
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x111, 0xf, 0xf, true));
+    constexpr int CPR = 16 / NS;
+    if constexpr (CPR >= 4) {
+        // ONE DPP move: row_shr:CPR into the banks of stages 1 .. NS-1; the masked-out banks keep `old` = xs (xs dies here: no copy)
+        constexpr int bank_mask = 0xf & ~((1 << (CPR / 4)) - 1);
+        return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(xs), __float_as_int(y), 0x110 + CPR, 0xf, bank_mask, false));
+    } else {
+        // 8 stages: the stage-0 lanes are half a bank -- shift (they read 0: bound_ctrl), then select
+        const float prev = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(y), 0x110 + CPR, 0xf, 0xf, true));
+        return first ? xs : prev;
+    }
 }
 
 // two complex samples per lane and load, through a buffer descriptor over the workgroup's channels: the lane's part of the address is
@@ -109,8 +134,10 @@ __global__ __launch_bounds__(64) void k_cw_fused(RxParams p, const TIn *__restri
     static_assert(BLK % CS == 0 && PRO <= TPC && 4 * PRO <= BLK, "block holds whole chunks; prologue inside the first chunk");
     __shared__ __attribute__((aligned(16))) float tile[CH * RS];
     __shared__ float tab[NCO == 1 ? 516 : 4];
+    constexpr int CPR = 16 / NS;                        // channels per 16-lane row
+    __shared__ float sink[2 * kWave + 6];               // where the lanes that are not a last stage put their four values of a trip (below)
     const int lane = threadIdx.x;
-    const int s = lane & (NS - 1), ch = lane / NS;
+    const int s = (lane & 15) / CPR, ch = (lane >> 4) * CPR + (lane & (CPR - 1));
     const uint32_t c0 = blockIdx.x * CH;
     // the last workgroup of a channel count that is not a multiple of CH: lanes past the end work on a
     // copy of the last channel (every load index is clamped) and none of their stores is issued
@@ -128,12 +155,14 @@ __global__ __launch_bounds__(64) void k_cw_fused(RxParams p, const TIn *__restri
     // load-phase geometry: load j of a chunk covers channel CPL*j + lane/LPC, samples 2*(lane%LPC), +1
     const int lch = lane / CG::LPC, lsm = 2 * (lane % CG::LPC);
     const uint32_t ph_own = NCO ? p.phase[c] : 0u, st_own = NCO ? p.step[c] : 0u;
-    // last-stage lanes write y[4i..4i+3] over x[4i..4i+3] of their channel's row (the other lanes are masked out: four dwords from wherever
-    // the step left them -- a 16-byte store would want them copied into one aligned register quad first, and vector instructions are what
-    // this kernel is short of)
+    // last-stage lanes write y[4i..4i+3] over x[4i..4i+3] of their channel's row (four dwords from wherever the step left them -- a 16-byte
+    // store would want them copied into one aligned register quad first, and instructions are what this kernel is short of)
     const bool last = s == NS - 1;
     float *wrow = tile + ch * RS;
     const float *rbase = tile + ch * RS;
+    typedef __attribute__((address_space(3))) float lds_f32;
+    const uint32_t wbase = last ? (uint32_t)(uintptr_t)(lds_f32 *)wrow : (uint32_t)(uintptr_t)(lds_f32 *)(sink + 2 * lane);   // LDS byte addresses of a trip's output group
+    const uint32_t winc = last ? 16u : 0u;                                                                                  // ... and what a trip advances them by
 
     typedef typename CwRaw<TIn>::type raw_t;
     // input prefetch: TWO chunks ahead where a DSP block is an even number of chunks (chunk q of every block lives in register slot q & 1:
@@ -209,15 +238,14 @@ __global__ __launch_bounds__(64) void k_cw_fused(RxParams p, const TIn *__restri
     // One DF1 step of this lane's stage; xs = stage-0 input of the step.  The delay lines live in TWO register pairs, A = (x1, y1) and
     // B = (x2, y2): the four products of a step are two packed multiplies, A * (b1, a1) and B * (b2, a2), and the shift of both delay
     // lines is a change of NAMES -- B's registers are dead once its products are formed, so the step writes the new (x1, y1) = (xin, y)
-    // into them and the next step calls the pairs the other way round.  No register copy, no operand swizzle: 9 vector instructions per
-    // step (DPP move, select, 1 + 2 multiplies, 4 adds).  Same products, same left-to-right sum as the reference
+    // into them and the next step calls the pairs the other way round.  No register copy, no operand swizzle: 8 vector instructions per
+    // step (DPP move that is also the input select, 1 + 2 multiplies, 4 adds; 9 with 8 stages).  Same products, same left-to-right sum as the reference
     // (arm_biquad_cascade_df1_f32.c:220: b0 x + b1 x1 + b2 x2 + a1 y1 + a2 y2).
     typedef float cw_v2f __attribute__((ext_vector_type(2)));
     const cw_v2f c1 = { b1, a1 }, c2 = { b2, a2 };
     cw_v2f PA = { st.x, st.z }, PB = { st.y, st.w };                  // (x1, y1), (x2, y2)
     auto step = [&](float xs, cw_v2f &A, cw_v2f &B) -> float {        // on return B holds the new (x1, y1), A the new (x2, y2)
-        const float prev = dpp_row_shr1(A.y);
-        const float xin = (s == 0) ? xs : prev;
+        const float xin = cw_stage_input<NS>(xs, A.y, s == 0);
         const cw_v2f t1 = A * c1, t2 = B * c2;
         const float p0 = b0 * xin;
         float y = p0 + t1.x;
@@ -228,7 +256,7 @@ __global__ __launch_bounds__(64) void k_cw_fused(RxParams p, const TIn *__restri
         return y;
     };
     // four steps of the steady state: an even number, so PA is (x1, y1) again behind them
-    auto trip4 = [&](const float4 &xq, float (&o)[4]) {
+    auto trip4 = [&](const cw_x4 &xq, float (&o)[4]) {
         o[0] = step(xq.x, PA, PB);
         o[1] = step(xq.y, PB, PA);
         o[2] = step(xq.z, PA, PB);
@@ -271,11 +299,11 @@ __global__ __launch_bounds__(64) void k_cw_fused(RxParams p, const TIn *__restri
             cw_lds_sync();
             // ---- 2. TPC trips of 4 systolic steps; stage-0 input is one aligned float4 per trip ----
             int i = TPC * q;
-            float4 xq = lds_ld4f(rbase + 4 * i);
+            cw_x4 xq = cw_ld4(rbase + 4 * i);
             if (q == 0) {                                             // block prologue: the D fill steps, first outputs into `car`
 #pragma unroll
                 for (int tpro = 0; tpro < PRO; ++tpro) {
-                    const float4 xn = lds_ld4f(rbase + 4 * (tpro + 1));
+                    const cw_x4 xn = cw_ld4(rbase + 4 * (tpro + 1));
                     const float o[4] = { step_masked(xq.x, 4 * tpro), step_masked(xq.y, 4 * tpro + 1),
                                          step_masked(xq.z, 4 * tpro + 2), step_masked(xq.w, 4 * tpro + 3) };
                     if (tpro == PRO - 1) {
@@ -291,17 +319,19 @@ __global__ __launch_bounds__(64) void k_cw_fused(RxParams p, const TIn *__restri
             }
             // one trip: four steps, the aligned group y[4(i-PRO) .. +3] -- NCAR outputs carried from the trip before, then the first R of
             // this one -- into the tile (last-stage lanes; four dword stores from the registers the steps left them in)
-            auto do_trip = [&](int it, const float4 &xin4) {
+            auto do_trip = [&](uint32_t wa, auto sub, const cw_x4 &xin4) {       // wa: LDS address of the output group of the round's first trip; sub: which trip of the round
                 float o[4];
                 trip4(xin4, o);
                 float gq[4];
 #pragma unroll
                 for (int v = 0; v < 4; ++v) gq[v] = v < NCAR ? car[v] : o[v - NCAR];
-                if (last) {
-                    // (volatile, in the LDS address space: four ds_write_b32 -- merged into one 16-byte store they cost three register copies)
-                    typedef __attribute__((address_space(3))) float lds_f32;
-                    volatile lds_f32 *w = (volatile lds_f32 *)(wrow + 4 * (it - PRO));
-                    w[0] = gq[0]; w[1] = gq[1]; w[2] = gq[2]; w[3] = gq[3];
+                // EVERY lane writes its four values, as two ds_write2_b32 from the registers the steps left them in (no copies into an aligned
+                // quad, no exec mask, no branch around the writes): the last-stage lanes into their channel's row, the others into `sink`
+                // (8 bytes apart: the 128 dwords of one instruction are spread over all the banks twice)
+                {
+                    constexpr int O = 4 * decltype(sub)::value;
+                    asm volatile("ds_write2_b32 %0, %1, %2 offset0:%5 offset1:%6\n\tds_write2_b32 %0, %3, %4 offset0:%7 offset1:%8"
+                                 : : "v"(wa), "v"(gq[0]), "v"(gq[1]), "v"(gq[2]), "v"(gq[3]), "n"(O), "n"(O + 1), "n"(O + 2), "n"(O + 3) : "memory");
                 }
                 m = fmaxf(fmaxf(m, fabsf(o[0])), fmaxf(fabsf(o[1]), fmaxf(fabsf(o[2]), fabsf(o[3]))));
 #pragma unroll
@@ -313,12 +343,13 @@ __global__ __launch_bounds__(64) void k_cw_fused(RxParams p, const TIn *__restri
             const int iend = TPC * q + TPC;
 #pragma unroll 1
             for (; i + 1 < iend; i += 2) {
-                const float4 xb = lds_ld4f(rbase + 4 * (i + 1));
-                do_trip(i, xq);
-                xq = lds_ld4f(rbase + 4 * (i + 2));
-                do_trip(i + 1, xb);
+                const uint32_t wa = wbase + winc * (uint32_t)(i - PRO);
+                const cw_x4 xb = cw_ld4(rbase + 4 * (i + 1));
+                do_trip(wa, std::integral_constant<int, 0>{}, xq);
+                xq = cw_ld4(rbase + 4 * (i + 2));
+                do_trip(wa, std::integral_constant<int, 1>{}, xb);
             }
-            if (i < iend) do_trip(i, xq);                             // (the first chunk of a block: an odd number of trips behind the prologue)
+            if (i < iend) do_trip(wbase + winc * (uint32_t)(i - PRO), std::integral_constant<int, 0>{}, xq);                             // (the first chunk of a block: an odd number of trips behind the prologue)
         };
         if constexpr (DEPTH == 2) {
 #pragma unroll 1
@@ -349,7 +380,7 @@ __global__ __launch_bounds__(64) void k_cw_fused(RxParams p, const TIn *__restri
         if (blk + 1 < nblk) mix_and_prefetch(slot0_t{}, n0 + BLK);   // (chunk 0 of every block: slot 0)
 #pragma unroll 4
         for (int r = 0; r < CH; ++r) {
-            const float g = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(gain), NS * r + NS - 1));     // (r is wave-uniform: a scalar lane select)
+            const float g = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(gain), 16 * (r / CPR) + CPR * (NS - 1) + (r % CPR)));     // (r is wave-uniform: a scalar lane select)
 #pragma unroll
             for (int h = 0; h < (BLK / 4 + 63) / 64; ++h) {
                 const int t = 4 * (lane + 64 * h);

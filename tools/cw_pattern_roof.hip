@@ -27,7 +27,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc(const void *p, unsigned b
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, bytes, 0x00020000);
 }
 
-template <int PL, int DEPTH>
+template <int PL, int DEPTH, int SPREAD = 0>
 __global__ __launch_bounds__(64) void k_pat(const char *__restrict__ in, char *__restrict__ out, float *__restrict__ state,
                                             unsigned groups, unsigned in_row, unsigned out_row, unsigned work)
 {
@@ -67,6 +67,23 @@ __global__ __launch_bounds__(64) void k_pat(const char *__restrict__ in, char *_
             acc.y = __float_as_uint(w0);
             __builtin_amdgcn_sched_barrier(0);
         };
+        // SPREAD: the burst's sixteen loads not back to back but one per sixteenth of the arithmetic (does a wave that dumps 16 KB of requests
+        // at once stand in its own way?)
+        auto issue_spread = [&](auto &R, unsigned t) {
+            const unsigned past = t >= T ? 0x70000000u : 0u;
+            const unsigned sc = t / PL, gq = t % PL;
+            float w0 = __uint_as_float(acc.y);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const unsigned row = gq * RB + j / PL, piece = j % PL;
+                R[j] = __builtin_amdgcn_raw_buffer_load_b128(ri, lane * 16, (int)(row * in_row + (sc * PL + piece) * 1024u + past), 2);
+                for (unsigned i = 0; i < work / 128u; ++i)
+                    asm volatile("v_fma_f32 %0, %0, %0, %0\n v_fma_f32 %0, %0, %0, %0\n v_fma_f32 %0, %0, %0, %0\n v_fma_f32 %0, %0, %0, %0\n"
+                                 "v_fma_f32 %0, %0, %0, %0\n v_fma_f32 %0, %0, %0, %0\n v_fma_f32 %0, %0, %0, %0\n v_fma_f32 %0, %0, %0, %0" : "+v"(w0));
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            acc.y = __float_as_uint(w0);
+        };
         auto stores = [&](unsigned blk) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) __builtin_amdgcn_raw_buffer_store_b128(acc, ro, lane * 16, (int)(r * out_row + blk * 1024u), 2);
@@ -74,7 +91,12 @@ __global__ __launch_bounds__(64) void k_pat(const char *__restrict__ in, char *_
         issue(A, 0);
         if constexpr (DEPTH == 2) issue(B, 1);
         for (unsigned t = 0; t < T; t += 2) {
-            if constexpr (DEPTH == 1) {
+            if constexpr (SPREAD) {
+                static_assert(DEPTH == 1, "spread: depth 1");
+                consume(A); issue_spread(A, t + 1);
+                consume(A); stores(t / 2); issue_spread(A, t + 2);
+                continue;
+            } else if constexpr (DEPTH == 1) {
                 consume(A); issue(A, t + 1); busy();
                 consume(A); issue(A, t + 2);
             } else {
@@ -111,8 +133,9 @@ int main(int argc, char **argv)
         { " 8 rows x 2 KB             depth 1", k_pat<2, 1> }, { " 8 rows x 2 KB             depth 2", k_pat<2, 2> },
         { " 4 rows x 4 KB             depth 1", k_pat<4, 1> }, { " 4 rows x 4 KB             depth 2", k_pat<4, 2> },
         { " 2 rows x 8 KB             depth 1", k_pat<8, 1> }, { " 1 row  x 16 KB            depth 1", k_pat<16, 1> },
+        { "16 rows x 1 KB spread      depth 1", k_pat<1, 1, 1> },
     };
-    const size_t ldss[] = { 16640, 20000, 32768 };              // 9, 8, 5 (4 with the allocation granule) workgroups per CU
+    const size_t ldss[] = { 16640, 20000, 32768, 13000, 10000, 6000 };   // 9, 8, 5 (4 with the allocation granule), 12, 16, 26 workgroups per CU
     const int NIT = 40;
     std::vector<hipEvent_t> ev(NIT + 1);
     for (auto &e : ev) (void)hipEventCreate(&e);
@@ -122,10 +145,11 @@ int main(int argc, char **argv)
     for (int rep = 0; rep < 2; ++rep)
         for (int persistent = 0; persistent < 2; ++persistent)
             for (size_t lds : ldss) {
-                if ((rep == 1 || sweep_work) && lds == 32768) continue;
+                if ((rep == 1 || sweep_work) && lds != 16640 && lds != 20000) continue;
                 for (const Variant &v : vs) for (unsigned work : works) {
                     if (!sweep_work && work != 0) continue;
-                    if (sweep_work && (&v != &vs[0] && &v != &vs[1])) continue;
+                    if (sweep_work && (&v != &vs[0] && &v != &vs[1] && &v != &vs[8])) continue;
+                    if (!sweep_work && &v == &vs[8]) continue;
                     int per_cu = 0;
                     (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, v.k, 64, lds);
                     const unsigned grid = persistent ? std::min(groups, (unsigned)(per_cu * cus)) : groups;

@@ -6,13 +6,16 @@
 # rx_split16.hip is compiled from the copy (bench kernel only, -DSRX_SPLIT16_BENCH_ONLY) with the flags of the Makefile and linked
 # with the objects of the regular build into selenite-lite_amd/variants/lib_<name>.so.  Run with SELENITE_RX_LIB=<that file>.
 # `main` (no patch) is the unpatched copy built the same way: the A side of every comparison.
+# UNIT=<translation unit without .hip> (default rx_split16) picks the unit the patch touches, e.g. UNIT=rx_cw for k_cw_fused.
 set -eu
+UNIT=${UNIT:-rx_split16}
+UDEF=""; [ "$UNIT" = rx_split16 ] && UDEF="-DSRX_SPLIT16_BENCH_ONLY"
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 cd "$R/selenite-lite_amd"
 make -s -j8 libselenite_rx.so
 FLAGS=$(make -s print-flags)
 mkdir -p variants
-OTHERS=$(ls build/*.o | grep -v 'rx_split16.hip.o')
+OTHERS=$(ls build/*.o | grep -v "$UNIT.hip.o")
 for spec in "$@"; do
   IFS=: read -r name patch extra <<<"$spec::"
   [ -n "$patch" ] || patch="$R/tools/variants/$name.patch"
@@ -21,7 +24,7 @@ for spec in "$@"; do
     if [ "$name" != main ]; then patch -s -p3 -d "$d" < "$patch"; fi
     # (the sources include ../../include/selenite_rx.h relative to csrc: the copy sits one level deeper)
     sed -i 's#"../../include/#"../../../include/#' "$d"/*.h "$d"/*.hip "$d"/*.cpp
-    /opt/rocm/bin/hipcc $FLAGS -DSRX_SPLIT16_BENCH_ONLY $extra -c "$d/rx_split16.hip" -o variants/$name.o 2>variants/$name.log &&
+    /opt/rocm/bin/hipcc $FLAGS $UDEF $extra -c "$d/$UNIT.hip" -o variants/$name.o 2>variants/$name.log &&
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o variants/lib_$name.so variants/$name.o $OTHERS 2>>variants/$name.log && echo "built $name" || { echo "FAILED $name (variants/$name.log)"; exit 1; }
   ) &
 done
