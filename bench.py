@@ -205,6 +205,16 @@ def side_workload(name, q15, arith, spinup_ms, iters=100, rank=0, parity=True, c
     # this shape at this moment -- the memory-bound shapes move with it from box to box and with what ran before them (d_out is overwritten)
     rx.time_streaming_roof(d_in.ptr, d_out.ptr, bs, 16, q15)
     roof = float(np.median(rx.time_streaming_roof(d_in.ptr, d_out.ptr, bs, 60, q15)))
+    pattern = None
+    if kernel.startswith("k_cw_fused"):
+        # the systolic CW kernel has a fetch pattern of its own (one wavefront = 16 channel rows at once, 1 KB of a row per load): the same
+        # bursts, stores, launch shape and residency with no DSP (k_cw_roof, selenite_rx_time_pattern_roof_device)
+        rx.time_pattern_roof(d_in.ptr, d_out.ptr, bs, 16, q15, 0)
+        p0 = float(np.median(rx.time_pattern_roof(d_in.ptr, d_out.ptr, bs, 60, q15, 0)))
+        pattern = {"kernel": "k_cw_roof", "pattern_roof_ms": round(p0, 4), "frac_of_pattern_roof": round(p0 / med, 4),
+                   "note": "k_cw_fused's own bursts (16 rows x 1 KB per burst, two bursts in flight), stores, one workgroup per 16 channels, same "
+                           "residency, no DSP.  The pattern costs nothing against 4 KB runs; what separates the kernel from it is the ~1400 vector "
+                           "instructions between two bursts of a wave: profiles/r6/cfg4_pattern_roof.md"}
     rx.sync()
     rx.close(); d_in.free(); d_out.free()
     wl = dict(ch.WORKLOADS, **{k + "_q15": v for k, v in ch.WORKLOADS.items()})
@@ -223,6 +233,8 @@ def side_workload(name, q15, arith, spinup_ms, iters=100, rank=0, parity=True, c
                         "streaming_roof_ms": round(roof, 4), "frac_of_streaming_roof": round(roof / med, 4)}}
     if note:
         out["note"] = note
+    if pattern:
+        out["roofline"]["pattern_roof"] = pattern
     if name == "cfg5":
         out["mall_note"] = ("per-channel state of this shape: %.0f MB read + as much written per call -- inside the 256 MiB Infinity Cache, whose hits the "
                             "memory-side counters count (MI355X_MICROARCH.md): part of the algorithmic bytes of this figure is served on-die"

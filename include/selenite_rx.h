@@ -319,6 +319,12 @@ int  selenite_rx_time_process_each_device(selenite_rx_instance *S, const void *d
  * bench.py reports the DSP kernels as a fraction of this floor beside the fraction of the nominal 8 TB/s. */
 int  selenite_rx_time_streaming_roof_device(selenite_rx_instance *S, const void *dSrcIQ, void *dDstAudio, uint32_t blockSize,
                                             uint32_t iters, float *ms_each, int q15);
+/* The same for the shapes of the systolic CW kernel (k_cw_fused: CW / CWR, no FIR stages, 2 / 4 / 8 biquad sections, DSP blocks of 128 / 256 /
+ * 512), whose fetch pattern is its own: one wavefront streams 64 / n_biquad channel rows at once, 1 KB of a row per load.  The kernel timed here
+ * issues exactly those bursts and stores (same descriptors, same number of bursts in flight, same residency) and `work` dependent vector
+ * instructions per chunk where the biquad steps are -- 0: what the pattern alone costs.  Other configurations: SELENITE_RX_ARGUMENT_ERROR. */
+int  selenite_rx_time_pattern_roof_device(selenite_rx_instance *S, const void *dSrcIQ, void *dDstAudio, uint32_t blockSize,
+                                          uint32_t iters, float *ms_each, int q15, uint32_t work);
 /* PCI bus id ("0000:05:00.0") of HIP device `ordinal` into buf; bench.py lists the devices of the ranks with it. */
 int  selenite_rx_device_pci_bus_id(int ordinal, char *buf, size_t len);
 

@@ -601,7 +601,7 @@ static int run_part(selenite_rx_instance *S, const void *src, bool src_q15, void
     // int16 load performs -- and run as an f32-input call whose gain pass stores int16; round 2 left them to the generic kernels)
     const bool fusable = phase != kPhase2 && !S->force_generic;
     const bool ssb_fused = fusable && S->plan.kind != 0;
-    const bool cw_fused = fusable && cw_fused_ok(g, block_size);
+    const bool cw_fused = fusable && cw_fused_ok(g, block_size) && cw_strides_ok(p.in_stride, p.out_stride);    // (wider strides: the generic kernels)
     if (global && src_q15 && (ssb_fused || cw_fused)) {
         const size_t nval = (size_t)p.channels * p.in_stride * 2;            // int16 values of the call (block_size % 4 == 0 for every fused shape)
         if (nval % 8 == 0) {
@@ -1157,6 +1157,37 @@ extern "C" int selenite_rx_time_streaming_roof_device(selenite_rx_instance *S, c
     HIPCHK(S, hipEventRecord(sc.e[0], S->stream));
     for (uint32_t i = 0; i < iters; ++i) {
         HIPCHK(S, launch_stream_roof(dSrcIQ, dDstAudio, sc.p, g.channels, in_bytes, out_bytes, words, S->stream));
+        HIPCHK(S, hipEventRecord(sc.e[i + 1], S->stream));
+    }
+    HIPCHK(S, hipEventSynchronize(sc.e[iters]));
+    for (uint32_t i = 0; i < iters; ++i) HIPCHK(S, hipEventElapsedTime(&ms_each[i], sc.e[i], sc.e[i + 1]));
+    return SELENITE_RX_SUCCESS;
+}
+
+extern "C" int selenite_rx_time_pattern_roof_device(selenite_rx_instance *S, const void *dSrcIQ, void *dDstAudio, uint32_t blockSize,
+                                                    uint32_t iters, float *ms_each, int q15, uint32_t work)
+{
+    if (!S || !ms_each || iters == 0 || !dSrcIQ || !dDstAudio) return SELENITE_RX_ARGUMENT_ERROR;
+    if (!block_size_ok(S, blockSize, "selenite_rx_time_pattern_roof_device")) return S->status;
+    const selenite_rx_config &g = S->cfg;
+    if (!cw_fused_ok(g, blockSize) || (g.block != 128 && g.block != 256 && g.block != 512) || (g.block == 512 && g.n_biquad == 2))
+        return fail(S, SELENITE_RX_ARGUMENT_ERROR, "selenite_rx_time_pattern_roof_device: only the shapes of the systolic CW kernel (DSP blocks of 128 / 256 / 512) have a pattern of their own");
+    HIPCHK(S, hipSetDevice(S->device));
+    struct Scratch {
+        float4 *p = nullptr; std::vector<hipEvent_t> e;
+        ~Scratch() { if (p) (void)hipFree(p); for (hipEvent_t x : e) if (x) (void)hipEventDestroy(x); }
+    } sc;
+    const uint32_t ch_per_wg = 64u / g.n_biquad;
+    const size_t nst = (size_t)((g.channels + ch_per_wg - 1) / ch_per_wg) * 64u;
+    HIPCHK(S, hipMalloc((void **)&sc.p, nst * sizeof(float4)));
+    HIPCHK(S, hipMemsetAsync(sc.p, 0, nst * sizeof(float4), S->stream));
+    sc.e.assign((size_t)iters + 1, nullptr);
+    for (auto &x : sc.e) HIPCHK(S, hipEventCreate(&x));
+    const RxParams p = make_params(S, blockSize);
+    for (int w = 0; w < 3; ++w) HIPCHK(S, launch_cw_roof(p, dSrcIQ, q15 != 0, dDstAudio, sc.p, work, S->stream));
+    HIPCHK(S, hipEventRecord(sc.e[0], S->stream));
+    for (uint32_t i = 0; i < iters; ++i) {
+        HIPCHK(S, launch_cw_roof(p, dSrcIQ, q15 != 0, dDstAudio, sc.p, work, S->stream));
         HIPCHK(S, hipEventRecord(sc.e[i + 1], S->stream));
     }
     HIPCHK(S, hipEventSynchronize(sc.e[iters]));

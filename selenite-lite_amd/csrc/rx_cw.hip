@@ -117,6 +117,8 @@ struct CwGeo {
     static constexpr int PRO = D / 4 + 1;
     static_assert(LPC <= 64 && 64 % LPC == 0, "a load covers whole channel rows");
 };
+// bursts in flight (k_cw_fused and its pattern roof): two where a DSP block is an even number of chunks and the registers allow it
+template <int NCHUNK, int NCO, typename TIn> struct CwDepth { static constexpr int value = (NCHUNK % 2 == 0 && !(NCO == 1 && sizeof(TIn) == 4)) ? 2 : 1; };
 // loads per chunk:
 // 16 where the DSP block is whole chunks of that size and a chunk row still fits a wave load (2 / 4 stages): 1 KB of ONE channel per load
 // instruction with 4 stages, half as many chunk prologues; else 8
@@ -135,7 +137,6 @@ __global__ __launch_bounds__(64) void k_cw_fused(RxParams p, const TIn *__restri
     __shared__ __attribute__((aligned(16))) float tile[CH * RS];
     __shared__ float tab[NCO == 1 ? 516 : 4];
     constexpr int CPR = 16 / NS;                        // channels per 16-lane row
-    __shared__ float sink[2 * kWave + 6];               // where the lanes that are not a last stage put their four values of a trip (below)
     const int lane = threadIdx.x;
     const int s = (lane & 15) / CPR, ch = (lane >> 4) * CPR + (lane & (CPR - 1));
     const uint32_t c0 = blockIdx.x * CH;
@@ -161,8 +162,9 @@ __global__ __launch_bounds__(64) void k_cw_fused(RxParams p, const TIn *__restri
     float *wrow = tile + ch * RS;
     const float *rbase = tile + ch * RS;
     typedef __attribute__((address_space(3))) float lds_f32;
-    const uint32_t wbase = last ? (uint32_t)(uintptr_t)(lds_f32 *)wrow : (uint32_t)(uintptr_t)(lds_f32 *)(sink + 2 * lane);   // LDS byte addresses of a trip's output group
-    const uint32_t winc = last ? 16u : 0u;                                                                                  // ... and what a trip advances them by
+    const uint32_t wbase = (uint32_t)(uintptr_t)(lds_f32 *)wrow;      // LDS byte address of the channel row (output groups: 16 bytes per trip)
+    constexpr uint32_t winc = 16u;
+    const uint64_t last_mask = __builtin_amdgcn_ballot_w64(last);     // the last-stage lanes (wave-uniform: an SGPR pair)
 
     typedef typename CwRaw<TIn>::type raw_t;
     // input prefetch: TWO chunks ahead where a DSP block is an even number of chunks (chunk q of every block lives in register slot q & 1:
@@ -171,7 +173,7 @@ __global__ __launch_bounds__(64) void k_cw_fused(RxParams p, const TIn *__restri
     // that many instructions between its bursts runs 9 % faster with two bursts in flight than with one; the pattern itself -- sixteen
     // 1 KB pieces 32 KB apart -- costs nothing against 4 KB runs).  (Round 5's "two chunks of 8 loads ahead" kept the same 16 KB in flight.)
     // (per-channel arm_sin/cos with f32 slots: its registers do not leave room for a second slot at two waves per SIMD)
-    constexpr int DEPTH = (NCHUNK % 2 == 0 && !(NCO == 1 && sizeof(TIn) == 4)) ? 2 : 1;
+    constexpr int DEPTH = CwDepth<NCHUNK, NCO, TIn>::value;
     raw_t raw[DEPTH][NL];
     u4v_cw lo4[DEPTH];
 #pragma unroll
@@ -325,13 +327,13 @@ __global__ __launch_bounds__(64) void k_cw_fused(RxParams p, const TIn *__restri
                 float gq[4];
 #pragma unroll
                 for (int v = 0; v < 4; ++v) gq[v] = v < NCAR ? car[v] : o[v - NCAR];
-                // EVERY lane writes its four values, as two ds_write2_b32 from the registers the steps left them in (no copies into an aligned
-                // quad, no exec mask, no branch around the writes): the last-stage lanes into their channel's row, the others into `sink`
-                // (8 bytes apart: the 128 dwords of one instruction are spread over all the banks twice)
+                // the last-stage lanes write their four values into their channel's row as two ds_write2_b32 from the registers the steps left them
+                // in (no copies into an aligned quad); the execution mask is narrowed to those lanes by two scalar moves around the pair -- the
+                // wave is whole here -- instead of a compare / branch / restore around four masked stores
                 {
                     constexpr int O = 4 * decltype(sub)::value;
-                    asm volatile("ds_write2_b32 %0, %1, %2 offset0:%5 offset1:%6\n\tds_write2_b32 %0, %3, %4 offset0:%7 offset1:%8"
-                                 : : "v"(wa), "v"(gq[0]), "v"(gq[1]), "v"(gq[2]), "v"(gq[3]), "n"(O), "n"(O + 1), "n"(O + 2), "n"(O + 3) : "memory");
+                    asm volatile("s_mov_b64 exec, %9\n\tds_write2_b32 %0, %1, %2 offset0:%5 offset1:%6\n\tds_write2_b32 %0, %3, %4 offset0:%7 offset1:%8\n\ts_mov_b64 exec, -1"
+                                 : : "v"(wa), "v"(gq[0]), "v"(gq[1]), "v"(gq[2]), "v"(gq[3]), "n"(O), "n"(O + 1), "n"(O + 2), "n"(O + 3), "s"(last_mask) : "memory");
                 }
                 m = fmaxf(fmaxf(m, fabsf(o[0])), fmaxf(fabsf(o[1]), fmaxf(fabsf(o[2]), fabsf(o[3]))));
 #pragma unroll
@@ -436,6 +438,13 @@ bool cw_fused_ok(const selenite_rx_config &g, uint32_t block_size)
            block_size % g.block == 0 && block_size <= (1u << 22);
 }
 
+// ... and the caller's channel strides (samples): 32 rows of either buffer inside 2^31 bytes -- a call with wider strides is served by the
+// generic kernels (the dispatcher asks; launch_cw_fused refuses what it was not asked about)
+bool cw_strides_ok(uint64_t in_stride, uint64_t out_stride)
+{
+    return in_stride * 32u * 8u < (1ull << 31) && out_stride * 32u * 4u < (1ull << 31);
+}
+
 template <int NS, int NCO, typename TIn, typename TOut>
 static hipError_t cw_launch(const RxParams &p, const void *src, void *dst, hipStream_t st)
 {
@@ -473,10 +482,143 @@ static hipError_t cw_launch_ns(const RxParams &p, const void *src, bool q15, voi
 hipError_t launch_cw_fused(const RxParams &p, const void *src, bool src_q15, void *dst, bool dst_q15, hipStream_t st)
 {
     if (src_q15 != dst_q15) return hipErrorNotSupported;
-    if ((uint64_t)p.in_stride * 32u * 8u >= (1ull << 31) || (uint64_t)p.out_stride * 32u * 4u >= (1ull << 31)) return hipErrorNotSupported;      // 32-bit offsets inside a workgroup's channels (cw_fused_ok)
+    if (!cw_strides_ok(p.in_stride, p.out_stride)) return hipErrorNotSupported;      // 32-bit offsets inside a workgroup's channels
     if (p.nbiq == 2) return cw_launch_ns<2>(p, src, src_q15, dst, st);
     if (p.nbiq == 4) return cw_launch_ns<4>(p, src, src_q15, dst, st);
     if (p.nbiq == 8) return cw_launch_ns<8>(p, src, src_q15, dst, st);
+    return hipErrorNotSupported;
+}
+
+// ------------------------------------------------------------------------------------------
+// k_cw_roof -- measurement support (bench.py `pattern_roof`, selenite_rx_time_pattern_roof_device): the memory traffic of k_cw_fused with
+// ITS access pattern and launch shape and no DSP -- the same descriptors, the same bursts (NL wave loads per chunk: 1 KB of one channel row
+// each with 4 stages, rows in_stride apart), the same number of bursts in flight, requested at the same points of the block loop, the
+// 16 KB store burst of a DSP block behind the first chunk of the next, one float4 of state per lane in and out, one workgroup per CH
+// channels.  One integer add per loaded register keeps the loads alive; `work` dependent vector instructions per chunk stand where the
+// systolic steps are (0: the pattern alone).  What this takes is what ANY kernel with this fetch pattern takes.
+// ------------------------------------------------------------------------------------------
+template <int NS, int BLK, typename TIn, typename TOut>
+__global__ __launch_bounds__(64) void k_cw_roof(RxParams p, const TIn *__restrict__ src, TOut *__restrict__ dst, float4 *__restrict__ state, uint32_t work)
+{
+    constexpr int NL = CwLoads<NS, BLK>::NL;
+    using CG = CwGeo<NS, NL>;
+    constexpr int CH = CG::CH, CS = CG::CS;
+    constexpr int NCHUNK = BLK / CS;
+    constexpr int DEPTH = CwDepth<NCHUNK, 2, TIn>::value;
+    constexpr int EB = CwRaw<TIn>::kBytes / 2;
+    extern __shared__ float roof_lds[];                      // (dynamic: sized by the launcher so that the residency is k_cw_fused's)
+    const int lane = threadIdx.x;
+    const uint32_t c0 = blockIdx.x * CH;
+    const uint32_t chs = min((uint32_t)CH, p.channels - c0);
+    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<TIn *>(src) + (size_t)c0 * p.in_stride * 2, 0,
+                                                                           (int)(((chs - 1) * p.in_stride + p.block_size) * EB), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(dst + (size_t)c0 * p.out_stride, 0,
+                                                                            (int)(((chs - 1) * p.out_stride + p.block_size) * (uint32_t)sizeof(TOut)), 0x00020000);
+    const int lch = lane / CG::LPC, lsm = 2 * (lane % CG::LPC);
+    const int voff_in = (int)((lch * p.in_stride + lsm) * EB);
+    const int joff_in = (int)(CG::CPL * p.in_stride * EB);
+    typedef typename CwRaw<TIn>::type raw_t;
+    raw_t raw[DEPTH][NL];
+    float4 st = state[(size_t)blockIdx.x * kWave + lane];
+    uint32_t acc = 0u;
+    auto issue = [&](auto slot, uint32_t n_first) {
+        constexpr int SL = decltype(slot)::value;
+        const int past = n_first < p.block_size ? 0 : 0x70000000;        // past the call: outside the descriptor, no access
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < NL; ++j) raw[SL][j] = CwRaw<TIn>::load(rs_in, voff_in, (int)(n_first * EB) + j * joff_in + past);
+    };
+    auto consume = [&](auto slot) {
+        constexpr int SL = decltype(slot)::value;
+#pragma unroll
+        for (int j = 0; j < NL; ++j) {
+            acc += raw[SL][j].x + raw[SL][j].y;
+            if constexpr (sizeof(raw_t) == 16) acc += raw[SL][j].z + raw[SL][j].w;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto busy = [&]() {
+        float w0 = __uint_as_float(acc);
+        for (uint32_t i = 0; i < work / 8u; ++i)
+            asm volatile("v_fma_f32 %0, %0, %0, %0\n v_fma_f32 %0, %0, %0, %0\n v_fma_f32 %0, %0, %0, %0\n v_fma_f32 %0, %0, %0, %0\n"
+                         "v_fma_f32 %0, %0, %0, %0\n v_fma_f32 %0, %0, %0, %0\n v_fma_f32 %0, %0, %0, %0\n v_fma_f32 %0, %0, %0, %0" : "+v"(w0));
+        acc = __float_as_uint(w0);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    typedef std::integral_constant<int, 0> slot0_t;
+    typedef std::integral_constant<int, DEPTH - 1> slot1_t;
+    issue(slot0_t{}, 0);
+    if constexpr (DEPTH == 2) issue(slot1_t{}, CS);
+    consume(slot0_t{}); issue(slot0_t{}, DEPTH * CS);
+    const uint32_t nblk = p.block_size / BLK;
+    for (uint32_t blk = 0; blk < nblk; ++blk) {
+        const uint32_t n0 = blk * BLK;
+        if constexpr (DEPTH == 2) {
+#pragma unroll 1
+            for (int q = 0; q < NCHUNK; q += 2) {
+                if (q != 0) { consume(slot0_t{}); issue(slot0_t{}, n0 + CS * q + 2 * CS); }
+                busy();
+                consume(slot1_t{}); issue(slot1_t{}, n0 + CS * (q + 1) + 2 * CS);
+                busy();
+            }
+        } else {
+#pragma unroll 1
+            for (int q = 0; q < NCHUNK; ++q) {
+                if (q != 0) { consume(slot0_t{}); issue(slot0_t{}, n0 + CS * q + CS); }
+                busy();
+            }
+        }
+        if (blk + 1 < nblk) { consume(slot0_t{}); issue(slot0_t{}, n0 + BLK + DEPTH * CS); }
+#pragma unroll 4
+        for (int r = 0; r < CH; ++r) {
+#pragma unroll
+            for (int h = 0; h < (BLK / 4 + 63) / 64; ++h) {
+                const int t = 4 * (lane + 64 * h);
+                const int voff = t < BLK ? t * (int)sizeof(TOut) : 0x40000000;
+                const int soff = (int)((r * p.out_stride + n0) * (uint32_t)sizeof(TOut));
+                if constexpr (sizeof(TOut) == 4) __builtin_amdgcn_raw_buffer_store_b128(u4v_cw{ acc, acc, acc, acc }, rs_out, voff, soff, 2);
+                else __builtin_amdgcn_raw_buffer_store_b64(u2v_cw{ acc, acc }, rs_out, voff, soff, 2);
+            }
+        }
+    }
+    st.x += __uint_as_float(acc & 1u);
+    state[(size_t)blockIdx.x * kWave + lane] = st;
+    if (acc == 0x12345678u) roof_lds[lane] = st.x;
+}
+
+template <int NS, typename TIn, typename TOut>
+static hipError_t cw_roof_launch(const RxParams &p, const void *src, void *dst, float4 *state, uint32_t work, hipStream_t st)
+{
+    constexpr int CH = CwGeo<NS>::CH;
+    const dim3 grid((p.channels + CH - 1) / CH);
+#define CW_ROOF_BLK(B_)                                                                                                                        \
+    if (p.block == B_) {                                                                                                                       \
+        /* the residency of the kernel it stands for: as much dynamic LDS as leaves that many workgroups on a CU */                          \
+        static size_t lds = 0;                                                                                                                 \
+        if (lds == 0) {                                                                                                                        \
+            int per_cu = 0;                                                                                                                    \
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_cw_fused<NS, 2, B_, TIn, TOut>, 64, 0) != hipSuccess || per_cu < 1)    \
+                per_cu = 8;                                                                                                                    \
+            lds = ((size_t)(160 * 1024) / (size_t)per_cu) & ~(size_t)1023;                                                                     \
+        }                                                                                                                                      \
+        hipLaunchKernelGGL((k_cw_roof<NS, B_, TIn, TOut>), grid, dim3(64), lds, st, p, static_cast<const TIn *>(src), static_cast<TOut *>(dst), \
+                           state, work);                                                                                                       \
+        return hipGetLastError();                                                                                                              \
+    }
+    CW_ROOF_BLK(256)
+    CW_ROOF_BLK(128)
+    if constexpr (NS != 2) { CW_ROOF_BLK(512) }
+#undef CW_ROOF_BLK
+    return hipErrorNotSupported;
+}
+
+// state: channels rounded up to whole workgroups x NS float4 (scratch of the caller's)
+hipError_t launch_cw_roof(const RxParams &p, const void *src, bool q15, void *dst, float4 *state, uint32_t work, hipStream_t st)
+{
+    if (!cw_strides_ok(p.in_stride, p.out_stride)) return hipErrorNotSupported;
+    if (p.nbiq == 4) return q15 ? cw_roof_launch<4, int16_t, int16_t>(p, src, dst, state, work, st) : cw_roof_launch<4, float, float>(p, src, dst, state, work, st);
+    if (p.nbiq == 2) return q15 ? cw_roof_launch<2, int16_t, int16_t>(p, src, dst, state, work, st) : cw_roof_launch<2, float, float>(p, src, dst, state, work, st);
+    if (p.nbiq == 8) return q15 ? cw_roof_launch<8, int16_t, int16_t>(p, src, dst, state, work, st) : cw_roof_launch<8, float, float>(p, src, dst, state, work, st);
     return hipErrorNotSupported;
 }
 

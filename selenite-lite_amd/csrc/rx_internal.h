@@ -177,6 +177,9 @@ bool ssb_split16_has_shape(int nd, int m, int nh);
 
 // fused CW kernel (rx_cw.hip): NCO -> real part -> 4-stage biquad cascade -> AGC
 bool cw_fused_ok(const selenite_rx_config &cfg, uint32_t block_size);
+bool cw_strides_ok(uint64_t in_stride, uint64_t out_stride);
+// no-DSP kernel with the fetch pattern, launch shape and residency of k_cw_fused (rx_cw.hip; bench.py `pattern_roof`)
+hipError_t launch_cw_roof(const RxParams &p, const void *src, bool q15, void *dst, float4 *state, uint32_t work, hipStream_t st);
 hipError_t launch_cw_fused(const RxParams &p, const void *src, bool src_q15, void *dst, bool dst_q15, hipStream_t st);
 
 // shared local-oscillator table for one call (rx_fused.hip)

@@ -63,7 +63,7 @@ ABI_SYMBOLS = [
     "selenite_rx_abi_version",
     "selenite_rx_global_process_f32_device",
     "selenite_rx_host_alloc", "selenite_rx_host_free", "selenite_rx_host_register", "selenite_rx_host_unregister",
-    "selenite_rx_time_process_each_device", "selenite_rx_time_streaming_roof_device", "selenite_rx_device_pci_bus_id",
+    "selenite_rx_time_process_each_device", "selenite_rx_time_streaming_roof_device", "selenite_rx_time_pattern_roof_device", "selenite_rx_device_pci_bus_id",
     "selenite_rx_set_guard_ratio", "selenite_rx_guard_stats", "selenite_rx_guard_channels", "selenite_rx_auto_words", "selenite_rx_guard_handover", "selenite_rx_set_handover_repair", "selenite_rx_set_auto_launches", "selenite_rx_auto_launches_last", "selenite_rx_guard_clear",
 ]
 
@@ -166,6 +166,7 @@ def lib():
         u64p = C.POINTER(C.c_uint64)
         L.selenite_rx_time_process_each_device.argtypes = [vp, vp, vp, C.c_uint32, C.c_uint32, f32p, C.c_int]
         L.selenite_rx_time_streaming_roof_device.argtypes = [vp, vp, vp, C.c_uint32, C.c_uint32, f32p, C.c_int]
+        L.selenite_rx_time_pattern_roof_device.argtypes = [vp, vp, vp, C.c_uint32, C.c_uint32, f32p, C.c_int, C.c_uint32]
         L.selenite_rx_device_pci_bus_id.argtypes = [C.c_int, C.c_char_p, C.c_size_t]
         L.selenite_rx_set_guard_ratio.argtypes = [vp, C.c_float]
         L.selenite_rx_guard_stats.argtypes = [vp, u64p, u64p, u64p]
@@ -443,6 +444,15 @@ class Rx:
         """per-launch durations (ms) of the no-arithmetic kernel that moves the algorithmic bytes of one call (d_dst is overwritten)"""
         ms = np.zeros(iters, np.float32)
         rc = self.L.selenite_rx_time_streaming_roof_device(self.h, d_src, d_dst, block_size, iters, _fp(ms), int(q15))
+        if rc:
+            raise RxError(rc, self.error())
+        return ms
+
+    def time_pattern_roof(self, d_src, d_dst, block_size, iters, q15=False, work=0):
+        """per-launch durations (ms) of the no-DSP kernel with the fetch pattern and launch shape of the systolic CW kernel, `work` dependent
+        vector instructions per chunk where its biquad steps are (d_dst is overwritten; CW shapes only)"""
+        ms = np.zeros(iters, np.float32)
+        rc = self.L.selenite_rx_time_pattern_roof_device(self.h, d_src, d_dst, block_size, iters, _fp(ms), int(q15), int(work))
         if rc:
             raise RxError(rc, self.error())
         return ms
