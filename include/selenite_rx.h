@@ -40,7 +40,15 @@
 extern "C" {
 #endif
 
-#define SELENITE_RX_ABI_VERSION 1
+/* ABI version of this header (selenite_rx_abi_version() returns the library's).
+ *   1  rounds 1-4: selenite_rx_config ends with agc_gain_init (112 bytes on LP64, the last 4 of them tail padding).
+ *   2  selenite_rx_config grows to 120 bytes: q15_rounding (in the former padding), abi_version, reserved -- same for selenite_tx_config
+ *      (96 -> 104 bytes).  selenite_rx_init / selenite_tx_init tell the two layouts apart by struct_size, CMSIS-style (the caller owns
+ *      the struct, the library reads only what that caller's header declared, cf. arm_math.h:3272-3312): a version-1 caller
+ *      (struct_size = SELENITE_RX_CONFIG_SIZE_V1) keeps working unchanged -- the bytes behind agc_gain_init are NOT read, whatever
+ *      they hold, and int16 output truncates as it always did; a version-2 caller (struct_size = sizeof) must set abi_version = 2. */
+#define SELENITE_RX_ABI_VERSION 2
+#define SELENITE_RX_CONFIG_SIZE_V1 112u
 
 /* Status codes: numerically identical to arm_status (arm_math.h:399-408). */
 #define SELENITE_RX_SUCCESS          0   /* ARM_MATH_SUCCESS          */
@@ -98,7 +106,7 @@ extern "C" {
                                     for those pairs alone; other configurations run as _CMSIS. */
 
 typedef struct selenite_rx_config {
-    uint32_t struct_size;     /* = sizeof(selenite_rx_config) */
+    uint32_t struct_size;     /* = sizeof(selenite_rx_config) (a caller built against the version-1 header passes SELENITE_RX_CONFIG_SIZE_V1) */
     uint32_t channels;        /* C: independent I/Q channels handled by this instance */
     uint32_t block;           /* DSP block: complex input samples per CMSIS call / AGC update */
     uint32_t decim;           /* M (arm_fir_decimate_instance_f32.M); 1 = no decimator */
@@ -126,8 +134,10 @@ typedef struct selenite_rx_config {
     float agc_gain_init;      /* gain before the first block */
     uint32_t q15_rounding;    /* int16 output (arm_float_to_q15): 0 = truncate -- the reference's code as the firmware builds it
                                  (ARM_MATH_ROUNDING undefined, arm_float_to_q15.c:117) --, 1 = the ARM_MATH_ROUNDING variant
-                                 (arm_float_to_q15.c:90-101: +-0.5 in float before the truncation).  The field sits where the struct had
-                                 tail padding: zero the struct before filling it in (memset / = {0}); any other value is an ARGUMENT_ERROR. */
+                                 (arm_float_to_q15.c:90-101: +-0.5 in float before the truncation); any other value is an ARGUMENT_ERROR.
+                                 ABI version 2: read only when struct_size == sizeof(selenite_rx_config) (it sits where version 1 had padding). */
+    uint32_t abi_version;     /* ABI version 2: = SELENITE_RX_ABI_VERSION (anything else with the version-2 struct_size: ARGUMENT_ERROR) */
+    uint32_t reserved;        /* 0 */
 } selenite_rx_config;
 
 /* Host-side view of the per-channel streaming state (what CMSIS keeps in pState).
@@ -325,6 +335,20 @@ int  selenite_rx_time_streaming_roof_device(selenite_rx_instance *S, const void 
  * instructions per chunk where the biquad steps are -- 0: what the pattern alone costs.  Other configurations: SELENITE_RX_ARGUMENT_ERROR. */
 int  selenite_rx_time_pattern_roof_device(selenite_rx_instance *S, const void *dSrcIQ, void *dDstAudio, uint32_t blockSize,
                                           uint32_t iters, float *ms_each, int q15, uint32_t work);
+
+/* ---- kernel-selection overrides (tests, diagnosis) -------------------------------------
+ * Process-wide words, NOT configuration: results never depend on them.  The test suite uses them to reach every product path (the generic
+ * per-stage kernels, the NCO flavours, both grids of SELENITE_ARITH_AUTO's rerun pass).  Read by selenite_rx_init / selenite_tx_init when an
+ * instance is planned (SELENITE_RX_OPT_RERUN_GRID: by every rerun launch).  The library reads no environment variable for any of this; its
+ * only environment setting is SELENITE_RX_HOST_CHUNK_MB (chunk of the host-pointer pipeline, default 32). */
+#define SELENITE_RX_OPT_FORCE_GENERIC     0   /* 1: RX instances created from now on use the generic per-stage kernels only */
+#define SELENITE_RX_OPT_NO_SHARED_LO      1   /* 1: per-channel NCO in the kernel even when all channels share step and phase */
+#define SELENITE_RX_OPT_NO_PERIODIC_LO    2   /* 1: a shared LO always as a per-call table, never a 256-sample period in registers (RX and TX) */
+#define SELENITE_RX_OPT_RERUN_GRID        3   /* workgroups of SELENITE_ARITH_AUTO's rerun pass (1 .. 2^20); 0: sized from the last call's list */
+#define SELENITE_RX_OPT_TX_FORCE_GENERIC  4   /* 1: TX instances created from now on use the generic kernels only */
+#define SELENITE_RX_OPT_COUNT             5
+int      selenite_rx_set_plan_option(int option, uint32_t value);   /* SELENITE_RX_ARGUMENT_ERROR: unknown option / value out of range */
+uint32_t selenite_rx_get_plan_option(int option);
 /* PCI bus id ("0000:05:00.0") of HIP device `ordinal` into buf; bench.py lists the devices of the ranks with it. */
 int  selenite_rx_device_pci_bus_id(int ordinal, char *buf, size_t len);
 

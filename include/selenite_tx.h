@@ -37,8 +37,10 @@ extern "C" {
 
 typedef struct selenite_tx_instance selenite_tx_instance;
 
+#define SELENITE_TX_CONFIG_SIZE_V1 96u
+
 typedef struct {
-    uint32_t struct_size;      /* sizeof(selenite_tx_config) */
+    uint32_t struct_size;      /* sizeof(selenite_tx_config); a caller built against the version-1 header passes SELENITE_TX_CONFIG_SIZE_V1 (selenite_rx.h: ABI versions) */
     uint32_t channels;
     uint32_t block;            /* ALC block, audio samples */
     uint32_t interp;           /* L >= 1 (1: no interpolator, ni_taps must be 0) */
@@ -56,7 +58,9 @@ typedef struct {
     const uint32_t *nco_step;     /* [channels] or NULL */
     float alc_target, alc_attack, alc_decay, alc_gain_min, alc_gain_max, alc_env_floor, alc_gain_init;
     uint32_t q15_rounding;     /* int16 I/Q output (arm_float_to_q15): 0 = truncate (the firmware's build, arm_float_to_q15.c:117), 1 = the ARM_MATH_ROUNDING
-                                  build (arm_float_to_q15.c:90-101).  Sits where the struct had tail padding: zero the struct first; other values: ARGUMENT_ERROR */
+                                  build (arm_float_to_q15.c:90-101); other values: ARGUMENT_ERROR.  ABI version 2: read only when struct_size == sizeof (version 1 had padding here) */
+    uint32_t abi_version;      /* ABI version 2: = SELENITE_RX_ABI_VERSION */
+    uint32_t reserved;         /* 0 */
 } selenite_tx_config;
 
 typedef struct {

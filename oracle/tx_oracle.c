@@ -71,7 +71,7 @@ static float *dupf(const float *p, size_t n)
 int orc_tx_create(orc_tx **out, const selenite_tx_config *g)
 {
     *out = NULL;
-    if (!g || g->struct_size != sizeof(*g) || g->q15_rounding > 1u || !g->channels || !g->block || !g->interp || !mode_ok(g->mode) || g->arith > 2)
+    if (!g || (g->struct_size != sizeof(*g) && g->struct_size != SELENITE_TX_CONFIG_SIZE_V1) || (g->struct_size == sizeof(*g) && g->q15_rounding > 1u) || !g->channels || !g->block || !g->interp || !mode_ok(g->mode) || g->arith > 2)
         return SELENITE_RX_ARGUMENT_ERROR;
     if ((g->interp > 1) != (g->ni_taps > 0)) return SELENITE_RX_ARGUMENT_ERROR;
     if (g->ni_taps && !g->interp_coeffs) return SELENITE_RX_ARGUMENT_ERROR;

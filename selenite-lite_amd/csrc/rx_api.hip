@@ -7,6 +7,7 @@
 #include "rx_internal.h"
 
 #include <cmath>
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -164,6 +165,23 @@ static int check_device_flags(selenite_rx_instance *S)
 
 extern "C" int selenite_rx_abi_version(void) { return SELENITE_RX_ABI_VERSION; }
 
+// ---- plan options (rx_diag.h) ----
+namespace { uint32_t g_plan_opt[SELENITE_RX_OPT_COUNT] = { 0u, 0u, 0u, 0u, 0u }; }
+namespace srx {
+uint32_t plan_option(int option)
+{
+    return option >= 0 && option < SELENITE_RX_OPT_COUNT ? __atomic_load_n(&g_plan_opt[option], __ATOMIC_RELAXED) : 0u;
+}
+}  // namespace srx
+extern "C" int selenite_rx_set_plan_option(int option, uint32_t value)
+{
+    if (option < 0 || option >= SELENITE_RX_OPT_COUNT) return SELENITE_RX_ARGUMENT_ERROR;
+    if (option == SELENITE_RX_OPT_RERUN_GRID ? value > (1u << 20) : value > 1u) return SELENITE_RX_ARGUMENT_ERROR;
+    __atomic_store_n(&g_plan_opt[option], value, __ATOMIC_RELAXED);
+    return SELENITE_RX_SUCCESS;
+}
+extern "C" uint32_t selenite_rx_get_plan_option(int option) { return srx::plan_option(option); }
+
 extern "C" int selenite_rx_device_count(void)
 {
     int n = 0;
@@ -177,14 +195,29 @@ extern "C" int selenite_rx_set_device(int ordinal)
     return SELENITE_RX_SUCCESS;
 }
 
-extern "C" int selenite_rx_init(selenite_rx_instance **out, const selenite_rx_config *cfg)
+extern "C" int selenite_rx_init(selenite_rx_instance **out, const selenite_rx_config *caller_cfg)
 {
     if (!out) return fail(nullptr, SELENITE_RX_ARGUMENT_ERROR, "selenite_rx_init: S is NULL");
     *out = nullptr;
-    if (!cfg || cfg->struct_size != sizeof(selenite_rx_config))
-        return fail(nullptr, SELENITE_RX_ARGUMENT_ERROR, "selenite_rx_init: bad config / struct_size");
-    if (cfg->q15_rounding > 1u)
-        return fail(nullptr, SELENITE_RX_ARGUMENT_ERROR, "selenite_rx_init: q15_rounding is 0 or 1 (zero the struct before filling it in)");
+    if (!caller_cfg) return fail(nullptr, SELENITE_RX_ARGUMENT_ERROR, "selenite_rx_init: cfg is NULL");
+    // The caller owns the struct and says, through struct_size, which header it was built against (include/selenite_rx.h: ABI versions).
+    // Version 1 ends with agc_gain_init: nothing behind it is read (it is padding of the caller's), int16 output truncates.
+    static_assert(offsetof(selenite_rx_config, q15_rounding) == 108 && sizeof(selenite_rx_config) == 120, "selenite_rx_config layout (LP64)");
+    selenite_rx_config own{};
+    if (caller_cfg->struct_size == SELENITE_RX_CONFIG_SIZE_V1) {
+        std::memcpy(&own, caller_cfg, offsetof(selenite_rx_config, q15_rounding));
+        own.abi_version = 1;
+    } else if (caller_cfg->struct_size == sizeof(selenite_rx_config)) {
+        own = *caller_cfg;
+        if (own.abi_version != SELENITE_RX_ABI_VERSION || own.reserved != 0)
+            return fail(nullptr, SELENITE_RX_ARGUMENT_ERROR, "selenite_rx_init: abi_version must be SELENITE_RX_ABI_VERSION (2) and reserved 0 with this struct_size");
+        if (own.q15_rounding > 1u)
+            return fail(nullptr, SELENITE_RX_ARGUMENT_ERROR, "selenite_rx_init: q15_rounding is 0 or 1");
+    } else {
+        return fail(nullptr, SELENITE_RX_ARGUMENT_ERROR, "selenite_rx_init: struct_size matches neither this header's selenite_rx_config nor version 1's");
+    }
+    own.struct_size = (uint32_t)sizeof(selenite_rx_config);
+    const selenite_rx_config *cfg = &own;
     if (cfg->channels == 0 || cfg->block == 0 || cfg->decim == 0)
         return fail(nullptr, SELENITE_RX_ARGUMENT_ERROR, "selenite_rx_init: channels, block, decim must be non-zero");
     if (!mode_valid(cfg->mode, cfg->nh_taps))
@@ -229,12 +262,10 @@ extern "C" int selenite_rx_init(selenite_rx_instance **out, const selenite_rx_co
     for (size_t c = 1; c < C; ++c) S->steps_uniform = S->steps_uniform && S->h_step[c] == S->h_step[0];
     S->steps_grid256 = true;
     for (size_t c = 0; c < C; ++c) S->steps_grid256 = S->steps_grid256 && (S->h_step[c] & 0x00FFFFFFu) == 0;
-    const char *fg = std::getenv("SELENITE_RX_FORCE_GENERIC");
-    S->force_generic = (fg && fg[0] == '1') ? 1 : 0;
-    const char *nl = std::getenv("SELENITE_RX_NO_SHARED_LO");
-    S->no_shared_lo = (nl && nl[0] == '1') ? 1 : 0;
-    const char *npl = std::getenv("SELENITE_RX_NO_PERIODIC_LO");
-    S->no_periodic_lo = (npl && npl[0] == '1') ? 1 : 0;
+    // kernel-selection overrides of the tests (selenite_rx_set_plan_option): taken over at init, results do not depend on them
+    S->force_generic = plan_option(SELENITE_RX_OPT_FORCE_GENERIC) ? 1 : 0;
+    S->no_shared_lo = plan_option(SELENITE_RX_OPT_NO_SHARED_LO) ? 1 : 0;
+    S->no_periodic_lo = plan_option(SELENITE_RX_OPT_NO_PERIODIC_LO) ? 1 : 0;
 
 #define INITCHK(call)                                                                        \
     do {                                                                                     \
@@ -271,7 +302,7 @@ extern "C" int selenite_rx_init(selenite_rx_instance **out, const selenite_rx_co
         *S->h_rerun_seen = 0u;
     }
     if (cfg->arith == SELENITE_ARITH_AUTO && cfg->nd_taps >= 2 && cfg->nh_taps >= 2 &&
-        split16_template_nd((int)cfg->nd_taps, (int)cfg->decim, (int)cfg->nh_taps) > 0 && !std::getenv("SELENITE_RX_NO_HIST_EXT")) {
+        split16_template_nd((int)cfg->nd_taps, (int)cfg->decim, (int)cfg->nh_taps) > 0 && !diag_env("SELENITE_RX_NO_HIST_EXT")) {
         // k_ssb_split16 leaves the mixed samples in front of the decimator state here (two buffers: the one a channel's state points
         // at stays intact while the next call fills the other), for k_hist_exact
         // (round 4: allocated by the first call that needs it -- 2 x channels x ext_len x 8 bytes, 4 KB per channel for the cfg3 chain --

@@ -449,7 +449,11 @@ template <int NS, int NCO, typename TIn, typename TOut>
 static hipError_t cw_launch(const RxParams &p, const void *src, void *dst, hipStream_t st)
 {
     constexpr int CH = CwGeo<NS>::CH;
-    static const size_t pad = std::getenv("SELENITE_RX_CW_LDS_PAD") ? (size_t)std::atoi(std::getenv("SELENITE_RX_CW_LDS_PAD")) : 0;   // occupancy experiments
+    static const size_t pad = [] {                        // occupancy experiments (diagnostic builds): extra LDS per workgroup, inside what a workgroup may have
+        const char *e = diag_env("SELENITE_RX_CW_LDS_PAD");
+        const long v = e ? std::atol(e) : 0;
+        return (size_t)(v > 0 && v <= 40 * 1024 ? v : 0);
+    }();
     const dim3 grid((p.channels + CH - 1) / CH);
 #define CW_BLK(B_)                                                                                                          \
     if (p.block == B_) {                                                                                                    \

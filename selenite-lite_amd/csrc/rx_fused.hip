@@ -499,7 +499,7 @@ static hipError_t launch_mfma(const RxParams &p, const FusedArgs &fa, const floa
             resident = per_cu * prop.multiProcessorCount;
         else
             resident = -1;
-        if (const char *ge = std::getenv("SELENITE_RX_MFMA_GRID")) resident = std::atoi(ge) > 0 ? std::atoi(ge) : -1;
+        if (const char *ge = diag_env("SELENITE_RX_MFMA_GRID")) resident = std::atoi(ge) > 0 ? std::atoi(ge) : -1;
     }
     uint32_t grid = p.channels / kMfmaWaves;
     if (resident > 0 && (uint32_t)resident < grid) grid = (uint32_t)resident;
@@ -551,7 +551,7 @@ static hipError_t launch_shape(const RxParams &p, const FusedArgs &fa, const Fus
         // even ones; SELENITE_RX_DEC2_PARITY=2 selects the odd ones: a diagnostic that shows the tests notice)
         // (only the value 2 is taken, and said so on stderr: anything else keeps the chain's outputs)
         static const uint32_t par = [] {
-            const char *e = std::getenv("SELENITE_RX_DEC2_PARITY");
+            const char *e = diag_env("SELENITE_RX_DEC2_PARITY");
             if (e && e[0] == '2' && e[1] == 0) { fprintf(stderr, "selenite_rx: SELENITE_RX_DEC2_PARITY=2 -- decimation by 8 keeps the ODD by-4 outputs (diagnostic, wrong audio)\n"); return 2u; }
             return 1u;
         }();
@@ -698,7 +698,7 @@ hipError_t plan_fused(const selenite_rx_config &g, bool delay_is_impulse, int de
         plan.tables_built = true;
     }
     plan.kind = kind;
-    const char *nm = std::getenv("SELENITE_RX_NO_MFMA");
+    const char *nm = diag_env("SELENITE_RX_NO_MFMA");
     plan.use_mfma = plan.d_btab != nullptr && !(nm && nm[0] == '1');
     const std::string shape = "<" + std::to_string(g.nd_taps) + "," + std::to_string(g.decim) + "," + std::to_string(g.nh_taps) + ">";
     plan.name_buf = "k_ssb_fused" + shape;
@@ -769,8 +769,12 @@ hipError_t launch_fused(const FusedPlan &plan, const RxParams &p, int arith, con
     fa.inl = 0u;                                          // (launch_shape: SELENITE_ARITH_AUTO in one launch)
     fa.dec2 = 0u;                                         // (launch_shape sets it for decimation by 8 on the by-4 matrix kernel)
     {
-        const char *e = std::getenv("SELENITE_RX_GRP_SHIFT");
-        fa.grp_shift = e ? (uint32_t)std::atoi(e) : 2u;
+        static const uint32_t shift = [] {                // (diagnostic builds: another workgroup -> channel-group mapping; read once, 0 .. 8)
+            const char *e = diag_env("SELENITE_RX_GRP_SHIFT");
+            const int v = e ? std::atoi(e) : 2;
+            return (uint32_t)(v >= 0 && v <= 8 ? v : 2);
+        }();
+        fa.grp_shift = shift;
     }
     if (plan.dense) {
         // the FIR pair with arbitrary taps: k_ssb_fused's DENSE flavour, bit-exact (CMSIS; AUTO runs as CMSIS) or fma (FMA; SPLIT16 runs as fma)

@@ -11,10 +11,6 @@ namespace srx {
 hipError_t launch_exact(int nd, int m, int nh, bool q15, const RxParams &p, const FusedArgs &fa, const void *src, void *dst,
                         hipStream_t st)
 {
-#ifdef SRX_EXACT_BENCH_ONLY     // A/B builds (tools/build_exact_variants.sh): only the cfg3 shape with f32 slots
-    if (nd == 256 && m == 4 && nh == 63 && !q15) return launch_one<0, 256, 4, 63, float, float>(p, fa, src, dst, st);
-    return hipErrorNotSupported;
-#endif
 #define X(ND_, M_, NH_, ID_)                                                                             \
     if (nd == ND_ && m == M_ && nh == NH_)                                                               \
         return q15 ? launch_one<0, ND_, M_, NH_, int16_t, int16_t>(p, fa, src, dst, st)                   \

@@ -669,8 +669,7 @@ static hipError_t launch_one(const RxParams &p, const FusedArgs &fa_in, const vo
     // when it held more than an eighth of the channels: more workgroups than the device keeps resident let the dispatcher even the load
     // out -- 3-6 % on a call that recomputes 80 % of the channels (profiles/r4/rerun_grid_sweep.txt).  The count is the one the LAST
     // rerun pass wrote into a page-locked host word, read here without synchronising: a hint, never a result.
-    static const uint32_t rerun_grid_env = [] { const char *e = std::getenv("SELENITE_RX_RERUN_GRID"); return e && std::atoi(e) > 0 ? (uint32_t)std::atoi(e) : 0u; }();
-    uint32_t rerun_grid = rerun_grid_env;
+    uint32_t rerun_grid = plan_option(SELENITE_RX_OPT_RERUN_GRID);        // (the tests pin it: selenite_rx_set_plan_option)
     if (!rerun_grid) {
         const uint32_t seen = p.rerun_seen ? __atomic_load_n(p.rerun_seen, __ATOMIC_RELAXED) : 0u;
         rerun_grid = seen > p.channels / 8u ? 16384u : 2048u;

@@ -582,7 +582,7 @@ hipError_t launch_hist_exact(const RxParams &p, bool all, hipStream_t st)
     if (!p.chan_flags) return hipSuccess;
     // (in front of an AM call too, round 4: AM neither reads nor moves the Hilbert-pair history, but the decimator state moves on under it --
     // the last moment the samples kept in front of that state still belong to the history is now)
-    static const bool off = std::getenv("SELENITE_RX_NO_HIST_EXACT") != nullptr;      // diagnostic: what the rerun does without it
+    static const bool off = diag_env("SELENITE_RX_NO_HIST_EXACT") != nullptr;      // diagnostic: what the rerun does without it
     const bool repair = p.hist_ext && p.nd >= 2 && p.nh >= 2 && !off;
     if (!repair && !p.chan_list) return hipSuccess;
     const uint32_t nwin = (p.channels + 63u) / 64u;

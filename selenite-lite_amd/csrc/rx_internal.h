@@ -8,6 +8,7 @@
 
 #include "../../include/selenite_rx.h"
 #include "rx_device.h"
+#include "rx_diag.h"
 
 namespace srx {
 

@@ -48,20 +48,11 @@ bool ssb_split16_periodic_lo(int nd, int m, int nh)
 hipError_t launch_ssb_split16(int nd, int m, int nh, const RxParams &p, const FusedArgs &fa, const void *src, bool q15,
                               void *dst, hipStream_t st)
 {
-#ifdef SRX_SPLIT16_BENCH_ONLY     // A/B builds: only the bench.py default kernel
-    if (nd == 256 && m == 4 && nh == 63 && p.nco == 2 && !fa.am && fa.group == 16) {
-        if (q15) return launch_ssb_split16_q15(nd, m, nh, p, fa, src, dst, st);          // (the regular build's object)
-        return p.lo_period == 256 ? launch_k<3, 256, 4, 63, float, float, 0, 16>(p, fa, src, dst, st)
-                                  : launch_k<2, 256, 4, 63, float, float, 0, 16>(p, fa, src, dst, st);
-    }
-    return hipErrorNotSupported;
-#else
     if (q15) return launch_ssb_split16_q15(nd, m, nh, p, fa, src, dst, st);              // rx_split16_q15.hip
 #define X(ND_, M_, NH_) if (nd == ND_ && m == M_ && nh == NH_) return launch_nco<ND_, M_, NH_, float>(p, fa, src, dst, st);
     SRX_SPLIT16_SHAPES(X)
 #undef X
     return hipErrorNotSupported;
-#endif
 }
 
 template <int NH, typename TIn, typename TOut>

@@ -1142,7 +1142,7 @@ static hipError_t launch_k(const RxParams &p, const FusedArgs &fa, const void *s
             resident = -1;
         else
             resident = per_cu * prop.multiProcessorCount;
-        if (const char *e = std::getenv("SELENITE_RX_SPLIT16_GRID")) resident = std::atoi(e) > 0 ? std::atoi(e) : -1;
+        if (const char *e = diag_env("SELENITE_RX_SPLIT16_GRID")) resident = std::atoi(e) > 0 ? std::atoi(e) : -1;
     }
     const uint32_t grid = resident > 0 && (uint32_t)resident < p.channels ? (uint32_t)resident : p.channels;
     if constexpr (GROUP == 16 && AM == 0 && sizeof(TOut) == 4) {

@@ -7,7 +7,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <cmath>
+#include <cstddef>
 #include <cstdlib>
+#include <cstring>
 #include <string>
 #include <vector>
 
@@ -26,7 +28,7 @@ struct selenite_tx_instance {
     size_t io_in_bytes = 0, io_out_bytes = 0;
     std::vector<uint32_t> h_step;
     // fused-kernel planning (tx_fused.hip) and the shared LO of a call
-    bool delay_is_impulse = false, hilb_odd_only = false, phase_uniform = true, steps_same = true, force_generic = false;
+    bool delay_is_impulse = false, hilb_odd_only = false, phase_uniform = true, steps_same = true, force_generic = false, no_periodic_lo = false;
     uint32_t delay_index = 0, phase_host = 0;
     float2 *d_lo = nullptr;
     bool lo_valid = false; uint32_t lo_phase = 0, lo_step = 0, lo_n = 0;   // what d_lo holds
@@ -293,8 +295,7 @@ int run(selenite_tx_instance *S, const void *src, void *dst, bool q15, uint32_t 
         }
         if (g.arith == SELENITE_ARITH_SPLIT16 && S->d_ttab16) {
             TxParams ps = p;
-            const char *npl = std::getenv("SELENITE_RX_NO_PERIODIC_LO");
-            ps.lo_period = (lo && (S->h_step[0] & 0x00FFFFFFu) == 0 && !(npl && npl[0] == '1')) ? 256u : 0u;   // k_tx_split16 keeps it in registers
+            ps.lo_period = (lo && (S->h_step[0] & 0x00FFFFFFu) == 0 && !S->no_periodic_lo) ? 256u : 0u;   // k_tx_split16 keeps it in registers
             TCHK(S, launch_tx_split16(ps, S->delay_index, lo, S->d_ttab16, S->tpost, src, q15, dst, S->stream));
         }
         else
@@ -363,11 +364,26 @@ void process_host(selenite_tx_instance *S, const void *src, void *dst, uint32_t 
 
 }  // namespace
 
-extern "C" int selenite_tx_init(selenite_tx_instance **out, const selenite_tx_config *g)
+extern "C" int selenite_tx_init(selenite_tx_instance **out, const selenite_tx_config *caller_cfg)
 {
     if (!out) return SELENITE_RX_ARGUMENT_ERROR;
     *out = nullptr;
-    if (!g || g->struct_size != sizeof(*g) || g->q15_rounding > 1u || !g->channels || !g->block || !g->interp || !tx_mode_ok(g->mode) ||
+    if (!caller_cfg) return SELENITE_RX_ARGUMENT_ERROR;
+    // struct_size says which header the caller was built against (include/selenite_rx.h: ABI versions); version 1 ends with alc_gain_init
+    static_assert(offsetof(selenite_tx_config, q15_rounding) == 92 && sizeof(selenite_tx_config) == 104, "selenite_tx_config layout (LP64)");
+    selenite_tx_config own{};
+    if (caller_cfg->struct_size == SELENITE_TX_CONFIG_SIZE_V1) {
+        std::memcpy(&own, caller_cfg, offsetof(selenite_tx_config, q15_rounding));
+        own.abi_version = 1;
+    } else if (caller_cfg->struct_size == sizeof(selenite_tx_config)) {
+        own = *caller_cfg;
+        if (own.abi_version != SELENITE_RX_ABI_VERSION || own.reserved != 0) return SELENITE_RX_ARGUMENT_ERROR;
+    } else {
+        return SELENITE_RX_ARGUMENT_ERROR;
+    }
+    own.struct_size = (uint32_t)sizeof(selenite_tx_config);
+    const selenite_tx_config *g = &own;
+    if (g->q15_rounding > 1u || !g->channels || !g->block || !g->interp || !tx_mode_ok(g->mode) ||
         g->arith > SELENITE_ARITH_SPLIT16)
         return SELENITE_RX_ARGUMENT_ERROR;
     if ((g->interp > 1) != (g->ni_taps > 0)) return SELENITE_RX_ARGUMENT_ERROR;
@@ -410,8 +426,9 @@ extern "C" int selenite_tx_init(selenite_tx_instance **out, const selenite_tx_co
                 }
             S->hilb_odd_only = ok;
         }
-        const char *fg = std::getenv("SELENITE_TX_FORCE_GENERIC");
-        S->force_generic = fg && fg[0] == '1';
+        // kernel-selection overrides of the tests (selenite_rx_set_plan_option)
+        S->force_generic = srx::plan_option(SELENITE_RX_OPT_TX_FORCE_GENERIC) != 0;
+        S->no_periodic_lo = srx::plan_option(SELENITE_RX_OPT_NO_PERIODIC_LO) != 0;
     }
     if (g->arith == SELENITE_ARITH_SPLIT16 && tx_fused_ok(*g, S->delay_is_impulse, S->hilb_odd_only, 256) &&
         build_tx_split16_table(g->interp_coeffs, &S->d_ttab16, &S->tpost) != hipSuccess)

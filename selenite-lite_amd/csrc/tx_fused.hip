@@ -572,7 +572,7 @@ hipError_t launch_s16(const TxParams &p, uint32_t delay_idx, const float2 *lo, c
             resident = -1;
         else
             resident = per_cu * prop.multiProcessorCount;
-        if (const char *e = std::getenv("SELENITE_TX_SPLIT16_GRID")) resident = std::atoi(e) > 0 ? std::atoi(e) : -1;
+        if (const char *e = diag_env("SELENITE_TX_SPLIT16_GRID")) resident = std::atoi(e) > 0 ? std::atoi(e) : -1;
     }
     const dim3 grid(resident > 0 && (uint32_t)resident < p.channels ? (uint32_t)resident : p.channels), blk(64);
     const TIn *s = static_cast<const TIn *>(src);

@@ -38,6 +38,7 @@ int main(int argc, char **argv)
     memset(&cfg, 0, sizeof cfg);
     if (selenite_rx_design_lowpass(dec, 256, 0.4 / 4) || selenite_rx_design_hilbert(hilb, dly, 63)) return 1;
     cfg.struct_size = sizeof cfg;
+    cfg.abi_version = SELENITE_RX_ABI_VERSION;
     cfg.channels = channels; cfg.block = 256; cfg.decim = 4; cfg.nd_taps = 256; cfg.nh_taps = 63;
     cfg.arith = (uint8_t)arith; cfg.mode = SELENITE_MODE_USB;
     cfg.nco_enable = 1; cfg.nco_step_all = 0x01000000u; cfg.agc_enable = 1;

@@ -37,6 +37,7 @@ int DSP_Init(void)
     if (selenite_rx_design_lowpass(dec, DSP_ND_TAPS, 0.4 / DSP_DECIM)) return -1;
     if (selenite_rx_design_hilbert(hilb, dly, DSP_NH_TAPS)) return -1;
     cfg.struct_size = sizeof cfg;
+    cfg.abi_version = SELENITE_RX_ABI_VERSION;
     cfg.channels = DSP_CHANNELS; cfg.block = DSP_BLOCK; cfg.decim = DSP_DECIM;
     cfg.nd_taps = DSP_ND_TAPS; cfg.nh_taps = DSP_NH_TAPS;
     cfg.arith = SELENITE_ARITH_CMSIS;

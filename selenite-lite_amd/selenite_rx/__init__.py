@@ -18,6 +18,8 @@ if os.environ.get("SELENITE_RX_LIB"):            # A/B experiments: another buil
 
 MODE_LSB, MODE_USB, MODE_CW, MODE_CWR, MODE_AM, MODE_FM, MODE_DIG, MODE_PKT = 0, 1, 2, 3, 4, 8, 0x0A, 0x0C
 ARITH_CMSIS, ARITH_FMA, ARITH_SPLIT16, ARITH_AUTO = 0, 1, 2, 3
+ABI_VERSION, CONFIG_SIZE_V1, TX_CONFIG_SIZE_V1 = 2, 112, 96      # include/selenite_rx.h, selenite_tx.h
+OPT_FORCE_GENERIC, OPT_NO_SHARED_LO, OPT_NO_PERIODIC_LO, OPT_RERUN_GRID, OPT_TX_FORCE_GENERIC = 0, 1, 2, 3, 4      # selenite_rx_set_plan_option
 SUCCESS, ARGUMENT_ERROR, LENGTH_ERROR, NANINF, DEVICE_ERROR = 0, -1, -2, -4, -7
 
 f32p = C.POINTER(C.c_float)
@@ -38,7 +40,7 @@ class Config(C.Structure):
         ("agc_target", C.c_float), ("agc_attack", C.c_float), ("agc_decay", C.c_float),
         ("agc_gain_min", C.c_float), ("agc_gain_max", C.c_float), ("agc_env_floor", C.c_float),
         ("agc_gain_init", C.c_float),
-        ("q15_rounding", C.c_uint32),
+        ("q15_rounding", C.c_uint32), ("abi_version", C.c_uint32), ("reserved", C.c_uint32),     # ABI version 2 (version 1 ends with agc_gain_init)
     ]
 
 
@@ -63,7 +65,7 @@ ABI_SYMBOLS = [
     "selenite_rx_abi_version",
     "selenite_rx_global_process_f32_device",
     "selenite_rx_host_alloc", "selenite_rx_host_free", "selenite_rx_host_register", "selenite_rx_host_unregister",
-    "selenite_rx_time_process_each_device", "selenite_rx_time_streaming_roof_device", "selenite_rx_time_pattern_roof_device", "selenite_rx_device_pci_bus_id",
+    "selenite_rx_time_process_each_device", "selenite_rx_time_streaming_roof_device", "selenite_rx_time_pattern_roof_device", "selenite_rx_device_pci_bus_id", "selenite_rx_set_plan_option", "selenite_rx_get_plan_option",
     "selenite_rx_set_guard_ratio", "selenite_rx_guard_stats", "selenite_rx_guard_channels", "selenite_rx_auto_words", "selenite_rx_guard_handover", "selenite_rx_set_handover_repair", "selenite_rx_set_auto_launches", "selenite_rx_auto_launches_last", "selenite_rx_guard_clear",
 ]
 
@@ -78,7 +80,7 @@ class TxConfig(C.Structure):
         ("alc_target", C.c_float), ("alc_attack", C.c_float), ("alc_decay", C.c_float),
         ("alc_gain_min", C.c_float), ("alc_gain_max", C.c_float), ("alc_env_floor", C.c_float),
         ("alc_gain_init", C.c_float),
-        ("q15_rounding", C.c_uint32),
+        ("q15_rounding", C.c_uint32), ("abi_version", C.c_uint32), ("reserved", C.c_uint32),     # ABI version 2
     ]
 
 
@@ -166,6 +168,9 @@ def lib():
         u64p = C.POINTER(C.c_uint64)
         L.selenite_rx_time_process_each_device.argtypes = [vp, vp, vp, C.c_uint32, C.c_uint32, f32p, C.c_int]
         L.selenite_rx_time_streaming_roof_device.argtypes = [vp, vp, vp, C.c_uint32, C.c_uint32, f32p, C.c_int]
+        L.selenite_rx_set_plan_option.argtypes = [C.c_int, C.c_uint32]
+        L.selenite_rx_get_plan_option.argtypes = [C.c_int]
+        L.selenite_rx_get_plan_option.restype = C.c_uint32
         L.selenite_rx_time_pattern_roof_device.argtypes = [vp, vp, vp, C.c_uint32, C.c_uint32, f32p, C.c_int, C.c_uint32]
         L.selenite_rx_device_pci_bus_id.argtypes = [C.c_int, C.c_char_p, C.c_size_t]
         L.selenite_rx_set_guard_ratio.argtypes = [vp, C.c_float]
@@ -288,6 +293,24 @@ class RxError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__("selenite_rx error %d: %s" % (code, msg))
         self.code = code
+
+
+class plan_option:
+    """`with plan_option(OPT_FORCE_GENERIC):` -- a kernel-selection override of the library (selenite_rx_set_plan_option) for the instances created
+    inside the block; restored afterwards.  Results do not depend on it: the tests use it to reach every product path."""
+
+    def __init__(self, option, value=1):
+        self.option, self.value = option, value
+
+    def __enter__(self):
+        self.old = lib().selenite_rx_get_plan_option(self.option)
+        if lib().selenite_rx_set_plan_option(self.option, self.value) != SUCCESS:
+            raise ValueError("selenite_rx_set_plan_option(%d, %d)" % (self.option, self.value))
+        return self
+
+    def __exit__(self, *exc):
+        lib().selenite_rx_set_plan_option(self.option, self.old)
+        return False
 
 
 class Rx:

@@ -88,7 +88,10 @@ class ChainSpec:
 
     def config(self):
         g = Config()
-        g.struct_size = C.sizeof(Config)
+        # (SELENITE_RX_LIB may name an older build for an A/B comparison: a version-1 library gets the version-1 struct_size -- the library
+        # then reads nothing behind agc_gain_init but q15_rounding, which the round-5 builds kept in that padding)
+        from . import lib, CONFIG_SIZE_V1
+        g.struct_size = C.sizeof(Config) if lib().selenite_rx_abi_version() >= 2 else CONFIG_SIZE_V1
         g.channels, g.block, g.decim = self.channels, self.block, self.decim
         g.nd_taps, g.nh_taps, g.n_biquad, g.arith = self.nd_taps, self.nh_taps, self.n_biquad, self.arith
         g.mode, g.nco_enable = self.mode, int(self.nco)
@@ -102,6 +105,7 @@ class ChainSpec:
         g.agc_gain_min, g.agc_gain_max = p["gain_min"], p["gain_max"]
         g.agc_env_floor, g.agc_gain_init = p["env_floor"], p["gain_init"]
         g.q15_rounding = int(self.q15_rounding)
+        g.abi_version = 2
         g._keepalive = self          # the struct only holds raw pointers into this spec's arrays
         return g
 

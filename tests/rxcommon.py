@@ -400,6 +400,7 @@ class TxSpec:
         g.alc_gain_min, g.alc_gain_max = p["gain_min"], p["gain_max"]
         g.alc_env_floor, g.alc_gain_init = p["env_floor"], p["gain_init"]
         g.q15_rounding = int(self.q15_rounding)
+        g.abi_version = 2
         g._keepalive = self
         return g
 

@@ -632,9 +632,8 @@ def test_per_channel_lo_on_the_fs256_grid_is_held_in_registers_and_bit_identical
     steps = (rng.integers(0, 256, nch).astype(np.uint32) << 24).astype(np.uint32)
     phases = rng.integers(0, 1 << 32, nch, dtype=np.uint64).astype(np.uint32)
     kw = dict(nco=True, nco_steps=steps, agc=True)
-    os.environ["SELENITE_RX_NO_PERIODIC_LO"] = "1"
-    g1 = sr.Rx(spec_of(shape, nch, ARITH_SPLIT16, **kw).config())
-    del os.environ["SELENITE_RX_NO_PERIODIC_LO"]
+    with sr.plan_option(sr.OPT_NO_PERIODIC_LO):
+        g1 = sr.Rx(spec_of(shape, nch, ARITH_SPLIT16, **kw).config())
     g4 = sr.Rx(spec_of(shape, nch, ARITH_SPLIT16, **kw).config())
     o = CpuChain(spec_of(shape, nch, ARITH_CMSIS, **kw), "orc")
     st = o.state(); st["nco_phase"] = phases
@@ -814,6 +813,7 @@ import rxcommon as rc
 import selenite_rx as sr
 nch = 6144
 steps = np.where(np.arange(nch) % 4 == 0, 0x01000000, 0x40000000).astype(np.uint32)      # three channels in four out of band: guarded
+assert sr.lib().selenite_rx_set_plan_option(sr.OPT_RERUN_GRID, int(sys.argv[3])) == 0
 g = sr.Rx(rc.ChainSpec(nch, 256, 4, 256, 63, 0, rc.MODE_USB, rc.ARITH_AUTO, nco=True, nco_steps=steps).config())
 h = hashlib.sha256()
 for k in range(4):
@@ -829,7 +829,7 @@ print(h.hexdigest(), g.guard_stats()["rerun_channel_calls"])
 
 def test_the_size_of_the_rerun_grid_never_changes_a_result():
     """The rerun pass of SELENITE_ARITH_AUTO strides a dense list whose ORDER varies from run to run (one atomic per 1024 channels) with
-    a grid the host sizes from the last call's list length (2048 or 16 384 workgroups; SELENITE_RX_RERUN_GRID pins it).  Every channel is
+    a grid the host sizes from the last call's list length (2048 or 16 384 workgroups; selenite_rx_set_plan_option(SELENITE_RX_OPT_RERUN_GRID) pins it).  Every channel is
     computed on its own, so audio, state and channel words must be the same bits for any grid -- here 64, 2048, 16 384 workgroups and the
     adaptive default (which switches after the first call: three channels in four are guarded), each in a process of its own."""
     import subprocess
@@ -837,12 +837,8 @@ def test_the_size_of_the_rerun_grid_never_changes_a_result():
     here = os.path.dirname(os.path.abspath(__file__))
     pkg = os.path.join(os.path.dirname(here), "selenite-lite_amd")
     outs = []
-    for grid in ("64", "2048", "16384", None):
-        env = dict(os.environ)
-        env.pop("SELENITE_RX_RERUN_GRID", None)
-        if grid:
-            env["SELENITE_RX_RERUN_GRID"] = grid
-        r = subprocess.run([sys.executable, "-c", _GRID_SCRIPT, here, pkg], capture_output=True, text=True, timeout=300, env=env)
+    for grid in ("64", "2048", "16384", "0"):
+        r = subprocess.run([sys.executable, "-c", _GRID_SCRIPT, here, pkg, grid], capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append(r.stdout.split())
     assert int(outs[0][1]) >= 3 * 4608                                 # the guarded channels were recomputed (held from the second call on)

@@ -51,6 +51,7 @@ def test_bench_json_contract_default_shape():
     assert d["config"]["kernel"].startswith("k_ssb_split16<256,4,63>+exact rerun") and d["config"]["arith"].startswith("auto")
     assert d["guard_blocks"] == d["guard"]["blocks"] == 0 and d["guard"]["rerun_channel_calls"] == 0      # steady state of the bench signal
     assert d["parity"]["worst_rel"] == d["parity_worst_rel"] <= 1e-5 and d["parity"]["blocks"] > 0 and d["parity"]["against"] in ("reference", "port")
+    assert d["parity"]["bar"] == 1e-5 and d["parity"]["within_bar"] is True
     assert r["launch_ms_median"] > 0 and r["launch_ms_min"] <= r["launch_ms_median"] <= r["launch_ms_p90"]
     for grp, names in (("other_arith_modes", ("split16", "fma", "cmsis")), ("other_nco_modes", ("per_channel", "per_channel_grid", "shared_table"))):
         for n in names:
@@ -79,11 +80,22 @@ def test_bench_json_contract_default_shape():
         assert r2["frac_of_streaming_roof"] < 1.5, (n, r2)               # (a copy slower than the kernel by a few percent happens at 10 us per launch; not by half)
         p2 = e["parity"]
         assert p2["channels"] == 64 and p2["blocks"] > 0 and p2["against"] in ("reference", "port"), n
+        # round 6: every parity figure carries its bar and the verdict against it -- int16 slots: per DSP block
+        # |gpu - ref| <= 1 LSB + 1e-5 x block maximum (LSB), blocks at full scale counted apart (none on the bench signal)
+        assert p2["bar"] is not None and p2["within_bar"] is True, (n, p2)
         if n == "cfg3_q15":
-            assert p2["worst_lsb"] <= 1
+            assert p2["worst_lsb"] <= 1 and p2["worst_margin_lsb"] <= 0 and p2["blocks_at_full_scale"] == 0, p2
         else:
-            assert p2["worst_rel"] <= 1e-5, (n, p2)
+            assert p2["bar"] == 1e-5 and p2["worst_rel"] <= 1e-5, (n, p2)
     assert w["cfg4"]["kernel"] == "k_cw_fused<4,256>" and w["cfg4"]["parity"]["worst_rel"] == 0.0      # bit-exact in every arithmetic mode
+    # round 6: the CW kernel against the roof of ITS fetch pattern (k_cw_roof: same bursts, stores, launch shape, residency; no DSP)
+    pr = w["cfg4"]["roofline"]["pattern_roof"]
+    assert pr["kernel"] == "k_cw_roof" and 0 < pr["pattern_roof_ms"] and abs(pr["frac_of_pattern_roof"] - pr["pattern_roof_ms"] / w["cfg4"]["ms_per_step"]) < 5e-3 + 1.5e-4 / w["cfg4"]["ms_per_step"]
+    # round 6: cfg2 in both placements of its buffers, same run
+    pl = w["cfg2"]["placement"]
+    for k in ("separate_allocations", "one_allocation"):
+        assert pl[k]["ms_per_step"] > 0 and 0 < pl[k]["frac"] < 1 and pl[k]["streaming_roof_ms"] > 0, k
+    assert pl["separate_allocations"]["ms_per_step"] == w["cfg2"]["ms_per_step"]
     assert w["cfg2"]["kernel"].startswith("k_hilb_split16<127>") and w["cfg5"]["kernel"].startswith("k_hilb_split16<127>")
     assert "mall_note" in w["cfg5"] and w["cfg3_q15"]["io"] == "q15"
 

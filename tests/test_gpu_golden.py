@@ -43,12 +43,8 @@ def test_chain_fixture(name, generic):
     kind, arg, channels, nblocks, ncalls = mg.CHAIN_CASES[name]
     spec = mg.chain_spec(kind, arg, channels)
     gold = np.load(os.path.join(G, "chain_%s.npz" % name))
-    if generic:
-        os.environ["SELENITE_RX_FORCE_GENERIC"] = "1"
-    try:
+    with sr.plan_option(sr.OPT_FORCE_GENERIC, 1 if generic else 0):
         rx = sr.Rx(spec.config())
-    finally:
-        os.environ.pop("SELENITE_RX_FORCE_GENERIC", None)
     bs = spec.block * nblocks
     for call in range(ncalls):
         iq = rc.synth_iq(0, channels, call * bs, bs)

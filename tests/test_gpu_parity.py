@@ -212,11 +212,8 @@ def test_generic_and_fused_paths_agree():
         spec = baseline_spec(name, 300)
         iq = synth_iq(0, 300, 0, 2048)
         fused = gpu_rx(spec)
-        os.environ["SELENITE_RX_FORCE_GENERIC"] = "1"
-        try:
+        with sr.plan_option(sr.OPT_FORCE_GENERIC):
             gen = gpu_rx(spec)
-        finally:
-            del os.environ["SELENITE_RX_FORCE_GENERIC"]
         assert gen.kernel_name() == "generic"
         for _ in range(2):
             assert bits_equal(fused.process(iq), gen.process(iq)), name
@@ -227,11 +224,9 @@ def test_shared_lo_table_path_equals_per_channel_nco():
     be indistinguishable from the per-channel in-kernel NCO, also across set_state/reset."""
     spec = baseline_spec("cfg3", 5)
     shared = gpu_rx(spec)
-    os.environ["SELENITE_RX_NO_SHARED_LO"] = "1"
-    try:
+    import selenite_rx as sr
+    with sr.plan_option(sr.OPT_NO_SHARED_LO):
         per_ch = gpu_rx(spec)
-    finally:
-        del os.environ["SELENITE_RX_NO_SHARED_LO"]
     o = CpuChain(spec, "orc")
     for call in range(3):
         iq = synth_iq(0, 5, call * 1024, 1024)
@@ -289,11 +284,9 @@ def test_cw_fused_q15_and_vs_generic_large():
     spec = baseline_spec("cfg4", 1024)
     iq = synth_iq(0, 1024, 0, 2048)
     fused = gpu_rx(spec)
-    os.environ["SELENITE_RX_FORCE_GENERIC"] = "1"
-    try:
+    import selenite_rx as sr
+    with sr.plan_option(sr.OPT_FORCE_GENERIC):
         gen = gpu_rx(spec)
-    finally:
-        del os.environ["SELENITE_RX_FORCE_GENERIC"]
     assert fused.kernel_name() == "k_cw_fused<4,256>" and gen.kernel_name() == "generic"
     for _ in range(2):
         assert bits_equal(fused.process(iq), gen.process(iq))
@@ -806,11 +799,9 @@ def test_periodic_shared_lo_in_registers_equals_the_table_path_bit_for_bit(q15):
     nch = 70
     spec = baseline_spec("cfg3", nch, rc.ARITH_SPLIT16)           # step 0x01000000
     reg = gpu_rx(spec)
-    os.environ["SELENITE_RX_NO_PERIODIC_LO"] = "1"
-    try:
+    import selenite_rx as sr
+    with sr.plan_option(sr.OPT_NO_PERIODIC_LO):
         tab = gpu_rx(spec)
-    finally:
-        del os.environ["SELENITE_RX_NO_PERIODIC_LO"]
     assert "registers" in reg.nco_path() and reg.kernel_name() == "k_ssb_split16<256,4,63>"
     assert tab.nco_path() == "shared LO table per call"
     st = reg.state()

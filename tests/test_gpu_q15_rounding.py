@@ -36,12 +36,8 @@ def test_fixture(name, path):
     arg, channels, bs, ncalls = m.CASES[name]
     gold = np.load(os.path.join(G, "q15_rounding.npz"))["chain_" + name]
     spec = m.case_spec(arg, channels, arith=rc.ARITH_FMA if path == "fma" else rc.ARITH_CMSIS)
-    if path == "generic":
-        os.environ["SELENITE_RX_FORCE_GENERIC"] = "1"
-    try:
+    with sr.plan_option(sr.OPT_FORCE_GENERIC, 1 if path == "generic" else 0):
         rx = sr.Rx(spec.config())
-    finally:
-        os.environ.pop("SELENITE_RX_FORCE_GENERIC", None)
     for call in range(ncalls):
         y = rx.process_q15(m.case_input(channels, call, bs))
         if path == "fma":
@@ -117,3 +113,25 @@ def test_tx_init_refuses_other_values():
     h = C.c_void_p()
     sr.lib().selenite_tx_init.argtypes = [C.POINTER(C.c_void_p), C.POINTER(sr.TxConfig)]
     assert sr.lib().selenite_tx_init(C.byref(h), C.byref(g)) == rc.ARGUMENT_ERROR
+
+
+def test_version_1_caller_with_garbage_in_its_padding_truncates():
+    """ABI version 2 (include/selenite_rx.h): q15_rounding sits where version 1's selenite_rx_config had tail padding.  A caller built against
+    the version-1 header (struct_size 112) whose padding bytes are 0xFF initialises and gets the firmware's truncating arm_float_to_q15
+    (arm_float_to_q15.c:117) -- the words of round 4 -- not an ARGUMENT_ERROR and not the rounding build."""
+    import selenite_rx as sr
+    spec = rc.baseline_spec("cfg4", 40)
+    cfg = spec.config()
+    cfg.struct_size = sr.CONFIG_SIZE_V1
+    cfg.q15_rounding, cfg.abi_version, cfg.reserved = 0xFFFFFFFF, 0xFFFFFFFF, 0xFFFFFFFF
+    rx = sr.Rx(cfg)
+    o = CpuChain(spec, "orc")                                          # q15_rounding False: truncation
+    orr = CpuChain(rc.baseline_spec("cfg4", 40, q15_rounding=True), "orc")
+    differs = False
+    for call in range(2):
+        iq = rc.synth_iq(0, 40, 1024 * call, 1024)
+        q = np.clip(np.trunc(iq * np.float32(32768.0)), -32768, 32767).astype(np.int16)
+        y, yt, yr = rx.process_q15(q), o.process_q15(q), orr.process_q15(q)
+        assert np.array_equal(y, yt), call
+        differs = differs or not np.array_equal(yt, yr)
+    assert differs                                                     # (the two builds of arm_float_to_q15 do differ on this input)

@@ -170,11 +170,9 @@ def test_tx_fused_q15_and_against_generic_large():
     nch, bs = 4096, 1024
     big = rc.TxSpec(nch)
     fused = gpu_tx(big)
-    os.environ["SELENITE_TX_FORCE_GENERIC"] = "1"
-    try:
+    import selenite_rx as sr
+    with sr.plan_option(sr.OPT_TX_FORCE_GENERIC):
         gen = gpu_tx(big)
-    finally:
-        del os.environ["SELENITE_TX_FORCE_GENERIC"]
     assert fused.kernel_name() == "k_tx_fused<4,256,63>" and gen.kernel_name() == "k_tx_generic"
     a = np.concatenate([rc.synth_audio(c0, 512, 0, bs) for c0 in range(0, nch, 512)], axis=0)
     for _ in range(2):
@@ -266,7 +264,10 @@ def test_tx_periodic_shared_lo_in_registers_equals_the_table_path_bit_for_bit(q1
     import os
     spec = rc.TxSpec(70, arith=rc.ARITH_SPLIT16)
     assert spec.nco_step_all & 0x00FFFFFF == 0
-    reg, tab = gpu_tx(spec), gpu_tx(spec)
+    import selenite_rx as sr
+    reg = gpu_tx(spec)
+    with sr.plan_option(sr.OPT_NO_PERIODIC_LO):                       # (taken over when the instance is created)
+        tab = gpu_tx(spec)
     st = reg.state()
     st["nco_phase"][:] = 0x3456789A
     reg.set_state(st)
@@ -276,11 +277,7 @@ def test_tx_periodic_shared_lo_in_registers_equals_the_table_path_bit_for_bit(q1
         if q15:
             a = np.clip(np.round(a * 20000.0), -32768, 32767).astype(np.int16)
         ya = reg.process_q15(a) if q15 else reg.process(a)
-        os.environ["SELENITE_RX_NO_PERIODIC_LO"] = "1"
-        try:
-            yb = tab.process_q15(a) if q15 else tab.process(a)
-        finally:
-            del os.environ["SELENITE_RX_NO_PERIODIC_LO"]
+        yb = tab.process_q15(a) if q15 else tab.process(a)
         assert np.array_equal(ya.view(np.uint32) if not q15 else ya, yb.view(np.uint32) if not q15 else yb)
     sa, sb = reg.state(), tab.state()
     for key in sa:
