@@ -168,10 +168,11 @@ def lib():
         u64p = C.POINTER(C.c_uint64)
         L.selenite_rx_time_process_each_device.argtypes = [vp, vp, vp, C.c_uint32, C.c_uint32, f32p, C.c_int]
         L.selenite_rx_time_streaming_roof_device.argtypes = [vp, vp, vp, C.c_uint32, C.c_uint32, f32p, C.c_int]
-        L.selenite_rx_set_plan_option.argtypes = [C.c_int, C.c_uint32]
-        L.selenite_rx_get_plan_option.argtypes = [C.c_int]
-        L.selenite_rx_get_plan_option.restype = C.c_uint32
-        L.selenite_rx_time_pattern_roof_device.argtypes = [vp, vp, vp, C.c_uint32, C.c_uint32, f32p, C.c_int, C.c_uint32]
+        if hasattr(L, "selenite_rx_set_plan_option"):      # (round-6 entry points: an older build named by SELENITE_RX_LIB for an A/B run lacks them)
+            L.selenite_rx_set_plan_option.argtypes = [C.c_int, C.c_uint32]
+            L.selenite_rx_get_plan_option.argtypes = [C.c_int]
+            L.selenite_rx_get_plan_option.restype = C.c_uint32
+            L.selenite_rx_time_pattern_roof_device.argtypes = [vp, vp, vp, C.c_uint32, C.c_uint32, f32p, C.c_int, C.c_uint32]
         L.selenite_rx_device_pci_bus_id.argtypes = [C.c_int, C.c_char_p, C.c_size_t]
         L.selenite_rx_set_guard_ratio.argtypes = [vp, C.c_float]
         L.selenite_rx_guard_stats.argtypes = [vp, u64p, u64p, u64p]
