@@ -274,12 +274,13 @@ def side_workload(name, q15, arith, spinup_ms, iters=100, rank=0, parity=True, c
     return out
 
 
-def cfg5_scaling_leg(env, rank, world, arith, steps, warmup, spinup_ms):
+def cfg5_scaling_leg(env, rank, world, arith, steps, warmup, spinup_ms, channels_override=0, n1_ms=0.0):
     """N > 1: the shape BASELINE.json's weak-scaling config names -- 131 072 channels per GPU of the cfg2 chain, 1024 samples per call -- timed on
     every rank the way the headline is (barrier + synchronize on both sides, MAX over ranks), beside the default cfg3 leg of the same line."""
     import selenite_rx as sr
     from selenite_rx import chain as ch
     cfg_name, channels, bs = ch.WORKLOADS["cfg5"]
+    channels = channels_override or channels             # (--channels: a scaled-down run scales this leg with it, 2 x the headline's count as in BASELINE)
     spec = ch.baseline_spec(cfg_name, channels, arith)
     rx = sr.Rx(spec.config())
     d_in = sr.DeviceBuffer(channels * bs * 8)
@@ -304,7 +305,8 @@ def cfg5_scaling_leg(env, rank, world, arith, steps, warmup, spinup_ms):
     kernel = rx.kernel_name()
     rx.close(); d_in.free(); d_out.free()
     ms = elapsed * 1e3 / steps
-    return {"workload": "cfg5: %d channels/GPU x %d complex samples/call, %s" % (channels, bs, WORKLOAD_TEXT["cfg5"]), "kernel": kernel,
+    eff = {"weak_scaling_efficiency": round(n1_ms / ms, 4), "n1_ms_per_step": n1_ms} if n1_ms > 0 else {}
+    return {**eff, "workload": "cfg5: %d channels/GPU x %d complex samples/call, %s" % (channels, bs, WORKLOAD_TEXT["cfg5"]), "kernel": kernel,
             "value": round(float(world) * channels * bs * steps / elapsed / 1e6, 2), "unit": "Msamples/s", "n_gpus": world, "scaling": "weak",
             "steps": steps, "ms_per_step": round(ms, 4), "per_gpu_msamples_s": round(channels * bs * steps / elapsed / 1e6, 2),
             "roofline_frac_per_gpu": round(alg_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
@@ -391,6 +393,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--main-only", action="store_true", help="profiling runs: skip the cpu_baseline and other-mode legs")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"])
+    ap.add_argument("--n1-ms", type=float, default=0.0,
+                    help="ms_per_step of the SAME command at --gpus 1 (a stored figure): the N > 1 line then carries weak_scaling_efficiency = that / its own "
+                         "ms_per_step (the driver computes its own from the per-N values; this is for a human running one N)")
+    ap.add_argument("--n1-cfg5-ms", type=float, default=0.0, help="... and of the cfg5 shard (workloads.cfg5.ms_per_step of the N = 1 line) for cfg5_weak_scaling")
     ap.add_argument("--selftest-launch", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
@@ -553,9 +559,11 @@ def main():
             roof_ms = np.sort(rx.time_streaming_roof(d_in.ptr, d_out.ptr, bs, 200, q15))
     env.barrier()
     cfg5_line = None
-    if world > 1 and args.workload == "cfg3" and not args.global_gain and not q15 and not args.channels and not args.block_size:
+    # (every run that has a process group: N > 1, and the one-rank group of SELENITE_BENCH_FORCE_DIST -- the N > 1 code path on a one-GPU box)
+    if (world > 1 or env.dist is not None) and args.workload == "cfg3" and not args.global_gain and not q15 and not args.block_size:
         env.stage("cfg5 weak-scaling leg")
-        cfg5_line = cfg5_scaling_leg(env, rank, world, arith, args.steps, args.warmup, args.spinup_ms / 3.0)
+        cfg5_line = cfg5_scaling_leg(env, rank, world, arith, args.steps, args.warmup, args.spinup_ms / 3.0,
+                                     channels_override=2 * args.channels, n1_ms=args.n1_cfg5_ms)
 
     if rank == 0:
         ms_per_step = elapsed * 1e3 / args.steps
@@ -647,6 +655,9 @@ def main():
             out["dist"] = dist_block(env, devices, 1 if args.global_gain else 0, per_rank_ms, comm)
         if cfg5_line is not None:
             out["cfg5_weak_scaling"] = cfg5_line
+        if args.n1_ms > 0:
+            out["weak_scaling_efficiency"] = round(args.n1_ms / ms_per_step, 4)      # T_1 / T_N at fixed work per GPU, from the figure handed in
+            out["n1_ms_per_step"] = args.n1_ms
         if world == 1 and not args.global_gain and not args.main_only:
             # the same workload in the other arithmetic contracts and with the general NCO flavours, outside the timed
             # region; every leg: own spin-up, >= 100 launches, median of per-launch HIP-event durations

@@ -293,7 +293,7 @@ __device__ __forceinline__ void demod_agc_store(const RxParams &p, const FusedAr
             // went through the caches until round 5)
             const v4f av = { au[0], au[1], au[2], au[3] };
             if (p.out_cached) *at = av;                                       // global gain, phase 1: the gain pass reads it back
-            else asm volatile("global_store_dwordx4 %0, %1, off nt" :: "v"(at), "v"(av) : "memory");
+            else asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" :: "v"(at), "v"(av) : "memory");      // (s_nop: the wait states a VALU write of the data registers needs behind a store wider than 64 bits -- the compiler does not see into the asm)
         } else {
             typedef uint32_t w2v __attribute__((ext_vector_type(2)));
             uint32_t w0, w1;

@@ -72,19 +72,29 @@ def launch_ranks(nproc, script, argv, env=None, timeout=None):
     stage_dir = tempfile.mkdtemp(prefix="selenite_ranks_")
     procs = []
 
-    def die_with_parent():
-        # a rank outlives its launcher only if the launcher is killed outright (SIGKILL skips every handler below): ask the kernel to
-        # kill the rank then.  Runs in the child between fork and exec -- the rank has not touched the GPU yet.
+    # a rank outlives its launcher only if the launcher is killed outright (SIGKILL skips every handler below): ask the kernel to kill the
+    # rank then (PR_SET_PDEATHSIG).  libc's prctl is resolved HERE, in the parent: between fork and exec the child calls that one C function and
+    # nothing else (no import, no dlopen -- neither is safe in the child of a process that may have threads).  The signal fires when the
+    # forking THREAD exits, so it is only armed when the launcher runs in the main thread, whose exit is the process's.
+    prctl = None
+    if threading.current_thread() is threading.main_thread():
         try:
             import ctypes
-            ctypes.CDLL("libc.so.6", use_errno=True).prctl(1, signal.SIGKILL, 0, 0, 0)      # PR_SET_PDEATHSIG
-        except Exception:
-            pass
+            prctl = ctypes.CDLL(None, use_errno=True).prctl
+            prctl.argtypes = [ctypes.c_int, ctypes.c_ulong, ctypes.c_ulong, ctypes.c_ulong, ctypes.c_ulong]
+            prctl.restype = ctypes.c_int
+        except (OSError, AttributeError):
+            prctl = None
+    kill_sig = int(signal.SIGKILL)
+
+    def die_with_parent():
+        prctl(1, kill_sig, 0, 0, 0)                          # PR_SET_PDEATHSIG
 
     for r in range(nproc):
         e = dict(base, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(nproc), LOCAL_WORLD_SIZE=str(nproc),
                  MASTER_ADDR="127.0.0.1", MASTER_PORT=port, SELENITE_RANK_STAGE_DIR=stage_dir)
-        procs.append(subprocess.Popen([sys.executable, script] + list(argv), env=e, start_new_session=True, preexec_fn=die_with_parent))
+        procs.append(subprocess.Popen([sys.executable, script] + list(argv), env=e, start_new_session=True,
+                                      preexec_fn=die_with_parent if prctl is not None else None))
 
     def stage(r):
         try:
@@ -139,6 +149,12 @@ def launch_ranks(nproc, script, argv, env=None, timeout=None):
                 break
             time.sleep(0.05)
     finally:
+        # (a second SIGTERM while the ranks are being taken down must not abort the taking down: from here on the signals are ignored)
+        for sg in previous:
+            try:
+                signal.signal(sg, signal.SIG_IGN)
+            except (OSError, ValueError):
+                pass
         kill_all()
         for sg, h in previous.items():
             try:

@@ -139,6 +139,9 @@ def test_bench_launches_its_own_ranks_and_shards_the_channels():
     assert ds["backend"] == "gloo" and ds["world"] == 2 and len(ds["devices"]) == 2 and ds["collectives_per_step"] == 0
     assert all(":" in x for x in ds["devices"]) and len(ds["per_rank_ms_per_step"]) == 2
     assert max(ds["per_rank_ms_per_step"]) <= d["ms_per_step"] * 1.001 + 1e-3
+    assert ds["comm_count"] == 2
+    w5 = d["cfg5_weak_scaling"]                                        # the BASELINE cfg5 leg of every N > 1 line (scaled by --channels here)
+    assert w5["n_gpus"] == 2 and abs(w5["per_gpu_msamples_s"] * 2 - w5["value"]) <= 0.01 * w5["value"]
     g = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--dist-backend", "gloo", "--steps", "3", "--warmup", "1",
                         "--spinup-ms", "0", "--channels", "1024", "--main-only", "--global-gain"], capture_output=True,
                        text=True, timeout=900, env=env)
@@ -153,7 +156,7 @@ def test_bench_under_the_nccl_backend_with_one_rank_carries_the_dist_block():
     all-reduce on the library's stream."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
     env.update(SELENITE_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29611", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    for extra, coll in (([], 0), (["--global-gain"], 1)):
+    for extra, coll in ((["--n1-ms", "0.5", "--n1-cfg5-ms", "0.25"], 0), (["--global-gain"], 1)):
         out = subprocess.run([sys.executable, BENCH, "--steps", "3", "--warmup", "4", "--spinup-ms", "0", "--channels", "1024",
                               "--main-only"] + extra, capture_output=True, text=True, timeout=900, env=env)
         assert out.returncode == 0, out.stderr[-2000:]
@@ -161,6 +164,17 @@ def test_bench_under_the_nccl_backend_with_one_rank_carries_the_dist_block():
         ds = d["dist"]
         assert ds["backend"] == "nccl" and ds["world"] == 1 and ds["collectives_per_step"] == coll
         assert len(ds["devices"]) == 1 and ":" in ds["devices"][0] and len(ds["per_rank_ms_per_step"]) == 1
+        # round 6: what an N > 1 line carries, asserted on the N > 1 code path a one-GPU box can run -- the communicator's size as
+        # RCCL counted it equals the world, one distinct PCI bus id per rank, and (per-channel AGC) the cfg5 weak-scaling leg with its efficiency field
+        assert ds["comm_count"] == ds["world"] == d["n_gpus"] and len(set(ds["devices"])) == ds["world"]
+        if not coll:
+            w5 = d["cfg5_weak_scaling"]
+            assert w5["n_gpus"] == 1 and w5["scaling"] == "weak" and w5["kernel"].startswith("k_hilb_split16<127>") and w5["value"] > 0
+            assert "2048 channels/GPU x 1024" in w5["workload"]                          # (--channels 1024 scales the leg: twice the headline's count, as in BASELINE)
+            assert abs(w5["weak_scaling_efficiency"] - 0.25 / w5["ms_per_step"]) < 1e-3 * 0.25 / w5["ms_per_step"] + 1e-4
+            assert abs(d["weak_scaling_efficiency"] - 0.5 / d["ms_per_step"]) < 1e-3 * 0.5 / d["ms_per_step"] + 1e-4
+        else:
+            assert "cfg5_weak_scaling" not in d
 
 
 def test_global_gain_ranks_on_one_stream_match_the_unsharded_oracle():
