@@ -33,7 +33,7 @@ sys.path.insert(0, os.path.join(ROOT, "selenite-lite_amd"))
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 F32_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: f32 vector (= f32 MFMA) peak
-TRAFFIC_JSON = next((p for p in (os.path.join(ROOT, "profiles", r, "traffic.json") for r in ("r5", "r4", "r3", "r2")) if os.path.exists(p)),
+TRAFFIC_JSON = next((p for p in (os.path.join(ROOT, "profiles", r, "traffic.json") for r in ("r6", "r5", "r4", "r3", "r2")) if os.path.exists(p)),
                     os.path.join(ROOT, "profiles", "r3", "traffic.json"))
 
 WORKLOAD_TEXT = {"cfg3": "NCO + 256-tap arm_fir_decimate/4 + 63-tap Hilbert SSB (USB) + AGC",
@@ -176,6 +176,10 @@ class _View:
             self.buf.free()
 
 
+# vector instructions of k_cw_fused<4,2,256> per 128-sample chunk of a wavefront (profiles/r6/sq_cfg4.txt: SQ_INSTS_VALU 1.777e8 / 4096 groups / 32 chunks = 1356)
+CW_VALU_PER_CHUNK = 1360
+
+
 def side_workload(name, q15, arith, spinup_ms, iters=100, rank=0, parity=True, channels_override=0, one_allocation=False):
     """One of the other single-GPU BASELINE configurations on its own resident synthetic batch (the `workloads` block of the default line):
     own instance, own buffers, own clock spin-up, `iters` launches with a HIP event between launches -> MEDIAN per-launch duration
@@ -240,10 +244,14 @@ def side_workload(name, q15, arith, spinup_ms, iters=100, rank=0, parity=True, c
         # bursts, stores, launch shape and residency with no DSP (k_cw_roof, selenite_rx_time_pattern_roof_device)
         rx.time_pattern_roof(d_in.ptr, d_out.ptr, bs, 16, q15, 0)
         p0 = float(np.median(rx.time_pattern_roof(d_in.ptr, d_out.ptr, bs, 60, q15, 0)))
+        p1 = float(np.median(rx.time_pattern_roof(d_in.ptr, d_out.ptr, bs, 60, q15, CW_VALU_PER_CHUNK)))
         pattern = {"kernel": "k_cw_roof", "pattern_roof_ms": round(p0, 4), "frac_of_pattern_roof": round(p0 / med, 4),
-                   "note": "k_cw_fused's own bursts (16 rows x 1 KB per burst, two bursts in flight), stores, one workgroup per 16 channels, same "
-                           "residency, no DSP.  The pattern costs nothing against 4 KB runs; what separates the kernel from it is the ~1400 vector "
-                           "instructions between two bursts of a wave: profiles/r6/cfg4_pattern_roof.md"}
+                   "pattern_roof_with_arith_ms": round(p1, 4), "frac_of_pattern_roof_with_arith": round(p1 / med, 4),
+                   "arith_vector_instructions_per_chunk": CW_VALU_PER_CHUNK,
+                   "note": "k_cw_fused's own bursts (16 rows x 1 KB per burst, two bursts in flight), stores, persistent launch shape and residency, no DSP -- "
+                           "and the same with as many (dependent) vector instructions between two bursts of a wave as the kernel's biquad steps issue "
+                           "(SQ_INSTS_VALU of profiles/r6/sq_cfg4.txt / workgroups / chunks).  The pattern costs nothing against 4 KB runs; what separates "
+                           "the kernel from the plain pattern roof is that arithmetic: profiles/r6/cfg4_pattern_roof.md"}
     rx.sync()
     rx.close(); d_in.free(); d_out.free()
     wl = dict(ch.WORKLOADS, **{k + "_q15": v for k, v in ch.WORKLOADS.items()})

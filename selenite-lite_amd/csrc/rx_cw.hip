@@ -139,23 +139,32 @@ __global__ __launch_bounds__(64) void k_cw_fused(RxParams p, const TIn *__restri
     constexpr int CPR = 16 / NS;                        // channels per 16-lane row
     const int lane = threadIdx.x;
     const int s = (lane & 15) / CPR, ch = (lane >> 4) * CPR + (lane & (CPR - 1));
-    const uint32_t c0 = blockIdx.x * CH;
-    // the last workgroup of a channel count that is not a multiple of CH: lanes past the end work on a
-    // copy of the last channel (every load index is clamped) and none of their stores is issued
-    const bool live = c0 + ch < p.channels;
-    const uint32_t c = live ? c0 + ch : p.channels - 1;
-
+    // Persistent over channel groups: workgroup b takes the groups b, b + gridDim.x, ... (the launcher hands out whole multiples only, else one
+    // group per workgroup) and requests the first two chunks of its NEXT group -- and that group's state -- during the last DSP block of the
+    // present one: a group switch costs no cold memory round trip and no workgroup launch.
+    const uint32_t ngroups = (p.channels + CH - 1) / CH;
+    uint32_t grp = blockIdx.x;
     if constexpr (NCO == 1)
         for (int i = lane; i < 513; i += kWave) tab[i] = p.sintab[i];
     // per-lane stage constants and state
     const float b0 = p.biq_c[5 * s], b1 = p.biq_c[5 * s + 1], b2 = p.biq_c[5 * s + 2];
     const float a1 = p.biq_c[5 * s + 3], a2 = p.biq_c[5 * s + 4];
-    const float4 st = *reinterpret_cast<const float4 *>(p.biq_state + ((size_t)c * NS + s) * 4);      // { x1, x2, y1, y2 } (arm_biquad_cascade_df1_f32.c:73-82)
-    float gain = p.agc ? p.gain[c] : 1.0f;
     bool nonfinite = false;                                           // any audio sample of this wavefront NaN / Inf
+    // the last workgroup of a channel count that is not a multiple of CH: lanes past the end work on a
+    // copy of the last channel (every load index is clamped) and none of their stores is issued
+    auto chan_of = [&](uint32_t g) { const uint32_t cc = g * CH + ch; return cc < p.channels ? cc : p.channels - 1; };
+    struct GroupState { float4 st; float gain; uint32_t ph, stp; };
+    auto load_group_state = [&](uint32_t g) {
+        const uint32_t cc = chan_of(g);
+        GroupState gs;
+        gs.st = *reinterpret_cast<const float4 *>(p.biq_state + ((size_t)cc * NS + s) * 4);      // { x1, x2, y1, y2 } (arm_biquad_cascade_df1_f32.c:73-82)
+        gs.gain = p.agc ? p.gain[cc] : 1.0f;
+        gs.ph = NCO ? p.phase[cc] : 0u; gs.stp = NCO ? p.step[cc] : 0u;
+        return gs;
+    };
+    GroupState gs_cur = load_group_state(grp);
     // load-phase geometry: load j of a chunk covers channel CPL*j + lane/LPC, samples 2*(lane%LPC), +1
     const int lch = lane / CG::LPC, lsm = 2 * (lane % CG::LPC);
-    const uint32_t ph_own = NCO ? p.phase[c] : 0u, st_own = NCO ? p.step[c] : 0u;
     // last-stage lanes write y[4i..4i+3] over x[4i..4i+3] of their channel's row (four dwords from wherever the step left them -- a 16-byte
     // store would want them copied into one aligned register quad first, and instructions are what this kernel is short of)
     const bool last = s == NS - 1;
@@ -180,18 +189,19 @@ __global__ __launch_bounds__(64) void k_cw_fused(RxParams p, const TIn *__restri
     for (int d = 0; d < DEPTH; ++d) lo4[d] = u4v_cw{ 0u, 0u, 0u, 0u };
     // the workgroup's CH channels (fewer in the last workgroup: the range ends with the array), 32-bit offsets inside them
     constexpr int EB = CwRaw<TIn>::kBytes / 2;                        // bytes per complex sample
-    const uint32_t chs = min((uint32_t)CH, p.channels - c0);
-    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<TIn *>(src) + (size_t)c0 * p.in_stride * 2, 0,
-                                                                           (int)(((chs - 1) * p.in_stride + p.block_size) * EB), 0x00020000);
+    auto in_rsrc = [&](uint32_t g) {                                   // the CH channel rows of group g (none past the last group: every load reads 0, no access)
+        const uint32_t cg = g * CH, n = g < ngroups ? min((uint32_t)CH, p.channels - cg) : 0u;
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<TIn *>(src) + (size_t)(n ? cg : 0u) * p.in_stride * 2, 0,
+                                                 n ? (int)(((n - 1) * p.in_stride + p.block_size) * EB) : 0, 0x00020000);
+    };
+    __amdgpu_buffer_rsrc_t rs_in = in_rsrc(grp);
     const __amdgpu_buffer_rsrc_t rs_lo = __builtin_amdgcn_make_buffer_rsrc(const_cast<float2 *>(p.lo), 0, NCO == 2 ? (int)(p.block_size * 8u) : 0, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(dst + (size_t)c0 * p.out_stride, 0,
-                                                                            (int)(((chs - 1) * p.out_stride + p.block_size) * (uint32_t)sizeof(TOut)), 0x00020000);
     const int voff_in = (int)((lch * p.in_stride + lsm) * EB);        // this lane's part of every load address
     const int joff_in = (int)(CG::CPL * p.in_stride * EB);            // ... load j of a chunk adds j of these (wave-uniform)
-    auto issue_loads = [&](auto slot, uint32_t n_first) {          // chunk of CS samples x CH channels starting at n_first, into register slot `slot`
+    auto issue_loads = [&](auto slot, const __amdgpu_buffer_rsrc_t &rs, uint32_t n_first) {          // chunk of CS samples x CH channels of the group behind `rs` starting at n_first, into register slot `slot`
         constexpr int SL = decltype(slot)::value;
 #pragma unroll
-        for (int j = 0; j < NL; ++j) raw[SL][j] = CwRaw<TIn>::load(rs_in, voff_in, (int)(n_first * EB) + j * joff_in);
+        for (int j = 0; j < NL; ++j) raw[SL][j] = CwRaw<TIn>::load(rs, voff_in, (int)(n_first * EB) + j * joff_in);
         if constexpr (NCO == 2) lo4[SL] = __builtin_amdgcn_raw_buffer_load_b128(rs_lo, lsm * 8, (int)(n_first * 8u), 0);
     };
     float *mrow = tile + lch * RS + lsm;                 // this lane's slot of load 0 in chunk 0
@@ -199,6 +209,7 @@ __global__ __launch_bounds__(64) void k_cw_fused(RxParams p, const TIn *__restri
     // (tile_write).  In between sits, at a block boundary, the audio store burst of the block before: loads and stores complete out of
     // order with respect to each other on this target, so a wait for loaded data is a wait for every vector-memory operation in flight
     // (s_waitcnt vmcnt(0)) -- behind the burst that was a wait for 16 KB of write acknowledgements per block.
+    uint32_t c0 = grp * CH;                              // first channel of the present group
     float xm[NL][2];
     auto mix_regs = [&](auto slot, uint32_t n_first) {  // NCO mix (real part) of the chunk loaded into `slot`
         constexpr int SL = decltype(slot)::value;
@@ -245,7 +256,7 @@ __global__ __launch_bounds__(64) void k_cw_fused(RxParams p, const TIn *__restri
     // (arm_biquad_cascade_df1_f32.c:220: b0 x + b1 x1 + b2 x2 + a1 y1 + a2 y2).
     typedef float cw_v2f __attribute__((ext_vector_type(2)));
     const cw_v2f c1 = { b1, a1 }, c2 = { b2, a2 };
-    cw_v2f PA = { st.x, st.z }, PB = { st.y, st.w };                  // (x1, y1), (x2, y2)
+    cw_v2f PA, PB;                                                    // (x1, y1), (x2, y2): set when a group starts
     auto step = [&](float xs, cw_v2f &A, cw_v2f &B) -> float {        // on return B holds the new (x1, y1), A the new (x2, y2)
         const float xin = cw_stage_input<NS>(xs, A.y, s == 0);
         const cw_v2f t1 = A * c1, t2 = B * c2;
@@ -278,13 +289,25 @@ __global__ __launch_bounds__(64) void k_cw_fused(RxParams p, const TIn *__restri
     const uint32_t nblk = p.block_size / BLK;
     typedef std::integral_constant<int, 0> slot0_t;
     typedef std::integral_constant<int, DEPTH - 1> slot1_t;
+    __amdgpu_buffer_rsrc_t rs_next = in_rsrc(grp + gridDim.x);
     auto mix_and_prefetch = [&](auto slot, uint32_t n_first) {     // the loaded chunk (at n_first) out of its registers, the chunk DEPTH behind it requested into them
         mix_regs(slot, n_first);
-        const uint32_t nxt = n_first + DEPTH * CS;         // (may be in the next block)
-        if (nxt < p.block_size) issue_loads(slot, nxt);
+        const uint32_t nxt = n_first + DEPTH * CS;         // (may be in the next block -- or in the workgroup's next group: its first chunks)
+        if (nxt < p.block_size) issue_loads(slot, rs_in, nxt);
+        else if constexpr (DEPTH == 2) issue_loads(slot, rs_next, nxt - p.block_size);
     };
-    issue_loads(slot0_t{}, 0);
-    if constexpr (DEPTH == 2) issue_loads(slot1_t{}, CS);   // (a call is whole DSP blocks: at least two chunks)
+    if constexpr (DEPTH == 2) { issue_loads(slot0_t{}, rs_in, 0); issue_loads(slot1_t{}, rs_in, CS); }   // (a call is whole DSP blocks: at least two chunks)
+    for (;;) {
+    const bool live = c0 + ch < p.channels;
+    const uint32_t c = chan_of(grp);
+    const uint32_t chs = min((uint32_t)CH, p.channels - c0);
+    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(dst + (size_t)c0 * p.out_stride, 0,
+                                                                            (int)(((chs - 1) * p.out_stride + p.block_size) * (uint32_t)sizeof(TOut)), 0x00020000);
+    PA = cw_v2f{ gs_cur.st.x, gs_cur.st.z }; PB = cw_v2f{ gs_cur.st.y, gs_cur.st.w };
+    float gain = gs_cur.gain;
+    const uint32_t ph_own = gs_cur.ph, st_own = gs_cur.stp;
+    const uint32_t grp_next = grp + gridDim.x;
+    if constexpr (DEPTH == 1) issue_loads(slot0_t{}, rs_in, 0);     // (one slot: nothing of this group was requested ahead)
     mix_and_prefetch(slot0_t{}, 0);
     cw_lds_sync();
     for (uint32_t blk = 0; blk < nblk; ++blk) {
@@ -411,13 +434,18 @@ __global__ __launch_bounds__(64) void k_cw_fused(RxParams p, const TIn *__restri
         }
         cw_lds_sync();
     }
-    if (nonfinite) p.flags[kFlagNanInf] = 1u;                         // read by selenite_rx_sync / the host-pointer calls
-    if (!live) return;
-    *reinterpret_cast<float4 *>(p.biq_state + ((size_t)c * NS + s) * 4) = make_float4(PA.x, PB.x, PA.y, PB.y);
-    if (s == NS - 1) {
-        if (p.agc) p.gain[c] = gain;
-        if constexpr (NCO != 0) p.phase[c] = ph_own + p.block_size * st_own;
+    if (live) {
+        *reinterpret_cast<float4 *>(p.biq_state + ((size_t)c * NS + s) * 4) = make_float4(PA.x, PB.x, PA.y, PB.y);
+        if (s == NS - 1) {
+            if (p.agc) p.gain[c] = gain;
+            if constexpr (NCO != 0) p.phase[c] = ph_own + p.block_size * st_own;
+        }
     }
+    if (grp_next >= ngroups) break;
+    grp = grp_next; c0 = grp * CH; gs_cur = load_group_state(grp);
+    rs_in = rs_next; rs_next = in_rsrc(grp + gridDim.x);
+    }
+    if (nonfinite) p.flags[kFlagNanInf] = 1u;                         // read by selenite_rx_sync / the host-pointer calls
 }
 
 // DSP blocks the systolic kernel is instantiated for: whole input chunks of CS = 1024 / (64 / NS) samples (32 / 64 / 128 for
@@ -445,6 +473,28 @@ bool cw_strides_ok(uint64_t in_stride, uint64_t out_stride)
     return in_stride * 32u * 8u < (1ull << 31) && out_stride * 32u * 4u < (1ull << 31);
 }
 
+// One workgroup per group of CH channels -- or, where the groups are a whole multiple K of (nearly) what the device keeps resident, that many
+// workgroups taking K groups each, the next group's first chunks requested ahead (k_cw_fused / k_cw_roof: persistent over groups).  Never an uneven
+// share: a one-shot grid lets the dispatcher balance what does not divide.
+static uint32_t cw_grid(uint32_t ngroups, int resident)
+{
+    if (resident > 0 && ngroups > (uint32_t)resident) {
+        const uint32_t k = (ngroups + (uint32_t)resident - 1) / (uint32_t)resident;
+        if (ngroups % k == 0 && (uint64_t)(ngroups / k) * 100u >= (uint64_t)resident * 85u) return ngroups / k;
+    }
+    return ngroups;
+}
+template <typename K>
+static int cw_resident(K kernel, size_t dyn_lds)
+{
+    int per_cu = 0, dev = 0;
+    hipDeviceProp_t prop;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 64, dyn_lds) == hipSuccess && per_cu > 0 && hipGetDevice(&dev) == hipSuccess &&
+        hipGetDeviceProperties(&prop, dev) == hipSuccess)
+        return per_cu * prop.multiProcessorCount;
+    return -1;
+}
+
 template <int NS, int NCO, typename TIn, typename TOut>
 static hipError_t cw_launch(const RxParams &p, const void *src, void *dst, hipStream_t st)
 {
@@ -454,11 +504,13 @@ static hipError_t cw_launch(const RxParams &p, const void *src, void *dst, hipSt
         const long v = e ? std::atol(e) : 0;
         return (size_t)(v > 0 && v <= 40 * 1024 ? v : 0);
     }();
-    const dim3 grid((p.channels + CH - 1) / CH);
+    const uint32_t ngroups = (p.channels + CH - 1) / CH;
 #define CW_BLK(B_)                                                                                                          \
     if (p.block == B_) {                                                                                                    \
-        hipLaunchKernelGGL((k_cw_fused<NS, NCO, B_, TIn, TOut>), grid, dim3(64), pad, st, p, static_cast<const TIn *>(src), \
-                           static_cast<TOut *>(dst));                                                                      \
+        static int resident = 0;                                                                                            \
+        if (resident == 0) resident = cw_resident(k_cw_fused<NS, NCO, B_, TIn, TOut>, pad);                                 \
+        hipLaunchKernelGGL((k_cw_fused<NS, NCO, B_, TIn, TOut>), dim3(cw_grid(ngroups, resident)), dim3(64), pad, st, p,    \
+                           static_cast<const TIn *>(src), static_cast<TOut *>(dst));                                       \
         return hipGetLastError();                                                                                           \
     }
     CW_BLK(256)
@@ -512,25 +564,23 @@ __global__ __launch_bounds__(64) void k_cw_roof(RxParams p, const TIn *__restric
     constexpr int EB = CwRaw<TIn>::kBytes / 2;
     extern __shared__ float roof_lds[];                      // (dynamic: sized by the launcher so that the residency is k_cw_fused's)
     const int lane = threadIdx.x;
-    const uint32_t c0 = blockIdx.x * CH;
-    const uint32_t chs = min((uint32_t)CH, p.channels - c0);
-    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<TIn *>(src) + (size_t)c0 * p.in_stride * 2, 0,
-                                                                           (int)(((chs - 1) * p.in_stride + p.block_size) * EB), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(dst + (size_t)c0 * p.out_stride, 0,
-                                                                            (int)(((chs - 1) * p.out_stride + p.block_size) * (uint32_t)sizeof(TOut)), 0x00020000);
+    const uint32_t ngroups = (p.channels + CH - 1) / CH;
+    auto in_rsrc = [&](uint32_t g) {
+        const uint32_t cg = g * CH, n = g < ngroups ? min((uint32_t)CH, p.channels - cg) : 0u;
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<TIn *>(src) + (size_t)(n ? cg : 0u) * p.in_stride * 2, 0,
+                                                 n ? (int)(((n - 1) * p.in_stride + p.block_size) * EB) : 0, 0x00020000);
+    };
     const int lch = lane / CG::LPC, lsm = 2 * (lane % CG::LPC);
     const int voff_in = (int)((lch * p.in_stride + lsm) * EB);
     const int joff_in = (int)(CG::CPL * p.in_stride * EB);
     typedef typename CwRaw<TIn>::type raw_t;
     raw_t raw[DEPTH][NL];
-    float4 st = state[(size_t)blockIdx.x * kWave + lane];
     uint32_t acc = 0u;
-    auto issue = [&](auto slot, uint32_t n_first) {
+    auto issue = [&](auto slot, const __amdgpu_buffer_rsrc_t &rs, uint32_t n_first) {
         constexpr int SL = decltype(slot)::value;
-        const int past = n_first < p.block_size ? 0 : 0x70000000;        // past the call: outside the descriptor, no access
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int j = 0; j < NL; ++j) raw[SL][j] = CwRaw<TIn>::load(rs_in, voff_in, (int)(n_first * EB) + j * joff_in + past);
+        for (int j = 0; j < NL; ++j) raw[SL][j] = CwRaw<TIn>::load(rs, voff_in, (int)(n_first * EB) + j * joff_in);
     };
     auto consume = [&](auto slot) {
         constexpr int SL = decltype(slot)::value;
@@ -551,62 +601,78 @@ __global__ __launch_bounds__(64) void k_cw_roof(RxParams p, const TIn *__restric
     };
     typedef std::integral_constant<int, 0> slot0_t;
     typedef std::integral_constant<int, DEPTH - 1> slot1_t;
-    issue(slot0_t{}, 0);
-    if constexpr (DEPTH == 2) issue(slot1_t{}, CS);
-    consume(slot0_t{}); issue(slot0_t{}, DEPTH * CS);
     const uint32_t nblk = p.block_size / BLK;
-    for (uint32_t blk = 0; blk < nblk; ++blk) {
-        const uint32_t n0 = blk * BLK;
-        if constexpr (DEPTH == 2) {
+    uint32_t grp = blockIdx.x;
+    __amdgpu_buffer_rsrc_t rs_in = in_rsrc(grp), rs_next = in_rsrc(grp + gridDim.x);
+    auto request = [&](auto slot, uint32_t n_first) {                 // (past the call: the first chunks of the workgroup's next group, as k_cw_fused)
+        if (n_first < p.block_size) issue(slot, rs_in, n_first);
+        else if constexpr (DEPTH == 2) issue(slot, rs_next, n_first - p.block_size);
+    };
+    if constexpr (DEPTH == 2) { issue(slot0_t{}, rs_in, 0); issue(slot1_t{}, rs_in, CS); }
+    for (;;) {
+        const uint32_t c0 = grp * CH, chs = min((uint32_t)CH, p.channels - c0);
+        const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(dst + (size_t)c0 * p.out_stride, 0,
+                                                                                (int)(((chs - 1) * p.out_stride + p.block_size) * (uint32_t)sizeof(TOut)), 0x00020000);
+        float4 st = state[(size_t)grp * kWave + lane];
+        if constexpr (DEPTH == 1) issue(slot0_t{}, rs_in, 0);
+        consume(slot0_t{}); request(slot0_t{}, DEPTH * CS);
+        for (uint32_t blk = 0; blk < nblk; ++blk) {
+            const uint32_t n0 = blk * BLK;
+            if constexpr (DEPTH == 2) {
 #pragma unroll 1
-            for (int q = 0; q < NCHUNK; q += 2) {
-                if (q != 0) { consume(slot0_t{}); issue(slot0_t{}, n0 + CS * q + 2 * CS); }
-                busy();
-                consume(slot1_t{}); issue(slot1_t{}, n0 + CS * (q + 1) + 2 * CS);
-                busy();
-            }
-        } else {
+                for (int q = 0; q < NCHUNK; q += 2) {
+                    if (q != 0) { consume(slot0_t{}); request(slot0_t{}, n0 + CS * q + 2 * CS); }
+                    busy();
+                    consume(slot1_t{}); request(slot1_t{}, n0 + CS * (q + 1) + 2 * CS);
+                    busy();
+                }
+            } else {
 #pragma unroll 1
-            for (int q = 0; q < NCHUNK; ++q) {
-                if (q != 0) { consume(slot0_t{}); issue(slot0_t{}, n0 + CS * q + CS); }
-                busy();
+                for (int q = 0; q < NCHUNK; ++q) {
+                    if (q != 0) { consume(slot0_t{}); request(slot0_t{}, n0 + CS * q + CS); }
+                    busy();
+                }
             }
-        }
-        if (blk + 1 < nblk) { consume(slot0_t{}); issue(slot0_t{}, n0 + BLK + DEPTH * CS); }
+            if (blk + 1 < nblk) { consume(slot0_t{}); request(slot0_t{}, n0 + BLK + DEPTH * CS); }
 #pragma unroll 4
-        for (int r = 0; r < CH; ++r) {
+            for (int r = 0; r < CH; ++r) {
 #pragma unroll
-            for (int h = 0; h < (BLK / 4 + 63) / 64; ++h) {
-                const int t = 4 * (lane + 64 * h);
-                const int voff = t < BLK ? t * (int)sizeof(TOut) : 0x40000000;
-                const int soff = (int)((r * p.out_stride + n0) * (uint32_t)sizeof(TOut));
-                if constexpr (sizeof(TOut) == 4) __builtin_amdgcn_raw_buffer_store_b128(u4v_cw{ acc, acc, acc, acc }, rs_out, voff, soff, 2);
-                else __builtin_amdgcn_raw_buffer_store_b64(u2v_cw{ acc, acc }, rs_out, voff, soff, 2);
+                for (int h = 0; h < (BLK / 4 + 63) / 64; ++h) {
+                    const int t = 4 * (lane + 64 * h);
+                    const int voff = t < BLK ? t * (int)sizeof(TOut) : 0x40000000;
+                    const int soff = (int)((r * p.out_stride + n0) * (uint32_t)sizeof(TOut));
+                    if constexpr (sizeof(TOut) == 4) __builtin_amdgcn_raw_buffer_store_b128(u4v_cw{ acc, acc, acc, acc }, rs_out, voff, soff, 2);
+                    else __builtin_amdgcn_raw_buffer_store_b64(u2v_cw{ acc, acc }, rs_out, voff, soff, 2);
+                }
             }
         }
+        st.x += __uint_as_float(acc & 1u);
+        state[(size_t)grp * kWave + lane] = st;
+        if (grp + gridDim.x >= ngroups) break;
+        grp += gridDim.x; rs_in = rs_next; rs_next = in_rsrc(grp + gridDim.x);
     }
-    st.x += __uint_as_float(acc & 1u);
-    state[(size_t)blockIdx.x * kWave + lane] = st;
-    if (acc == 0x12345678u) roof_lds[lane] = st.x;
+    if (acc == 0x12345678u) roof_lds[lane] = __uint_as_float(acc);
 }
 
 template <int NS, typename TIn, typename TOut>
 static hipError_t cw_roof_launch(const RxParams &p, const void *src, void *dst, float4 *state, uint32_t work, hipStream_t st)
 {
     constexpr int CH = CwGeo<NS>::CH;
-    const dim3 grid((p.channels + CH - 1) / CH);
+    const uint32_t ngroups = (p.channels + CH - 1) / CH;
 #define CW_ROOF_BLK(B_)                                                                                                                        \
     if (p.block == B_) {                                                                                                                       \
         /* the residency of the kernel it stands for: as much dynamic LDS as leaves that many workgroups on a CU */                          \
         static size_t lds = 0;                                                                                                                 \
+        static int resident = 0;                                                                                                               \
         if (lds == 0) {                                                                                                                        \
             int per_cu = 0;                                                                                                                    \
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_cw_fused<NS, 2, B_, TIn, TOut>, 64, 0) != hipSuccess || per_cu < 1)    \
                 per_cu = 8;                                                                                                                    \
             lds = ((size_t)(160 * 1024) / (size_t)per_cu) & ~(size_t)1023;                                                                     \
+            resident = cw_resident(k_cw_roof<NS, B_, TIn, TOut>, lds);                                                                         \
         }                                                                                                                                      \
-        hipLaunchKernelGGL((k_cw_roof<NS, B_, TIn, TOut>), grid, dim3(64), lds, st, p, static_cast<const TIn *>(src), static_cast<TOut *>(dst), \
-                           state, work);                                                                                                       \
+        hipLaunchKernelGGL((k_cw_roof<NS, B_, TIn, TOut>), dim3(cw_grid(ngroups, resident)), dim3(64), lds, st, p,                              \
+                           static_cast<const TIn *>(src), static_cast<TOut *>(dst), state, work);                                              \
         return hipGetLastError();                                                                                                              \
     }
     CW_ROOF_BLK(256)
