@@ -346,7 +346,9 @@ int  selenite_rx_time_pattern_roof_device(selenite_rx_instance *S, const void *d
 #define SELENITE_RX_OPT_NO_PERIODIC_LO    2   /* 1: a shared LO always as a per-call table, never a 256-sample period in registers (RX and TX) */
 #define SELENITE_RX_OPT_RERUN_GRID        3   /* workgroups of SELENITE_ARITH_AUTO's rerun pass (1 .. 2^20); 0: sized from the last call's list */
 #define SELENITE_RX_OPT_TX_FORCE_GENERIC  4   /* 1: TX instances created from now on use the generic kernels only */
-#define SELENITE_RX_OPT_COUNT             5
+#define SELENITE_RX_OPT_CW_GRID           5   /* workgroups of the systolic CW kernel (each takes the channel groups b, b + grid, ...; 1 .. 2^20);
+                                               * 0: one per group, or a whole share of groups each where they divide evenly over the device */
+#define SELENITE_RX_OPT_COUNT             6
 int      selenite_rx_set_plan_option(int option, uint32_t value);   /* SELENITE_RX_ARGUMENT_ERROR: unknown option / value out of range */
 uint32_t selenite_rx_get_plan_option(int option);
 /* PCI bus id ("0000:05:00.0") of HIP device `ordinal` into buf; bench.py lists the devices of the ranks with it. */

@@ -166,7 +166,7 @@ static int check_device_flags(selenite_rx_instance *S)
 extern "C" int selenite_rx_abi_version(void) { return SELENITE_RX_ABI_VERSION; }
 
 // ---- plan options (rx_diag.h) ----
-namespace { uint32_t g_plan_opt[SELENITE_RX_OPT_COUNT] = { 0u, 0u, 0u, 0u, 0u }; }
+namespace { uint32_t g_plan_opt[SELENITE_RX_OPT_COUNT] = { 0u, 0u, 0u, 0u, 0u, 0u }; }
 namespace srx {
 uint32_t plan_option(int option)
 {
@@ -176,7 +176,7 @@ uint32_t plan_option(int option)
 extern "C" int selenite_rx_set_plan_option(int option, uint32_t value)
 {
     if (option < 0 || option >= SELENITE_RX_OPT_COUNT) return SELENITE_RX_ARGUMENT_ERROR;
-    if (option == SELENITE_RX_OPT_RERUN_GRID ? value > (1u << 20) : value > 1u) return SELENITE_RX_ARGUMENT_ERROR;
+    if (option == SELENITE_RX_OPT_RERUN_GRID || option == SELENITE_RX_OPT_CW_GRID ? value > (1u << 20) : value > 1u) return SELENITE_RX_ARGUMENT_ERROR;
     __atomic_store_n(&g_plan_opt[option], value, __ATOMIC_RELAXED);
     return SELENITE_RX_SUCCESS;
 }

@@ -478,6 +478,7 @@ bool cw_strides_ok(uint64_t in_stride, uint64_t out_stride)
 // share: a one-shot grid lets the dispatcher balance what does not divide.
 static uint32_t cw_grid(uint32_t ngroups, int resident)
 {
+    if (const uint32_t forced = plan_option(SELENITE_RX_OPT_CW_GRID)) return forced < ngroups ? forced : ngroups;      // (the tests: uneven shares, a partial last group)
     if (resident > 0 && ngroups > (uint32_t)resident) {
         const uint32_t k = (ngroups + (uint32_t)resident - 1) / (uint32_t)resident;
         if (ngroups % k == 0 && (uint64_t)(ngroups / k) * 100u >= (uint64_t)resident * 85u) return ngroups / k;

@@ -19,7 +19,7 @@ if os.environ.get("SELENITE_RX_LIB"):            # A/B experiments: another buil
 MODE_LSB, MODE_USB, MODE_CW, MODE_CWR, MODE_AM, MODE_FM, MODE_DIG, MODE_PKT = 0, 1, 2, 3, 4, 8, 0x0A, 0x0C
 ARITH_CMSIS, ARITH_FMA, ARITH_SPLIT16, ARITH_AUTO = 0, 1, 2, 3
 ABI_VERSION, CONFIG_SIZE_V1, TX_CONFIG_SIZE_V1 = 2, 112, 96      # include/selenite_rx.h, selenite_tx.h
-OPT_FORCE_GENERIC, OPT_NO_SHARED_LO, OPT_NO_PERIODIC_LO, OPT_RERUN_GRID, OPT_TX_FORCE_GENERIC = 0, 1, 2, 3, 4      # selenite_rx_set_plan_option
+OPT_FORCE_GENERIC, OPT_NO_SHARED_LO, OPT_NO_PERIODIC_LO, OPT_RERUN_GRID, OPT_TX_FORCE_GENERIC, OPT_CW_GRID = 0, 1, 2, 3, 4, 5      # selenite_rx_set_plan_option
 SUCCESS, ARGUMENT_ERROR, LENGTH_ERROR, NANINF, DEVICE_ERROR = 0, -1, -2, -4, -7
 
 f32p = C.POINTER(C.c_float)

@@ -608,6 +608,35 @@ def test_cw_fused_kernel_any_channel_count(nch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("stages,nch,grid,q15,variant", [(4, 75, 2, False, "shared"), (4, 75, 2, True, "shared"), (4, 64, 4, False, "per_channel"),
+                                                         (4, 81, 3, False, "none"), (2, 150, 2, False, "shared"), (8, 37, 2, False, "shared"), (4, 70, 1, True, "per_channel")])
+def test_cw_fused_kernel_persistent_over_channel_groups(stages, nch, grid, q15, variant):
+    """Round 6: a workgroup of k_cw_fused takes SEVERAL channel groups (b, b + grid, ...), requesting the first chunks of its next group during
+    the last DSP block of the present one -- what the launcher does where the groups divide evenly over the device (cfg4: 4096 groups on 2048
+    workgroups).  Pinned here to 1 / 2 / 3 / 4 workgroups (selenite_rx_set_plan_option(SELENITE_RX_OPT_CW_GRID)) so that small inputs cover uneven
+    shares, a partial last group, every NCO flavour and both slot formats: audio and state bit for bit the oracle's, over several calls."""
+    import selenite_rx as sr
+    kw = dict(nco=variant != "none", agc=True)
+    if variant == "per_channel":
+        kw["nco_steps"] = (np.arange(nch, dtype=np.uint64) * 0x9E3779B1 % (1 << 27) + 0x00400000).astype(np.uint32)
+    else:
+        kw["nco_step_all"] = 0x00800000
+    spec = rc.ChainSpec(nch, 256, 1, 0, 0, stages, MODE_CW, ARITH_CMSIS, **kw)
+    with sr.plan_option(sr.OPT_CW_GRID, grid):
+        g = gpu_rx(spec)
+        o = CpuChain(spec, "orc")
+        assert g.kernel_name() == "k_cw_fused<%d,256>" % stages
+        for call, bs in enumerate((512, 256, 1024)):
+            iq = synth_iq(0, nch, 2048 * call, bs)
+            if q15:
+                q = np.clip(np.trunc(iq * 32768.0), -32768, 32767).astype(np.int16)
+                assert np.array_equal(g.process_q15(q), o.process_q15(q)), call
+            else:
+                assert bits_equal(g.process(iq), o.process(iq)), call
+        assert_state_equal(g, o)
+
+
+@pytest.mark.gpu
 def test_instances_run_concurrently_on_their_own_streams():
     """Distinct instances are independent (SURVEY.md 8b "Threading"): each has its own stream; calls
     issued back to back without synchronisation in between must give what sequential runs give."""
