@@ -194,8 +194,8 @@ def side_workload(name, q15, arith, spinup_ms, iters=100, rank=0, parity=True, c
     rx = sr.Rx(spec.config())
     nout = bs // spec.decim
     if one_allocation:
-        # input and output inside ONE device allocation (f32 slots only): the placement in which cfg2 has landed in its slower mode every time
-        # it was tried (profiles/r5/placement_probe.txt, pattern C) -- separate hipMalloc calls land it in either
+        # input and output inside ONE device allocation (f32 slots only): a second placement of the same buffers (profiles/r5/placement_probe.txt,
+        # pattern C: the slower mode of cfg2 in every process of that box; on other boxes either)
         pool = sr.DeviceBuffer(channels * bs * 8 + channels * nout * 4)
         d_in, d_out = _View(pool, 0), _View(pool, channels * bs * 8)
     else:
@@ -727,14 +727,16 @@ def main():
             for nm, wq in (("cfg2", False), ("cfg4", False), ("cfg5", False), ("cfg3", True)):
                 wls[nm + ("_q15" if wq else "")] = side_workload(nm, wq, arith, args.spinup_ms / 3.0, parity=not args.no_cpu_baseline, channels_override=args.channels)
             # cfg2 runs in one of two modes of the memory system depending on where its buffers land (kernel and plain copy alike): the entry above is
-            # what two plain hipMalloc calls gave THIS process; the same workload with both buffers inside one allocation -- the slower mode every time it
-            # was tried -- right behind it, so that the line carries both and a reader can tell the placement's share from the kernel's
+            # what two plain hipMalloc calls gave THIS process; the same workload with both buffers inside one allocation right behind it, so that the
+            # line carries two placements and a reader can tell the placement's share from the kernel's (frac_of_streaming_roof stays put)
             one = side_workload("cfg2", False, arith, args.spinup_ms / 3.0, parity=False, channels_override=args.channels, one_allocation=True)
             pick = lambda w: {"ms_per_step": w["ms_per_step"], "value": w["value"], "frac": w["roofline"]["frac"],
                               "streaming_roof_ms": w["roofline"]["streaming_roof_ms"], "frac_of_streaming_roof": w["roofline"]["frac_of_streaming_roof"]}
             wls["cfg2"]["placement"] = {"separate_allocations": pick(wls["cfg2"]), "one_allocation": pick(one),
-                                        "note": "separate_allocations = the entry itself (two hipMalloc calls: lands in either mode, per process); one_allocation = input and "
-                                                "output inside one hipMalloc (the slower mode in every run so far); quote the slower of the two"}
+                                        "note": "separate_allocations = the entry itself (two hipMalloc calls); one_allocation = input and output inside one hipMalloc.  Which of "
+                                                "the two modes a placement lands in differs from box to box and from process to process (profiles/r5/placement_probe.txt: "
+                                                "one_allocation slow in 9 of 9 processes on one box; profiles/r6: both fast on another) -- the copy of the same bytes "
+                                                "(streaming_roof_ms) moves with it; quote the slower of the two"}
             wls["note"] = ("every entry: its own instance and resident synthetic batch, own spin-up, median of 100 per-launch HIP-event durations; cfg2 = BASELINE's 4096 channels x "
                            "48 000 samples (one second per call); cfg4 = the CW chain (bit-exact in every arithmetic mode); cfg5 = the per-GPU shard of the weak-scaling "
                            "config (131 072 channels x 1024); cfg3_q15 = the headline with int16 slots in and out")
