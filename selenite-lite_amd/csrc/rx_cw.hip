@@ -17,16 +17,18 @@
 // Per DSP block (BLK samples) and workgroup (one wavefront, 16 channels with 4 stages):
 //   1. buffer loads (2 complex samples per lane, 1 KB of one channel per instruction with 4 stages), NCO mix real part -- into
 //      REGISTERS first, then into ONE LDS tile x[16][BLK+4] (f32).  Shared LO: all loads of a chunk use the same LO float4.
-//   2. BLK+NS-1 systolic steps (NS-1 masked fill + NS-1 masked drain steps so a block's envelope is complete before it is scaled), 9 vector
-//      instructions each; the last stage writes y[n] over x[n] in place (x[n] was consumed NS-1 steps ago) and tracks max|y|.
+//   2. BLK+NS-1 systolic steps (NS-1 masked fill + NS-1 masked drain steps so a block's envelope is complete before it is scaled), 8 vector
+//      instructions each (9 with 8 stages); the last stage writes y[n] over x[n] in place (x[n] was consumed NS-1 steps ago) and tracks max|y|.
 //   3. AGC gain law per channel; the tile goes out as 16 rows of 1 KiB: ds_read_b128, scale by the channel's gain (v_readlane), one
 //      non-temporal buffer store per lane per row.
 // State (4 floats per channel-stage) is one coalesced dwordx4 load/store per lane per call.
-// Round 5 (profiles/r5/README.md): the audio stores of a block are a 16 KB burst, and a wait for loaded data is a wait for every vector-memory
-// operation in flight (loads and stores complete out of order with respect to each other: s_waitcnt vmcnt(0)) -- the first chunk of a
-// block is therefore taken out of its load registers BEFORE the burst of the block in front of it goes out (-6.5 %); the step's delay
-// lines became (x1, y1) / (x2, y2) register pairs that swap names (52 -> 39 vector instructions per four steps: -12 % with int16 slots,
-// nothing with f32 slots, which are bound by the memory system at 5.0 TB/s of a 2 : 1 read / write mix).
+// What bounds it (profiles/r6/cfg4_pattern_roof.md): NOT its fetch pattern (sixteen 1 KB pieces 32 KB apart per burst: a no-DSP kernel with exactly
+// these bursts is faster than one with 4 KB runs) but the balance of ~1360 vector instructions per chunk of a wave against the memory time of a
+// chunk, with two waves per SIMD to overlap them.  Hence: two chunks in flight (register slot q & 1), as few vector instructions per step as
+// the data flow allows (the step is bound by their COUNT: 4 cycles each at the SIMD whatever the number of waves), workgroups persistent over
+// channel groups.  Carried over from round 5: a wait for loaded data is a wait for every vector-memory operation in flight whenever stores are
+// (s_waitcnt vmcnt(0)), so the first chunk of a block is taken out of its load registers BEFORE the 16 KB store burst of the block in front of it
+// goes out; the delay lines are (x1, y1) / (x2, y2) register pairs that swap names.
 #include "rx_internal.h"
 #include <cstdlib>
 #include <type_traits>
