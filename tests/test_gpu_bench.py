@@ -172,8 +172,10 @@ def test_bench_under_the_nccl_backend_with_one_rank_carries_the_dist_block():
             w5 = d["cfg5_weak_scaling"]
             assert w5["n_gpus"] == 1 and w5["scaling"] == "weak" and w5["kernel"].startswith("k_hilb_split16<127>") and w5["value"] > 0
             assert "2048 channels/GPU x 1024" in w5["workload"]                          # (--channels 1024 scales the leg: twice the headline's count, as in BASELINE)
-            assert abs(w5["weak_scaling_efficiency"] - 0.25 / w5["ms_per_step"]) < 1e-3 * 0.25 / w5["ms_per_step"] + 1e-4
-            assert abs(d["weak_scaling_efficiency"] - 0.5 / d["ms_per_step"]) < 1e-3 * 0.5 / d["ms_per_step"] + 1e-4
+            # (ms_per_step is rounded to 0.1 us in the JSON, the efficiency is formed from the unrounded time: at this test's 10-us steps that is up to half a percent)
+            for e, n1 in ((w5, 0.25), (d, 0.5)):
+                want = n1 / e["ms_per_step"]
+                assert abs(e["weak_scaling_efficiency"] - want) <= want * (1e-3 + 6e-5 / e["ms_per_step"]) + 1e-4, (e["weak_scaling_efficiency"], want)
         else:
             assert "cfg5_weak_scaling" not in d
 
