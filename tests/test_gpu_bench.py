@@ -90,7 +90,7 @@ def test_bench_json_contract_default_shape():
     assert w["cfg4"]["kernel"] == "k_cw_fused<4,256>" and w["cfg4"]["parity"]["worst_rel"] == 0.0      # bit-exact in every arithmetic mode
     # round 6: the CW kernel against the roof of ITS fetch pattern (k_cw_roof: same bursts, stores, launch shape, residency; no DSP)
     pr = w["cfg4"]["roofline"]["pattern_roof"]
-    assert 0 < pr["pattern_roof_ms"] <= pr["pattern_roof_with_arith_ms"] * 1.1 and pr["arith_vector_instructions_per_chunk"] > 1000
+    assert 0 < pr["pattern_roof_ms"] <= pr["pattern_roof_with_arith_ms"] * 1.5 and pr["arith_vector_instructions_per_chunk"] > 1000
     assert pr["kernel"] == "k_cw_roof" and 0 < pr["pattern_roof_ms"] and abs(pr["frac_of_pattern_roof"] - pr["pattern_roof_ms"] / w["cfg4"]["ms_per_step"]) < 5e-3 + 1.5e-4 / w["cfg4"]["ms_per_step"]
     # round 6: cfg2 in both placements of its buffers, same run
     pl = w["cfg2"]["placement"]
