@@ -161,6 +161,25 @@ def test_version_1_caller_is_accepted_whatever_its_padding_holds():
     assert tx_code(lambda g: setattr(g, "q15_rounding", 2)) == rc.ARGUMENT_ERROR
 
 
+def test_plan_options_are_validated_words_not_environment():
+    """selenite_rx_set_plan_option (round 6: the switches the tests need are a C-ABI call, the library reads no environment variable for them):
+    unknown options and out-of-range values are refused, accepted values read back, and everything is 0 unless somebody sets it."""
+    L = sr.lib()
+    for opt in range(6):
+        assert L.selenite_rx_get_plan_option(opt) == 0
+    assert L.selenite_rx_set_plan_option(-1, 1) == rc.ARGUMENT_ERROR and L.selenite_rx_set_plan_option(6, 1) == rc.ARGUMENT_ERROR
+    assert L.selenite_rx_set_plan_option(sr.OPT_FORCE_GENERIC, 2) == rc.ARGUMENT_ERROR
+    assert L.selenite_rx_set_plan_option(sr.OPT_RERUN_GRID, (1 << 20) + 1) == rc.ARGUMENT_ERROR
+    with sr.plan_option(sr.OPT_CW_GRID, 7), sr.plan_option(sr.OPT_NO_SHARED_LO):
+        assert L.selenite_rx_get_plan_option(sr.OPT_CW_GRID) == 7 and L.selenite_rx_get_plan_option(sr.OPT_NO_SHARED_LO) == 1
+    assert L.selenite_rx_get_plan_option(sr.OPT_CW_GRID) == 0 and L.selenite_rx_get_plan_option(sr.OPT_NO_SHARED_LO) == 0
+    os.environ["SELENITE_RX_FORCE_GENERIC"] = "1"                      # (round 5's switch: no longer read)
+    try:
+        assert L.selenite_rx_get_plan_option(sr.OPT_FORCE_GENERIC) == 0
+    finally:
+        del os.environ["SELENITE_RX_FORCE_GENERIC"]
+
+
 def test_no_cpu_fallback_without_gpu():
     if has_gpu():
         pytest.skip("a GPU is present")
