@@ -637,6 +637,26 @@ def test_cw_fused_kernel_persistent_over_channel_groups(stages, nch, grid, q15, 
 
 
 @pytest.mark.gpu
+def test_the_library_reads_no_kernel_selection_switch_from_the_environment():
+    """Round 6: the round-5 environment switches are gone from the default build -- set, they change nothing; the same
+    selections through selenite_rx_set_plan_option do."""
+    import selenite_rx as sr
+    spec = baseline_spec("cfg4", 33)
+    env = {"SELENITE_RX_FORCE_GENERIC": "1", "SELENITE_RX_NO_SHARED_LO": "1", "SELENITE_RX_NO_PERIODIC_LO": "1", "SELENITE_RX_CW_LDS_PAD": "20000",
+           "SELENITE_RX_SPLIT16_GRID": "1", "SELENITE_RX_RERUN_GRID": "1", "SELENITE_RX_NO_HIST_EXT": "1", "SELENITE_RX_DEC2_PARITY": "2"}
+    os.environ.update(env)
+    try:
+        g = gpu_rx(spec)
+        h = gpu_rx(baseline_spec("cfg3", 33, rc.ARITH_SPLIT16))
+        assert g.kernel_name() == "k_cw_fused<4,256>" and h.kernel_name() == "k_ssb_split16<256,4,63>" and "registers" in h.nco_path()
+    finally:
+        for k in env:
+            del os.environ[k]
+    with sr.plan_option(sr.OPT_FORCE_GENERIC), sr.plan_option(sr.OPT_NO_PERIODIC_LO):
+        assert gpu_rx(spec).kernel_name() == "generic"
+
+
+@pytest.mark.gpu
 def test_instances_run_concurrently_on_their_own_streams():
     """Distinct instances are independent (SURVEY.md 8b "Threading"): each has its own stream; calls
     issued back to back without synchronisation in between must give what sequential runs give."""
